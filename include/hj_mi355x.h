@@ -1,0 +1,163 @@
+/*
+ * hj_mi355x.h -- C ABI of libhj_mi355x.so: the MI355X (gfx950) implementation of
+ * LevelSetPy's Hamilton-Jacobi time-stepping hot path
+ *
+ *     odeCFLn -> termLaxFriedrichs -> upwindFirst{ENO2,ENO3,WENO5}
+ *             -> artificialDissipationGLF -> addGhost{Extrapolate,Periodic}
+ *
+ * The reference (robotsorcerer/LevelSetPy) is pure Python: the "FFI" a
+ * maintainer binds is ctypes (INTEGRATION.md shows the stub).  Every entry
+ * point below names the reference callable it replaces (file:line relative to
+ * the reference checkout).
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, scalars.  No torch / C++ types.
+ *  - every `const void* / void*` array argument is a DEVICE pointer (HIP) to a
+ *    C-order (last axis contiguous) array of the ctx's dtype, owned by the
+ *    caller.  `double*` outputs documented as "host" are host pointers.
+ *  - calls are stream-ordered on the ctx stream (hj_ctx_set_stream) and return
+ *    without synchronising unless they hand back a host scalar.
+ *  - return 0 on success, a negative HJ_E* code otherwise; the message is in
+ *    hj_last_error() (thread-local).  The Python side raises ValueError, as the
+ *    reference's error() does (Utilities/matlab_utils.py:134-137).
+ *  - one ctx per device per thread; not re-entrant.
+ */
+#ifndef HJ_MI355X_H
+#define HJ_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HJ_MAX_DIM 4
+#define HJ_STENCIL 3 /* ghost width of the widest scheme (ENO3aHelper.py:61) */
+
+enum { HJ_OK = 0, HJ_EINVAL = -1, HJ_EHIP = -2, HJ_EUNSUPPORTED = -3, HJ_ESTATE = -4 };
+
+/* grid.bdry[dim]: addGhostExtrapolate | addGhostPeriodic (Grids/create_grid.py:61-65) */
+enum { HJ_BC_EXTRAPOLATE = 0, HJ_BC_PERIODIC = 1 };
+
+/* schemeData.CoStateCalc / derivFunc */
+enum {
+    HJ_ENO2 = 0,            /* SpatialDerivative/upwind_first_eno2.py:12  */
+    HJ_ENO3 = 1,            /* SpatialDerivative/upwind_first_eno3a.py:14 */
+    HJ_WENO5 = 2,           /* intended O&F WENO5 (upwind_first_weno5a.py:13, ENO3bHelper.py:135-160) */
+    HJ_WENO5_ASSHIPPED = 3  /* what upwind_first_weno5a.py computes as shipped: linear weights */
+};
+
+/* schemeData.hamFunc / partialFunc pairs with a native implementation */
+enum {
+    HJ_HAM_DUBINS_REL = 0,        /* DynamicalSystems/dubins_relative.py:63-111; params {v_e, v_p, w, w_e+w_p}; aux0=cos(vs[2]) aux1=sin(vs[2]) */
+    HJ_HAM_DOUBLE_INTEGRATOR = 1, /* DynamicalSystems/double_integrator.py:49-89; params {u_bound} */
+    HJ_HAM_DOUBLE_PENDULUM = 2    /* build-defined 4-D stress case (BASELINE C5); params {u_max}; aux0..3 = sin th1, cos th1, sin th2, cos th2 */
+};
+
+enum { HJ_F64 = 0, HJ_F32 = 1 };
+
+/* how one fused substep combines its result (ExplicitIntegration/Integration/ode_cfl_{1,2,3}.py) */
+enum {
+    HJ_STAGE_YDOT = 0,   /* out = ydot                         termLaxFriedrichs (term_lax_friedrich.py:124-128) */
+    HJ_STAGE_EULER = 1,  /* out = y + dt*ydot                  ode_cfl_3.py:151,184 */
+    HJ_STAGE_RK3_HALF = 2, /* out = 0.25*(3*y0 + (y + dt*ydot))  ode_cfl_3.py:184,193 */
+    HJ_STAGE_RK3_FULL = 3, /* out = (1/3)*(y0 + 2*(y + dt*ydot)) ode_cfl_3.py:226,241 */
+    HJ_STAGE_RK2_FULL = 4  /* out = 0.5*(y0 + (y + dt*ydot))     ode_cfl_2.py:184,201 */
+};
+
+/* hj_minmax_with ops: HJIPDE_solve post-step operators (ValueFuncs/hji_solver.py:566-599) */
+enum { HJ_OP_MIN = 0, HJ_OP_MAX = 1, HJ_OP_MAX_NEG = 2 /* max(y, -other): obstacle mask :641-644 */ };
+
+typedef struct hj_ctx hj_ctx;
+
+/* ---- context = the reference's grid Bundle fields the path uses (Grids/process_grid.py:185-293) ----
+ * N[ndim] grid.N, xmin[ndim] grid.min, dx[ndim] grid.dx, bc[ndim] HJ_BC_*, toward_zero[ndim]
+ * (ghostData.towardZero, add_ghost_extrapolate.py:60-64; may be NULL = all 0). */
+int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,
+                  const int* bc, const int* toward_zero, int dtype, int device);
+void hj_ctx_destroy(hj_ctx* ctx);
+
+/* HIP stream (hipStream_t) all later calls are ordered on; NULL = the default stream. */
+int hj_ctx_set_stream(hj_ctx* ctx, void* hip_stream);
+
+/* Exact node coordinates grid.vs[dim] (host, N[dim] doubles; process_grid.py:204).  Optional:
+ * default is xmin + i*dx.  Passing np.linspace values keeps coordinates bit-identical. */
+int hj_ctx_set_coords(hj_ctx* ctx, int dim, const double* vs_host);
+
+/* Hamiltonian-specific 1-D tables (host, n doubles), e.g. numpy's cos/sin of vs[2] for Dubins so
+ * the trig values are bit-identical to the reference's cp.cos(grid.xs[2]) (dubins_relative.py:84-85).
+ * Optional: default is libm on the coordinates. */
+int hj_ctx_set_aux(hj_ctx* ctx, int slot, const double* table_host, int64_t n);
+
+/* Slab decomposition along axis 0 (no reference counterpart).  When halo_lo / halo_hi
+ * is nonzero, the HJ_STENCIL planes below / above every stencil-input array (`y` arguments) are
+ * caller-provided ghost planes (received from the neighbour rank) instead of boundary-rule ghosts:
+ * the `y` pointer still addresses the first interior plane, and the planes at negative offsets /
+ * past N[0] must be readable. */
+int hj_ctx_set_slab(hj_ctx* ctx, int halo_lo, int halo_hi);
+
+/* ---- boundary padding: grid.bdry[dim](data, dim, width, bdryData)
+ * addGhostExtrapolate (BoundaryCondition/add_ghost_extrapolate.py:16) / addGhostPeriodic
+ * (add_ghost_periodic.py:12).  `out` has N[dim]+2*width entries along dim.  Bit-exact. */
+int hj_ghost(hj_ctx* ctx, int dim, int width, const void* in, void* out);
+
+/* ---- derivL, derivR = CoStateCalc(grid, data, dim)  (upwindFirst{ENO2,ENO3,WENO5})
+ * minmax4 (host, nullable): {min L, max L, min R, max R} -- the four global reductions
+ * artificialDissipationGLF takes per dim (artificial_diss_glf.py:80-88); reading them syncs. */
+int hj_upwind(hj_ctx* ctx, int scheme, int dim, const void* phi, void* derivL, void* derivR,
+              double* minmax4_host);
+
+/* ---- ydot, stepBound = termLaxFriedrichs(t, y, schemeData) with a native hamFunc/partialFunc and
+ * artificialDissipationGLF (term_lax_friedrich.py:8, artificial_diss_glf.py:7), one fused kernel.
+ * restrict_sign: 0 none; +1 ydot=max(ydot,0); -1 ydot=min(ydot,0) (termRestrictUpdate,
+ * term_restrict_update.py:99-102).  step_bound_host nullable (non-null syncs). */
+int hj_lf_term(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, double t,
+               int restrict_sign, const void* y, void* ydot, double* step_bound_host);
+
+/* ---- one fused RK substep: out = stage(y0, y + dt*ydot(y)); see HJ_STAGE_*.  y0 may be NULL for
+ * YDOT/EULER.  The per-dim max of alpha (CFL reduction) of this substep is left on the device in
+ * `bound_slot` (0..HJ_BOUND_SLOTS-1) for hj_read_step_bound.  Planes [plane_begin, plane_end) of
+ * axis 0 are updated (use 0, N[0] for all): the slab driver launches edge and interior ranges
+ * separately to overlap the halo exchange. */
+#define HJ_BOUND_SLOTS 64
+int hj_rk_substep(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, double t,
+                  int stage, double dt, int restrict_sign, const void* y, const void* y0, void* out,
+                  int bound_slot, int64_t plane_begin, int64_t plane_end);
+
+/* stepBound (artificial_diss_glf.py:107-109) of the substep that used `bound_slot`; synchronises. */
+int hj_read_step_bound(hj_ctx* ctx, int bound_slot, double* step_bound_host, double* alpha_max_host);
+
+/* ---- t, y = odeCFL{1,2,3}(termLaxFriedrichs|termRestrictUpdate, [t0, tf], y, options{singleStep:'on'})
+ * with a native Hamiltonian whose alpha does not depend on the data (all HJ_HAM_* above): ONE step,
+ * `order` fused substeps, no host synchronisation.  dt = min(factor_cfl*stepBound, tf-t0, max_step)
+ * (ode_cfl_3.py:142).  work0/work1: caller scratch, same size as y (work1 unused for order<3,
+ * may be NULL).  y_out may alias y_in for order 1 only.  t_out/dt_out: host. */
+int hj_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double t0,
+               double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
+               void* y_out, void* work0, void* work1, double* t_out, double* dt_out);
+
+/* stepBound of a native Hamiltonian on this grid (alpha is data-independent for all HJ_HAM_*);
+ * computed once per (ham_id, params) and cached.  Synchronises on the first call. */
+int hj_static_step_bound(hj_ctx* ctx, int ham_id, const double* ham_params, double* step_bound_host);
+
+/* max over the (unstripped) first-divided-difference table of D1^2, per dim: the 'maxOverGrid'
+ * epsilon of true WENO5 (upwind_first_weno5a.py:69-70,153-156).  out_dev: ndim values of the ctx
+ * dtype on the device.  hj_rk_substep/hj_lf_term with HJ_WENO5 run this themselves unless
+ * hj_ctx_set_weno_eps_source was given a caller-reduced vector (slab decomposition: all-reduced). */
+int hj_max_d1sq(hj_ctx* ctx, const void* y, void* out_dev);
+int hj_ctx_set_weno_eps_source(hj_ctx* ctx, const void* max_d1sq_dev /* NULL = compute per call */);
+
+/* ---- elementwise y = min/max(y, other)  (HJIPDE_solve compMethod, hji_solver.py:566-599,641-644) */
+int hj_minmax_with(hj_ctx* ctx, int op, void* y, const void* other, int64_t n);
+
+/* NaN guard of HJIPDE_solve (hji_solver.py:544-545): *has_nan_host = 1 if any NaN.  Synchronises. */
+int hj_any_nan(hj_ctx* ctx, const void* y, int64_t n, int* has_nan_host);
+
+int hj_sync(hj_ctx* ctx);
+const char* hj_last_error(void);
+const char* hj_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJ_MI355X_H */

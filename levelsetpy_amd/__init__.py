@@ -1,0 +1,24 @@
+"""levelsetpy_amd -- MI355X (gfx950) implementation of LevelSetPy's Hamilton-Jacobi time-stepping
+hot path, behind the reference's own names and callback protocol:
+
+    odeCFL1/2/3, odeCFLset  ->  termLaxFriedrichs / termRestrictUpdate
+        ->  upwindFirstENO2 / ENO3 / WENO5  +  artificialDissipationGLF  +  addGhost*
+
+All arithmetic on the path runs in hand-written HIP kernels (csrc/, C ABI in
+include/hj_mi355x.h, bound with ctypes).  There is no CPU fallback.
+"""
+from .utilities import *            # noqa: F401,F403
+from .boundary import addGhostExtrapolate, addGhostPeriodic, addGhostAllDims   # noqa: F401
+from .grids import createGrid, processGrid                                      # noqa: F401
+from .init_conds import shapeCylinder, shapeSphere                              # noqa: F401
+from .spatial import (upwindFirstENO2, upwindFirstENO3, upwindFirstENO3a, upwindFirstWENO5,   # noqa: F401
+                      upwindFirstWENO5a, upwindFirstWENO5Intended, upwindFirstENO3aHelper,
+                      set_weno5_mode, get_weno5_mode)
+from .dissipation import artificialDissipationGLF                               # noqa: F401
+from .dynamics import DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D      # noqa: F401
+from .term import termLaxFriedrichs, termRestrictUpdate                         # noqa: F401
+from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      # noqa: F401
+                          odeCFLmultipleSteps, odeCFLcallPostTimestep)
+from .hji_solver import HJIPDE_solve                                            # noqa: F401
+
+__version__ = "0.1.0"

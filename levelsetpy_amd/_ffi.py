@@ -1,0 +1,80 @@
+"""ctypes binding of libhj_mi355x.so (include/hj_mi355x.h).
+
+The product path is HIP only: if the shared library is missing or cannot be
+loaded, every compute entry point raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libhj_mi355x.so")
+
+# enums of include/hj_mi355x.h
+BC_EXTRAPOLATE, BC_PERIODIC = 0, 1
+ENO2, ENO3, WENO5, WENO5_ASSHIPPED = 0, 1, 2, 3
+HAM_DUBINS_REL, HAM_DOUBLE_INTEGRATOR, HAM_DOUBLE_PENDULUM = 0, 1, 2
+F64, F32 = 0, 1
+STAGE_YDOT, STAGE_EULER, STAGE_RK3_HALF, STAGE_RK3_FULL, STAGE_RK2_FULL = 0, 1, 2, 3, 4
+OP_MIN, OP_MAX, OP_MAX_NEG = 0, 1, 2
+STENCIL = 3
+BOUND_SLOTS = 64
+
+SCHEME_IDS = {"ENO2": ENO2, "ENO3": ENO3, "WENO5": WENO5, "WENO5_ASSHIPPED": WENO5_ASSHIPPED}
+
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_pd, _pi, _pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes): every symbol the header declares
+SIGNATURES = {
+    "hj_ctx_create": (_i, [C.POINTER(_vp), _i, _pi64, _pd, _pd, _pi, _pi, _i, _i]),
+    "hj_ctx_destroy": (None, [_vp]),
+    "hj_ctx_set_stream": (_i, [_vp, _vp]),
+    "hj_ctx_set_coords": (_i, [_vp, _i, _pd]),
+    "hj_ctx_set_aux": (_i, [_vp, _i, _pd, _i64]),
+    "hj_ctx_set_slab": (_i, [_vp, _i, _i]),
+    "hj_ghost": (_i, [_vp, _i, _i, _vp, _vp]),
+    "hj_upwind": (_i, [_vp, _i, _i, _vp, _vp, _vp, _pd]),
+    "hj_lf_term": (_i, [_vp, _i, _i, _pd, _d, _i, _vp, _vp, _pd]),
+    "hj_rk_substep": (_i, [_vp, _i, _i, _pd, _d, _i, _d, _i, _vp, _vp, _vp, _i, _i64, _i64]),
+    "hj_read_step_bound": (_i, [_vp, _i, _pd, _pd]),
+    "hj_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _pd, _pd]),
+    "hj_static_step_bound": (_i, [_vp, _i, _pd, _pd]),
+    "hj_max_d1sq": (_i, [_vp, _vp, _vp]),
+    "hj_ctx_set_weno_eps_source": (_i, [_vp, _vp]),
+    "hj_minmax_with": (_i, [_vp, _i, _vp, _vp, _i64]),
+    "hj_any_nan": (_i, [_vp, _vp, _i64, _pi]),
+    "hj_sync": (_i, [_vp]),
+    "hj_last_error": (C.c_char_p, []),
+    "hj_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError (loudly) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "levelsetpy_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C levelsetpy_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Non-zero return code -> ValueError, as the reference's error() (matlab_utils.py:134-137)."""
+    if rc != 0:
+        msg = lib().hj_last_error()
+        raise ValueError((msg or b"hj_mi355x error").decode("utf-8", "replace") + " (code %d)" % rc)
+
+
+def darr(values):
+    values = [float(v) for v in values]
+    return (C.c_double * max(1, len(values)))(*values)

@@ -1,0 +1,166 @@
+"""Device-side twin of a grid Bundle: owns the hj_ctx (C ABI) for one grid, dtype and
+GPU, and marshals NumPy / torch arrays across the boundary.
+
+torch is plumbing here: device memory, the current HIP stream, (in dist.py)
+torch.distributed.  All arithmetic on the path runs in libhj_mi355x.so.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _ffi
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("levelsetpy_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is "
+                           "False and there is no CPU fallback")
+    return torch
+
+
+def is_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def grid_bc(grid):
+    """(bc[], toward_zero[]) from grid.bdry / grid.bdryData (Grids/create_grid.py:61-65,
+    add_ghost_extrapolate.py:60-64).  Only the two boundary functions of the path are known."""
+    from .boundary import addGhostExtrapolate, addGhostPeriodic
+    bc, tz = [], []
+    bdata = getattr(grid, "bdryData", None) or [None] * grid.dim
+    for i in range(grid.dim):
+        f = grid.bdry[i]
+        if f is addGhostPeriodic or getattr(f, "__name__", "") == "addGhostPeriodic":
+            bc.append(_ffi.BC_PERIODIC)
+        elif f is addGhostExtrapolate or getattr(f, "__name__", "") == "addGhostExtrapolate":
+            bc.append(_ffi.BC_EXTRAPOLATE)
+        else:
+            raise ValueError("grid.bdry[%d]=%r: only addGhostExtrapolate / addGhostPeriodic have a "
+                             "device implementation" % (i, f))
+        gd = bdata[i]
+        tz.append(1 if (gd is not None and hasattr(gd, "towardZero") and gd.towardZero) else 0)
+    return bc, tz
+
+
+class DeviceGrid(object):
+    """hj_ctx + array marshalling for one (grid, dtype, device[, slab])."""
+
+    def __init__(self, grid, dtype="float64", device=None, slab=None):
+        torch = require_gpu()
+        self.torch = torch
+        self.lib = _ffi.lib()
+        self.dim = int(grid.dim)
+        self.shape = tuple(int(n) for n in np.asarray(grid.N).ravel())
+        self.dtype_name = dtype
+        self.tdtype = torch.float64 if dtype == "float64" else torch.float32
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.dx = [float(v) for v in np.asarray(grid.dx).ravel()]
+        xmin = [float(v) for v in np.asarray(grid.min).ravel()]
+        bc, tz = grid_bc(grid)
+        self.bc = bc
+        vs = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()) for v in grid.vs]
+        # slab = (plane_begin, plane_end, halo_lo, halo_hi): this rank owns planes [b, e) of axis 0
+        self.slab = slab
+        if slab is not None:
+            b, e, hlo, hhi = slab
+            self.shape = (e - b,) + self.shape[1:]
+            vs[0] = np.ascontiguousarray(vs[0][b:e])
+            xmin[0] = float(vs[0][0])
+        self.numel = int(np.prod(self.shape))
+        self.plane = self.numel // self.shape[0]
+        n = (C.c_int64 * self.dim)(*self.shape)
+        ctx = C.c_void_p()
+        _ffi.check(self.lib.hj_ctx_create(C.byref(ctx), self.dim, n, _ffi.darr(xmin), _ffi.darr(self.dx),
+                                          (C.c_int * self.dim)(*bc), (C.c_int * self.dim)(*tz),
+                                          _ffi.F64 if dtype == "float64" else _ffi.F32,
+                                          self.device.index))
+        self.ctx = ctx
+        self._finalizer = weakref.finalize(self, self.lib.hj_ctx_destroy, ctx)
+        for d in range(self.dim):
+            _ffi.check(self.lib.hj_ctx_set_coords(ctx, d, vs[d].ctypes.data_as(_ffi._pd)))
+        # trig tables computed by NumPy so they are bit-identical to cp.cos(grid.xs[2]) etc.
+        if self.dim == 3:
+            self._aux(0, np.cos(vs[2]))
+            self._aux(1, np.sin(vs[2]))
+        elif self.dim == 4:
+            self._aux(0, np.sin(vs[0]))
+            self._aux(1, np.cos(vs[0]))
+            self._aux(2, np.sin(vs[2]))
+            self._aux(3, np.cos(vs[2]))
+        if slab is not None:
+            _ffi.check(self.lib.hj_ctx_set_slab(ctx, int(slab[2]), int(slab[3])))
+        self._work = {}
+
+    def _aux(self, slot, tab):
+        tab = np.ascontiguousarray(tab, dtype=np.float64)
+        _ffi.check(self.lib.hj_ctx_set_aux(self.ctx, slot, tab.ctypes.data_as(_ffi._pd), tab.size))
+
+    # ------------------------------------------------------------------ marshalling
+    def bind_stream(self):
+        s = self.torch.cuda.current_stream(self.device)
+        _ffi.check(self.lib.hj_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)))
+
+    def to_device(self, a):
+        """NumPy array or torch tensor -> contiguous device tensor of the ctx dtype (flat view ok)."""
+        torch = self.torch
+        if is_tensor(a):
+            t = a
+            if t.device != self.device or t.dtype != self.tdtype:
+                t = t.to(device=self.device, dtype=self.tdtype)
+            return t.contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(
+            device=self.device, dtype=self.tdtype)
+
+    def like(self, t, proto, shape=None):
+        """Return `t` in the array type of `proto` (NumPy in -> NumPy out, tensor in -> tensor out)."""
+        if shape is not None:
+            t = t.reshape(shape)
+        if is_tensor(proto):
+            return t
+        return t.detach().cpu().numpy()
+
+    def empty(self, shape=None):
+        return self.torch.empty(self.shape if shape is None else shape, dtype=self.tdtype,
+                                device=self.device)
+
+    def work(self, key):
+        w = self._work.get(key)
+        if w is None:
+            w = self._work[key] = self.empty()
+        return w
+
+    @staticmethod
+    def ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def sync(self):
+        _ffi.check(self.lib.hj_sync(self.ctx))
+
+
+def device_grid(grid, dtype="float64"):
+    """Cached DeviceGrid of a grid Bundle (kept on the Bundle itself)."""
+    cache = grid.__dict__.get("_hj_device")
+    if cache is None:
+        cache = {}
+        object.__setattr__(grid, "_hj_device", cache)
+    torch = require_gpu()
+    key = (dtype, torch.cuda.current_device())
+    dg = cache.get(key)
+    if dg is None:
+        dg = cache[key] = DeviceGrid(grid, dtype)
+    return dg
+
+
+def array_dtype_name(a):
+    """'float32' only when the caller hands float32 data explicitly; the reference path is fp64
+    (ghost functions force float64: add_ghost_extrapolate.py:77)."""
+    if is_tensor(a):
+        return "float32" if str(a.dtype) == "torch.float32" else "float64"
+    return "float64"

@@ -1,0 +1,831 @@
+// C ABI of libhj_mi355x.so (see include/hj_mi355x.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/hj_mi355x.h"
+#include "hj_fused.h"
+#include "hj_split.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(HJ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys)
+
+struct Tiling {
+    int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
+    int ntiles, chunk, nchunks, nblocks, bpx;
+    size_t lds_bytes;
+    double score;
+    bool ok;
+};
+
+struct KernelCfg { int NT, R, KH; };
+
+}  // namespace
+
+struct hj_ctx {
+    int ndim, dtype, device;
+    int64_t N[HJ_MAX_DIM];
+    double xmin[HJ_MAX_DIM], dx[HJ_MAX_DIM];
+    int bc[HJ_MAX_DIM], tz[HJ_MAX_DIM];
+    int halo_lo, halo_hi;
+    hipStream_t stream;
+    size_t esz;
+    int64_t total;
+    void* coord[HJ_MAX_DIM];           // device, dtype
+    std::vector<double> coord_host[HJ_MAX_DIM];
+    void* aux[4];
+    int64_t aux_n[4];
+    unsigned long long* ring;          // RING_SLOTS * HJ_MAX_DIM keys
+    int ring_pos;
+    int slot_ring[HJ_BOUND_SLOTS];     // user slot -> ring index (-1 = none)
+    unsigned long long* keys;          // scratch keys (upwind min/max, weno eps): 8
+    void* weno_vals;                   // HJ_MAX_DIM values of dtype
+    const void* weno_src;              // caller-provided eps source or null
+    int* flag;                         // nan flag
+    // static step bound cache
+    int sb_ham;
+    double sb_par[4], sb_val, sb_alpha[HJ_MAX_DIM];
+    bool sb_valid;
+    int internal_slot;
+    // tuning
+    KernelCfg cfg;
+    int force_direct;
+    int target_blocks, min_chunk;
+    size_t lds_limit;
+};
+
+namespace {
+
+using namespace hj;
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// ------------------------------------------------------------------------------------ tiling
+// Pick tile extents E[1..nd-1] (cells <= NT*R, halo slots <= KH*NT, LDS <= limit) minimising
+// (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) {
+    const int nd = c->ndim;
+    const int cap = k.NT * k.R;
+    Tiling best;
+    best.ok = false;
+    best.score = 1e300;
+    int n[HJ_MAX_DIM];
+    for (int d = 0; d < nd; ++d) n[d] = (int)c->N[d];
+    std::vector<int> cand[HJ_MAX_DIM];
+    for (int d = 1; d < nd; ++d) {
+        for (int parts = 1; parts <= 64; ++parts) {
+            int e = (n[d] + parts - 1) / parts;
+            if (e < 1) e = 1;
+            if (cand[d].empty() || cand[d].back() != e) cand[d].push_back(e);
+            if (e == 1) break;
+        }
+    }
+    int E[HJ_MAX_DIM] = {1, 1, 1, 1};
+    // enumerate extents of all plane axes except the first, which takes what is left
+    std::vector<int> it(HJ_MAX_DIM, 0);
+    while (true) {
+        long long cells = 1;
+        for (int d = 2; d < nd; ++d) { E[d] = cand[d][it[d]]; cells *= E[d]; }
+        if (cells <= cap) {
+            E[1] = (int)std::min<long long>(n[1], std::max<long long>(1, cap / cells));
+            // E[1] must also be one of "n/parts" only for balance; any value works for correctness
+            cells *= E[1];
+            long long halo = 0, box = 1;
+            for (int d = 1; d < nd; ++d) { halo += 6 * (cells / E[d]); box *= (E[d] + 6); }
+            size_t lds = 512 + 2 * (size_t)box * c->esz;
+            if (halo <= (long long)k.KH * k.NT && lds <= c->lds_limit) {
+                double util = (double)cells / (double)(((cells + k.NT - 1) / k.NT) * k.NT);
+                // cells recomputed by the shifted last tile on each axis
+                double waste = 1.0;
+                for (int d = 1; d < nd; ++d) {
+                    int nt = (n[d] + E[d] - 1) / E[d];
+                    waste *= (double)nt * E[d] / (double)n[d];
+                }
+                double score = ((double)(cells + halo) / (double)cells) * waste / util;
+                if (score < best.score) {
+                    best.ok = true;
+                    best.score = score;
+                    best.lds_bytes = lds;
+                    best.ntiles = 1;
+                    for (int d = 1; d < nd; ++d) {
+                        best.E[d] = E[d];
+                        best.ntile[d] = (n[d] + E[d] - 1) / E[d];
+                        best.ntiles *= best.ntile[d];
+                    }
+                    best.E[0] = 1; best.ntile[0] = 1;
+                }
+            }
+        }
+        int d = 2;
+        for (; d < nd; ++d) {
+            if (++it[d] < (int)cand[d].size()) break;
+            it[d] = 0;
+        }
+        if (d >= nd) break;
+    }
+    if (!best.ok) return best;
+    const int64_t planes = p1 - p0;
+    int64_t want = std::max<int64_t>(1, c->target_blocks / best.ntiles);
+    int64_t max_chunks = std::max<int64_t>(1, planes / c->min_chunk);
+    int64_t nch = std::min(want, max_chunks);
+    best.chunk = (int)((planes + nch - 1) / nch);
+    best.nchunks = (int)((planes + best.chunk - 1) / best.chunk);
+    best.nblocks = best.nchunks * best.ntiles;
+    best.bpx = (best.nblocks + 7) / 8;
+    return best;
+}
+
+template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
+    for (int d = 0; d < HJ_MAX_DIM; ++d) H.coord[d] = (const T*)c->coord[d];
+    for (int s = 0; s < 4; ++s) H.aux[s] = (const T*)c->aux[s];
+    for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
+}
+
+int ham_ndim(int ham) {
+    switch (ham) {
+        case HJ_HAM_DUBINS_REL: return 3;
+        case HJ_HAM_DOUBLE_INTEGRATOR: return 2;
+        case HJ_HAM_DOUBLE_PENDULUM: return 4;
+    }
+    return -1;
+}
+int ham_npar(int ham) {
+    switch (ham) {
+        case HJ_HAM_DUBINS_REL: return 4;
+        case HJ_HAM_DOUBLE_INTEGRATOR: return 1;
+        case HJ_HAM_DOUBLE_PENDULUM: return 1;
+    }
+    return 0;
+}
+
+template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G) {
+    long long s = 1;
+    for (int d = ND - 1; d >= 0; --d) {
+        G.n[d] = (int)c->N[d];
+        G.bc[d] = c->bc[d];
+        G.km[d] = c->tz[d] ? T(-1) : T(1);
+        G.dx[d] = (T)c->dx[d];
+        G.inv_dx[d] = (T)(1.0 / c->dx[d]);
+        G.stride[d] = s;
+        s *= c->N[d];
+    }
+    G.halo_lo = c->halo_lo;
+    G.halo_hi = c->halo_hi;
+    G.total = c->total;
+}
+
+struct SubstepCall {
+    int scheme, ham, stage, restrict_sign;
+    const double* par;
+    double dt;
+    const void *y, *y0;
+    void* out;
+    unsigned long long* bound;
+    int64_t p0, p1;
+};
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH>
+int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
+    constexpr int ND = HAM::ND;
+    FusedArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.y = (const T*)s.y;
+    A.y0 = (const T*)s.y0;
+    A.out = (T*)s.out;
+    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    A.bound = s.bound;
+    long long st = 1;
+    for (int d = ND - 1; d >= 0; --d) {
+        A.n[d] = (int)c->N[d];
+        A.bc[d] = c->bc[d];
+        A.km[d] = c->tz[d] ? T(-1) : T(1);
+        A.dx[d] = (T)c->dx[d];
+        A.inv_dx[d] = (T)(1.0 / c->dx[d]);
+        A.pstride[d] = (d >= 1) ? (int)st : 0;
+        if (d == 0) A.stride0 = st;
+        st *= c->N[d];
+        A.E[d] = t.E[d];
+        A.ntile[d] = t.ntile[d];
+    }
+    A.halo_lo = c->halo_lo;
+    A.halo_hi = c->halo_hi;
+    A.ntiles = t.ntiles;
+    A.chunk = t.chunk;
+    A.nchunks = t.nchunks;
+    A.plane_begin = (int)s.p0;
+    A.plane_end = (int)s.p1;
+    A.nblocks = t.nblocks;
+    A.blocks_per_xcd = t.bpx;
+    A.stage = s.stage;
+    A.restrict_sign = s.restrict_sign;
+    A.dt = (T)s.dt;
+    fill_ham<T>(c, s.par, A.ham);
+    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH>;
+    if (t.lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    }
+    hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME>
+int launch_direct(hj_ctx* c, const SubstepCall& s) {
+    constexpr int ND = HAM::ND;
+    DirectArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.y = (const T*)s.y;
+    A.y0 = (const T*)s.y0;
+    A.out = (T*)s.out;
+    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    A.bound = s.bound;
+    fill_grid<T, ND>(c, A.G);
+    const long long plane = c->total / c->N[0];
+    A.cell_begin = s.p0 * plane;
+    A.cell_end = s.p1 * plane;
+    A.stage = s.stage;
+    A.restrict_sign = s.restrict_sign;
+    A.dt = (T)s.dt;
+    fill_ham<T>(c, s.par, A.ham);
+    const long long cells = A.cell_end - A.cell_begin;
+    if (cells <= 0) return HJ_OK;
+    int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME>
+int launch_cfg(hj_ctx* c, const SubstepCall& s) {
+    if constexpr (HAM::ND <= 3) {
+      if (!c->force_direct) {
+        const KernelCfg k = c->cfg;
+        Tiling t = make_tiling(c, k, s.p0, s.p1);
+        if (t.ok) {
+            if (k.NT == 512 && k.R == 4) return launch_tiled<T, HAM, SCHEME, 512, 4, 4>(c, s, t);
+            if (k.NT == 256 && k.R == 4) return launch_tiled<T, HAM, SCHEME, 256, 4, 6>(c, s, t);
+            if (k.NT == 1024 && k.R == 2) return launch_tiled<T, HAM, SCHEME, 1024, 2, 2>(c, s, t);
+            if (k.NT == 256 && k.R == 8) return launch_tiled<T, HAM, SCHEME, 256, 8, 6>(c, s, t);
+        }
+      }
+    }
+    return launch_direct<T, HAM, SCHEME>(c, s);
+}
+
+template <typename T, typename HAM>
+int launch_scheme(hj_ctx* c, const SubstepCall& s) {
+    switch (s.scheme) {
+        case HJ_ENO2: return launch_cfg<T, HAM, HJ_ENO2>(c, s);
+        case HJ_ENO3: return launch_cfg<T, HAM, HJ_ENO3>(c, s);
+        case HJ_WENO5: return launch_cfg<T, HAM, HJ_WENO5>(c, s);
+        case HJ_WENO5_ASSHIPPED: return launch_cfg<T, HAM, HJ_WENO5_ASSHIPPED>(c, s);
+    }
+    return fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
+}
+
+template <typename T>
+int launch_ham(hj_ctx* c, const SubstepCall& s) {
+    switch (s.ham) {
+        case HJ_HAM_DUBINS_REL: return launch_scheme<T, HamDubinsRel<T>>(c, s);
+        case HJ_HAM_DOUBLE_INTEGRATOR: return launch_scheme<T, HamDoubleIntegrator<T>>(c, s);
+        case HJ_HAM_DOUBLE_PENDULUM: return launch_scheme<T, HamDoublePendulum<T>>(c, s);
+    }
+    return fail(HJ_EINVAL, "unknown Hamiltonian id %d", s.ham);
+}
+
+int check_ham(const hj_ctx* c, int ham, const double* par) {
+    const int nd = ham_ndim(ham);
+    if (nd < 0) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham);
+    if (nd != c->ndim)
+        return fail(HJ_EINVAL, "Hamiltonian %d is %d-dimensional but the grid has dim %d", ham, nd, c->ndim);
+    if (!par) return fail(HJ_EINVAL, "ham_params is NULL");
+    if (ham == HJ_HAM_DUBINS_REL && (!c->aux[0] || !c->aux[1] || c->aux_n[0] != c->N[2] || c->aux_n[1] != c->N[2]))
+        return fail(HJ_ESTATE, "Dubins tables missing (internal)");
+    return HJ_OK;
+}
+
+template <typename T> int upload_table(hj_ctx* c, void** dst, const double* src, int64_t n) {
+    std::vector<T> tmp((size_t)n);
+    for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = (T)src[i];
+    if (*dst) { HIP_TRY(hipFree(*dst)); *dst = nullptr; }
+    HIP_TRY(hipMalloc(dst, (size_t)n * sizeof(T)));
+    // synchronous copy from a temporary: tables are set up rarely
+    HIP_TRY(hipMemcpy(*dst, tmp.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    return HJ_OK;
+}
+
+int upload(hj_ctx* c, void** dst, const double* src, int64_t n) {
+    return c->dtype == HJ_F64 ? upload_table<double>(c, dst, src, n) : upload_table<float>(c, dst, src, n);
+}
+
+// default trig tables from the coordinates (libm); Python overrides them with NumPy's values
+int default_aux(hj_ctx* c) {
+    std::vector<double> t;
+    auto mk = [&](int slot, int dim, double (*f)(double)) -> int {
+        const auto& v = c->coord_host[dim];
+        t.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) t[i] = f(v[i]);
+        c->aux_n[slot] = (int64_t)v.size();
+        return upload(c, &c->aux[slot], t.data(), (int64_t)v.size());
+    };
+    int rc = HJ_OK;
+    if (c->ndim == 3) {
+        if ((rc = mk(0, 2, cos))) return rc;
+        if ((rc = mk(1, 2, sin))) return rc;
+    } else if (c->ndim == 4) {
+        if ((rc = mk(0, 0, sin))) return rc;
+        if ((rc = mk(1, 0, cos))) return rc;
+        if ((rc = mk(2, 2, sin))) return rc;
+        if ((rc = mk(3, 2, cos))) return rc;
+    }
+    return rc;
+}
+
+unsigned long long* next_ring(hj_ctx* c, int user_slot, int* rc) {
+    *rc = HJ_OK;
+    if (c->ring_pos >= RING_SLOTS) {
+        hipError_t e = hipMemsetAsync(c->ring, 0, sizeof(unsigned long long) * RING_SLOTS * HJ_MAX_DIM, c->stream);
+        if (e != hipSuccess) { *rc = fail(HJ_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e)); return nullptr; }
+        c->ring_pos = 0;
+        for (int i = 0; i < HJ_BOUND_SLOTS; ++i) c->slot_ring[i] = -1;
+    }
+    const int pos = c->ring_pos++;
+    if (user_slot >= 0 && user_slot < HJ_BOUND_SLOTS) c->slot_ring[user_slot] = pos;
+    return c->ring + (size_t)pos * HJ_MAX_DIM;
+}
+
+double key_to_double(unsigned long long k) {
+    unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    memcpy(&v, &b, 8);
+    return v;
+}
+
+int weno_eps_pass(hj_ctx* c, const void* y) {
+    HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 8);
+#define HJ_MAXD1(T, ND)                                                                          \
+    {                                                                                            \
+        GridArgs<T, ND> G;                                                                       \
+        fill_grid<T, ND>(c, G);                                                                  \
+        hipLaunchKernelGGL((max_d1sq_kernel<T, ND>), dim3(blocks), dim3(256), 0, c->stream,      \
+                           (const T*)y, G, c->keys);                                             \
+    }
+    if (c->dtype == HJ_F64) {
+        if (c->ndim == 2) HJ_MAXD1(double, 2) else if (c->ndim == 3) HJ_MAXD1(double, 3) else HJ_MAXD1(double, 4)
+    } else {
+        if (c->ndim == 2) HJ_MAXD1(float, 2) else if (c->ndim == 3) HJ_MAXD1(float, 3) else HJ_MAXD1(float, 4)
+    }
+#undef HJ_MAXD1
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+int keys_to_vals(hj_ctx* c, void* out) {
+    if (c->dtype == HJ_F64)
+        hipLaunchKernelGGL((keys_to_values_kernel<double>), dim3(1), dim3(64), 0, c->stream, c->keys, (double*)out, c->ndim);
+    else
+        hipLaunchKernelGGL((keys_to_values_kernel<float>), dim3(1), dim3(64), 0, c->stream, c->keys, (float*)out, c->ndim);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
+    int rc = check_ham(c, s.ham, s.par);
+    if (rc) return rc;
+    if (s.scheme < 0 || s.scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
+    if (s.p0 < 0 || s.p1 > c->N[0] || s.p0 > s.p1) return fail(HJ_EINVAL, "bad plane range [%lld,%lld)", (long long)s.p0, (long long)s.p1);
+    if (!s.y || !s.out) return fail(HJ_EINVAL, "null array argument");
+    if (s.y == s.out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
+    if (s.stage >= HJ_STAGE_RK3_HALF && !s.y0) return fail(HJ_EINVAL, "stage %d needs y0", s.stage);
+    if (s.stage < 0 || s.stage > HJ_STAGE_RK2_FULL) return fail(HJ_EINVAL, "unknown stage %d", s.stage);
+    for (int d = 0; d < c->ndim; ++d)
+        if (c->N[d] < HJ_STENCIL)
+            return fail(HJ_EINVAL, "grid too small along dim %d (N=%lld)", d, (long long)c->N[d]);
+    if (s.p0 == s.p1) return HJ_OK;
+    if (s.scheme == HJ_WENO5 && !c->weno_src) {
+        if ((rc = weno_eps_pass(c, s.y))) return rc;
+        if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+    }
+    s.bound = next_ring(c, user_slot, &rc);
+    if (rc) return rc;
+    return c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
+}
+
+int read_ring(hj_ctx* c, int pos, double* sb, double* amax) {
+    unsigned long long k[HJ_MAX_DIM];
+    HIP_TRY(hipMemcpyAsync(k, c->ring + (size_t)pos * HJ_MAX_DIM, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double inv = 0.0;
+    for (int d = 0; d < c->ndim; ++d) {
+        if (k[d] == 0) return fail(HJ_ESTATE, "bound slot holds no reduction for dim %d", d);
+        // alpha arrives as the ctx dtype; the reference divides by grid.dx in fp64 (artificial_diss_glf.py:107)
+        const double a = key_to_double(k[d]);
+        if (amax) amax[d] = a;
+        inv += a / c->dx[d];
+    }
+    if (sb) *sb = 1.0 / inv;
+    return HJ_OK;
+}
+
+}  // namespace
+
+static int dim_view(const hj_ctx* c, int dim, long long* outer, long long* inner) {
+    long long o = 1, i = 1;
+    for (int d = 0; d < dim; ++d) o *= c->N[d];
+    for (int d = dim + 1; d < c->ndim; ++d) i *= c->N[d];
+    *outer = o; *inner = i;
+    return 0;
+}
+
+template <typename T> static DimView<T> make_view(const hj_ctx* c, int dim, bool with_halo) {
+    DimView<T> V;
+    dim_view(c, dim, &V.outer, &V.inner);
+    V.n = (int)c->N[dim];
+    V.bc = c->bc[dim];
+    V.halo_lo = (with_halo && dim == 0) ? c->halo_lo : 0;
+    V.halo_hi = (with_halo && dim == 0) ? c->halo_hi : 0;
+    V.km = c->tz[dim] ? T(-1) : T(1);
+    V.dx = (T)c->dx[dim];
+    V.inv_dx = (T)(1.0 / c->dx[dim]);
+    return V;
+}
+
+template <typename T> static int upwind_launch(hj_ctx* c, int scheme, int dim, const void* phi, void* dL, void* dR, unsigned long long* keys, const T* epsv) {
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 8);
+    DimView<T> V = make_view<T>(c, dim, true);
+    T eps = T(0);
+    if (scheme == HJ_WENO5) {
+        // tiny D2H of one value: the split path is the host-synchronous compatibility path anyway
+        T m;
+        HIP_TRY(hipMemcpyAsync(&m, epsv + dim, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        eps = T(1e-6) * m + Lim<T>::tiny;
+    }
+#define HJ_UPW(S) hipLaunchKernelGGL((upwind_kernel<T, S>), dim3(blocks), dim3(256), 0, c->stream, (const T*)phi, (T*)dL, (T*)dR, V, eps, keys)
+    switch (scheme) {
+        case HJ_ENO2: HJ_UPW(HJ_ENO2); break;
+        case HJ_ENO3: HJ_UPW(HJ_ENO3); break;
+        case HJ_WENO5: HJ_UPW(HJ_WENO5); break;
+        case HJ_WENO5_ASSHIPPED: HJ_UPW(HJ_WENO5_ASSHIPPED); break;
+        default: return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    }
+#undef HJ_UPW
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+// =========================================================================================== ABI
+extern "C" {
+
+const char* hj_last_error(void) { return g_err; }
+const char* hj_version(void) { return "hj_mi355x 0.1 (gfx950)"; }
+
+int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,
+                  const int* bc, const int* toward_zero, int dtype, int device) {
+    if (!out || !N || !xmin || !dx || !bc) return fail(HJ_EINVAL, "null argument");
+    if (ndim < 2 || ndim > HJ_MAX_DIM) return fail(HJ_EUNSUPPORTED, "grid.dim must be 2..4, got %d", ndim);
+    if (dtype != HJ_F64 && dtype != HJ_F32) return fail(HJ_EINVAL, "unknown dtype %d", dtype);
+    int64_t total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (N[d] < 1) return fail(HJ_EINVAL, "number of grid cells must be strictly positive");
+        if (!(dx[d] > 0)) return fail(HJ_EINVAL, "grid cell size dx must be strictly positive");
+        if (bc[d] != HJ_BC_EXTRAPOLATE && bc[d] != HJ_BC_PERIODIC) return fail(HJ_EINVAL, "unknown bc %d", bc[d]);
+        total *= N[d];
+    }
+    if (total / N[0] >= (1ll << 31)) return fail(HJ_EUNSUPPORTED, "axis-0 plane exceeds 2^31 cells");
+    HIP_TRY(hipSetDevice(device));
+    hj_ctx* c = new hj_ctx();
+    c->ndim = ndim; c->dtype = dtype; c->device = device;
+    c->esz = dtype == HJ_F64 ? 8 : 4;
+    c->total = total;
+    c->halo_lo = c->halo_hi = 0;
+    c->stream = nullptr;
+    for (int d = 0; d < HJ_MAX_DIM; ++d) { c->coord[d] = nullptr; c->N[d] = 1; c->bc[d] = 0; c->tz[d] = 0; c->dx[d] = 1; c->xmin[d] = 0; }
+    for (int s = 0; s < 4; ++s) { c->aux[s] = nullptr; c->aux_n[s] = 0; }
+    c->ring = nullptr; c->keys = nullptr; c->weno_vals = nullptr; c->weno_src = nullptr; c->flag = nullptr;
+    c->sb_valid = false; c->internal_slot = 0;
+    for (int d = 0; d < ndim; ++d) {
+        c->N[d] = N[d]; c->xmin[d] = xmin[d]; c->dx[d] = dx[d]; c->bc[d] = bc[d];
+        c->tz[d] = toward_zero ? (toward_zero[d] != 0) : 0;
+    }
+    c->cfg.NT = env_int("HJ_NT", 512);
+    c->cfg.R = env_int("HJ_R", 4);
+    c->cfg.KH = 0;
+    c->force_direct = env_int("HJ_FORCE_DIRECT", 0);
+    c->target_blocks = env_int("HJ_TARGET_BLOCKS", 1024);
+    c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 8));
+    c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
+    {
+        const int nt = c->cfg.NT, r = c->cfg.R;
+        if (nt == 512 && r == 4) c->cfg.KH = 4;
+        else if (nt == 256 && r == 4) c->cfg.KH = 6;
+        else if (nt == 1024 && r == 2) c->cfg.KH = 2;
+        else if (nt == 256 && r == 8) c->cfg.KH = 6;
+        else { delete c; return fail(HJ_EINVAL, "unsupported HJ_NT/HJ_R combination %d/%d", nt, r); }
+    }
+    *out = c;
+    int rc = HJ_OK;
+    auto bail = [&](int code) { hj_ctx_destroy(c); *out = nullptr; return code; };
+    for (int d = 0; d < ndim; ++d) {
+        c->coord_host[d].resize((size_t)N[d]);
+        for (int64_t i = 0; i < N[d]; ++i) c->coord_host[d][(size_t)i] = xmin[d] + (double)i * dx[d];
+        if ((rc = upload(c, &c->coord[d], c->coord_host[d].data(), N[d]))) return bail(rc);
+    }
+    if ((rc = default_aux(c))) return bail(rc);
+    hipError_t e;
+    if ((e = hipMalloc((void**)&c->ring, sizeof(unsigned long long) * RING_SLOTS * HJ_MAX_DIM)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->keys, sizeof(unsigned long long) * 8)) != hipSuccess ||
+        (e = hipMalloc(&c->weno_vals, 8 * HJ_MAX_DIM)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->flag, sizeof(int))) != hipSuccess)
+        return bail(fail(HJ_EHIP, "hipMalloc: %s", hipGetErrorString(e)));
+    c->ring_pos = RING_SLOTS;  // forces the first use to zero the ring
+    for (int i = 0; i < HJ_BOUND_SLOTS; ++i) c->slot_ring[i] = -1;
+    return HJ_OK;
+}
+
+void hj_ctx_destroy(hj_ctx* c) {
+    if (!c) return;
+    for (int d = 0; d < HJ_MAX_DIM; ++d) if (c->coord[d]) (void)hipFree(c->coord[d]);
+    for (int s = 0; s < 4; ++s) if (c->aux[s]) (void)hipFree(c->aux[s]);
+    if (c->ring) (void)hipFree(c->ring);
+    if (c->keys) (void)hipFree(c->keys);
+    if (c->weno_vals) (void)hipFree(c->weno_vals);
+    if (c->flag) (void)hipFree(c->flag);
+    delete c;
+}
+
+int hj_ctx_set_stream(hj_ctx* c, void* s) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    c->stream = (hipStream_t)s;
+    return HJ_OK;
+}
+
+int hj_ctx_set_coords(hj_ctx* c, int dim, const double* vs) {
+    if (!c || !vs) return fail(HJ_EINVAL, "null argument");
+    if (dim < 0 || dim >= c->ndim) return fail(HJ_EINVAL, "Illegal dim parameter");
+    c->coord_host[dim].assign(vs, vs + c->N[dim]);
+    c->sb_valid = false;
+    int rc = upload(c, &c->coord[dim], vs, c->N[dim]);
+    if (rc) return rc;
+    return default_aux(c);
+}
+
+int hj_ctx_set_aux(hj_ctx* c, int slot, const double* tab, int64_t n) {
+    if (!c || !tab) return fail(HJ_EINVAL, "null argument");
+    if (slot < 0 || slot >= 4 || n <= 0) return fail(HJ_EINVAL, "bad aux slot/size");
+    c->aux_n[slot] = n;
+    c->sb_valid = false;
+    return upload(c, &c->aux[slot], tab, n);
+}
+
+int hj_ctx_set_slab(hj_ctx* c, int lo, int hi) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    c->halo_lo = lo != 0;
+    c->halo_hi = hi != 0;
+    return HJ_OK;
+}
+
+int hj_ghost(hj_ctx* c, int dim, int width, const void* in, void* out) {
+    if (!c || !in || !out) return fail(HJ_EINVAL, "null argument");
+    if (dim < 0 || dim >= c->ndim) return fail(HJ_EINVAL, "Illegal dim parameter");
+    if (width <= 0 || width > c->N[dim]) return fail(HJ_EINVAL, "Illegal width parameter");
+    if (c->bc[dim] == HJ_BC_EXTRAPOLATE && c->N[dim] < 2) return fail(HJ_EINVAL, "extrapolation needs two nodes");
+    const long long total = c->total / c->N[dim] * (c->N[dim] + 2 * width);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    if (c->dtype == HJ_F64)
+        hipLaunchKernelGGL((ghost_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, (const double*)in, (double*)out, make_view<double>(c, dim, false), width);
+    else
+        hipLaunchKernelGGL((ghost_kernel<float>), dim3(blocks), dim3(256), 0, c->stream, (const float*)in, (float*)out, make_view<float>(c, dim, false), width);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+int hj_upwind(hj_ctx* c, int scheme, int dim, const void* phi, void* dL, void* dR, double* mm) {
+    if (!c || !phi || !dL || !dR) return fail(HJ_EINVAL, "null argument");
+    if (dim < 0 || dim >= c->ndim) return fail(HJ_EINVAL, "Illegal dim parameter");
+    if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    if (c->N[dim] < HJ_STENCIL) return fail(HJ_EINVAL, "grid too small along dim %d (N=%lld)", dim, (long long)c->N[dim]);
+    int rc;
+    const void* epsv = c->weno_src ? c->weno_src : c->weno_vals;
+    if (scheme == HJ_WENO5 && !c->weno_src) {
+        if ((rc = weno_eps_pass(c, phi))) return rc;
+        if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+    }
+    unsigned long long* keys = nullptr;
+    if (mm) {
+        keys = c->keys + 4;
+        HIP_TRY(hipMemsetAsync(keys, 0, 4 * sizeof(unsigned long long), c->stream));
+    }
+    rc = c->dtype == HJ_F64 ? upwind_launch<double>(c, scheme, dim, phi, dL, dR, keys, (const double*)epsv)
+                            : upwind_launch<float>(c, scheme, dim, phi, dL, dR, keys, (const float*)epsv);
+    if (rc) return rc;
+    if (mm) {
+        unsigned long long k[4];
+        HIP_TRY(hipMemcpyAsync(k, keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        mm[0] = -key_to_double(k[0]); mm[1] = key_to_double(k[1]);
+        mm[2] = -key_to_double(k[2]); mm[3] = key_to_double(k[3]);
+    }
+    return HJ_OK;
+}
+
+int hj_rk_substep(hj_ctx* c, int scheme, int ham, const double* par, double t, int stage, double dt,
+                  int restrict_sign, const void* y, const void* y0, void* out, int bound_slot,
+                  int64_t p0, int64_t p1) {
+    (void)t;
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (bound_slot < 0 || bound_slot >= HJ_BOUND_SLOTS) return fail(HJ_EINVAL, "bound_slot out of range");
+    SubstepCall s{scheme, ham, stage, restrict_sign, par, dt, y, y0, out, nullptr, p0, p1};
+    return do_substep(c, s, bound_slot);
+}
+
+int hj_read_step_bound(hj_ctx* c, int slot, double* sb, double* amax) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (slot < 0 || slot >= HJ_BOUND_SLOTS || c->slot_ring[slot] < 0)
+        return fail(HJ_ESTATE, "bound slot %d holds no result", slot);
+    return read_ring(c, c->slot_ring[slot], sb, amax);
+}
+
+int hj_lf_term(hj_ctx* c, int scheme, int ham, const double* par, double t, int restrict_sign,
+               const void* y, void* ydot, double* sb) {
+    (void)t;
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    const int slot = HJ_BOUND_SLOTS - 1;
+    SubstepCall s{scheme, ham, HJ_STAGE_YDOT, restrict_sign, par, 0.0, y, nullptr, ydot, nullptr, 0, c->N[0]};
+    int rc = do_substep(c, s, slot);
+    if (rc) return rc;
+    if (sb) return read_ring(c, c->slot_ring[slot], sb, nullptr);
+    return HJ_OK;
+}
+
+int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb) {
+    if (!c || !sb) return fail(HJ_EINVAL, "null argument");
+    int rc = check_ham(c, ham, par);
+    if (rc) return rc;
+    const int np = ham_npar(ham);
+    if (c->sb_valid && c->sb_ham == ham && memcmp(c->sb_par, par, sizeof(double) * np) == 0) {
+        *sb = c->sb_val;
+        return HJ_OK;
+    }
+    HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 8);
+#define HJ_AB(T, HAM)                                                                            \
+    {                                                                                            \
+        GridArgs<T, HAM<T>::ND> G;                                                               \
+        fill_grid<T, HAM<T>::ND>(c, G);                                                          \
+        HamTables<T> P;                                                                          \
+        fill_ham<T>(c, par, P);                                                                  \
+        hipLaunchKernelGGL((alpha_bound_kernel<T, HAM<T>>), dim3(blocks), dim3(256), 0,          \
+                           c->stream, G, P, c->keys);                                            \
+    }
+    if (c->dtype == HJ_F64) {
+        if (ham == HJ_HAM_DUBINS_REL) HJ_AB(double, HamDubinsRel)
+        else if (ham == HJ_HAM_DOUBLE_INTEGRATOR) HJ_AB(double, HamDoubleIntegrator)
+        else HJ_AB(double, HamDoublePendulum)
+    } else {
+        if (ham == HJ_HAM_DUBINS_REL) HJ_AB(float, HamDubinsRel)
+        else if (ham == HJ_HAM_DOUBLE_INTEGRATOR) HJ_AB(float, HamDoubleIntegrator)
+        else HJ_AB(float, HamDoublePendulum)
+    }
+#undef HJ_AB
+    HIP_TRY(hipGetLastError());
+    unsigned long long k[HJ_MAX_DIM];
+    HIP_TRY(hipMemcpyAsync(k, c->keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double inv = 0.0;
+    for (int d = 0; d < c->ndim; ++d) {
+        c->sb_alpha[d] = key_to_double(k[d]);
+        inv += c->sb_alpha[d] / c->dx[d];
+    }
+    c->sb_val = 1.0 / inv;
+    c->sb_ham = ham;
+    memset(c->sb_par, 0, sizeof(c->sb_par));
+    memcpy(c->sb_par, par, sizeof(double) * np);
+    c->sb_valid = true;
+    *sb = c->sb_val;
+    return HJ_OK;
+}
+
+int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf,
+               double factor_cfl, double max_step, int restrict_sign, const void* y_in, void* y_out,
+               void* work0, void* work1, double* t_out, double* dt_out) {
+    if (!c || !y_in || !y_out) return fail(HJ_EINVAL, "null argument");
+    if (order < 1 || order > 3) return fail(HJ_EINVAL, "order must be 1, 2 or 3");
+    if (order >= 2 && !work0) return fail(HJ_EINVAL, "work0 required for order >= 2");
+    if (order == 3 && !work1) return fail(HJ_EINVAL, "work1 required for order 3");
+    if (y_out == y_in) return fail(HJ_EINVAL, "y_out must not alias y_in");
+    double sb;
+    int rc = hj_static_step_bound(c, ham, par, &sb);
+    if (rc) return rc;
+    // deltaT = min(factorCFL*stepBound, tspan[1]-t, maxStep)  (ode_cfl_3.py:142)
+    const double dt = std::min(std::min(factor_cfl * sb, tf - t0), max_step);
+    const int64_t n0 = c->N[0];
+    auto slot = [&]() { int s = c->internal_slot; c->internal_slot = (s + 1) % (HJ_BOUND_SLOTS - 1); return s; };
+    double t = t0;
+    if (order == 1) {
+        SubstepCall s{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, y_out, nullptr, 0, n0};
+        if ((rc = do_substep(c, s, slot()))) return rc;
+        t = t0 + dt;
+    } else if (order == 2) {
+        SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, work0, nullptr, 0, n0};
+        if ((rc = do_substep(c, a, slot()))) return rc;
+        SubstepCall b{scheme, ham, HJ_STAGE_RK2_FULL, restrict_sign, par, dt, work0, y_in, y_out, nullptr, 0, n0};
+        if ((rc = do_substep(c, b, slot()))) return rc;
+        const double t1 = t0 + dt, t2 = t1 + dt;
+        t = 0.5 * (t0 + t2);  // ode_cfl_2.py:200
+    } else {
+        SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, work0, nullptr, 0, n0};
+        if ((rc = do_substep(c, a, slot()))) return rc;
+        SubstepCall b{scheme, ham, HJ_STAGE_RK3_HALF, restrict_sign, par, dt, work0, y_in, work1, nullptr, 0, n0};
+        if ((rc = do_substep(c, b, slot()))) return rc;
+        SubstepCall d{scheme, ham, HJ_STAGE_RK3_FULL, restrict_sign, par, dt, work1, y_in, y_out, nullptr, 0, n0};
+        if ((rc = do_substep(c, d, slot()))) return rc;
+        const double t1 = t0 + dt, t2 = t1 + dt;
+        const double tHalf = 0.25 * (3 * t0 + t2);       // ode_cfl_3.py:188
+        const double tThreeHalf = tHalf + dt;            // :221
+        t = (1.0 / 3.0) * (t0 + 2 * tThreeHalf);         // :236
+    }
+    if (t_out) *t_out = t;
+    if (dt_out) *dt_out = dt;
+    return HJ_OK;
+}
+
+int hj_max_d1sq(hj_ctx* c, const void* y, void* out_dev) {
+    if (!c || !y || !out_dev) return fail(HJ_EINVAL, "null argument");
+    int rc = weno_eps_pass(c, y);
+    if (rc) return rc;
+    return keys_to_vals(c, out_dev);
+}
+
+int hj_ctx_set_weno_eps_source(hj_ctx* c, const void* src) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    c->weno_src = src;
+    return HJ_OK;
+}
+
+int hj_minmax_with(hj_ctx* c, int op, void* y, const void* other, int64_t n) {
+    if (!c || !y || !other) return fail(HJ_EINVAL, "null argument");
+    if (op < HJ_OP_MIN || op > HJ_OP_MAX_NEG) return fail(HJ_EINVAL, "unknown op %d", op);
+    if (n <= 0) return HJ_OK;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    if (c->dtype == HJ_F64)
+        hipLaunchKernelGGL((minmax_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, (double*)y, (const double*)other, (long long)n, op);
+    else
+        hipLaunchKernelGGL((minmax_kernel<float>), dim3(blocks), dim3(256), 0, c->stream, (float*)y, (const float*)other, (long long)n, op);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+int hj_any_nan(hj_ctx* c, const void* y, int64_t n, int* has) {
+    if (!c || !y || !has) return fail(HJ_EINVAL, "null argument");
+    HIP_TRY(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    if (n > 0) {
+        if (c->dtype == HJ_F64)
+            hipLaunchKernelGGL((any_nan_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, (const double*)y, (long long)n, c->flag);
+        else
+            hipLaunchKernelGGL((any_nan_kernel<float>), dim3(blocks), dim3(256), 0, c->stream, (const float*)y, (long long)n, c->flag);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(has, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_sync(hj_ctx* c) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// Device-side building blocks shared by the fused and split kernels (gfx950 only).
+//
+//  * ghost_value     -- addGhostExtrapolate's rule          (add_ghost_extrapolate.py:88-110)
+//  * upwind<SCHEME>  -- left/right first derivative from the 7 values phi[i-3..i+3]
+//                       ENO2 (upwind_first_eno2.py:78-148), ENO3 (ENO3aHelper.py:76-189 +
+//                       upwind_first_eno3a.py:105-141), WENO5 as shipped / intended
+//                       (upwind_first_weno5a.py:106-196)
+//  * Ham*            -- native hamFunc/partialFunc pairs (dubins_relative.py:83-111,
+//                       double_integrator.py:71-89, build-defined double pendulum)
+//
+// Arithmetic follows the reference's divided-difference tables (D1, D2, D3) in the same
+// operation order so that results agree to rounding (not bit-for-bit: the compiler may
+// contract a*b+c into FMAs here; ghost_value is the exception and is bit-exact).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/hj_mi355x.h"
+
+namespace hj {
+
+template <typename T> struct Lim;
+template <> struct Lim<double> { static constexpr double tiny = 1e-99; };
+template <> struct Lim<float>  { static constexpr float  tiny = 1e-30f; };
+
+template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+template <> __device__ __forceinline__ double t_abs<double>(double x) { return __builtin_fabs(x); }
+template <> __device__ __forceinline__ float  t_abs<float>(float x)   { return __builtin_fabsf(x); }
+template <typename T> __device__ __forceinline__ T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
+
+// ghost cell k cells outside the edge: edge + k*slope, slope = mult*|edge-inner|*sign(edge),
+// sign(0)=0.  `km` = k*mult (mult=+-1, exact).  Contraction is disabled so the value is
+// bit-identical to NumPy's (edge + k*(mult*abs(d)*sign(edge))).
+template <typename T>
+__device__ __forceinline__ T ghost_value(T edge, T inner, T km) {
+#pragma clang fp contract(off)
+    T d = edge - inner;
+    T sgn = (edge > T(0)) ? T(1) : ((edge < T(0)) ? T(-1) : T(0));
+    T slope = t_abs(d) * sgn;
+    T ks = km * slope;
+    return edge + ks;
+}
+
+// ------------------------------------------------------------------------------------------
+// v[0..6] = phi at i-3 .. i+3 along the differentiated axis.
+// local tables: D1[j] = (v[j+1]-v[j])/dx (j=0..5), D2[j] = (D1[j+1]-D1[j])/(2dx) (j=0..4),
+//               D3[j] = (D2[j+1]-D2[j])/(3dx) (j=0..3)
+template <typename T> struct DD {
+    T D1[6], D2[5], D3[4];
+};
+
+template <typename T>
+__device__ __forceinline__ void dd_tables(const T* v, T inv_dx, DD<T>& t) {
+    const T h2 = T(0.5) * inv_dx;
+    const T h3 = (T(1) / T(3)) * inv_dx;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t.D1[j] = inv_dx * (v[j + 1] - v[j]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t.D2[j] = h2 * (t.D1[j + 1] - t.D1[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.D3[j] = h3 * (t.D2[j + 1] - t.D2[j]);
+}
+
+// the three third-order candidates per side (ENO3aHelper.py:116-189)
+template <typename T>
+__device__ __forceinline__ void eno3_candidates(const DD<T>& t, T dx, T* dL, T* dR) {
+    const T dx2 = dx * dx;
+    const T l = t.D1[2] + dx * t.D2[1];
+    dL[0] = l + (T(2) * dx2) * t.D3[0];
+    dL[1] = l + (T(2) * dx2) * t.D3[1];
+    dL[2] = (t.D1[2] + dx * t.D2[2]) - dx2 * t.D3[2];
+    const T r = t.D1[3] - dx * t.D2[2];
+    dR[0] = r - dx2 * t.D3[1];
+    dR[1] = r - dx2 * t.D3[2];
+    dR[2] = (t.D1[3] - dx * t.D2[3]) + (T(2) * dx2) * t.D3[3];
+}
+
+template <typename T>
+__device__ __forceinline__ T weno_combine(T d0, T d1, T d2, T s0, T s1, T s2, T w0, T w1, T w2,
+                                          T eps) {
+    // weightWENO (upwind_first_weno5a.py:177-196): alpha_k = w_k/(s_k+eps)^2.
+    // Same quotient written with ONE division: multiply through by prod (s_k+eps)^2, each
+    // factor first scaled by 1/eps so the products stay O(1..1e30) (eps >= 1e-99 > 0).
+    const T ie = T(1) / eps;
+    T q0 = (s0 + eps) * ie, q1 = (s1 + eps) * ie, q2 = (s2 + eps) * ie;
+    q0 *= q0; q1 *= q1; q2 *= q2;
+    const T a0 = w0 * (q1 * q2), a1 = w1 * (q0 * q2), a2 = w2 * (q0 * q1);
+    return (a0 * d0 + a1 * d1 + a2 * d2) / (a0 + a1 + a2);
+}
+
+template <typename T>
+__device__ __forceinline__ void weno_smooth(T v1, T v2, T v3, T v4, T v5, T& s1, T& s2, T& s3) {
+    const T c = T(13) / T(12), q = T(0.25);
+    T a = v1 - T(2) * v2 + v3, b = v1 - T(4) * v2 + T(3) * v3;
+    s1 = c * a * a + q * b * b;
+    a = v2 - T(2) * v3 + v4; b = v2 - v4;
+    s2 = c * a * a + q * b * b;
+    a = v3 - T(2) * v4 + v5; b = T(3) * v3 - T(4) * v4 + v5;
+    s3 = c * a * a + q * b * b;
+}
+
+// eps: only used by HJ_WENO5 (= 1e-6*max(D1^2)+tiny for this dim)
+template <int SCHEME, typename T>
+__device__ __forceinline__ void upwind(const T* v, T dx, T inv_dx, T eps, T& L, T& R) {
+    DD<T> t;
+    dd_tables(v, inv_dx, t);
+    if constexpr (SCHEME == HJ_ENO2) {
+        // upwind_first_eno2.py:97-148 in local indices
+        const bool sl = t_abs(t.D2[1]) < t_abs(t.D2[2]);
+        const bool sr = t_abs(t.D2[2]) < t_abs(t.D2[3]);
+        L = t.D1[2] + dx * (sl ? t.D2[1] : t.D2[2]);
+        R = t.D1[3] - dx * (sr ? t.D2[2] : t.D2[3]);
+    } else {
+        T dL[3], dR[3];
+        eno3_candidates(t, dx, dL, dR);
+        if constexpr (SCHEME == HJ_ENO3) {
+            // upwind_first_eno3a.py:105-141: strict '<', ties go right
+            const bool sL0 = t_abs(t.D2[1]) < t_abs(t.D2[2]);
+            const bool sL1 = t_abs(t.D2[2]) < t_abs(t.D2[3]);
+            const bool sT0 = t_abs(t.D3[0]) < t_abs(t.D3[1]);
+            const bool sT1 = t_abs(t.D3[1]) < t_abs(t.D3[2]);
+            const bool sT2 = t_abs(t.D3[2]) < t_abs(t.D3[3]);
+            // left: LL = sT0&sL0, M = (sT1&!sL0)|(!sT0&sL0), RR = !sT1&!sL0
+            L = sL0 ? (sT0 ? dL[0] : dL[1]) : (sT1 ? dL[1] : dL[2]);
+            R = sL1 ? (sT1 ? dR[0] : dR[1]) : (sT2 ? dR[1] : dR[2]);
+        } else if constexpr (SCHEME == HJ_WENO5_ASSHIPPED) {
+            // all smoothness estimates are (rounding-level) zero as shipped, so
+            // weightWENO returns the fixed-weight combination.
+            L = T(0.1) * dL[0] + T(0.6) * dL[1] + T(0.3) * dL[2];
+            R = T(0.3) * dR[0] + T(0.6) * dR[1] + T(0.1) * dR[2];
+        } else {
+            T s1, s2, s3;
+            weno_smooth(t.D1[0], t.D1[1], t.D1[2], t.D1[3], t.D1[4], s1, s2, s3);
+            L = weno_combine(dL[0], dL[1], dL[2], s1, s2, s3, T(0.1), T(0.6), T(0.3), eps);
+            weno_smooth(t.D1[5], t.D1[4], t.D1[3], t.D1[2], t.D1[1], s1, s2, s3);
+            // dR[0]=psi3, dR[1]=psi2, dR[2]=psi1 (upwind_first_weno5a.py:136-147)
+            R = weno_combine(dR[0], dR[1], dR[2], s3, s2, s1, T(0.3), T(0.6), T(0.1), eps);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Native Hamiltonians.  eval(): idx[d] = node index per dim, p[d] = centred costate
+// 0.5*(derivL+derivR) (term_lax_friedrich.py:108); returns H and alpha[d] = partialFunc(.., d).
+template <typename T> struct HamTables {
+    const T* coord[HJ_MAX_DIM];  // grid.vs[d]
+    const T* aux[4];             // Hamiltonian-specific 1-D tables
+    T par[4];
+};
+
+template <typename T> struct HamDubinsRel {
+    static constexpr int ND = 3;
+    static constexpr int ID = HJ_HAM_DUBINS_REL;
+    // H = p1(v_e - v_p cos x3) - p2 v_p sin x3 - w|p1 x2 - p2 x1 - p3| + w|p3|   (:83-88)
+    // alpha = { |v_e - v_p cos x3| + |w x2|, |v_p sin x3| + |w x1|, w_e + w_p }      (:106-111)
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const int* idx, const T* p,
+                                                T& H, T* alpha) {
+        const T ve = P.par[0], vp = P.par[1], w = P.par[2], wsum = P.par[3];
+        const T x0 = P.coord[0][idx[0]], x1 = P.coord[1][idx[1]];
+        const T c = P.aux[0][idx[2]], s = P.aux[1][idx[2]];
+        const T a = ve - vp * c;
+        const T b = vp * s;
+        H = p[0] * a - p[1] * b - w * t_abs(p[0] * x1 - p[1] * x0 - p[2]) + w * t_abs(p[2]);
+        alpha[0] = t_abs(a) + t_abs(w * x1);
+        alpha[1] = t_abs(b) + t_abs(w * x0);
+        alpha[2] = wsum;
+    }
+};
+
+template <typename T> struct HamDoubleIntegrator {
+    static constexpr int ND = 2;
+    static constexpr int ID = HJ_HAM_DOUBLE_INTEGRATOR;
+    // H = -(p1 x2 - |p2| u)  (:71-74); alpha = { |x2|, |u| }  (:84-89)
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const int* idx, const T* p,
+                                                T& H, T* alpha) {
+        const T u = P.par[0];
+        const T x1 = P.coord[1][idx[1]];
+        H = -(p[0] * x1 - t_abs(p[1]) * u);
+        alpha[0] = t_abs(x1);
+        alpha[1] = t_abs(u);
+    }
+};
+
+template <typename T> struct HamDoublePendulum {
+    static constexpr int ND = 4;
+    static constexpr int ID = HJ_HAM_DOUBLE_PENDULUM;
+    // state (th1, w1, th2, w2); drift f of the frictionless double pendulum with unit masses and
+    // lengths, g = 9.8 (dynamics as in the reference's Tests/double_pendulum.py:29-51);
+    // H = sum p_i f_i + u(|p2|+|p4|), alpha_i = |f_i| + u*[i in {1,3}].  aux = sin/cos tables.
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const int* idx, const T* p,
+                                                T& H, T* alpha) {
+        const T G = T(9.8), L1 = T(1), L2 = T(1), M1 = T(1), M2 = T(1);
+        const T u = P.par[0];
+        const T w1 = P.coord[1][idx[1]], w2 = P.coord[3][idx[3]];
+        const T s1 = P.aux[0][idx[0]], c1 = P.aux[1][idx[0]];
+        const T s2 = P.aux[2][idx[2]], c2 = P.aux[3][idx[2]];
+        const T sd = s2 * c1 - c2 * s1;  // sin(th2-th1)
+        const T cd = c2 * c1 + s2 * s1;  // cos(th2-th1)
+        const T den1 = (M1 + M2) * L1 - M2 * L1 * cd * cd;
+        const T f1 = (M2 * L1 * w1 * w1 * sd * cd + M2 * G * s2 * cd + M2 * L2 * w2 * w2 * sd
+                      - (M1 + M2) * G * s1) / den1;
+        const T den2 = (L2 / L1) * den1;
+        const T f3 = (-M2 * L2 * w2 * w2 * sd * cd + (M1 + M2) * G * s1 * cd
+                      - (M1 + M2) * L1 * w1 * w1 * sd - (M1 + M2) * G * s2) / den2;
+        H = p[0] * w1 + p[1] * f1 + p[2] * w2 + p[3] * f3 + u * (t_abs(p[1]) + t_abs(p[3]));
+        alpha[0] = t_abs(w1);
+        alpha[1] = t_abs(f1) + u;
+        alpha[2] = t_abs(w2);
+        alpha[3] = t_abs(f3) + u;
+    }
+};
+
+// order-preserving map double -> uint64 so atomicMax on the key is max on the value
+__device__ __forceinline__ unsigned long long max_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace hj

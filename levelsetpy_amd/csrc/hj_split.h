@@ -1,0 +1,310 @@
+// Split-path and helper kernels (gfx950): the pieces of the path that the reference exposes as
+// separate callables (ghost padding, one-dimension upwind derivatives with their global
+// min/max), the 'maxOverGrid' WENO epsilon reduction, the HJIPDE_solve post-step operators,
+// and a direct (untiled) form of the fused substep used for shapes the tiled kernel does not
+// map (4-D grids) and as an independent cross-check of it.
+#pragma once
+#include "hj_device.h"
+
+namespace hj {
+
+template <typename T> struct DimView {
+    long long outer, inner;  // product of sizes before / after `dim`
+    int n;                   // size along dim
+    int bc;
+    int halo_lo, halo_hi;    // only meaningful for dim 0
+    T km, dx, inv_dx;
+};
+
+// value of phi at position j (may be outside [0,n)) on the line through `line` (element 0 of the
+// line), element stride `s`
+template <typename T>
+__device__ __forceinline__ T line_value(const T* line, long long s, int j, int n, int bc, T km,
+                                        int halo_lo, int halo_hi) {
+    if (j >= 0 && j < n) return line[j * s];
+    if (j < 0) {
+        if (halo_lo) return line[j * s];
+        if (bc == HJ_BC_PERIODIC) return line[(j + n) * s];
+        return ghost_value(line[0], line[s], T(-j) * km);
+    }
+    if (halo_hi) return line[j * s];
+    if (bc == HJ_BC_PERIODIC) return line[(j - n) * s];
+    return ghost_value(line[(n - 1) * s], line[(n - 2) * s], T(j - n + 1) * km);
+}
+
+// ---- dataOut = grid.bdry[dim](dataIn, dim, width, ghostData): one thread per output element
+template <typename T>
+__global__ void ghost_kernel(const T* __restrict__ in, T* __restrict__ out, DimView<T> V, int width) {
+    const long long no = (long long)V.n + 2 * width;
+    const long long total = V.outer * no * V.inner;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long in_i = t % V.inner;
+        const long long r = t / V.inner;
+        const int j = (int)(r % no) - width;
+        const long long o = r / no;
+        const T* line = in + o * V.n * V.inner + in_i;
+        out[t] = line_value(line, V.inner, j, V.n, V.bc, V.km, 0, 0);
+    }
+}
+
+// ---- derivL, derivR = upwindFirst*(grid, data, dim) + {min L, max L, min R, max R}
+// keys[0..3]: atomicMax keys of {-min L, max L, -min R, max R}
+template <typename T, int SCHEME>
+__global__ __launch_bounds__(256) void upwind_kernel(const T* __restrict__ phi, T* __restrict__ dL,
+                                                     T* __restrict__ dR, DimView<T> V, T eps,
+                                                     unsigned long long* keys) {
+    const long long total = V.outer * V.n * V.inner;
+    double m[4] = {-1e300, -1e300, -1e300, -1e300};
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long in_i = t % V.inner;
+        const long long r = t / V.inner;
+        const int i = (int)(r % V.n);
+        const long long o = r / V.n;
+        const T* line = phi + o * V.n * V.inner + in_i;
+        T v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            v[k] = line_value(line, V.inner, i + k - 3, V.n, V.bc, V.km, V.halo_lo, V.halo_hi);
+        T L, R;
+        upwind<SCHEME, T>(v, V.dx, V.inv_dx, eps, L, R);
+        dL[t] = L;
+        dR[t] = R;
+        m[0] = fmax(m[0], -(double)L); m[1] = fmax(m[1], (double)L);
+        m[2] = fmax(m[2], -(double)R); m[3] = fmax(m[3], (double)R);
+    }
+    if (keys) {
+        __shared__ double red[4][4];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double w = wave_max(m[k]);
+            if (lane == 0) red[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int k = threadIdx.x;
+            const double w = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
+            if (w > -1e299) atomicMax(keys + k, max_key(w));
+        }
+    }
+}
+
+// ---- grid description shared by the whole-grid helper kernels
+template <typename T, int ND> struct GridArgs {
+    int n[ND];
+    int bc[ND];
+    int halo_lo, halo_hi;
+    T km[ND], dx[ND], inv_dx[ND];
+    long long stride[ND];
+    long long total;
+};
+
+template <typename T, int ND>
+__device__ __forceinline__ void decode(const GridArgs<T, ND>& G, long long t, int* idx) {
+#pragma unroll
+    for (int d = ND - 1; d >= 0; --d) {
+        const long long q = t / G.n[d];
+        idx[d] = (int)(t - q * G.n[d]);
+        t = q;
+    }
+}
+
+// ---- max over the unstripped D1 table of D1^2 per dim (upwind_first_weno5a.py:153-156).
+// Ghost-to-ghost differences repeat the first interior one (extrapolation) or interior ones
+// (periodic), so the max runs over forward differences of interior cells, the periodic wrap
+// pair, and -- on a slab face -- the pair reaching into the lower halo plane.
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, GridArgs<T, ND> G,
+                                                       unsigned long long* keys) {
+    double m[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) m[d] = -1e300;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < G.total;
+         t += (long long)gridDim.x * blockDim.x) {
+        int idx[ND];
+        decode<T, ND>(G, t, idx);
+        const T c = y[t];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            T nb;
+            bool have = true;
+            if (idx[d] + 1 < G.n[d]) nb = y[t + G.stride[d]];
+            else if (d == 0 && G.halo_hi) nb = y[t + G.stride[d]];
+            else if (G.bc[d] == HJ_BC_PERIODIC) nb = y[t - (long long)(G.n[d] - 1) * G.stride[d]];
+            else { nb = c; have = false; }
+            if (have) { const T D1 = G.inv_dx[d] * (nb - c); m[d] = fmax(m[d], (double)(D1 * D1)); }
+            if (d == 0 && G.halo_lo && idx[0] == 0) {
+                const T D1 = G.inv_dx[0] * (c - y[t - G.stride[0]]);
+                m[0] = fmax(m[0], (double)(D1 * D1));
+            }
+        }
+    }
+    __shared__ double red[4][ND];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < ND) {
+        const int d = threadIdx.x;
+        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
+        atomicMax(keys + d, max_key(fmax(w, 0.0)));
+    }
+}
+
+// keys -> values of dtype T (single thread)
+template <typename T>
+__global__ void keys_to_values_kernel(const unsigned long long* keys, T* out, int n) {
+    if (threadIdx.x < n) {
+        unsigned long long k = keys[threadIdx.x];
+        unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+        out[threadIdx.x] = (T)__longlong_as_double((long long)b);
+    }
+}
+
+// ---- max alpha per dim with p = 0: stepBound of a Hamiltonian whose alpha ignores the data
+template <typename T, typename HAM>
+__global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G, HamTables<T> P,
+                                                          unsigned long long* keys) {
+    constexpr int ND = HAM::ND;
+    double m[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) m[d] = -1e300;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < G.total;
+         t += (long long)gridDim.x * blockDim.x) {
+        int idx[ND];
+        decode<T, ND>(G, t, idx);
+        T p[ND], H, a[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) p[d] = T(0);
+        HAM::eval(P, idx, p, H, a);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) m[d] = fmax(m[d], (double)a[d]);
+    }
+    __shared__ double red[4][ND];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < ND) {
+        const int d = threadIdx.x;
+        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
+        if (w > -1e299) atomicMax(keys + d, max_key(w));
+    }
+}
+
+// ---- direct (untiled) fused substep: one thread per cell, stencil neighbours straight from
+// global memory (L1/L2 absorb the reuse).  Same arithmetic as fused_substep_kernel.
+template <typename T, int ND> struct DirectArgs {
+    const T* y;
+    const T* y0;
+    T* out;
+    const T* max_d1sq;
+    unsigned long long* bound;
+    GridArgs<T, ND> G;
+    long long cell_begin, cell_end;   // linear cell range (whole axis-0 planes)
+    int stage, restrict_sign;
+    T dt;
+    HamTables<T> ham;
+};
+
+template <typename T, typename HAM, int SCHEME>
+__global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T, HAM::ND> A) {
+    constexpr int ND = HAM::ND;
+    double amax[ND];
+    T eps[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        amax[d] = -1e300;
+        eps[d] = T(0);
+        if constexpr (SCHEME == HJ_WENO5) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+    }
+    for (long long t = A.cell_begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+         t < A.cell_end; t += (long long)gridDim.x * blockDim.x) {
+        int idx[ND];
+        decode<T, ND>(A.G, t, idx);
+        T dL[ND], dR[ND], pc[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const T* line = A.y + (t - (long long)idx[d] * A.G.stride[d]);
+            T v[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                v[k] = line_value(line, A.G.stride[d], idx[d] + k - 3, A.G.n[d], A.G.bc[d],
+                                  A.G.km[d], d == 0 ? A.G.halo_lo : 0, d == 0 ? A.G.halo_hi : 0);
+            upwind<SCHEME, T>(v, A.G.dx[d], A.G.inv_dx[d], eps[d], dL[d], dR[d]);
+            pc[d] = T(0.5) * (dL[d] + dR[d]);
+        }
+        T H, alpha[ND];
+        HAM::eval(A.ham, idx, pc, H, alpha);
+        T diss = T(0);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            diss += (T(0.5) * (dR[d] - dL[d])) * alpha[d];
+            amax[d] = fmax(amax[d], (double)alpha[d]);
+        }
+        T ydot = -(H - diss);
+        if (A.restrict_sign > 0) ydot = t_max(ydot, T(0));
+        else if (A.restrict_sign < 0) ydot = t_min(ydot, T(0));
+        T o;
+        if (A.stage == HJ_STAGE_YDOT) o = ydot;
+        else {
+            const T ye = A.y[t] + A.dt * ydot;
+            if (A.stage == HJ_STAGE_EULER) o = ye;
+            else if (A.stage == HJ_STAGE_RK3_HALF) o = T(0.25) * (T(3) * A.y0[t] + ye);
+            else if (A.stage == HJ_STAGE_RK3_FULL) o = (T(1) / T(3)) * (A.y0[t] + T(2) * ye);
+            else o = T(0.5) * (A.y0[t] + ye);
+        }
+        A.out[t] = o;
+    }
+    __shared__ double red[4][ND];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double w = wave_max(amax[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < ND) {
+        const int d = threadIdx.x;
+        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
+        if (w > -1e299) atomicMax(A.bound + d, max_key(w));
+    }
+}
+
+// ---- HJIPDE_solve post-step operators and NaN guard
+template <typename T>
+__global__ void minmax_kernel(T* __restrict__ y, const T* __restrict__ o, long long n, int op) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const T a = y[t], b = o[t];
+        // NumPy minimum/maximum propagate NaN (hji_solver.py:573-580)
+        T r;
+        if (a != a) r = a;
+        else if (b != b) r = b;
+        else if (op == HJ_OP_MIN) r = a < b ? a : b;
+        else if (op == HJ_OP_MAX) r = a > b ? a : b;
+        else r = a > -b ? a : -b;
+        y[t] = r;
+    }
+}
+
+template <typename T>
+__global__ void any_nan_kernel(const T* __restrict__ y, long long n, int* flag) {
+    bool bad = false;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const T a = y[t];
+        bad = bad || (a != a);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace hj

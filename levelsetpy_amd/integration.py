@@ -1,0 +1,297 @@
+"""CFL-constrained TVD Runge-Kutta integrators odeCFL1/2/3 and their option helpers (reference
+ExplicitIntegration/Integration/ode_cfl_{1,2,3,set,get,mult,call}.py):
+    t, y, schemeData = odeCFLn(schemeFunc, tspan, y0, options, schemeData)
+
+Device path: when schemeFunc is this package's termLaxFriedrichs (or termRestrictUpdate around
+it) with a native Hamiltonian, every time step is `order` fused HIP launches (hj_rk_step); y
+stays in HBM for the whole tspan and no host synchronisation happens inside a step.
+Generic path: any other schemeFunc is integrated with the reference's own sequence of array
+expressions (the arrays may be NumPy or device tensors), so user terms keep working.
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .context import device_grid, array_dtype_name, is_tensor
+from .term import termLaxFriedrichs, termRestrictUpdate, native_plan
+from .utilities import (Bundle, isbundle, isfield, iscell, strcmp, warn, info, cputime, eps,
+                        realmax, error)
+
+__all__ = ["odeCFL1", "odeCFL2", "odeCFL3", "odeCFLset", "odeCFLget", "odeCFLmultipleSteps",
+           "odeCFLcallPostTimestep"]
+
+
+def odeCFLset(*args, **kw):
+    """ode_cfl_set.py:5.  Takes a Bundle (as the reference) or keyword arguments.  factorCFL
+    default 0.5; maxStep is read from key 'maxStep' and, as the reference does, from 'realmax'
+    (ode_cfl_set.py:96); postTimeStep / postTimestep both accepted."""
+    if args and args[0] is not None:
+        kwargs = args[0]
+        assert isbundle(kwargs), "kwargs must be a bundle type."
+        d = dict(kwargs.__dict__)
+    else:
+        d = {}
+    d.update(kw)
+    if not d:
+        raise ValueError('kwargs cannot be None')      # ode_cfl_set.py:91
+    options = Bundle({})
+    options.factorCFL = d.get('factorCFL', 0.5)
+    options.maxStep = d.get('maxStep', d.get('realmax', realmax))
+    post = d.get('postTimeStep', d.get('postTimestep', None))
+    options.postTimeStep = post
+    options.postTimestep = post
+    options.singleStep = d.get('singleStep', 'off')
+    options.stats = d.get('stats', 'off')
+    options.terminalEvent = d.get('terminalEvent', None)
+    if options.factorCFL < 0.0:
+        raise ValueError('FactorCFL must be a positive scalar double value')
+    if options.maxStep < 0.0:
+        raise ValueError('MaxStep must be a positive scalar double value')
+    if post is not None:
+        items = post if isinstance(post, list) else [post]
+        for f in items:
+            if not callable(f):
+                raise ValueError('Each element in a postTimeStep cell vector must be a function handle.')
+    if options.singleStep not in ('on', 'off'):
+        raise ValueError("SingleStep must be one of the strings 'on' or 'off'")
+    if options.stats not in ('on', 'off'):
+        raise ValueError("Stats must be one of the strings 'on' or 'off'")
+    if options.terminalEvent is not None and not callable(options.terminalEvent):
+        raise ValueError('terminalEvent parameter must be a function handle.')
+    return options
+
+
+def odeCFLget(options, name, default=None):
+    """ode_cfl_get.py: value of one option field (case-insensitive prefix match)."""
+    if options is None:
+        return default
+    names = ['factorCFL', 'maxStep', 'postTimeStep', 'singleStep', 'stats', 'terminalEvent']
+    match = [n for n in names if n.lower().startswith(str(name).lower())]
+    if len(match) != 1:
+        error('Unrecognized or ambiguous property name %s' % name)
+    val = getattr(options, match[0], None)
+    return default if val is None else val
+
+
+def odeCFLcallPostTimestep(t, yIn, schemeDataIn, options):
+    """ode_cfl_call.py:6: run options.postTimeStep (callable or list) on (t, y, schemeData)."""
+    yOut, schemeDataOut = copy.copy(yIn), copy.copy(schemeDataIn)
+    if not options:
+        return yOut, schemeDataOut
+    post = getattr(options, 'postTimeStep', None) or getattr(options, 'postTimestep', None)
+    if not post:
+        return yOut, schemeDataOut
+    for f in (post if isinstance(post, list) else [post]):
+        yOut, schemeDataOut = f(t, yOut, schemeDataOut)
+    return yOut, schemeDataOut
+
+
+def odeCFLmultipleSteps(intFunc, schemeFunc, tspan, y0, options, schemeData):
+    """ode_cfl_mult.py:7: solution at every entry of tspan, one row of y per time."""
+    tspan = np.asarray(tspan, dtype=np.float64)
+    numT = len(tspan)
+    if numT <= 2:
+        error('tspan must contain at least three entries')
+    t = tspan.reshape(numT, 1).copy()
+    flat0 = (y0.detach().cpu().numpy() if is_tensor(y0) else np.asarray(y0)).reshape(-1)
+    y = np.zeros((numT, flat0.size), dtype=np.float64)
+    y[0, :] = flat0
+    yout = y0
+    for n in range(1, numT):
+        tn, yout, schemeData = intFunc(schemeFunc, [t[n - 1, 0], t[n, 0]], yout, options, schemeData)
+        t[n, 0] = tn
+        y[n, :] = (yout.detach().cpu().numpy() if is_tensor(yout) else np.asarray(yout)).reshape(-1)
+    return t, y, schemeData
+
+
+# ----------------------------------------------------------------------------------------------
+def _options(options):
+    if not options:
+        return odeCFLset(factorCFL=0.5)
+    o = options
+    for k, v in (('factorCFL', 0.5), ('maxStep', realmax), ('singleStep', 'off'), ('stats', 'off')):
+        if not isfield(o, k):
+            setattr(o, k, v)
+    return o
+
+
+def _post_hook(options):
+    return getattr(options, 'postTimeStep', None) or getattr(options, 'postTimestep', None)
+
+
+def _device_plan(schemeFunc, schemeData, y0):
+    """(plan, restrict_sign) if the integrator can run fused on the device."""
+    if iscell(y0) or iscell(schemeData):
+        return None
+    if schemeFunc is termLaxFriedrichs:
+        plan, rs = native_plan(schemeData), 0
+    elif schemeFunc is termRestrictUpdate and isfield(schemeData, 'innerFunc') \
+            and schemeData.innerFunc is termLaxFriedrichs and isfield(schemeData, 'innerData'):
+        plan = native_plan(schemeData.innerData)
+        positive = schemeData.positive if isfield(schemeData, 'positive') else True
+        rs = +1 if positive else -1
+    else:
+        return None
+    if plan is None:
+        return None
+    return plan, rs
+
+
+def _check_shape(schemeFunc, y0):
+    # termLaxFriedrichs returns an (N,1) column, termRestrictUpdate an (N,) vector; the reference
+    # silently broadcasts the mixed case to (N,N) -- reject it instead.
+    nd = y0.dim() if is_tensor(y0) else np.ndim(y0)
+    if schemeFunc is termLaxFriedrichs and nd != 2:
+        raise ValueError('termLaxFriedrichs needs y0 as an (N,1) column (got %d-D)' % nd)
+    if schemeFunc is termRestrictUpdate and nd != 1:
+        raise ValueError('termRestrictUpdate needs y0 as an (N,) vector (got %d-D)' % nd)
+
+
+def _integrate(order, schemeFunc, tspan, y0, options, schemeData):
+    small = 100 * eps                                    # ode_cfl_3.py:81
+    options = _options(options)
+    safetyFactorCFL = min(1.0, 1.2 * options.factorCFL)  # :95
+    numT = len(tspan)
+    if numT > 2:
+        intFunc = {1: odeCFL1, 2: odeCFL2, 3: odeCFL3}[order]
+        return odeCFLmultipleSteps(intFunc, schemeFunc, tspan, y0, options, schemeData)
+    if numT < 2:
+        raise ValueError('tspan must contain at least two entries')
+    if iscell(y0):
+        raise ValueError('vector level sets (list y0) are not supported (broken in the reference: '
+                         'ode_cfl_3.py:147-149)')
+    dev = _device_plan(schemeFunc, schemeData, y0)
+    if dev is not None:
+        _check_shape(schemeFunc, y0)
+        return _integrate_device(order, dev, tspan, y0, options, schemeData)
+    return _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small, safetyFactorCFL)
+
+
+def _integrate_device(order, dev, tspan, y0, options, schemeData):
+    (grid, sid, ham, par), rs = dev
+    small = 100 * eps
+    dg = device_grid(grid, array_dtype_name(y0))
+    if int(np.prod(y0.shape)) != dg.numel:
+        raise ValueError('y0 does not agree in size with grid')
+    dg.bind_stream()
+    shape0 = tuple(y0.shape)
+    cur = dg.to_device(y0).reshape(dg.shape)
+    if is_tensor(y0) and cur.data_ptr() == y0.data_ptr():
+        cur = cur.clone()                                 # inputs are never mutated
+    nxt, w0, w1 = dg.work('rk_out'), dg.work('rk_w0'), (dg.work('rk_w1') if order == 3 else None)
+    if nxt.data_ptr() == cur.data_ptr():
+        nxt = dg.work('rk_out2')
+    parv = _ffi.darr(par)
+    t = float(tspan[0])
+    tf = float(tspan[1])
+    steps = 0
+    startTime = cputime()
+    post = _post_hook(options)
+    tout, dtout = C.c_double(), C.c_double()
+    eventValueOld = None
+    while tf - t >= small * abs(tf):
+        tOld = t
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
+                                     float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0),
+                                     dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+        yOld = cur
+        cur, nxt = nxt, cur
+        t = float(tout.value)
+        steps += 1
+        if post:
+            yv = dg.like(cur.reshape(shape0), y0)
+            yv, schemeData = odeCFLcallPostTimestep(t, yv, schemeData, options)
+            cur = dg.to_device(yv).reshape(dg.shape)
+            if cur.data_ptr() in (nxt.data_ptr(),):
+                cur = cur.clone()
+        if strcmp(options.singleStep, 'on'):
+            break
+        if getattr(options, 'terminalEvent', None):
+            # the old state lives in `nxt` until the next step overwrites it
+            eventValue, schemeData = options.terminalEvent(
+                t, dg.like(cur.reshape(shape0), y0), tOld, dg.like(yOld.reshape(shape0), y0), schemeData)
+            if steps > 1 and np.any(np.sign(eventValue) != np.sign(eventValueOld)):
+                break
+            eventValueOld = eventValue
+    if strcmp(options.stats, 'on'):
+        dg.sync()
+        info('%d steps in %.2g seconds from  %.2f to %.2f.' % (steps, cputime() - startTime, tspan[0], t))
+    out = cur.reshape(shape0)
+    if is_tensor(y0):
+        out = out.clone()          # `cur` is ctx scratch that the next call reuses
+    return np.float64(t), dg.like(out, y0), schemeData
+
+
+def _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small, safetyFactorCFL):
+    t = tspan[0]
+    tf = tspan[1]
+    steps = 0
+    startTime = cputime()
+    y = copy.copy(y0)
+    post = _post_hook(options)
+    eventValueOld = None
+
+    def bound_check(deltaT, stepBound, which):
+        if deltaT > safetyFactorCFL * stepBound:          # ode_cfl_3.py:173-175,215-217
+            warn('%s substep violated CFL effective number %s' % (which, deltaT / stepBound))
+
+    while tf - t >= small * np.abs(tf):
+        ydot, stepBound, schemeData = schemeFunc(t, y, schemeData)
+        if tuple(ydot.shape) != tuple(y.shape):
+            raise ValueError('schemeFunc returned shape %s for a state of shape %s (use an (N,1) state '
+                             'with termLaxFriedrichs and an (N,) state with termRestrictUpdate)'
+                             % (tuple(ydot.shape), tuple(y.shape)))
+        deltaT = min(options.factorCFL * stepBound, tf - t, options.maxStep)    # :142
+        t1 = t + deltaT
+        y1 = y + deltaT * ydot
+        yOld, tOld = y, t
+        if order == 1:
+            y, t = y1, t1
+        else:
+            ydot, stepBound, schemeData = schemeFunc(t1, y1, schemeData)
+            bound_check(deltaT, stepBound, 'Second')
+            t2 = t1 + deltaT
+            y2 = y1 + deltaT * ydot
+            if order == 2:
+                t = 0.5 * (t + t2)                        # ode_cfl_2.py:200-201
+                y = 0.5 * (y + y2)
+            else:
+                tHalf = 0.25 * (3 * t + t2)               # ode_cfl_3.py:188-193
+                yHalf = 0.25 * (3 * y + y2)
+                ydot, stepBound, schemeData = schemeFunc(tHalf, yHalf, schemeData)
+                bound_check(deltaT, stepBound, 'Third')
+                tThreeHalf = tHalf + deltaT
+                yThreeHalf = yHalf + deltaT * ydot
+                t = (1 / 3) * (t + 2 * tThreeHalf)        # :236-241
+                y = (1 / 3) * (y + 2 * yThreeHalf)
+        steps += 1
+        if post:
+            y, schemeData = odeCFLcallPostTimestep(t, y, schemeData, options)
+        if strcmp(options.singleStep, 'on'):
+            break
+        if getattr(options, 'terminalEvent', None):
+            eventValue, schemeData = options.terminalEvent(t, y, tOld, yOld, schemeData)
+            if steps > 1 and np.any(np.sign(eventValue) != np.sign(eventValueOld)):
+                break
+            eventValueOld = eventValue
+    if strcmp(options.stats, 'on'):
+        info('%d steps in %.2g seconds from  %.2f to %.2f.' % (steps, cputime() - startTime, tspan[0], t))
+    return np.float64(t), y, schemeData
+
+
+def odeCFL1(schemeFunc, tspan, y0, options=None, schemeData=None):
+    """Forward Euler (ode_cfl_1.py:9; the shipped version never stores the new state, :142 --
+    this is the intended integrator)."""
+    return _integrate(1, schemeFunc, tspan, y0, options, schemeData)
+
+
+def odeCFL2(schemeFunc, tspan, y0, options=None, schemeData=None):
+    """TVD RK2 (ode_cfl_2.py:13)."""
+    return _integrate(2, schemeFunc, tspan, y0, options, schemeData)
+
+
+def odeCFL3(schemeFunc, tspan, y0, options=None, schemeData=None):
+    """TVD RK3 (ode_cfl_3.py:11)."""
+    return _integrate(3, schemeFunc, tspan, y0, options, schemeData)

@@ -1,0 +1,549 @@
+"""GPU parity tests: the HIP path (through the C ABI / the reference-named Python API) against
+the CPU oracle and against the golden vectors generated from the reference.
+
+Tolerances (fp64): ghost cells bit-exact; derivatives / ydot abs <= 1e-11*max(1,|ref|_inf)
+(the kernels contract a*b+c into FMAs and evaluate WENO quotients with one division, so they
+are not bit-identical to NumPy); stepBound / t relative 1e-13; states after 5 RK3 steps 1e-11.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import levelsetpy_amd as L  # noqa: E402
+from levelsetpy_amd import _ffi  # noqa: E402
+from levelsetpy_amd.context import DeviceGrid, device_grid  # noqa: E402
+from oracle import hj_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCHEMES = ["ENO2", "ENO3", "WENO5_ASSHIPPED", "WENO5"]
+DERIV = {"ENO2": L.upwindFirstENO2, "ENO3": L.upwindFirstENO3, "WENO5_ASSHIPPED": L.upwindFirstWENO5,
+         "WENO5": L.upwindFirstWENO5Intended}
+
+
+def close(a, ref, tol=1e-11, what=""):
+    a, ref = np.asarray(a), np.asarray(ref)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    err = float(np.max(np.abs(a - ref)))
+    assert err <= tol * scale, "%s err %.3e > %.1e*%.3g" % (what, err, tol, scale)
+
+
+def mk(gmin, gmax, N, pd):
+    """(product grid Bundle, oracle Grid) with identical parameters."""
+    N = [int(n) for n in N]
+    g = L.createGrid(np.asarray(gmin, dtype=np.float64).reshape(-1, 1), np.asarray(gmax, dtype=np.float64).reshape(-1, 1),
+                     np.asarray(N, dtype=np.int64).reshape(-1, 1), pd if pd is not None else None)
+    if isinstance(pd, (list, tuple)):
+        og = O.Grid(gmin, gmax, N, list(pd))
+    else:
+        og = O.Grid(gmin, gmax, N, [pd] if pd else [])
+    return g, og
+
+
+def dubins(n, pd=2):
+    n = np.atleast_1d(n)
+    if n.size == 1:
+        n = np.repeat(n, 3)
+    return mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+
+
+def sdata(g, sys_, fn):
+    return L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation,
+                         dissFunc=L.artificialDissipationGLF, CoStateCalc=fn))
+
+
+# ------------------------------------------------------------------------------ ghosts
+@pytest.mark.parametrize("dim", [0, 1, 2])
+@pytest.mark.parametrize("w", [1, 2, 3])
+def test_ghost_bit_exact_vs_reference(golden, dim, w):
+    G = golden("ghost.npz")
+    x = G["x"]
+    assert np.array_equal(L.addGhostPeriodic(x, dim, w, None), G["per_d%d_w%d" % (dim, w)])
+    assert np.array_equal(L.addGhostExtrapolate(x, dim, w, None), G["ext_d%d_w%d_tz0" % (dim, w)])
+    assert np.array_equal(L.addGhostExtrapolate(x, dim, w, L.Bundle(dict(towardZero=True))),
+                          G["ext_d%d_w%d_tz1" % (dim, w)])
+
+
+def test_ghost_dtype_shapes_errors(golden):
+    G = golden("ghost.npz")
+    out = L.addGhostExtrapolate(G["x"].astype(np.float32), 1, 2, None)
+    assert out.dtype == np.float64 and np.array_equal(out, G["ext_f32in_d1_w2"])
+    x = np.arange(12.0).reshape(3, 4)
+    assert L.addGhostPeriodic(x, 1, None).shape == (3, 6)          # width None -> 1
+    with pytest.raises(ValueError):
+        L.addGhostExtrapolate(x, 0, 4)
+    t = torch.as_tensor(x, device="cuda")
+    o = L.addGhostPeriodic(t, 0, 2)
+    assert torch.is_tensor(o) and o.is_cuda and np.array_equal(o.cpu().numpy(), O.add_ghost_periodic(x, 0, 2))
+    # 1-D and 5-D arrays pad too
+    v = np.linspace(-1, 1, 7)
+    assert np.array_equal(L.addGhostExtrapolate(v, 0, 3), O.add_ghost_extrapolate(v, 0, 3))
+    z = np.random.default_rng(0).standard_normal((2, 3, 4, 3, 2))
+    assert np.array_equal(L.addGhostPeriodic(z, 2, 2), O.add_ghost_periodic(z, 2, 2))
+
+
+def test_add_ghost_all_dims():
+    g, og = dubins([6, 7, 8])
+    x = np.random.default_rng(3).standard_normal(g.shape)
+    assert np.array_equal(L.addGhostAllDims(g, x, 2), O.add_ghost_all_dims(og, x, 2))
+
+
+# ------------------------------------------------------------------------------ derivatives
+CASES = [("g2", 2), ("g3", 3), ("g3s", 3), ("g4", 4)]
+
+
+def _grids_for(G, tag):
+    base = "g3" if tag == "g3s" else tag
+    data = G[tag + "_data"]
+    pd = [i for i, b in enumerate(G[tag + "_bc"]) if b]
+    g, og = mk(G[base + "_min"], G[base + "_max"], data.shape, pd if len(pd) != 1 else pd[0])
+    return g, og, data
+
+
+@pytest.mark.parametrize("tag,nd", CASES)
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_upwind_vs_reference_golden(golden, tag, nd, scheme):
+    G = golden("deriv.npz")
+    g, og, data = _grids_for(G, tag)
+    for dim in range(nd):
+        dL, dR = DERIV[scheme](g, data, dim)
+        close(dL, G["%s_%s_L_d%d" % (tag, scheme, dim)], what="L d%d" % dim)
+        close(dR, G["%s_%s_R_d%d" % (tag, scheme, dim)], what="R d%d" % dim)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape,pd", [((37, 29), None), ((23, 41), 1), ((19, 17, 23), 2),
+                                       ((9, 8, 7, 6), (0, 1, 2, 3)), ((6, 7, 8, 9), None)])
+def test_upwind_vs_oracle_random(scheme, shape, pd):
+    nd = len(shape)
+    g, og = mk([-1.0] * nd, [1.0 + 0.1 * i for i in range(nd)], shape, pd)
+    rng = np.random.default_rng(5)
+    data = np.cos(3 * og.xs[0]) + 0.2 * rng.standard_normal(shape)
+    for dim in range(nd):
+        dL, dR = DERIV[scheme](g, data, dim)
+        oL, oR = O.SCHEMES[scheme](og, data, dim)
+        close(dL, oL, what="%s L d%d" % (scheme, dim))
+        close(dR, oR, what="%s R d%d" % (scheme, dim))
+
+
+def test_upwind_minmax_and_generate_all():
+    g, og = dubins([11, 12, 13])
+    data = np.random.default_rng(1).standard_normal(g.shape)
+    dg = device_grid(g)
+    dg.bind_stream()
+    phi = dg.to_device(data)
+    a, b = dg.empty(), dg.empty()
+    mm = (C.c_double * 4)()
+    _ffi.check(dg.lib.hj_upwind(dg.ctx, _ffi.ENO3, 1, dg.ptr(phi), dg.ptr(a), dg.ptr(b), mm))
+    oL, oR = O.upwind_first_eno3(og, data, 1)
+    ref = [oL.min(), oL.max(), oR.min(), oR.max()]
+    for k in range(4):
+        assert abs(mm[k] - ref[k]) <= 1e-11 * max(1, abs(ref[k]))
+    cl, cr = L.upwindFirstENO3(g, data, 1, True)
+    ol, orr, _ = O.eno3_helper(og, data, 1)
+    for k in range(3):
+        close(cl[k], ol[k])
+        close(cr[k], orr[k])
+    with pytest.raises(ValueError):
+        L.upwindFirstENO3(g, data, 3)
+    with pytest.raises(ValueError):
+        L.upwindFirstENO3(g, data[:-1], 0)
+
+
+# ------------------------------------------------------------------------------ LF term
+@pytest.mark.parametrize("ub,wb", [(1, 1), (5, 5), (2, 3)])
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_term_dubins_vs_reference_golden(golden, ub, wb, scheme):
+    G = golden("term.npz")
+    g, og = mk(G["dub_min"], G["dub_max"], G["dub_N"], 2)
+    sys_ = L.DubinsVehicleRel(g, ub, wb)
+    y = G["dub_data"].reshape(-1, 1)
+    yd, sb, _ = L.termLaxFriedrichs(0.3, y, sdata(g, sys_, DERIV[scheme]))
+    assert yd.shape == y.shape and isinstance(sb, float)
+    close(yd, G["dub_u%d_w%d_%s_ydot" % (ub, wb, scheme)])
+    ref = float(G["dub_u%d_w%d_%s_sb" % (ub, wb, scheme)])
+    assert abs(sb - ref) <= 1e-13 * ref
+
+
+@pytest.mark.parametrize("ub", [1, 2.5])
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_term_double_integrator_vs_reference_golden(golden, ub, scheme):
+    G = golden("term.npz")
+    g, og = mk(G["di_min"], G["di_max"], G["di_N"], None)
+    sys_ = L.DoubleIntegrator(g, ub)
+    yd, sb, _ = L.termLaxFriedrichs(0., G["di_data"].reshape(-1, 1), sdata(g, sys_, DERIV[scheme]))
+    close(yd, G["di_u%s_%s_ydot" % (ub, scheme)])
+    ref = float(G["di_u%s_%s_sb" % (ub, scheme)])
+    assert abs(sb - ref) <= 1e-13 * ref
+
+
+def _term_both_kernels(g, sys_, scheme, y, monkeypatch):
+    """ydot from the tiled kernel and from the direct kernel (fresh ctx each)."""
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+        g.__dict__.pop("_hj_device", None)
+        outs.append(L.termLaxFriedrichs(0., y, sdata(g, sys_, DERIV[scheme])))
+    g.__dict__.pop("_hj_device", None)
+    return outs
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n", [(33, 21, 19), (12, 70, 16), (40, 9, 130)])
+def test_term_tiled_and_direct_vs_oracle_3d(scheme, n, monkeypatch):
+    g, og = dubins(n)
+    rng = np.random.default_rng(7)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * rng.standard_normal(g.shape)
+    y = data.reshape(-1, 1)
+    (yt, sbt, _), (yd, sbd, _) = _term_both_kernels(g, L.DubinsVehicleRel(g, 2, 3), scheme, y, monkeypatch)
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 2, 3), scheme, 0., y)
+    close(yt, yo, what="tiled")
+    close(yd, yo, what="direct")
+    assert abs(sbt - sbo) <= 1e-13 * sbo and abs(sbd - sbo) <= 1e-13 * sbo
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((50, 45), None), ((20, 3000), 1), ((300, 12), 0)])
+def test_term_tiled_and_direct_vs_oracle_2d(scheme, n, pd, monkeypatch):
+    if pd == 0:
+        pd = (0,)
+    g, og = mk([-1, -1], [1, 1], n, pd)
+    rng = np.random.default_rng(8)
+    data = O.shape_sphere(og, None, .25) + 0.02 * rng.standard_normal(g.shape)
+    y = data.reshape(-1, 1)
+    (yt, sbt, _), (yd, sbd, _) = _term_both_kernels(g, L.DoubleIntegrator(g, 1.5), scheme, y, monkeypatch)
+    yo, sbo = O.term_lax_friedrichs(og, O.DoubleIntegrator(og, 1.5), scheme, 0., y)
+    close(yt, yo, what="tiled")
+    close(yd, yo, what="direct")
+    assert abs(sbt - sbo) <= 1e-13 * sbo and abs(sbd - sbo) <= 1e-13 * sbo
+
+
+@pytest.mark.parametrize("scheme", ["ENO3", "WENO5"])
+def test_term_4d_pendulum_vs_oracle(scheme):
+    n = (9, 8, 10, 7)
+    gmin = [-np.pi, -8, -np.pi, -8]
+    gmax = [np.pi * (1 - 2 / n[0]), 8 * (1 - 2 / n[1]), np.pi * (1 - 2 / n[2]), 8 * (1 - 2 / n[3])]
+    g, og = mk(gmin, gmax, n, (0, 1, 2, 3))
+    data = O.shape_sphere(og, None, .5) + 0.01 * np.random.default_rng(2).standard_normal(n)
+    y = data.reshape(-1, 1)
+    yd, sb, _ = L.termLaxFriedrichs(0., y, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), scheme, 0., y)
+    close(yd, yo, 1e-10)
+    assert abs(sb - sbo) <= 1e-12 * sbo
+
+
+def test_term_split_path_with_foreign_callbacks_matches_fused():
+    """A user hamFunc/partialFunc (plain functions -> split path) gives the fused result."""
+    g, og = dubins([14, 13, 12])
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    y = (O.shape_cylinder(og, 2, None, .5)).reshape(-1, 1)
+    fused, sbf, _ = L.termLaxFriedrichs(0., y, sdata(g, sys_, L.upwindFirstENO3))
+
+    def ham(t, data, derivs, sd):
+        return sys_.hamiltonian(t, data, derivs, sd)
+
+    def part(t, data, dmin, dmax, sd, dim):
+        return sys_.dissipation(t, data, dmin, dmax, sd, dim)
+    sd = L.Bundle(dict(grid=g, hamFunc=ham, partialFunc=part, dissFunc=L.artificialDissipationGLF,
+                       derivFunc=L.upwindFirstENO3))        # derivFunc spelling
+    split, sbs, _ = L.termLaxFriedrichs(0., y, sd)
+    close(split, fused, 1e-12)
+    assert abs(sbs - sbf) <= 1e-14
+    # device tensors in -> device tensors out, same numbers
+    yt = torch.as_tensor(y, device="cuda")
+    ft, sbt, _ = L.termLaxFriedrichs(0., yt, sdata(g, sys_, L.upwindFirstENO3))
+    assert torch.is_tensor(ft) and ft.is_cuda and ft.shape == yt.shape
+    assert np.array_equal(ft.cpu().numpy(), fused)
+    st, _, _ = L.termLaxFriedrichs(0., yt, sd)
+    close(st.cpu().numpy(), fused, 1e-12)
+
+
+def test_term_restrict_update_and_missing_fields():
+    g, og = dubins([12, 11, 10])
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    y = O.shape_cylinder(og, 2, None, .5).flatten()
+    inner = sdata(g, sys_, L.upwindFirstENO2)
+    sdr = L.Bundle(dict(innerFunc=L.termLaxFriedrichs, innerData=inner, positive=0))
+    yd, sb, _ = L.termRestrictUpdate(0., y, sdr)
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), "ENO2", 0., y)
+    assert yd.shape == (y.size,)
+    close(yd, np.minimum(yo, 0))
+    sdr.positive = 1
+    yd, _, _ = L.termRestrictUpdate(0., y, sdr)
+    close(yd, np.maximum(yo, 0))
+    bad = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, CoStateCalc=L.upwindFirstENO2))
+    with pytest.raises(AssertionError):
+        L.termLaxFriedrichs(0., y.reshape(-1, 1), bad)
+
+
+# ------------------------------------------------------------------------------ integrators
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_ode_cfl_vs_reference_golden(golden, scheme):
+    G = golden("ode.npz")
+    g, og = mk(G["dub_min"], G["dub_max"], G["dub_N"], 2)
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    sd = sdata(g, sys_, DERIV[scheme])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y = G["dub_data"].reshape(-1, 1)
+    t = 0.
+    for k in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+        if k in (0, 4):
+            ref_t = float(G["rk3_%s_t%d" % (scheme, k + 1)])
+            assert isinstance(t, np.float64) and abs(t - ref_t) <= 1e-13 * ref_t
+            close(y, G["rk3_%s_y%d" % (scheme, k + 1)], 1e-11)
+    op2 = L.odeCFLset(L.Bundle(dict(factorCFL=.95, singleStep='off')))
+    t, y, _ = L.odeCFL2(L.termLaxFriedrichs, [0., 0.02], G["dub_data"].reshape(-1, 1), op2, sd)
+    assert abs(t - float(G["rk2_%s_t" % scheme])) <= 1e-13
+    close(y, G["rk2_%s_y" % scheme], 1e-11)
+    sdr = L.Bundle(dict(innerFunc=L.termLaxFriedrichs, innerData=sd, positive=0))
+    t, y, _ = L.odeCFL2(L.termRestrictUpdate, [0., 0.02], G["dub_data"].flatten(), op2, sdr)
+    assert y.shape == G["rk2r_%s_y" % scheme].shape
+    assert abs(t - float(G["rk2r_%s_t" % scheme])) <= 1e-13
+    close(y, G["rk2r_%s_y" % scheme], 1e-11)
+
+
+def test_ode_cfl3_double_integrator_vs_reference_golden(golden):
+    G = golden("ode.npz")
+    g, og = mk([-1, -1], [1, 1], [32, 32], None)
+    sd = sdata(g, L.DoubleIntegrator(g, 1), L.upwindFirstENO3)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y = G["di_data"].reshape(-1, 1)
+    t = 0.
+    for _ in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    assert abs(t - float(G["di_rk3_ENO3_t5"])) <= 1e-13
+    close(y, G["di_rk3_ENO3_y5"], 1e-11)
+
+
+def test_ode_generic_path_equals_device_path_and_hooks():
+    g, og = dubins([13, 12, 11])
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    sd = sdata(g, sys_, L.upwindFirstENO3)
+    y0 = O.shape_cylinder(og, 2, None, .5).reshape(-1, 1)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off')))
+    t1, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 0.03], y0, op, sd)
+
+    def wrapped(t, y, s):        # a foreign schemeFunc -> generic integrator loop
+        return L.termLaxFriedrichs(t, y, s)
+    t2, y2, _ = L.odeCFL3(wrapped, [0., 0.03], y0, op, sd)
+    assert abs(t1 - t2) <= 1e-14 and abs(t1 - 0.03) <= 100 * L.eps * 0.03
+    close(y1, y2, 1e-12)
+    # RK1 (the reference's is broken; compare with the oracle's intended Euler)
+    term = lambda tt, yy: O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), "ENO3", tt, yy)  # noqa: E731
+    to, yo = O.ode_cfl_1(term, [0., 0.01], y0, 0.5)
+    t3, y3, _ = L.odeCFL1(L.termLaxFriedrichs, [0., 0.01], y0, L.odeCFLset(factorCFL=.5), sd)
+    assert abs(t3 - to) <= 1e-14
+    close(y3, yo, 1e-11)
+    # postTimeStep hook is called once per step with (t, y, schemeData) and may edit y
+    calls = []
+
+    def post(t, y, s):
+        calls.append(float(t))
+        return np.minimum(y, 2.0), s
+    opp = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off', postTimeStep=post)))
+    t4, y4, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 0.015], y0, opp, sd)
+    assert len(calls) >= 2 and calls[-1] == t4 and y4.max() <= 2.0
+    # mixed shapes are rejected instead of silently broadcasting to (N,N)
+    with pytest.raises(ValueError):
+        L.odeCFL3(L.termLaxFriedrichs, [0., 0.01], y0.flatten(), op, sd)
+    # multi-entry tspan returns one row per time
+    tt, yy, _ = L.odeCFL2(L.termLaxFriedrichs, [0., 0.005, 0.01], y0, op, sd)
+    assert tt.shape == (3, 1) and yy.shape == (3, y0.size)
+    # inputs are never mutated
+    assert np.array_equal(y0, O.shape_cylinder(og, 2, None, .5).reshape(-1, 1))
+
+
+def test_known_answers_51cubed_all_schemes():
+    with open(os.path.join(HERE, "golden", "known_answers.json")) as f:
+        KA = json.load(f)
+    g, og = dubins(51)
+    d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    for scheme in ("ENO2", "ENO3", "WENO5_ASSHIPPED"):
+        ka = KA["dubins51_" + scheme]
+        sd = sdata(g, sys_, DERIV[scheme])
+        y = d0.reshape(-1, 1)
+        yd, sb, _ = L.termLaxFriedrichs(0., y, sd)
+        assert abs(sb - ka["stepBound0"]) <= 1e-13 * sb
+        assert abs(np.linalg.norm(yd) - ka["ydot0_l2"]) <= 1e-11 * ka["ydot0_l2"]
+        op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+        t = 0.
+        for k in range(5):
+            t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+            if k == 0:
+                assert abs(t - ka["t1"]) <= 1e-14
+        assert abs(t - ka["t5"]) <= 1e-14
+        assert abs(y.sum() - ka["sum5"]) <= 1e-10 * abs(ka["sum5"])
+        assert abs(np.linalg.norm(y) - ka["l2_5"]) <= 1e-11 * ka["l2_5"]
+        assert abs(y.min() - ka["min5"]) <= 1e-11 and abs(y.max() - ka["max5"]) <= 1e-11
+    g2, og2 = mk([-1, -1], [1, 1], [128, 128], None)
+    ka = KA["dint128_ENO3"]
+    sd = sdata(g2, L.DoubleIntegrator(g2, 1), L.upwindFirstENO3)
+    y = L.shapeSphere(g2, np.zeros((2, 1)), .25).reshape(-1, 1)
+    t = 0.
+    for _ in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    assert abs(t - ka["t5"]) <= 1e-14 and abs(np.linalg.norm(y) - ka["l2_5"]) <= 1e-11 * ka["l2_5"]
+
+
+# ------------------------------------------------------------------------------ HJIPDE_solve
+@pytest.mark.parametrize("comp", ["minVOverTime", "maxVOverTime", "set"])
+def test_hjipde_solve_vs_reference_golden(golden, comp):
+    G = golden("hjipde.npz")
+    g, og = mk(G["dub_min"], G["dub_max"], G["dub_N"], 2)
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation,
+                       CoStateCalc=L.upwindFirstWENO5, uMode='min', dMode='max'))
+    extra = L.Bundle(dict(keepLast=True, quiet=True))
+    data, tau, _ = L.HJIPDE_solve(G["hj_data0"].copy(), G["hj_tau"].copy(), sd, comp, extra)
+    np.testing.assert_array_equal(tau, G["hj_%s_tau" % comp])
+    close(data, G["hj_%s_data" % comp], 1e-11)
+
+
+def test_hjipde_solve_store_all_targets_obstacles():
+    g, og = dubins([15, 14, 13])
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+    obst = L.shapeSphere(g, np.array([[1.5], [0.], [0.]]), .3)
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation,
+                       derivFunc=L.upwindFirstENO3))
+    tau = np.array([0., .02, .04])
+    data, tau_o, _ = L.HJIPDE_solve(d0, tau, sd, 'minVWithTarget',
+                                    L.Bundle(dict(quiet=True, targetFunction=d0, obstacleFunction=obst)))
+    assert data.shape == (3,) + g.shape and np.array_equal(data[0], d0)
+    # oracle replay of the same loop
+    osys = O.DubinsRel(og, 1, 1)
+    term = lambda tt, yy: O.term_lax_friedrichs(og, osys, "ENO3", tt, yy)  # noqa: E731
+    y = d0.reshape(-1, 1)
+    for i in (1, 2):
+        tn = tau[i - 1]
+        while tn < tau[i] - 1e-4:
+            tn, y = O.ode_cfl_3(term, [tn, tau[i]], y, 0.8, single_step=True)
+            y = np.minimum(y, d0.reshape(-1, 1))
+            y = np.maximum(y, -obst.reshape(-1, 1))
+        close(data[i], y.reshape(g.shape), 1e-11)
+    with pytest.raises(ValueError):
+        L.HJIPDE_solve(d0, tau, sd, 'minVWithTarget', L.Bundle(dict(quiet=True)))
+    with pytest.raises(ValueError):
+        L.HJIPDE_solve(d0, tau, sd, 'nonsense', L.Bundle(dict(quiet=True)))
+
+
+def test_nan_guard():
+    g, og = dubins([9, 9, 9])
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+    d0[4, 4, 4] = np.nan
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, derivFunc=L.upwindFirstENO2))
+    with pytest.raises(ValueError, match="Nans"):
+        L.HJIPDE_solve(d0, np.array([0., .01]), sd, 'set', L.Bundle(dict(quiet=True, keepLast=True)))
+
+
+# ------------------------------------------------------------------------------ C ABI direct
+def test_cabi_errors_and_rk_substep_ranges():
+    g, og = dubins([20, 11, 12])
+    dg = device_grid(g)
+    dg.bind_stream()
+    lib = dg.lib
+    par = _ffi.darr([1, 1, 1, 2])
+    y = dg.to_device(O.shape_cylinder(og, 2, None, .5))
+    out, out2 = dg.empty(), dg.empty()
+    # aliasing / bad arguments are refused with a message
+    assert lib.hj_rk_substep(dg.ctx, _ffi.ENO3, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 1e-3, 0,
+                             dg.ptr(y), None, dg.ptr(y), 0, 0, 20) == -1
+    assert b"alias" in lib.hj_last_error()
+    assert lib.hj_rk_substep(dg.ctx, 9, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 1e-3, 0,
+                             dg.ptr(y), None, dg.ptr(out), 0, 0, 20) == -1
+    assert lib.hj_rk_substep(dg.ctx, _ffi.ENO3, _ffi.HAM_DOUBLE_INTEGRATOR, par, 0., _ffi.STAGE_EULER, 1e-3, 0,
+                             dg.ptr(y), None, dg.ptr(out), 0, 0, 20) == -1
+    assert lib.hj_rk_substep(dg.ctx, _ffi.ENO3, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_RK3_HALF, 1e-3, 0,
+                             dg.ptr(y), None, dg.ptr(out), 0, 0, 20) == -1
+    # plane ranges: [0,7) + [7,20) == [0,20)
+    _ffi.check(lib.hj_rk_substep(dg.ctx, _ffi.ENO3, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 1e-3, 0,
+                                 dg.ptr(y), None, dg.ptr(out), 0, 0, 20))
+    out2.zero_()
+    _ffi.check(lib.hj_rk_substep(dg.ctx, _ffi.ENO3, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 1e-3, 0,
+                                 dg.ptr(y), None, dg.ptr(out2), 1, 0, 7))
+    _ffi.check(lib.hj_rk_substep(dg.ctx, _ffi.ENO3, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 1e-3, 0,
+                                 dg.ptr(y), None, dg.ptr(out2), 2, 7, 20))
+    dg.sync()
+    assert torch.equal(out, out2)
+    sb, am = C.c_double(), (C.c_double * 4)()
+    _ffi.check(lib.hj_read_step_bound(dg.ctx, 0, C.byref(sb), am))
+    sbs = C.c_double()
+    _ffi.check(lib.hj_static_step_bound(dg.ctx, _ffi.HAM_DUBINS_REL, par, C.byref(sbs)))
+    assert sb.value == sbs.value
+    _, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), "ENO3", 0., O.shape_cylinder(og, 2, None, .5).reshape(-1, 1))
+    assert abs(sb.value - sbo) <= 1e-13 * sbo
+
+
+# ------------------------------------------------------------------------------ slab decomposition
+@pytest.mark.parametrize("scheme", ["ENO3", "WENO5"])
+@pytest.mark.parametrize("periodic0", [False, True])
+def test_slab_halo_mode_equals_single_domain(scheme, periodic0):
+    """Two slabs of axis 0 with exchanged ghost planes == the undivided grid (bitwise)."""
+    n = (23, 14, 12)
+    gmin, gmax = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])]
+    pd = (0, 2) if periodic0 else 2
+    g, og = mk(gmin, gmax, n, pd)
+    rng = np.random.default_rng(11)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * rng.standard_normal(n)
+    sid = _ffi.SCHEME_IDS[scheme]
+    par = _ffi.darr([1, 1, 1, 2])
+    dg = device_grid(g)
+    dg.bind_stream()
+    y = dg.to_device(data)
+    ref = dg.empty()
+    _ffi.check(dg.lib.hj_rk_substep(dg.ctx, sid, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 2e-3, 0,
+                                    dg.ptr(y), None, dg.ptr(ref), 0, 0, n[0]))
+    eps_dev = None
+    if scheme == "WENO5":
+        eps_dev = torch.empty(3, dtype=torch.float64, device="cuda")
+        _ffi.check(dg.lib.hj_max_d1sq(dg.ctx, dg.ptr(y), dg.ptr(eps_dev)))
+    dg.sync()
+    cut = 10
+    pieces = []
+    for (b, e) in ((0, cut), (cut, n[0])):
+        lo = (b > 0) or periodic0
+        hi = (e < n[0]) or periodic0
+        sdg = DeviceGrid(g, "float64", None, (b, e, lo, hi))
+        sdg.bind_stream()
+        buf = torch.zeros((e - b + 6,) + n[1:], dtype=torch.float64, device="cuda")
+        buf[3:3 + e - b] = y[b:e]
+        if lo:
+            buf[0:3] = y[[(b - 3 + k) % n[0] for k in range(3)]]
+        if hi:
+            buf[3 + e - b:] = y[[(e + k) % n[0] for k in range(3)]]
+        outb = torch.zeros_like(buf)
+        if eps_dev is not None:
+            _ffi.check(sdg.lib.hj_ctx_set_weno_eps_source(sdg.ctx, sdg.ptr(eps_dev)))
+        _ffi.check(sdg.lib.hj_rk_substep(sdg.ctx, sid, _ffi.HAM_DUBINS_REL, par, 0., _ffi.STAGE_EULER, 2e-3, 0,
+                                         C.c_void_p(buf[3:].data_ptr()), None, C.c_void_p(outb[3:].data_ptr()),
+                                         0, 0, e - b))
+        sdg.sync()
+        pieces.append(outb[3:3 + e - b])
+    got = torch.cat(pieces, 0)
+    assert torch.equal(got, ref)
+    yo, _ = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), scheme, 0., data.reshape(-1, 1))
+    close(ref.cpu().numpy(), data + 2e-3 * yo.reshape(n), 1e-11)
+
+
+# ------------------------------------------------------------------------------ fp32
+def test_fp32_path_vs_fp64_oracle():
+    g, og = dubins([24, 22, 20])
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    data = O.shape_cylinder(og, 2, None, .5)
+    yt = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
+    yd, sb, _ = L.termLaxFriedrichs(0., yt, sdata(g, sys_, L.upwindFirstWENO5Intended))
+    assert yd.dtype == torch.float32
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), "WENO5", 0., data.reshape(-1, 1))
+    rel = np.max(np.abs(yd.cpu().numpy().astype(np.float64) - yo)) / np.max(np.abs(yo))
+    assert rel <= 1e-4, rel
+    assert abs(sb - sbo) <= 1e-6 * sbo
