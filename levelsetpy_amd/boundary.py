@@ -28,12 +28,16 @@ def _pad(dataIn, dim, width, bc, toward_zero):
     outer = int(np.prod(shape[:dim])) if dim > 0 else 1
     inner = int(np.prod(shape[dim + 1:])) if dim + 1 < nd else 1
     view, vdim = (outer, shape[dim], inner), 1
-    # the reference always returns float64 (add_ghost_extrapolate.py:77, add_ghost_periodic.py:74)
+    # the reference always returns float64 (add_ghost_extrapolate.py:77, add_ghost_periodic.py:74), but
+    # evaluates the slopes in the INPUT's precision: float32 data is extrapolated in float32 and then
+    # widened, which is what the golden vector for float32 input records
     dev = torch.device("cuda", torch.cuda.current_device())
+    f32 = (str(dataIn.dtype) in ("float32", "torch.float32"))
+    work = torch.float32 if f32 else torch.float64
     if is_tensor(dataIn):
-        src = dataIn.to(device=dev, dtype=torch.float64).contiguous()
+        src = dataIn.to(device=dev, dtype=work).contiguous()
     else:
-        src = torch.from_numpy(np.ascontiguousarray(dataIn, dtype=np.float64)).to(dev)
+        src = torch.from_numpy(np.ascontiguousarray(dataIn, dtype=np.float32 if f32 else np.float64)).to(dev)
     n = (C.c_int64 * len(view))(*view)
     ones = _ffi.darr([1.0] * len(view))
     zeros = _ffi.darr([0.0] * len(view))
@@ -44,16 +48,17 @@ def _pad(dataIn, dim, width, bc, toward_zero):
     ctx = C.c_void_p()
     _ffi.check(lib.hj_ctx_create(C.byref(ctx), len(view), n, zeros, ones,
                                  (C.c_int * len(view))(*bcs), (C.c_int * len(view))(*tz),
-                                 _ffi.F64, dev.index))
+                                 _ffi.F32 if f32 else _ffi.F64, dev.index))
     try:
         _ffi.check(lib.hj_ctx_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         oshape = list(shape)
         oshape[dim] += 2 * width
-        out = torch.empty(oshape, dtype=torch.float64, device=dev)
+        out = torch.empty(oshape, dtype=work, device=dev)
         _ffi.check(lib.hj_ghost(ctx, vdim, int(width), C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr())))
         _ffi.check(lib.hj_sync(ctx))
     finally:
         lib.hj_ctx_destroy(ctx)
+    out = out.to(torch.float64)
     return out if is_tensor(dataIn) else out.cpu().numpy()
 
 
