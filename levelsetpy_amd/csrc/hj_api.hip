@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hj_mi355x.h"
@@ -74,7 +76,7 @@ struct hj_ctx {
     int internal_slot;
     // tuning
     KernelCfg cfg;
-    int force_direct;
+    int force_direct, debug, full_rows;
     int target_blocks, min_chunk;
     size_t lds_limit;
 };
@@ -107,6 +109,9 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
             if (cand[d].empty() || cand[d].back() != e) cand[d].push_back(e);
             if (e == 1) break;
         }
+    }
+    if (c->full_rows) {   // tuning knob: the last axis is never split (contiguous tile planes)
+        cand[nd - 1].assign(1, n[nd - 1]);
     }
     int E[HJ_MAX_DIM] = {1, 1, 1, 1};
     // enumerate extents of all plane axes except the first, which takes what is left
@@ -192,8 +197,8 @@ template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G
         G.n[d] = (int)c->N[d];
         G.bc[d] = c->bc[d];
         G.km[d] = c->tz[d] ? T(-1) : T(1);
-        G.dx[d] = (T)c->dx[d];
         G.inv_dx[d] = (T)(1.0 / c->dx[d]);
+        fill_stencil_constants<T>(c->dx[d], G.K[d]);
         G.stride[d] = s;
         s *= c->N[d];
     }
@@ -212,14 +217,11 @@ struct SubstepCall {
     int64_t p0, p1;
 };
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH>
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
 int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
     constexpr int ND = HAM::ND;
     FusedArgs<T, ND> A;
     memset(&A, 0, sizeof(A));
-    A.y = (const T*)s.y;
-    A.y0 = (const T*)s.y0;
-    A.out = (T*)s.out;
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
     A.bound = s.bound;
     long long st = 1;
@@ -227,8 +229,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
         A.n[d] = (int)c->N[d];
         A.bc[d] = c->bc[d];
         A.km[d] = c->tz[d] ? T(-1) : T(1);
-        A.dx[d] = (T)c->dx[d];
-        A.inv_dx[d] = (T)(1.0 / c->dx[d]);
+        fill_stencil_constants<T>(c->dx[d], A.K[d]);
         A.pstride[d] = (d >= 1) ? (int)st : 0;
         if (d == 0) A.stride0 = st;
         st *= c->N[d];
@@ -244,16 +245,26 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
     A.plane_end = (int)s.p1;
     A.nblocks = t.nblocks;
     A.blocks_per_xcd = t.bpx;
-    A.stage = s.stage;
-    A.restrict_sign = s.restrict_sign;
+    A.ydot_only = (s.stage == HJ_STAGE_YDOT);
+    A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
+    switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
+        case HJ_STAGE_RK3_HALF: A.ca = T(0.75); A.cb = T(0.25); break;           // ode_cfl_3.py:184,193
+        case HJ_STAGE_RK3_FULL: A.ca = T(1.0 / 3.0); A.cb = T(2.0 / 3.0); break; // :226,241
+        case HJ_STAGE_RK2_FULL: A.ca = T(0.5); A.cb = T(0.5); break;             // ode_cfl_2.py:184,201
+        default: A.ca = T(0); A.cb = T(1); break;
+    }
     A.dt = (T)s.dt;
+    A.do_clamp = s.restrict_sign != 0;
+    A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
+    A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
     fill_ham<T>(c, s.par, A.ham);
-    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH>;
+    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
     if (t.lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     }
-    hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, A);
+    hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (const T*)s.y0,
+                       (T*)s.out, A);
     HIP_TRY(hipGetLastError());
     return HJ_OK;
 }
@@ -284,19 +295,44 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     return HJ_OK;
 }
 
+// (threads per workgroup, cells per thread, halo slots per thread) instantiated for the tiled kernel
+#ifndef HJ_CONFIGS
+#define HJ_CONFIGS(X) X(512, 4, 2, 2) X(1024, 2, 1, 4) X(512, 2, 1, 4) X(256, 4, 3, 2) X(256, 2, 2, 4) \
+                      X(512, 1, 1, 4) X(256, 1, 2, 6) X(1024, 1, 1, 4)
+#endif
+
+int cfg_kh(int nt, int r) {
+#define X(NT_, R_, KH_, OCC_) if (nt == NT_ && r == R_) return KH_;
+    HJ_CONFIGS(X)
+#undef X
+    return -1;
+}
+
 template <typename T, typename HAM, int SCHEME>
 int launch_cfg(hj_ctx* c, const SubstepCall& s) {
-    if constexpr (HAM::ND <= 3) {
-      if (!c->force_direct) {
-        const KernelCfg k = c->cfg;
-        Tiling t = make_tiling(c, k, s.p0, s.p1);
-        if (t.ok) {
-            if (k.NT == 512 && k.R == 4) return launch_tiled<T, HAM, SCHEME, 512, 4, 4>(c, s, t);
-            if (k.NT == 256 && k.R == 4) return launch_tiled<T, HAM, SCHEME, 256, 4, 6>(c, s, t);
-            if (k.NT == 1024 && k.R == 2) return launch_tiled<T, HAM, SCHEME, 1024, 2, 2>(c, s, t);
-            if (k.NT == 256 && k.R == 8) return launch_tiled<T, HAM, SCHEME, 256, 8, 6>(c, s, t);
+#ifdef HJ_TUNE_BUILD
+    // quick-iteration build: only fp64 Dubins with the two WENO5 arithmetics is compiled tiled
+    constexpr bool tiled_ok = std::is_same<T, double>::value && HAM::ID == HJ_HAM_DUBINS_REL &&
+                              (SCHEME == HJ_WENO5 || SCHEME == HJ_WENO5_ASSHIPPED);
+#else
+    constexpr bool tiled_ok = HAM::ND <= 3;
+#endif
+    if constexpr (tiled_ok) {
+        if (!c->force_direct) {
+            const KernelCfg k = c->cfg;
+            Tiling t = make_tiling(c, k, s.p0, s.p1);
+            if (c->debug) {
+                fprintf(stderr, "[hj] tiling ok=%d NT=%d R=%d KH=%d E=(%d,%d,%d) ntiles=%d chunk=%d nchunks=%d blocks=%d lds=%zu score=%.3f\n",
+                        (int)t.ok, k.NT, k.R, k.KH, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0,
+                        t.ntiles, t.chunk, t.nchunks, t.nblocks, t.lds_bytes, t.score);
+                c->debug = 0;
+            }
+            if (t.ok) {
+#define X(NT_, R_, KH_, OCC_) if (k.NT == NT_ && k.R == R_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_>(c, s, t);
+                HJ_CONFIGS(X)
+#undef X
+            }
         }
-      }
     }
     return launch_direct<T, HAM, SCHEME>(c, s);
 }
@@ -475,8 +511,7 @@ template <typename T> static DimView<T> make_view(const hj_ctx* c, int dim, bool
     V.halo_lo = (with_halo && dim == 0) ? c->halo_lo : 0;
     V.halo_hi = (with_halo && dim == 0) ? c->halo_hi : 0;
     V.km = c->tz[dim] ? T(-1) : T(1);
-    V.dx = (T)c->dx[dim];
-    V.inv_dx = (T)(1.0 / c->dx[dim]);
+    fill_stencil_constants<T>(c->dx[dim], V.K);
     return V;
 }
 
@@ -538,20 +573,20 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         c->N[d] = N[d]; c->xmin[d] = xmin[d]; c->dx[d] = dx[d]; c->bc[d] = bc[d];
         c->tz[d] = toward_zero ? (toward_zero[d] != 0) : 0;
     }
-    c->cfg.NT = env_int("HJ_NT", 512);
+    c->cfg.NT = env_int("HJ_NT", 512);   // defaults: best of the round-1 sweep (profiles/r01_cfgsweep.txt)
     c->cfg.R = env_int("HJ_R", 4);
     c->cfg.KH = 0;
     c->force_direct = env_int("HJ_FORCE_DIRECT", 0);
+    c->debug = env_int("HJ_DEBUG", 0);
+    c->full_rows = env_int("HJ_FULL_ROWS", 0);
     c->target_blocks = env_int("HJ_TARGET_BLOCKS", 1024);
     c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 8));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
-    {
+    c->cfg.KH = cfg_kh(c->cfg.NT, c->cfg.R);
+    if (c->cfg.KH < 0) {
         const int nt = c->cfg.NT, r = c->cfg.R;
-        if (nt == 512 && r == 4) c->cfg.KH = 4;
-        else if (nt == 256 && r == 4) c->cfg.KH = 6;
-        else if (nt == 1024 && r == 2) c->cfg.KH = 2;
-        else if (nt == 256 && r == 8) c->cfg.KH = 6;
-        else { delete c; return fail(HJ_EINVAL, "unsupported HJ_NT/HJ_R combination %d/%d", nt, r); }
+        delete c;
+        return fail(HJ_EINVAL, "unsupported HJ_NT/HJ_R combination %d/%d", nt, r);
     }
     *out = c;
     int rc = HJ_OK;

@@ -48,10 +48,28 @@ template <typename T> struct DD {
     T D1[6], D2[5], D3[4];
 };
 
+// Per-dimension stencil constants, computed on the HOST and passed in the kernel arguments so they
+// live in SGPRs (there is no scalar fp64 multiply: derived in-kernel they would be wave-uniform
+// values pinned in VGPR pairs for the whole march).
+//   K[0] = 1/dx        K[1] = 1/(2dx)     K[2] = 1/(3dx)     K[3] = dx    K[4] = dx^2   K[5] = 2dx^2
+//   as-shipped WENO5 (c = 1/(60dx)):  K[6] = 45c  K[7] = -9c  K[8] = c  K[9] = 15c  K[10] = -6c  K[11] = -20c
+constexpr int HJ_NK = 12;
+template <typename T> inline void fill_stencil_constants(double dx, T* K) {
+    const double inv = 1.0 / dx;
+    K[0] = (T)inv;
+    K[1] = (T)(0.5 * inv);
+    K[2] = (T)((1.0 / 3.0) * inv);
+    K[3] = (T)dx;
+    K[4] = (T)(dx * dx);
+    K[5] = (T)(2 * (dx * dx));
+    const double c = inv * (1.0 / 60.0);
+    K[6] = (T)(45 * c); K[7] = (T)(-9 * c); K[8] = (T)c;
+    K[9] = (T)(15 * c); K[10] = (T)(-6 * c); K[11] = (T)(-20 * c);
+}
+
 template <typename T>
-__device__ __forceinline__ void dd_tables(const T* v, T inv_dx, DD<T>& t) {
-    const T h2 = T(0.5) * inv_dx;
-    const T h3 = (T(1) / T(3)) * inv_dx;
+__device__ __forceinline__ void dd_tables(const T* v, const T* K, DD<T>& t) {
+    const T inv_dx = K[0], h2 = K[1], h3 = K[2];
 #pragma unroll
     for (int j = 0; j < 6; ++j) t.D1[j] = inv_dx * (v[j + 1] - v[j]);
 #pragma unroll
@@ -62,16 +80,16 @@ __device__ __forceinline__ void dd_tables(const T* v, T inv_dx, DD<T>& t) {
 
 // the three third-order candidates per side (ENO3aHelper.py:116-189)
 template <typename T>
-__device__ __forceinline__ void eno3_candidates(const DD<T>& t, T dx, T* dL, T* dR) {
-    const T dx2 = dx * dx;
+__device__ __forceinline__ void eno3_candidates(const DD<T>& t, const T* K, T* dL, T* dR) {
+    const T dx = K[3], dx2 = K[4], tdx2 = K[5];
     const T l = t.D1[2] + dx * t.D2[1];
-    dL[0] = l + (T(2) * dx2) * t.D3[0];
-    dL[1] = l + (T(2) * dx2) * t.D3[1];
+    dL[0] = l + tdx2 * t.D3[0];
+    dL[1] = l + tdx2 * t.D3[1];
     dL[2] = (t.D1[2] + dx * t.D2[2]) - dx2 * t.D3[2];
     const T r = t.D1[3] - dx * t.D2[2];
     dR[0] = r - dx2 * t.D3[1];
     dR[1] = r - dx2 * t.D3[2];
-    dR[2] = (t.D1[3] - dx * t.D2[3]) + (T(2) * dx2) * t.D3[3];
+    dR[2] = (t.D1[3] - dx * t.D2[3]) + tdx2 * t.D3[3];
 }
 
 template <typename T>
@@ -100,9 +118,10 @@ __device__ __forceinline__ void weno_smooth(T v1, T v2, T v3, T v4, T v5, T& s1,
 
 // eps: only used by HJ_WENO5 (= 1e-6*max(D1^2)+tiny for this dim)
 template <int SCHEME, typename T>
-__device__ __forceinline__ void upwind(const T* v, T dx, T inv_dx, T eps, T& L, T& R) {
+__device__ __forceinline__ void upwind(const T* v, const T* K, T eps, T& L, T& R) {
     DD<T> t;
-    dd_tables(v, inv_dx, t);
+    dd_tables(v, K, t);
+    const T dx = K[3];
     if constexpr (SCHEME == HJ_ENO2) {
         // upwind_first_eno2.py:97-148 in local indices
         const bool sl = t_abs(t.D2[1]) < t_abs(t.D2[2]);
@@ -111,7 +130,7 @@ __device__ __forceinline__ void upwind(const T* v, T dx, T inv_dx, T eps, T& L, 
         R = t.D1[3] - dx * (sr ? t.D2[2] : t.D2[3]);
     } else {
         T dL[3], dR[3];
-        eno3_candidates(t, dx, dL, dR);
+        eno3_candidates(t, K, dL, dR);
         if constexpr (SCHEME == HJ_ENO3) {
             // upwind_first_eno3a.py:105-141: strict '<', ties go right
             const bool sL0 = t_abs(t.D2[1]) < t_abs(t.D2[2]);
@@ -138,6 +157,29 @@ __device__ __forceinline__ void upwind(const T* v, T dx, T inv_dx, T eps, T& L, 
     }
 }
 
+// Centred costate pc = (L+R)/2 and half jump hd = (R-L)/2: all the Lax-Friedrichs term needs
+// (term_lax_friedrich.py:108, artificial_diss_glf.py:91,100).  The as-shipped WENO5 is linear in
+// phi, so both are short fixed stencils on the undivided differences u_j = v[j+1]-v[j]:
+//   L = (2u0 - 13u1 + 47u2 + 27u3 - 3u4)/(60dx),  R = (-3u1 + 27u2 + 47u3 - 13u4 + 2u5)/(60dx)
+// (SURVEY Appendix B), which collapse to the stencils below.  Nonlinear schemes go through upwind<>.
+template <int SCHEME, typename T>
+__device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, T& pc, T& hd) {
+    if constexpr (SCHEME == HJ_WENO5_ASSHIPPED) {
+        // in terms of phi: with D_k = phi[i+k]-phi[i-k], S_k = phi[i+k]+phi[i-k]
+        //   pc = (45 D1 - 9 D2 + D3)/(60dx)            (6th-order central difference)
+        //   hd = (S3 - 6 S2 + 15 S1 - 20 phi_i)/(60dx)  (scaled 6th difference)
+        const T D1 = v[4] - v[2], D2 = v[5] - v[1], D3 = v[6] - v[0];
+        const T S1 = v[4] + v[2], S2 = v[5] + v[1], S3 = v[6] + v[0];
+        pc = K[6] * D1 + (K[7] * D2 + K[8] * D3);
+        hd = K[9] * S1 + (K[10] * S2 + (K[8] * S3 + K[11] * v[3]));
+    } else {
+        T L, R;
+        upwind<SCHEME, T>(v, K, eps, L, R);
+        pc = T(0.5) * (L + R);
+        hd = T(0.5) * (R - L);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Native Hamiltonians.  eval(): idx[d] = node index per dim, p[d] = centred costate
 // 0.5*(derivL+derivR) (term_lax_friedrich.py:108); returns H and alpha[d] = partialFunc(.., d).
@@ -147,22 +189,42 @@ template <typename T> struct HamTables {
     T par[4];
 };
 
+// Interface (all three systems):
+//   Cell  cell(P, idx)      -- constants of a grid column (depend on idx[1..] only); the fused kernel
+//                              evaluates this once per block, outside the axis-0 march
+//   Plane plane(P, i0)      -- wave-uniform values of one axis-0 plane
+//   eval(P, cell, plane, p, H, alpha)
 template <typename T> struct HamDubinsRel {
     static constexpr int ND = 3;
     static constexpr int ID = HJ_HAM_DUBINS_REL;
     // H = p1(v_e - v_p cos x3) - p2 v_p sin x3 - w|p1 x2 - p2 x1 - p3| + w|p3|   (:83-88)
     // alpha = { |v_e - v_p cos x3| + |w x2|, |v_p sin x3| + |w x1|, w_e + w_p }      (:106-111)
-    __device__ static __forceinline__ void eval(const HamTables<T>& P, const int* idx, const T* p,
-                                                T& H, T* alpha) {
-        const T ve = P.par[0], vp = P.par[1], w = P.par[2], wsum = P.par[3];
-        const T x0 = P.coord[0][idx[0]], x1 = P.coord[1][idx[1]];
-        const T c = P.aux[0][idx[2]], s = P.aux[1][idx[2]];
-        const T a = ve - vp * c;
-        const T b = vp * s;
-        H = p[0] * a - p[1] * b - w * t_abs(p[0] * x1 - p[1] * x0 - p[2]) + w * t_abs(p[2]);
-        alpha[0] = t_abs(a) + t_abs(w * x1);
-        alpha[1] = t_abs(b) + t_abs(w * x0);
-        alpha[2] = wsum;
+    // alpha[d] varies along the march (axis 0) only for the dims in this mask; the others are
+    // column constants and their max is taken once, outside the plane loop
+    static constexpr unsigned PLANE_DEP = 0x2;
+    struct Cell { T a, b, x1, alpha0; };
+    struct Plane { T x0, awx0; };
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx) {
+        Cell c;
+        c.a = P.par[0] - P.par[1] * P.aux[0][idx[2]];
+        c.b = P.par[1] * P.aux[1][idx[2]];
+        c.x1 = P.coord[1][idx[1]];
+        c.alpha0 = t_abs(c.a) + t_abs(P.par[2] * c.x1);
+        return c;
+    }
+    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0) {
+        Plane u;
+        u.x0 = P.coord[0][i0];
+        u.awx0 = t_abs(P.par[2] * u.x0);
+        return u;
+    }
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& u,
+                                                const T* p, T& H, T* alpha) {
+        const T w = P.par[2];
+        H = p[0] * c.a - p[1] * c.b - w * t_abs(p[0] * c.x1 - p[1] * u.x0 - p[2]) + w * t_abs(p[2]);
+        alpha[0] = c.alpha0;
+        alpha[1] = t_abs(c.b) + u.awx0;
+        alpha[2] = P.par[3];
     }
 };
 
@@ -170,12 +232,20 @@ template <typename T> struct HamDoubleIntegrator {
     static constexpr int ND = 2;
     static constexpr int ID = HJ_HAM_DOUBLE_INTEGRATOR;
     // H = -(p1 x2 - |p2| u)  (:71-74); alpha = { |x2|, |u| }  (:84-89)
-    __device__ static __forceinline__ void eval(const HamTables<T>& P, const int* idx, const T* p,
-                                                T& H, T* alpha) {
+    static constexpr unsigned PLANE_DEP = 0x0;
+    struct Cell { T x1; };
+    struct Plane { int unused; };
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx) {
+        Cell c;
+        c.x1 = P.coord[1][idx[1]];
+        return c;
+    }
+    __device__ static __forceinline__ Plane plane(const HamTables<T>&, int) { return Plane{0}; }
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane&,
+                                                const T* p, T& H, T* alpha) {
         const T u = P.par[0];
-        const T x1 = P.coord[1][idx[1]];
-        H = -(p[0] * x1 - t_abs(p[1]) * u);
-        alpha[0] = t_abs(x1);
+        H = -(p[0] * c.x1 - t_abs(p[1]) * u);
+        alpha[0] = t_abs(c.x1);
         alpha[1] = t_abs(u);
     }
 };
@@ -186,13 +256,28 @@ template <typename T> struct HamDoublePendulum {
     // state (th1, w1, th2, w2); drift f of the frictionless double pendulum with unit masses and
     // lengths, g = 9.8 (dynamics as in the reference's Tests/double_pendulum.py:29-51);
     // H = sum p_i f_i + u(|p2|+|p4|), alpha_i = |f_i| + u*[i in {1,3}].  aux = sin/cos tables.
-    __device__ static __forceinline__ void eval(const HamTables<T>& P, const int* idx, const T* p,
-                                                T& H, T* alpha) {
+    static constexpr unsigned PLANE_DEP = 0xA;
+    struct Cell { T w1, w2, s2, c2; };
+    struct Plane { T s1, c1; };
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx) {
+        Cell c;
+        c.w1 = P.coord[1][idx[1]];
+        c.w2 = P.coord[3][idx[3]];
+        c.s2 = P.aux[2][idx[2]];
+        c.c2 = P.aux[3][idx[2]];
+        return c;
+    }
+    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0) {
+        Plane u;
+        u.s1 = P.aux[0][i0];
+        u.c1 = P.aux[1][i0];
+        return u;
+    }
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& pl,
+                                                const T* p, T& H, T* alpha) {
         const T G = T(9.8), L1 = T(1), L2 = T(1), M1 = T(1), M2 = T(1);
         const T u = P.par[0];
-        const T w1 = P.coord[1][idx[1]], w2 = P.coord[3][idx[3]];
-        const T s1 = P.aux[0][idx[0]], c1 = P.aux[1][idx[0]];
-        const T s2 = P.aux[2][idx[2]], c2 = P.aux[3][idx[2]];
+        const T w1 = c.w1, w2 = c.w2, s1 = pl.s1, c1 = pl.c1, s2 = c.s2, c2 = c.c2;
         const T sd = s2 * c1 - c2 * s1;  // sin(th2-th1)
         const T cd = c2 * c1 + s2 * s1;  // cos(th2-th1)
         const T den1 = (M1 + M2) * L1 - M2 * L1 * cd * cd;
@@ -208,6 +293,27 @@ template <typename T> struct HamDoublePendulum {
         alpha[3] = t_abs(f3) + u;
     }
 };
+
+// ---- buffer (SRD) addressing: wave-uniform 128-bit descriptor in SGPRs + per-lane 32-bit byte
+// offset, hardware range check (out-of-range loads return 0, stores are dropped)
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const T* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, /*stride*/ 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    using V = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(V, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    using V = decltype(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(V, v), r, off, 0, 0);
+}
 
 // order-preserving map double -> uint64 so atomicMax on the key is max on the value
 __device__ __forceinline__ unsigned long long max_key(double v) {

@@ -12,10 +12,17 @@
 //   * the centre plane of the tile, with a 3-cell halo on every in-plane axis, is staged in LDS
 //     (double buffered: one s_barrier per plane); in-plane stencils are read from LDS.
 //     Halo cells outside the domain are ghost cells computed at load time.
+//   * software pipeline: the HBM loads a plane needs (its own cells for the queue, the halo ring,
+//     the RK operand y0, the plane's Hamiltonian scalars) are issued TWO planes before they are
+//     consumed, into alternating register sets (the loop body is instantiated twice with the
+//     sets swapped, so in-flight data is never moved): a full plane of arithmetic always covers
+//     the memory latency and the memory queue does not drain at the barrier.
 //   * thread <-> cell: the tile's cells are numbered linearly (last axis fastest) and dealt
 //     round-robin to the NT threads, R cells per thread: consecutive lanes touch consecutive
 //     addresses in HBM (coalesced, full 64-lane waves even when N is not a multiple of 64) and
-//     consecutive 8-byte LDS words (bank-conflict free for ds_read_b64).
+//     consecutive 8-byte LDS words (bank-conflict free for ds_read_b64).  Threads beyond the
+//     tile's cell count shadow its last cell (identical values, duplicate stores): the hot loop
+//     has no per-lane validity branches.
 //   * blockIdx -> (chunk, tile) is XCD-aware: the 8 XCDs get contiguous ranges of the logical
 //     block order, so tiles sharing halo rows share an L2.
 //   * per-dim max(alpha) is reduced with wavefront shuffles, then LDS, then one 64-bit
@@ -26,16 +33,13 @@
 namespace hj {
 
 template <typename T, int ND> struct FusedArgs {
-    const T* y;    // stencil input; first interior plane
-    const T* y0;   // stage operand (may be null)
-    T* out;
     const T* max_d1sq;            // ND values (HJ_WENO5 only)
     unsigned long long* bound;    // ND keys (atomicMax)
     int n[ND];
     int bc[ND];
     int halo_lo, halo_hi;
     T km[ND];                     // slope multiplier (+1, -1 if towardZero)
-    T dx[ND], inv_dx[ND];
+    T K[ND][HJ_NK];               // per-dim stencil constants (fill_stencil_constants)
     long long stride0;            // elements per axis-0 plane
     int pstride[ND];              // in-plane element strides (pstride[0] unused)
     int E[ND];                    // tile extents on the plane axes (E[0] unused)
@@ -44,31 +48,53 @@ template <typename T, int ND> struct FusedArgs {
     int chunk, nchunks;
     int plane_begin, plane_end;
     int nblocks, blocks_per_xcd;
-    int stage, restrict_sign;
-    T dt;
+    // out = ydot                                   (ydot_only)
+    //     = ca*y0 + cb*(y + dt*ydot)               otherwise; y0 is read iff use_y0
+    int ydot_only, use_y0;
+    T ca, cb, dt;
+    int do_clamp;                 // termRestrictUpdate: ydot clamped to [lo, hi]
+    T clamp_lo, clamp_hi;
     HamTables<T> ham;
 };
 
+// where the values of axis-0 plane `p` (possibly a ghost plane) come from: wave-uniform
+template <typename T> struct PlaneSrc {
+    long long off;     // element offset of the source plane (edge plane for extrapolation)
+    long long off_in;  // inner plane (extrapolation only)
+    T km;              // k * slope multiplier
+    bool ghost;
+};
+
 template <typename T, int ND>
-__device__ __forceinline__ T load_axis0(const FusedArgs<T, ND>& A, int p, int g) {
+__device__ __forceinline__ PlaneSrc<T> plane_src(const FusedArgs<T, ND>& A, int p) {
+    PlaneSrc<T> s;
     const int n0 = A.n[0];
-    if (p >= 0 && p < n0) return A.y[(long long)p * A.stride0 + g];
-    if (p < 0) {
-        if (A.halo_lo) return A.y[(long long)p * A.stride0 + g];
-        if (A.bc[0] == HJ_BC_PERIODIC) return A.y[(long long)(p + n0) * A.stride0 + g];
-        const T e = A.y[g], i = A.y[A.stride0 + g];
-        return ghost_value(e, i, T(-p) * A.km[0]);
+    s.ghost = false;
+    s.km = T(0);
+    s.off_in = 0;
+    int src = p;
+    if (p < 0 && !A.halo_lo) {
+        if (A.bc[0] == HJ_BC_PERIODIC) src = p + n0;
+        else { src = 0; s.off_in = A.stride0; s.km = T(-p) * A.km[0]; s.ghost = true; }
+    } else if (p >= n0 && !A.halo_hi) {
+        if (A.bc[0] == HJ_BC_PERIODIC) src = p - n0;
+        else {
+            src = n0 - 1;
+            s.off_in = (long long)(n0 - 2) * A.stride0;
+            s.km = T(p - n0 + 1) * A.km[0];
+            s.ghost = true;
+        }
     }
-    if (A.halo_hi) return A.y[(long long)p * A.stride0 + g];
-    if (A.bc[0] == HJ_BC_PERIODIC) return A.y[(long long)(p - n0) * A.stride0 + g];
-    const T e = A.y[(long long)(n0 - 1) * A.stride0 + g], i = A.y[(long long)(n0 - 2) * A.stride0 + g];
-    return ghost_value(e, i, T(p - n0 + 1) * A.km[0]);
+    s.off = (long long)src * A.stride0;
+    return s;
 }
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH>
-__global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HAM::ND> A) {
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
+__global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restrict__ y,
+                                                           const T* __restrict__ y0,
+                                                           T* __restrict__ out,
+                                                           const FusedArgs<T, HAM::ND> A) {
     constexpr int ND = HAM::ND;
-    constexpr int PD = ND - 1;  // plane dims
     extern __shared__ __align__(16) unsigned char hj_smem[];
     // dynamic LDS only (keeps the carve base 16-byte aligned): [0,512) reduction scratch, then planes
     double (*red)[ND] = reinterpret_cast<double (*)[ND]>(hj_smem);
@@ -106,31 +132,35 @@ __global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HA
 
     const int tid = threadIdx.x;
 
-    // ---- own cells (loop-invariant along the march)
-    int own_lds[R], own_g[R], own_i[R][PD];
+    // ---- own cells (loop-invariant along the march); surplus threads shadow the last cell
+    int own_lds[R];
+    unsigned own_g[R];
+    typename HAM::Cell hcell[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int c = tid + r * NT;
-        bool ok = c < tile_cells;
+        int c = min(tid + r * NT, tile_cells - 1);
         int lo = 0, g = 0;
+        int idx[ND];
+        idx[0] = 0;
 #pragma unroll
         for (int d = ND - 1; d >= 1; --d) {
             const int q = c / A.E[d];
             const int j = c - q * A.E[d];
             c = q;
             const int gi = org[d] + j;
-            ok = ok && (gi < A.n[d]);
-            own_i[r][d - 1] = gi;
+            idx[d] = gi;
             lo += (j + HJ_STENCIL) * ls[d];
             g += gi * A.pstride[d];
         }
         own_lds[r] = lo;
-        own_g[r] = ok ? g : -1;
+        own_g[r] = (unsigned)g * (unsigned)sizeof(T);   // byte offset within a plane
+        hcell[r] = HAM::cell(A.ham, idx);   // per-column Hamiltonian constants
     }
 
     // ---- halo slots: for each plane axis d, 3 cells below and 3 above the tile, over the
-    // tile's extent on the other axes (a "cross": no corners).
-    int h_lds[KH], h_src[KH], h_dlt[KH];
+    // tile's extent on the other axes (a "cross": no corners).  Surplus slots shadow slot 0.
+    int h_lds[KH], h_dlt[KH];
+    unsigned h_src[KH];
     T h_km[KH];
     {
         int area[ND], base[ND + 1];
@@ -142,8 +172,9 @@ __global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HA
         }
 #pragma unroll
         for (int k = 0; k < KH; ++k) {
-            const int h = tid + k * NT;
-            h_lds[k] = -1; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
+            int h = tid + k * NT;
+            if (h >= base[ND]) h = 0;
+            h_lds[k] = 0; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
             // static loop over the axis the slot belongs to (runtime-indexed local arrays
             // would be demoted to scratch)
 #pragma unroll
@@ -153,7 +184,6 @@ __global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HA
                 const int lay = hh / area[d];          // 0..5: which halo layer
                 int c = hh - lay * area[d];            // index over the other axes (last fastest)
                 const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
-                bool ok = true;
                 int lo = 0, g = 0;
 #pragma unroll
                 for (int e = ND - 1; e >= 1; --e) {
@@ -161,16 +191,12 @@ __global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HA
                     const int q = c / A.E[e];
                     const int j = c - q * A.E[e];
                     c = q;
-                    const int gi = org[e] + j;
-                    ok = ok && (gi < A.n[e]);
                     lo += (j + HJ_STENCIL) * ls[e];
-                    g += gi * A.pstride[e];
+                    g += (org[e] + j) * A.pstride[e];
                 }
                 lo += (jd + HJ_STENCIL) * ls[d];
-                int gi = org[d] + jd;
+                int gi = org[d] + jd;                  // in [-3, n+2]: tiles never straddle the edge
                 const int nd = A.n[d];
-                if (gi >= nd + HJ_STENCIL) ok = false;   // never read
-                if (!ok) continue;
                 int dlt = 0;
                 T km = T(0);
                 if (gi < 0) {
@@ -181,22 +207,12 @@ __global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HA
                     else { km = T(gi - nd + 1) * A.km[d]; dlt = -A.pstride[d]; gi = nd - 1; }
                 }
                 h_lds[k] = lo;
-                h_src[k] = g + gi * A.pstride[d];
-                h_dlt[k] = dlt;
+                h_src[k] = (unsigned)(g + gi * A.pstride[d]) * (unsigned)sizeof(T);
+                h_dlt[k] = dlt * (int)sizeof(T);
                 h_km[k] = km;
             }
         }
     }
-
-    auto fetch_halo = [&](int p, int k) -> T {
-        const T* base = A.y + (long long)p * A.stride0;
-        const T e = base[h_src[k]];
-        if (h_dlt[k] != 0) {
-            const T i = base[h_src[k] + h_dlt[k]];
-            return ghost_value(e, i, h_km[k]);
-        }
-        return e;
-    };
 
     T eps[ND];
 #pragma unroll
@@ -206,99 +222,142 @@ __global__ __launch_bounds__(NT) void fused_substep_kernel(const FusedArgs<T, HA
         for (int d = 0; d < ND; ++d) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
     }
 
-    // ---- prologue: axis-0 queue q[r][j] <-> plane p-3+j, j = 0..6; qn = plane p+4
+    // ---- loaders.  p is wave-uniform and clamped by the callers to planes that exist; each plane
+    // is addressed through a buffer descriptor (SGPR base + per-lane 32-bit byte offset, range
+    // checked against the plane size)
+    const unsigned plane_bytes = (unsigned)(A.stride0 * (long long)sizeof(T));
+    auto load_own = [&](int p, T* dst) {
+        const PlaneSrc<T> s = plane_src<T, ND>(A, p);
+        const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
+        if (!s.ghost) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], T());
+        } else {
+            const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                dst[r] = ghost_value(buf_load(rb, own_g[r], T()), buf_load(ri, own_g[r], T()), s.km);
+        }
+    };
+    auto load_halo = [&](int p, T* dst) {
+        const __amdgpu_buffer_rsrc_t rb = make_srd(y + (long long)p * A.stride0, plane_bytes);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            const T e = buf_load(rb, h_src[k], T());
+            dst[k] = e;
+            if (h_dlt[k] != 0) dst[k] = ghost_value(e, buf_load(rb, h_src[k] + (unsigned)h_dlt[k], T()), h_km[k]);
+        }
+    };
+    auto load_y0 = [&](int p, T* dst) {
+        if (A.use_y0) {
+            const __amdgpu_buffer_rsrc_t rb = make_srd(y0 + (long long)p * A.stride0, plane_bytes);
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], T());
+        }
+    };
+    const int p_last = p_end - 1;
+
+    // ---- prologue: axis-0 queue q[r][j] <-> plane p-3+j, j = 0..6
     T q[R][7];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int j = 0; j < 7; ++j) {
+        T tmp[R];
+        load_own(p_begin - 3 + j, tmp);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) q[r][j] = T(0);
-        if (own_g[r] >= 0) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) q[r][j] = load_axis0<T, ND>(A, p_begin - 3 + j, own_g[r]);
-        }
+        for (int r = 0; r < R; ++r) q[r][j] = tmp[r];
     }
-    T hcur[KH];
+    // register sets of the pipeline: X is consumed by even iterations, Y by odd ones
+    T ownX[R], ownY[R], halX[KH], halY[KH], y0X[R], y0Y[R];
 #pragma unroll
-    for (int k = 0; k < KH; ++k) hcur[k] = (h_lds[k] >= 0) ? fetch_halo(p_begin, k) : T(0);
+    for (int k = 0; k < KH; ++k) { halX[k] = T(0); halY[k] = T(0); }
+    typename HAM::Plane plX, plY;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { y0X[r] = T(0); y0Y[r] = T(0); }
+    load_halo(p_begin, halX);
+    load_y0(p_begin, y0X);
+    plX = HAM::plane(A.ham, p_begin);
+    load_own(min(p_begin + 4, p_end + 2), ownX);          // plane p+4 enters the queue after plane p
+    load_halo(min(p_begin + 1, p_last), halY);
+    load_y0(min(p_begin + 1, p_last), y0Y);
+    plY = HAM::plane(A.ham, min(p_begin + 1, p_last));
 
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
-
-    for (int p = p_begin; p < p_end; ++p) {
-        T* buf = lds + ((p - p_begin) & 1) * lds_plane;
-        // loads for the next iteration first: their latency hides behind this plane's math
-        T qn[R], hn[KH], y0v[R];
-        const bool more = (p + 1 < p_end);
+    {   // alphas that are constant along the march: one max per column
+        T pz[ND], Hz, az[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) pz[d] = T(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            qn[r] = T(0);
-            if (more && own_g[r] >= 0) qn[r] = load_axis0<T, ND>(A, p + 4, own_g[r]);
-        }
+            HAM::eval(A.ham, hcell[r], plX, pz, Hz, az);
 #pragma unroll
-        for (int k = 0; k < KH; ++k) hn[k] = (more && h_lds[k] >= 0) ? fetch_halo(p + 1, k) : T(0);
-        if (A.stage >= HJ_STAGE_RK3_HALF) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                y0v[r] = (own_g[r] >= 0) ? A.y0[(long long)p * A.stride0 + own_g[r]] : T(0);
+            for (int d = 0; d < ND; ++d)
+                if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
         }
+    }
+
+    // one plane.  own_c holds plane p+4 (joins the queue at the end); own_n is refilled with plane
+    // p+5; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
+    // are refilled for plane p+2 once consumed.
+    auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* y0_c, typename HAM::Plane& pl_c) {
+        T* buf = lds + ((p - p_begin) & 1) * lds_plane;
+        load_own(min(p + 5, p_end + 2), own_n);
         // stage the centre plane
 #pragma unroll
-        for (int r = 0; r < R; ++r) if (own_g[r] >= 0) buf[own_lds[r]] = q[r][3];
+        for (int r = 0; r < R; ++r) buf[own_lds[r]] = q[r][3];
 #pragma unroll
-        for (int k = 0; k < KH; ++k) if (h_lds[k] >= 0) buf[h_lds[k]] = hcur[k];
+        for (int k = 0; k < KH; ++k) buf[h_lds[k]] = hal_c[k];
         __syncthreads();
-
+        const int p2 = min(p + 2, p_last);
+        load_halo(p2, hal_c);
+        const __amdgpu_buffer_rsrc_t ro = make_srd(out + (long long)p * A.stride0, plane_bytes);
+        const typename HAM::Plane pl_use = pl_c;
+        pl_c = HAM::plane(A.ham, p2);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (own_g[r] < 0) continue;
-            T dL[ND], dR[ND], pc[ND];
-            upwind<SCHEME, T>(q[r], A.dx[0], A.inv_dx[0], eps[0], dL[0], dR[0]);
+            T pc[ND], hd[ND];
+            upwind_cd<SCHEME, T>(q[r], A.K[0], eps[0], pc[0], hd[0]);
 #pragma unroll
             for (int d = 1; d < ND; ++d) {
                 T v[7];
                 const T* c = buf + own_lds[r];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) v[j] = (j == 3) ? q[r][3] : c[(j - 3) * ls[d]];
-                upwind<SCHEME, T>(v, A.dx[d], A.inv_dx[d], eps[d], dL[d], dR[d]);
+                upwind_cd<SCHEME, T>(v, A.K[d], eps[d], pc[d], hd[d]);
             }
-#pragma unroll
-            for (int d = 0; d < ND; ++d) pc[d] = T(0.5) * (dL[d] + dR[d]);
-            int idx[ND];
-            idx[0] = p;
-#pragma unroll
-            for (int d = 1; d < ND; ++d) idx[d] = own_i[r][d - 1];
             T H, alpha[ND];
-            HAM::eval(A.ham, idx, pc, H, alpha);
+            HAM::eval(A.ham, hcell[r], pl_use, pc, H, alpha);
             T diss = T(0);
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
-                diss += (T(0.5) * (dR[d] - dL[d])) * alpha[d];
-                amax[d] = fmax(amax[d], (double)alpha[d]);
+                diss += hd[d] * alpha[d];
+                if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = fmax(amax[d], (double)alpha[d]);
             }
             T ydot = -(H - diss);
-            if (A.restrict_sign > 0) ydot = t_max(ydot, T(0));
-            else if (A.restrict_sign < 0) ydot = t_min(ydot, T(0));
-            T o;
-            if (A.stage == HJ_STAGE_YDOT) o = ydot;
-            else {
-                const T ye = q[r][3] + A.dt * ydot;
-                if (A.stage == HJ_STAGE_EULER) o = ye;
-                else if (A.stage == HJ_STAGE_RK3_HALF) o = T(0.25) * (T(3) * y0v[r] + ye);
-                else if (A.stage == HJ_STAGE_RK3_FULL) o = (T(1) / T(3)) * (y0v[r] + T(2) * ye);
-                else o = T(0.5) * (y0v[r] + ye);
+            // termRestrictUpdate clamp; written so that a NaN stays a NaN
+            if (A.do_clamp) {
+                ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
+                ydot = (ydot > A.clamp_hi) ? A.clamp_hi : ydot;
             }
-            A.out[(long long)p * A.stride0 + own_g[r]] = o;
+            T o;
+            if (A.ydot_only) o = ydot;
+            else o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
+            buf_store(o, ro, own_g[r]);
         }
-        // rotate the queue
+        load_y0(p2, y0_c);
+        // rotate the queue: own_c was loaded two iterations ago
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) q[r][j] = q[r][j + 1];
-            q[r][6] = qn[r];
+            q[r][6] = own_c[r];
         }
-#pragma unroll
-        for (int k = 0; k < KH; ++k) hcur[k] = hn[k];
+    };
+
+    for (int p = p_begin; p < p_end; p += 2) {
+        body(p, ownX, ownY, halX, y0X, plX);
+        if (p + 1 < p_end) body(p + 1, ownY, ownX, halY, y0Y, plY);
     }
 
     // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim

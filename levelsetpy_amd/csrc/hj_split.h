@@ -13,7 +13,8 @@ template <typename T> struct DimView {
     int n;                   // size along dim
     int bc;
     int halo_lo, halo_hi;    // only meaningful for dim 0
-    T km, dx, inv_dx;
+    T km;
+    T K[HJ_NK];
 };
 
 // value of phi at position j (may be outside [0,n)) on the line through `line` (element 0 of the
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void upwind_kernel(const T* __restrict__ phi, 
         for (int k = 0; k < 7; ++k)
             v[k] = line_value(line, V.inner, i + k - 3, V.n, V.bc, V.km, V.halo_lo, V.halo_hi);
         T L, R;
-        upwind<SCHEME, T>(v, V.dx, V.inv_dx, eps, L, R);
+        upwind<SCHEME, T>(v, V.K, eps, L, R);
         dL[t] = L;
         dR[t] = R;
         m[0] = fmax(m[0], -(double)L); m[1] = fmax(m[1], (double)L);
@@ -96,7 +97,8 @@ template <typename T, int ND> struct GridArgs {
     int n[ND];
     int bc[ND];
     int halo_lo, halo_hi;
-    T km[ND], dx[ND], inv_dx[ND];
+    T km[ND], inv_dx[ND];
+    T K[ND][HJ_NK];
     long long stride[ND];
     long long total;
 };
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G
         T p[ND], H, a[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) p[d] = T(0);
-        HAM::eval(P, idx, p, H, a);
+        HAM::eval(P, HAM::cell(P, idx), HAM::plane(P, idx[0]), p, H, a);
 #pragma unroll
         for (int d = 0; d < ND; ++d) m[d] = fmax(m[d], (double)a[d]);
     }
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
          t < A.cell_end; t += (long long)gridDim.x * blockDim.x) {
         int idx[ND];
         decode<T, ND>(A.G, t, idx);
-        T dL[ND], dR[ND], pc[ND];
+        T pc[ND], hd[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const T* line = A.y + (t - (long long)idx[d] * A.G.stride[d]);
@@ -239,15 +241,14 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
             for (int k = 0; k < 7; ++k)
                 v[k] = line_value(line, A.G.stride[d], idx[d] + k - 3, A.G.n[d], A.G.bc[d],
                                   A.G.km[d], d == 0 ? A.G.halo_lo : 0, d == 0 ? A.G.halo_hi : 0);
-            upwind<SCHEME, T>(v, A.G.dx[d], A.G.inv_dx[d], eps[d], dL[d], dR[d]);
-            pc[d] = T(0.5) * (dL[d] + dR[d]);
+            upwind_cd<SCHEME, T>(v, A.G.K[d], eps[d], pc[d], hd[d]);
         }
         T H, alpha[ND];
-        HAM::eval(A.ham, idx, pc, H, alpha);
+        HAM::eval(A.ham, HAM::cell(A.ham, idx), HAM::plane(A.ham, idx[0]), pc, H, alpha);
         T diss = T(0);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            diss += (T(0.5) * (dR[d] - dL[d])) * alpha[d];
+            diss += hd[d] * alpha[d];
             amax[d] = fmax(amax[d], (double)alpha[d]);
         }
         T ydot = -(H - diss);

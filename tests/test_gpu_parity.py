@@ -35,18 +35,19 @@ def close(a, ref, tol=1e-11, what=""):
     assert err <= tol * scale, "%s err %.3e > %.1e*%.3g" % (what, err, tol, scale)
 
 
-def close_eno(a, ref, tol=1e-11, frac=1e-3, loose=1e-5, what=""):
-    """Multi-step ENO2/ENO3 comparison: where two |D2| or |D3| candidates tie to
-    rounding (exact ties on the symmetric SDF data), an implementation with different rounding
-    (FMA contraction here) may pick the other, equally valid stencil.  Allow a bounded fraction of
-    such cells, each off by no more than the candidates' O(dx^3) difference."""
+def close_eno(a, ref, tol=1e-11, loose=1e-4, what=""):
+    """Multi-step ENO2/ENO3 on TIE-PRONE data.  The signed-distance cylinder is
+    symmetric, so many |D2| / |D3| comparisons are exact ties in exact arithmetic; which of the two
+    equally valid stencils wins is decided by rounding noise -- in the reference too -- and a
+    flipped choice propagates to neighbours over the following substeps.  Any implementation whose
+    rounding differs (FMA contraction here) therefore agrees only to the candidates' O(dx^3 D^4 phi)
+    difference on such data.  The strict 1e-11 comparisons use the `*n_*` goldens, whose initial
+    data carry 1e-2 noise and have no exact ties."""
     a, ref = np.asarray(a), np.asarray(ref)
     assert a.shape == ref.shape
     scale = max(1.0, float(np.max(np.abs(ref))))
-    err = np.abs(a - ref)
-    bad = float(np.mean(err > tol * scale))
-    assert bad <= frac and float(err.max()) <= loose * scale, \
-        "%s flipped fraction %.2e, max err %.3e" % (what, bad, float(err.max()))
+    err = float(np.max(np.abs(a - ref)))
+    assert err <= loose * scale, "%s max err %.3e" % (what, err)
 
 
 def mk(gmin, gmax, N, pd):
@@ -313,6 +314,13 @@ def test_ode_cfl_vs_reference_golden(golden, scheme):
             ref_t = float(G["rk3_%s_t%d" % (scheme, k + 1)])
             assert isinstance(t, np.float64) and abs(t - ref_t) <= 1e-13 * ref_t
             (close if scheme.startswith("WENO") else close_eno)(y, G["rk3_%s_y%d" % (scheme, k + 1)], 1e-11)
+    # strict comparison on the noisy initial data (no exact ENO ties), every scheme
+    y = G["dubn_data"].reshape(-1, 1)
+    t = 0.
+    for k in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    assert abs(t - float(G["rk3n_%s_t5" % scheme])) <= 1e-13
+    close(y, G["rk3n_%s_y5" % scheme], 1e-11)
     op2 = L.odeCFLset(L.Bundle(dict(factorCFL=.95, singleStep='off')))
     t, y, _ = L.odeCFL2(L.termLaxFriedrichs, [0., 0.02], G["dub_data"].reshape(-1, 1), op2, sd)
     assert abs(t - float(G["rk2_%s_t" % scheme])) <= 1e-13
@@ -336,6 +344,11 @@ def test_ode_cfl3_double_integrator_vs_reference_golden(golden):
         t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
     assert abs(t - float(G["di_rk3_ENO3_t5"])) <= 1e-13
     close_eno(y, G["di_rk3_ENO3_y5"], 1e-11)
+    y = G["din_data"].reshape(-1, 1)
+    t = 0.
+    for _ in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    close(y, G["din_rk3_ENO3_y5"], 1e-11)
 
 
 def test_ode_generic_path_equals_device_path_and_hooks():

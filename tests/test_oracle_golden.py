@@ -179,6 +179,13 @@ def test_ode_cfl_vs_reference(golden, scheme):
             ref_t = float(G["rk3_%s_t%d" % (scheme, k + 1)])
             assert abs(t - ref_t) <= 1e-14 * ref_t
             close(y, G["rk3_%s_y%d" % (scheme, k + 1)], 1e-12)
+    # noisy initial data (no exact ENO ties)
+    y = G["dubn_data"].reshape(-1, 1)
+    t = 0.
+    for k in range(5):
+        t, y = O.ode_cfl_3(term, [t, 10.], y, 0.8, single_step=True)
+    assert abs(t - float(G["rk3n_%s_t5" % scheme])) <= 1e-14
+    close(y, G["rk3n_%s_y5" % scheme], 1e-12)
     t, y = O.ode_cfl_2(term, [0., 0.02], G["dub_data"].reshape(-1, 1), 0.95)
     assert abs(t - float(G["rk2_%s_t" % scheme])) <= 1e-14
     close(y, G["rk2_%s_y" % scheme], 1e-12)
@@ -201,6 +208,11 @@ def test_ode_cfl3_double_integrator_vs_reference(golden):
         t, y = O.ode_cfl_3(term, [t, 10.], y, 0.8, single_step=True)
     assert abs(t - float(G["di_rk3_ENO3_t5"])) <= 1e-14
     close(y, G["di_rk3_ENO3_y5"], 1e-12)
+    y = G["din_data"].reshape(-1, 1)
+    t = 0.
+    for _ in range(5):
+        t, y = O.ode_cfl_3(term, [t, 10.], y, 0.8, single_step=True)
+    close(y, G["din_rk3_ENO3_y5"], 1e-12)
 
 
 # ---------------------------------------------------------------- known answers
