@@ -131,14 +131,17 @@ int hj_read_step_bound(hj_ctx* ctx, int bound_slot, double* step_bound_host, dou
  * with a native Hamiltonian whose alpha does not depend on the data (all HJ_HAM_* above): ONE step,
  * `order` fused substeps, no host synchronisation.  dt = min(factor_cfl*stepBound, tf-t0, max_step)
  * (ode_cfl_3.py:142).  work0/work1: caller scratch, same size as y (work1 unused for order<3,
- * may be NULL).  y_out may alias y_in for order 1 only.  t_out/dt_out: host. */
+ * may be NULL).  y_out must not alias y_in (stencil).  t_out/dt_out: host. */
 int hj_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double t0,
                double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
                void* y_out, void* work0, void* work1, double* t_out, double* dt_out);
 
 /* stepBound of a native Hamiltonian on this grid (alpha is data-independent for all HJ_HAM_*);
- * computed once per (ham_id, params) and cached.  Synchronises on the first call. */
-int hj_static_step_bound(hj_ctx* ctx, int ham_id, const double* ham_params, double* step_bound_host);
+ * computed once per (ham_id, params) and cached.  Synchronises on the first call.
+ * alpha_max_host (nullable): the ndim per-dimension maxima of alpha (a slab-decomposed run
+ * all-reduces them and forms stepBound = 1/sum_d max alpha_d / dx_d itself). */
+int hj_static_step_bound(hj_ctx* ctx, int ham_id, const double* ham_params, double* step_bound_host,
+                         double* alpha_max_host);
 
 /* max over the (unstripped) first-divided-difference table of D1^2, per dim: the 'maxOverGrid'
  * epsilon of true WENO5 (upwind_first_weno5a.py:69-70,153-156).  out_dev: ndim values of the ctx

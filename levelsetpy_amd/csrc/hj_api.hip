@@ -723,13 +723,14 @@ int hj_lf_term(hj_ctx* c, int scheme, int ham, const double* par, double t, int 
     return HJ_OK;
 }
 
-int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb) {
+int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, double* amax) {
     if (!c || !sb) return fail(HJ_EINVAL, "null argument");
     int rc = check_ham(c, ham, par);
     if (rc) return rc;
     const int np = ham_npar(ham);
     if (c->sb_valid && c->sb_ham == ham && memcmp(c->sb_par, par, sizeof(double) * np) == 0) {
         *sb = c->sb_val;
+        if (amax) for (int d = 0; d < c->ndim; ++d) amax[d] = c->sb_alpha[d];
         return HJ_OK;
     }
     HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -768,6 +769,7 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb) {
     memcpy(c->sb_par, par, sizeof(double) * np);
     c->sb_valid = true;
     *sb = c->sb_val;
+    if (amax) for (int d = 0; d < c->ndim; ++d) amax[d] = c->sb_alpha[d];
     return HJ_OK;
 }
 
@@ -780,7 +782,7 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     if (order == 3 && !work1) return fail(HJ_EINVAL, "work1 required for order 3");
     if (y_out == y_in) return fail(HJ_EINVAL, "y_out must not alias y_in");
     double sb;
-    int rc = hj_static_step_bound(c, ham, par, &sb);
+    int rc = hj_static_step_bound(c, ham, par, &sb, nullptr);
     if (rc) return rc;
     // deltaT = min(factorCFL*stepBound, tspan[1]-t, maxStep)  (ode_cfl_3.py:142)
     const double dt = std::min(std::min(factor_cfl * sb, tf - t0), max_step);

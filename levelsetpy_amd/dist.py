@@ -1,0 +1,295 @@
+"""Multi-GPU time stepping: 1-D slab decomposition of axis 0 with ghost-plane halo exchange.
+
+No reference counterpart (the reference is single-process).  One process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
+
+  * axis 0 is the slowest-varying axis (C order), so a slab is one contiguous block and a ghost
+    plane is one contiguous run of N1*...*N_{D-1} values;
+  * every rank stores its slab with HJ_STENCIL (3) pad planes below and above; the pads on an
+    internal slab face are filled by the neighbour's edge planes (`HaloExchanger`), the pads on a
+    physical boundary are unused (the kernel synthesises extrapolated ghosts there).  With a
+    periodic axis 0 the ring closes rank P-1 <-> 0;
+  * per RK substep: (1) the EDGE plane ranges [0,3) and [n-3,n) of the output are computed first,
+    (2) their exchange is started on a second stream while (3) the INTERIOR planes are computed
+    on the compute stream, (4) the next substep waits for both.  Only nearest neighbours talk
+    (<= 2 of the 7 xGMI links), 3*plane bytes per direction;
+  * scalars: all native Hamiltonians have data-independent alpha, so stepBound is one
+    all-reduce(MAX) of D numbers at set-up; true WENO5 adds one all-reduce(MAX) of D numbers per
+    substep for its 'maxOverGrid' epsilon.
+
+`SlabIntegrator` holds the decomposition / exchange / RK sequencing and is device-agnostic: the
+arithmetic comes from a backend object.  `HipSlabBackend` (the product) calls libhj_mi355x.so; the
+CPU tests plug in an oracle-backed backend to exercise the same sequencing under gloo.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+HALO = _ffi.STENCIL
+
+
+class SlabDecomposition(object):
+    """Planes [begin, end) of axis 0 owned by `rank`; the remainder is spread over the low ranks
+    (513 = 8*64+1 -> rank 0 gets 65 planes)."""
+
+    def __init__(self, n0, world, rank, periodic0=False):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError("bad rank/world")
+        base, rem = divmod(int(n0), world)
+        if base < HALO:
+            raise ValueError("axis 0 has %d planes: fewer than %d per rank for %d ranks" % (n0, HALO, world))
+        self.n0, self.world, self.rank, self.periodic0 = int(n0), world, rank, bool(periodic0)
+        self.counts = [base + (1 if r < rem else 0) for r in range(world)]
+        self.begin = sum(self.counts[:rank])
+        self.end = self.begin + self.counts[rank]
+        self.n_local = self.counts[rank]
+        # neighbours (None on a physical boundary)
+        self.lo = rank - 1 if rank > 0 else (world - 1 if (periodic0 and world > 1) else None)
+        self.hi = rank + 1 if rank < world - 1 else (0 if (periodic0 and world > 1) else None)
+
+    @property
+    def halo_lo(self):
+        return self.lo is not None
+
+    @property
+    def halo_hi(self):
+        return self.hi is not None
+
+
+class HaloExchanger(object):
+    """Fills the pad planes of a padded slab buffer (n_local + 2*HALO planes) from the neighbours.
+
+    Message order per pair is fixed so that the case lo == hi (two ranks, periodic axis) matches:
+    sends  [my low planes -> lo, my high planes -> hi]; receives [hi pad <- hi, lo pad <- lo]."""
+
+    def __init__(self, slab, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.slab = slab
+        self.group = group
+
+    def start(self, buf):
+        """Post the sends/receives for `buf`; returns the request list (wait with finish())."""
+        dist, s = self.dist, self.slab
+        n = s.n_local
+        ops = []
+        if s.lo is not None:
+            ops.append(dist.P2POp(dist.isend, buf[HALO:2 * HALO], s.lo, group=self.group, tag=0))
+        if s.hi is not None:
+            ops.append(dist.P2POp(dist.isend, buf[n:n + HALO], s.hi, group=self.group, tag=1))
+        if s.hi is not None:
+            ops.append(dist.P2POp(dist.irecv, buf[n + HALO:n + 2 * HALO], s.hi, group=self.group, tag=0))
+        if s.lo is not None:
+            ops.append(dist.P2POp(dist.irecv, buf[0:HALO], s.lo, group=self.group, tag=1))
+        if not ops:
+            return []
+        return dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def finish(reqs):
+        for r in reqs:
+            r.wait()
+
+    def exchange(self, buf):
+        self.finish(self.start(buf))
+
+
+class SlabIntegrator(object):
+    """odeCFL{1,2,3} single steps on a slab-decomposed grid (native Hamiltonians)."""
+
+    # (stage, y source, y0 source, destination) per substep; buffers named cur/w0/w1/nxt
+    PLANS = {
+        1: [(_ffi.STAGE_EULER, "cur", None, "nxt")],
+        2: [(_ffi.STAGE_EULER, "cur", None, "w0"), (_ffi.STAGE_RK2_FULL, "w0", "cur", "nxt")],
+        3: [(_ffi.STAGE_EULER, "cur", None, "w0"), (_ffi.STAGE_RK3_HALF, "w0", "cur", "w1"),
+            (_ffi.STAGE_RK3_FULL, "w1", "cur", "nxt")],
+    }
+
+    def __init__(self, slab, backend, dx, order=3, factor_cfl=0.8, group=None, needs_eps=False,
+                 exchanger=None, allreduce_max=None):
+        """exchanger / allreduce_max: transport overrides (tests run several ranks inside one
+        process); default is torch.distributed (RCCL on GPUs, gloo on CPU)."""
+        import torch
+        self.torch = torch
+        self.slab, self.be, self.order, self.factor_cfl = slab, backend, order, factor_cfl
+        self.group = group
+        self.needs_eps = needs_eps
+        self.ex = exchanger if exchanger is not None else HaloExchanger(slab, group)
+        if allreduce_max is None:
+            def allreduce_max(t):
+                import torch.distributed as dist
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self._allreduce_max = allreduce_max
+        self.buf = {k: backend.alloc() for k in ("cur", "w0", "w1", "nxt")}
+        # stepBound = 1 / sum_d max_grid(alpha_d)/dx_d with the max over ALL ranks
+        # (artificial_diss_glf.py:101-109); alpha is data-independent for the native systems
+        amax = torch.tensor(backend.local_alpha_max(), dtype=torch.float64, device=backend.device)
+        if slab.world > 1:
+            self._allreduce_max(amax)
+        self.alpha_max = [float(v) for v in amax.cpu()]
+        self.step_bound = 1.0 / sum(a / d for a, d in zip(self.alpha_max, dx))
+
+    # -------------------------------------------------------------------------------------
+    def set_state(self, local_planes):
+        """local_planes: array of this rank's n_local planes; fills `cur` and its halos."""
+        n = self.slab.n_local
+        self.buf["cur"][HALO:HALO + n].copy_(local_planes)
+        self.ex.exchange(self.buf["cur"])
+        self.be.sync()
+
+    def state(self):
+        n = self.slab.n_local
+        return self.buf["cur"][HALO:HALO + n]
+
+    def _eps(self, src):
+        """global max(D1^2) per dim for true WENO5 (needs src's halos in place)."""
+        v = self.be.max_d1sq(src)
+        if self.slab.world > 1:
+            self._allreduce_max(v)
+        self.be.set_weno_eps(v)
+
+    def step(self, t, tf=float("inf"), max_step=float("inf")):
+        """One odeCFLn step: dt = min(factorCFL*stepBound, tf - t, maxStep) (ode_cfl_3.py:142)."""
+        be, s = self.be, self.slab
+        n = s.n_local
+        dt = min(self.factor_cfl * self.step_bound, tf - t, max_step)
+        for (stage, ysrc, y0src, dst) in self.PLANS[self.order]:
+            y, y0, out = self.buf[ysrc], (self.buf[y0src] if y0src else None), self.buf[dst]
+            if self.needs_eps:
+                self._eps(y)
+            # (1) edge planes first: they are what the neighbours wait for
+            lo_e = min(HALO, n) if s.halo_lo else 0
+            hi_b = max(n - HALO, lo_e) if s.halo_hi else n
+            if lo_e > 0:
+                be.substep(stage, dt, y, y0, out, 0, lo_e)
+            if hi_b < n:
+                be.substep(stage, dt, y, y0, out, hi_b, n)
+            # (2) start the exchange of `out`'s edge planes on the side stream
+            reqs = be.on_comm_stream(lambda: self.ex.start(out))
+            # (3) interior planes overlap with the exchange
+            if hi_b > lo_e:
+                be.substep(stage, dt, y, y0, out, lo_e, hi_b)
+            # (4) the next substep reads out's pads
+            be.join_comm(reqs, self.ex.finish)
+        self.buf["cur"], self.buf["nxt"] = self.buf["nxt"], self.buf["cur"]
+        if self.order == 1:
+            return t + dt, dt
+        t1 = t + dt
+        t2 = t1 + dt
+        if self.order == 2:
+            return 0.5 * (t + t2), dt                       # ode_cfl_2.py:200
+        t_half = 0.25 * (3 * t + t2)                       # ode_cfl_3.py:188
+        return (1.0 / 3.0) * (t + 2 * (t_half + dt)), dt   # :221,236
+
+
+class HipSlabBackend(object):
+    """The product backend: padded device buffers + hj_rk_substep over plane ranges."""
+
+    def __init__(self, grid, slab, scheme_id, ham_id, ham_params, dtype="float64", overlap=True):
+        import torch
+        from .context import DeviceGrid
+        self.torch = torch
+        self.slab = slab
+        self.dg = DeviceGrid(grid, dtype, None, (slab.begin, slab.end, slab.halo_lo, slab.halo_hi))
+        self.device = self.dg.device
+        self.sid, self.ham, self.par = scheme_id, ham_id, _ffi.darr(ham_params)
+        self.plane_shape = self.dg.shape[1:]
+        self.n = slab.n_local
+        self.comm_stream = torch.cuda.Stream(device=self.device) if overlap else None
+        self._slot = 0
+        self._eps = None
+        self.dg.bind_stream()
+
+    def alloc(self):
+        return self.torch.zeros((self.n + 2 * HALO,) + tuple(self.plane_shape), dtype=self.dg.tdtype,
+                                device=self.device)
+
+    def _interior_ptr(self, buf):
+        return C.c_void_p(buf[HALO:].data_ptr()) if buf is not None else C.c_void_p(0)
+
+    def substep(self, stage, dt, y, y0, out, p0, p1):
+        dg = self.dg
+        self._slot = (self._slot + 1) % (_ffi.BOUND_SLOTS - 1)
+        _ffi.check(dg.lib.hj_rk_substep(dg.ctx, self.sid, self.ham, self.par, 0.0, stage, float(dt), 0,
+                                        self._interior_ptr(y), self._interior_ptr(y0),
+                                        self._interior_ptr(out), self._slot, int(p0), int(p1)))
+
+    def local_alpha_max(self):
+        dg = self.dg
+        sb = C.c_double()
+        am = (C.c_double * 4)()
+        _ffi.check(dg.lib.hj_static_step_bound(dg.ctx, self.ham, self.par, C.byref(sb), am))
+        return [am[d] for d in range(dg.dim)]
+
+    def max_d1sq(self, y):
+        dg = self.dg
+        v = self.torch.empty(dg.dim, dtype=dg.tdtype, device=self.device)
+        _ffi.check(dg.lib.hj_max_d1sq(dg.ctx, self._interior_ptr(y), C.c_void_p(v.data_ptr())))
+        return v
+
+    def set_weno_eps(self, v):
+        self._eps = v   # keep alive
+        _ffi.check(self.dg.lib.hj_ctx_set_weno_eps_source(self.dg.ctx, C.c_void_p(v.data_ptr())))
+
+    def on_comm_stream(self, fn):
+        torch = self.torch
+        if self.comm_stream is None:
+            return fn()
+        cur = torch.cuda.current_stream(self.device)
+        self.comm_stream.wait_stream(cur)           # edge planes are complete before they are sent
+        with torch.cuda.stream(self.comm_stream):
+            return fn()
+
+    def join_comm(self, reqs, finish):
+        torch = self.torch
+        if self.comm_stream is None:
+            finish(reqs)
+            return
+        with torch.cuda.stream(self.comm_stream):
+            finish(reqs)                            # NCCL: orders the comm stream after the transfers
+        torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def bench_slab(args, rank, world):
+    """bench.py's N > 1 leg: every rank owns an n^3 slab of an (N*n) x n x n Dubins grid."""
+    import time
+    import torch
+    import torch.distributed as dist
+    import levelsetpy_amd as L
+    n = args.n
+    dx0 = 4.0 / (n - 1)
+    gmin = np.array([[-.75, -1.25, -np.pi]]).T
+    gmax = np.array([[-.75 + dx0 * (world * n - 1), 1.25, np.pi * (1 - 2 / n)]]).T
+    g = L.createGrid(gmin, gmax, np.array([[world * n], [n], [n]], dtype=np.int64), 2, low_mem=True)
+    slab = SlabDecomposition(world * n, world, rank, False)
+    be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS[args.scheme], _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], args.dtype)
+    integ = SlabIntegrator(slab, be, [float(v) for v in np.asarray(g.dx).ravel()], 3, 0.8,
+                           needs_eps=(args.scheme == "WENO5"))
+    # cylinder initial data for this slab only (sparse xs: broadcasting)
+    x0 = np.asarray(g.vs[0]).ravel()[slab.begin:slab.end].reshape(-1, 1, 1)
+    x1 = np.asarray(g.vs[1]).ravel().reshape(1, -1, 1)
+    d0 = np.sqrt(x0 ** 2 + x1 ** 2) - 0.5 + np.zeros((1, 1, n))
+    integ.set_state(torch.as_tensor(d0, dtype=be.dg.tdtype, device=be.device))
+    t = 0.0
+    for _ in range(args.warmup):
+        t, _dt = integ.step(t)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        t, _dt = integ.step(t)
+    e1.record()
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    assert bool(torch.isfinite(integ.state()).all())
+    return {"wall": wall, "dev_ms": e0.elapsed_time(e1), "cells": n ** 3,
+            "parallelism": "slab%d (axis-0 slabs, 3-plane halo exchange over RCCL, edge-first overlap)" % world}

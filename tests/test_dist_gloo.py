@@ -1,0 +1,173 @@
+"""CPU, world_size 2, gloo: the slab decomposition, halo exchange and RK sequencing of
+levelsetpy_amd.dist (the N>1 path) with the arithmetic supplied by the CPU oracle.  The same
+SlabIntegrator drives the HIP backend on GPUs; here it must reproduce the undivided oracle run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from levelsetpy_amd import _ffi  # noqa: E402
+from levelsetpy_amd.dist import SlabDecomposition, SlabIntegrator, HaloExchanger, HALO  # noqa: E402
+from oracle import hj_oracle as O  # noqa: E402
+
+
+class OracleSlabBackend(object):
+    """Test double for HipSlabBackend: padded CPU buffers, arithmetic by the NumPy oracle."""
+    device = torch.device("cpu")
+
+    def __init__(self, og_global, slab, scheme):
+        self.slab, self.scheme = slab, scheme
+        b, e = slab.begin, slab.end
+        g = O.Grid(og_global.min, og_global.max, og_global.N.ravel(), None)
+        g.bc = list(og_global.bc)
+        g.vs = [v.copy() for v in og_global.vs]
+        g.vs[0] = g.vs[0][b:e]
+        g.xs = np.meshgrid(*g.vs, indexing='ij')
+        g.shape = (e - b,) + og_global.shape[1:]
+        self.g = g
+        self.sys = O.DubinsRel(g, 1, 1)
+        self.n = e - b
+        self.eps = None
+
+    def alloc(self):
+        return torch.zeros((self.n + 2 * HALO,) + self.g.shape[1:], dtype=torch.float64)
+
+    def _halo(self, buf):
+        lo = buf[:HALO].numpy() if self.slab.halo_lo else None
+        hi = buf[self.n + HALO:].numpy() if self.slab.halo_hi else None
+        return (lo, hi)
+
+    def substep(self, stage, dt, y, y0, out, p0, p1):
+        yi = y[HALO:HALO + self.n].numpy()
+        ydot, _ = O.term_lax_friedrichs(self.g, self.sys, self.scheme, 0., yi.reshape(-1), self._halo(y),
+                                        self.eps)
+        ye = yi + dt * ydot.reshape(yi.shape)
+        if stage == _ffi.STAGE_EULER:
+            o = ye
+        else:
+            y0i = y0[HALO:HALO + self.n].numpy()
+            if stage == _ffi.STAGE_RK3_HALF:
+                o = 0.25 * (3 * y0i + ye)
+            elif stage == _ffi.STAGE_RK3_FULL:
+                o = (1 / 3) * (y0i + 2 * ye)
+            else:
+                o = 0.5 * (y0i + ye)
+        out[HALO + p0:HALO + p1] = torch.from_numpy(np.ascontiguousarray(o[p0:p1]))
+
+    def local_alpha_max(self):
+        return [float(np.max(self.sys.dissipation(0, None, None, None, None, d))) for d in range(3)]
+
+    def max_d1sq(self, y):
+        yi = y[HALO:HALO + self.n].numpy()
+        v = [O.max_d1_squared(self.g, yi, d, self._halo(y) if d == 0 else None) for d in range(3)]
+        return torch.tensor(v, dtype=torch.float64)
+
+    def set_weno_eps(self, v):
+        self.eps = [float(x) for x in v]
+
+    def on_comm_stream(self, fn):
+        return fn()
+
+    def join_comm(self, reqs, finish):
+        finish(reqs)
+
+    def sync(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CASES = [("WENO5_ASSHIPPED", False, 3), ("ENO3", True, 3), ("WENO5", False, 2), ("ENO2", True, 1)]
+N, NSTEPS = (13, 8, 9), 2
+
+
+def _data(og):
+    return O.shape_cylinder(og, 2, None, .5) + 0.05 * np.random.default_rng(3).standard_normal(og.shape)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for ci, (scheme, periodic0, order) in enumerate(CASES):
+            pd = [0, 2] if periodic0 else [2]
+            og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / N[2])], N, pd)
+            data = _data(og)
+            slab = SlabDecomposition(N[0], world, rank, periodic0)
+            be = OracleSlabBackend(og, slab, scheme)
+            integ = SlabIntegrator(slab, be, [float(v) for v in og.dx.ravel()], order, 0.8,
+                                   needs_eps=(scheme == "WENO5"))
+            integ.set_state(torch.from_numpy(np.ascontiguousarray(data[slab.begin:slab.end])))
+            t = 0.0
+            for _ in range(NSTEPS):
+                t, _dt = integ.step(t)
+            q.put((ci, rank, slab.begin, slab.end, t, integ.step_bound, integ.state().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference(scheme, periodic0, order):
+    pd = [0, 2] if periodic0 else [2]
+    og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / N[2])], N, pd)
+    data = _data(og)
+    sys_ = O.DubinsRel(og, 1, 1)
+    term = lambda t, y: O.term_lax_friedrichs(og, sys_, scheme, t, y)  # noqa: E731
+    ode = {1: O.ode_cfl_1, 2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
+    y, t = data.reshape(-1, 1), 0.0
+    for _ in range(NSTEPS):
+        t, y = ode(term, [t, 10.], y, 0.8, single_step=True)
+    return t, y.reshape(og.shape), term(0., data.reshape(-1, 1))[1]
+
+
+def test_two_rank_slab_runs_equal_single_domain():
+    """All CASES in one pair of gloo ranks (one spawn): extrapolated and periodic axis 0 (the ring
+    closes rank 1 <-> 0 through the same peer), RK1/2/3, ENO2's width-2 stencil inside the 3-plane
+    halo, and true WENO5 with its all-reduced epsilon."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2 * len(CASES))]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for ci, (scheme, periodic0, order) in enumerate(CASES):
+        t_ref, y_ref, sb_ref = _reference(scheme, periodic0, order)
+        got = np.zeros(N)
+        parts = [r for r in res if r[0] == ci]
+        assert len(parts) == 2
+        for (_ci, _rank, b, e, t, sb, y) in parts:
+            got[b:e] = y
+            assert abs(t - t_ref) <= 1e-14
+            assert abs(sb - sb_ref) <= 1e-14 * sb_ref        # all-reduced alpha maxima
+        assert np.max(np.abs(got - y_ref)) <= 1e-12, (scheme, periodic0, order)
+
+
+def test_slab_decomposition_bookkeeping():
+    s = [SlabDecomposition(513, 8, r) for r in range(8)]
+    assert [x.n_local for x in s] == [65] + [64] * 7
+    assert s[0].begin == 0 and s[-1].end == 513 and all(a.end == b.begin for a, b in zip(s, s[1:]))
+    assert s[0].lo is None and s[0].hi == 1 and s[7].hi is None and not s[0].halo_lo and s[0].halo_hi
+    p = [SlabDecomposition(129, 8, r, True) for r in range(8)]
+    assert p[0].lo == 7 and p[7].hi == 0
+    one = SlabDecomposition(20, 1, 0, True)
+    assert one.lo is None and one.hi is None        # a single rank wraps inside the kernel
+    with pytest.raises(ValueError):
+        SlabDecomposition(10, 8, 0)
