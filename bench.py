@@ -36,12 +36,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=201, help="grid points per axis (per rank along axis 0)")
-    ap.add_argument("--scheme", default="WENO5", choices=["WENO5", "WENO5_ASSHIPPED", "ENO3", "ENO2"])
+    ap.add_argument("--scheme", default="WENO5_ASSHIPPED", choices=["WENO5", "WENO5_ASSHIPPED", "ENO3", "ENO2"],
+                    help="WENO5_ASSHIPPED = what the reference's upwindFirstWENO5 computes (parity-pinned; "
+                         "headline); WENO5 = the intended nonlinear scheme (reported in 'also')")
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=81, help="grid size of the CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--extra-schemes", default="WENO5_ASSHIPPED",
+    ap.add_argument("--cpu-n", type=int, default=101, help="grid size of the CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=16)
+    ap.add_argument("--extra-schemes", default="WENO5",
                     help="comma list of further schemes timed after the headline (reported in 'also')")
     return ap.parse_args()
 
@@ -104,6 +106,19 @@ def cpu_baseline(n, steps, scheme):
     return {"value": n ** 3 * 3 * steps / sec, "unit": "cell-substeps/s", "cores": 1, "kind": "port",
             "sample": "%d RK3 steps of Dubins-relative %d^3 %s+GLF fp64 with oracle/hj_oracle.py (NumPy, "
                       "single-threaded) in %.1f s; host has %d cores" % (steps, n, scheme, sec, os.cpu_count())}
+
+
+def measured_traffic(n, scheme, dtype, world):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md's gfx950 correction); None when no pass exists for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tab = json.load(f)
+        rec = tab.get("%d/%s/%s" % (n, scheme, dtype))
+        return rec["bytes_per_launch"] if (rec and world == 1) else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
@@ -174,7 +189,7 @@ def main():
                                (("%d" % n) if world == 1 else ("%dx%d" % (world, n)), n, n, a.scheme),
                    "scheme": a.scheme, "parallelism": sched, "substeps_per_step": 3},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, a.scheme, a.dtype, world),
                      "kernel": "fused_substep_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": cells * bps},
         "per_gpu_value": per_gpu,
@@ -182,7 +197,7 @@ def main():
     if also:
         out["also"] = also
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, "WENO5_ASSHIPPED")
+        out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.scheme)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
