@@ -162,6 +162,11 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
     int64_t max_chunks = std::max<int64_t>(1, planes / c->min_chunk);
     int64_t nch = std::min(want, max_chunks);
     best.chunk = (int)((planes + nch - 1) / nch);
+    // one buffer descriptor spans a chunk plus 3 planes either side: keep it below 4 GiB
+    const double plane_bytes = (double)(c->total / c->N[0]) * (double)c->esz;
+    const int64_t chunk_cap = (int64_t)(4294967295.0 / plane_bytes) - 2 * HJ_STENCIL;
+    if (chunk_cap < 1) { best.ok = false; return best; }
+    if (best.chunk > chunk_cap) best.chunk = (int)chunk_cap;
     best.nchunks = (int)((planes + best.chunk - 1) / best.chunk);
     best.nblocks = best.nchunks * best.ntiles;
     best.bpx = (best.nblocks + 7) / 8;
@@ -230,6 +235,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
         A.bc[d] = c->bc[d];
         A.km[d] = c->tz[d] ? T(-1) : T(1);
         fill_stencil_constants<T>(c->dx[d], A.K[d]);
+        A.sc[d] = (SCHEME == HJ_WENO5_ASSHIPPED) ? (T)((1.0 / c->dx[d]) * (1.0 / 60.0)) : T(1);
         A.pstride[d] = (d >= 1) ? (int)st : 0;
         if (d == 0) A.stride0 = st;
         st *= c->N[d];
@@ -280,6 +286,8 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
     A.bound = s.bound;
     fill_grid<T, ND>(c, A.G);
+    for (int d = 0; d < ND; ++d)
+        A.sc[d] = (SCHEME == HJ_WENO5_ASSHIPPED) ? (T)((1.0 / c->dx[d]) * (1.0 / 60.0)) : T(1);
     const long long plane = c->total / c->N[0];
     A.cell_begin = s.p0 * plane;
     A.cell_end = s.p1 * plane;

@@ -168,10 +168,12 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, T& pc, 
         // in terms of phi: with D_k = phi[i+k]-phi[i-k], S_k = phi[i+k]+phi[i-k]
         //   pc = (45 D1 - 9 D2 + D3)/(60dx)            (6th-order central difference)
         //   hd = (S3 - 6 S2 + 15 S1 - 20 phi_i)/(60dx)  (scaled 6th difference)
+        // returned WITHOUT the 1/(60dx) factor (see the scaling note at the Hamiltonians):
+        // the coefficients are compile-time constants.
         const T D1 = v[4] - v[2], D2 = v[5] - v[1], D3 = v[6] - v[0];
         const T S1 = v[4] + v[2], S2 = v[5] + v[1], S3 = v[6] + v[0];
-        pc = K[6] * D1 + (K[7] * D2 + K[8] * D3);
-        hd = K[9] * S1 + (K[10] * S2 + (K[8] * S3 + K[11] * v[3]));
+        pc = T(45) * D1 + (T(-9) * D2 + D3);
+        hd = T(15) * S1 + (T(-6) * S2 + (S3 + T(-20) * v[3]));
     } else {
         T L, R;
         upwind<SCHEME, T>(v, K, eps, L, R);
@@ -190,10 +192,15 @@ template <typename T> struct HamTables {
 };
 
 // Interface (all three systems):
-//   Cell  cell(P, idx)      -- constants of a grid column (depend on idx[1..] only); the fused kernel
+//   Cell  cell(P, idx, sc)  -- constants of a grid column (depend on idx[1..] only); the fused kernel
 //                              evaluates this once per block, outside the axis-0 march
-//   Plane plane(P, i0)      -- wave-uniform values of one axis-0 plane
-//   eval(P, cell, plane, p, H, alpha)
+//   Plane plane(P, i0, sc)  -- wave-uniform values of one axis-0 plane
+//   eval(P, cell, plane, sc, q, H, alpha_s)
+// Scaling: the derivative stencils may hand over UNSCALED costates q with p_d = sc[d]*q_d (the
+// as-shipped WENO5 does, sc[d] = 1/(60 dx_d), so that its stencil coefficients are compile-time
+// constants instead of 18 runtime SGPR pairs).  cell/plane fold sc into their constants; eval
+// returns H(x, p) exactly and alpha_s[d] = sc[d]*alpha_d (what multiplies the unscaled half-jump).
+// The kernel divides the max of alpha_s by sc[d] before publishing it.  Other schemes pass sc = 1.
 template <typename T> struct HamDubinsRel {
     static constexpr int ND = 3;
     static constexpr int ID = HJ_HAM_DUBINS_REL;
@@ -202,29 +209,35 @@ template <typename T> struct HamDubinsRel {
     // alpha[d] varies along the march (axis 0) only for the dims in this mask; the others are
     // column constants and their max is taken once, outside the plane loop
     static constexpr unsigned PLANE_DEP = 0x2;
-    struct Cell { T a, b, x1, alpha0; };
-    struct Plane { T x0, awx0; };
-    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx) {
+    // with p_d = sc_d q_d:  a' = sc0 a, b' = sc1 b, x1' = sc0 x1, x0' = sc1 x0
+    struct Cell { T a, b, x1, alpha0; };      // a', b', x1', sc0*alpha0
+    struct Plane { T x0, awx0; };             // x0', sc1*|w x0|
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
         Cell c;
-        c.a = P.par[0] - P.par[1] * P.aux[0][idx[2]];
-        c.b = P.par[1] * P.aux[1][idx[2]];
-        c.x1 = P.coord[1][idx[1]];
-        c.alpha0 = t_abs(c.a) + t_abs(P.par[2] * c.x1);
+        const T a = P.par[0] - P.par[1] * P.aux[0][idx[2]];
+        const T b = P.par[1] * P.aux[1][idx[2]];
+        const T x1 = P.coord[1][idx[1]];
+        c.alpha0 = sc[0] * (t_abs(a) + t_abs(P.par[2] * x1));
+        c.a = sc[0] * a;
+        c.b = sc[1] * b;
+        c.x1 = sc[0] * x1;
         return c;
     }
-    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0) {
+    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T* sc) {
         Plane u;
-        u.x0 = P.coord[0][i0];
-        u.awx0 = t_abs(P.par[2] * u.x0);
+        const T x0 = P.coord[0][i0];
+        u.x0 = sc[1] * x0;
+        u.awx0 = sc[1] * t_abs(P.par[2] * x0);
         return u;
     }
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& u,
-                                                const T* p, T& H, T* alpha) {
+                                                const T* sc, const T* q, T& H, T* alpha) {
         const T w = P.par[2];
-        H = p[0] * c.a - p[1] * c.b - w * t_abs(p[0] * c.x1 - p[1] * u.x0 - p[2]) + w * t_abs(p[2]);
+        const T p2 = sc[2] * q[2];
+        H = q[0] * c.a - q[1] * c.b - w * t_abs(q[0] * c.x1 - q[1] * u.x0 - p2) + w * t_abs(p2);
         alpha[0] = c.alpha0;
         alpha[1] = t_abs(c.b) + u.awx0;
-        alpha[2] = P.par[3];
+        alpha[2] = sc[2] * P.par[3];
     }
 };
 
@@ -233,20 +246,22 @@ template <typename T> struct HamDoubleIntegrator {
     static constexpr int ID = HJ_HAM_DOUBLE_INTEGRATOR;
     // H = -(p1 x2 - |p2| u)  (:71-74); alpha = { |x2|, |u| }  (:84-89)
     static constexpr unsigned PLANE_DEP = 0x0;
-    struct Cell { T x1; };
+    struct Cell { T x1, alpha0; };            // sc0*x2, sc0*|x2|
     struct Plane { int unused; };
-    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx) {
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
         Cell c;
-        c.x1 = P.coord[1][idx[1]];
+        const T x1 = P.coord[1][idx[1]];
+        c.x1 = sc[0] * x1;
+        c.alpha0 = sc[0] * t_abs(x1);
         return c;
     }
-    __device__ static __forceinline__ Plane plane(const HamTables<T>&, int) { return Plane{0}; }
+    __device__ static __forceinline__ Plane plane(const HamTables<T>&, int, const T*) { return Plane{0}; }
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane&,
-                                                const T* p, T& H, T* alpha) {
-        const T u = P.par[0];
-        H = -(p[0] * c.x1 - t_abs(p[1]) * u);
-        alpha[0] = t_abs(c.x1);
-        alpha[1] = t_abs(u);
+                                                const T* sc, const T* q, T& H, T* alpha) {
+        const T us = sc[1] * P.par[0];
+        H = -(q[0] * c.x1 - t_abs(q[1]) * us);
+        alpha[0] = c.alpha0;
+        alpha[1] = t_abs(us);
     }
 };
 
@@ -259,7 +274,7 @@ template <typename T> struct HamDoublePendulum {
     static constexpr unsigned PLANE_DEP = 0xA;
     struct Cell { T w1, w2, s2, c2; };
     struct Plane { T s1, c1; };
-    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx) {
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T*) {
         Cell c;
         c.w1 = P.coord[1][idx[1]];
         c.w2 = P.coord[3][idx[3]];
@@ -267,14 +282,18 @@ template <typename T> struct HamDoublePendulum {
         c.c2 = P.aux[3][idx[2]];
         return c;
     }
-    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0) {
+    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T*) {
         Plane u;
         u.s1 = P.aux[0][i0];
         u.c1 = P.aux[1][i0];
         return u;
     }
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& pl,
-                                                const T* p, T& H, T* alpha) {
+                                                const T* sc, const T* q, T& H, T* alpha) {
+        // the generic (unfolded) form: scale the costates first
+        T p[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) p[d] = sc[d] * q[d];
         const T G = T(9.8), L1 = T(1), L2 = T(1), M1 = T(1), M2 = T(1);
         const T u = P.par[0];
         const T w1 = c.w1, w2 = c.w2, s1 = pl.s1, c1 = pl.c1, s2 = c.s2, c2 = c.c2;
@@ -287,10 +306,10 @@ template <typename T> struct HamDoublePendulum {
         const T f3 = (-M2 * L2 * w2 * w2 * sd * cd + (M1 + M2) * G * s1 * cd
                       - (M1 + M2) * L1 * w1 * w1 * sd - (M1 + M2) * G * s2) / den2;
         H = p[0] * w1 + p[1] * f1 + p[2] * w2 + p[3] * f3 + u * (t_abs(p[1]) + t_abs(p[3]));
-        alpha[0] = t_abs(w1);
-        alpha[1] = t_abs(f1) + u;
-        alpha[2] = t_abs(w2);
-        alpha[3] = t_abs(f3) + u;
+        alpha[0] = sc[0] * t_abs(w1);
+        alpha[1] = sc[1] * (t_abs(f1) + u);
+        alpha[2] = sc[2] * t_abs(w2);
+        alpha[3] = sc[3] * (t_abs(f3) + u);
     }
 };
 
@@ -300,19 +319,20 @@ template <typename T>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const T* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, /*stride*/ 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, double) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+// off: per-lane byte offset (VGPR); soff: wave-uniform byte offset (SGPR), e.g. the plane
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
 }
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, float) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
 }
-__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    using V = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(V, v), r, off, 0, 0);
+__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    using V = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(V, v), r, off, soff, 0);
 }
-__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    using V = decltype(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(V, v), r, off, 0, 0);
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    using V = decltype(__builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(V, v), r, off, soff, 0);
 }
 
 // order-preserving map double -> uint64 so atomicMax on the key is max on the value

@@ -40,6 +40,7 @@ template <typename T, int ND> struct FusedArgs {
     int halo_lo, halo_hi;
     T km[ND];                     // slope multiplier (+1, -1 if towardZero)
     T K[ND][HJ_NK];               // per-dim stencil constants (fill_stencil_constants)
+    T sc[ND];                     // costate scale of the scheme: 1/(60dx) as-shipped WENO5, else 1
     long long stride0;            // elements per axis-0 plane
     int pstride[ND];              // in-plane element strides (pstride[0] unused)
     int E[ND];                    // tile extents on the plane axes (E[0] unused)
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);   // byte offset within a plane
-        hcell[r] = HAM::cell(A.ham, idx);   // per-column Hamiltonian constants
+        hcell[r] = HAM::cell(A.ham, idx, A.sc);   // per-column Hamiltonian constants
     }
 
     // ---- halo slots: for each plane axis d, 3 cells below and 3 above the tile, over the
@@ -214,6 +215,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
     }
 
+    // does any halo slot of this tile lie outside the domain on an extrapolated axis?  (block-uniform:
+    // interior tiles skip the ghost arithmetic and its second load altogether)
+    bool any_ghost = false;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) any_ghost = any_ghost || (h_dlt[k] != 0);
+    const bool tile_ghost = __syncthreads_or(any_ghost ? 1 : 0) != 0;
+
     T eps[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) eps[d] = T(0);
@@ -222,37 +230,55 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         for (int d = 0; d < ND; ++d) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
     }
 
-    // ---- loaders.  p is wave-uniform and clamped by the callers to planes that exist; each plane
-    // is addressed through a buffer descriptor (SGPR base + per-lane 32-bit byte offset, range
-    // checked against the plane size)
+    // ---- loaders.  p is wave-uniform and clamped by the callers to planes that exist.  One buffer
+    // descriptor per array for the whole chunk (base = 3 planes below the chunk; SGPRs), the plane
+    // goes into the scalar offset and the cell into the per-lane 32-bit byte offset; the hardware
+    // range check covers the chunk's planes.  Ghost / wrapped planes of axis 0 (first and last chunk
+    // only) build their own descriptor.
     const unsigned plane_bytes = (unsigned)(A.stride0 * (long long)sizeof(T));
+    const int p_lo = p_begin - HJ_STENCIL;                       // lowest plane the chunk touches
+    const unsigned span = (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;   // host keeps this < 4 GiB
+    const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
+    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, A.use_y0 ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
     auto load_own = [&](int p, T* dst) {
-        const PlaneSrc<T> s = plane_src<T, ND>(A, p);
-        const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
-        if (!s.ghost) {
+        const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
+        if (direct) {
+            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load(ry, own_g[r], so, T());
         } else {
-            const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
+            const PlaneSrc<T> s = plane_src<T, ND>(A, p);
+            const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
+            if (!s.ghost) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                dst[r] = ghost_value(buf_load(rb, own_g[r], T()), buf_load(ri, own_g[r], T()), s.km);
+                for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], 0u, T());
+            } else {
+                const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    dst[r] = ghost_value(buf_load(rb, own_g[r], 0u, T()), buf_load(ri, own_g[r], 0u, T()), s.km);
+            }
         }
     };
     auto load_halo = [&](int p, T* dst) {
-        const __amdgpu_buffer_rsrc_t rb = make_srd(y + (long long)p * A.stride0, plane_bytes);
+        const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-        for (int k = 0; k < KH; ++k) {
-            const T e = buf_load(rb, h_src[k], T());
-            dst[k] = e;
-            if (h_dlt[k] != 0) dst[k] = ghost_value(e, buf_load(rb, h_src[k] + (unsigned)h_dlt[k], T()), h_km[k]);
+        for (int k = 0; k < KH; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
+        if (tile_ghost) {
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                // h_km = 0 for in-domain slots: edge + 0*slope = edge
+                const T in = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
+                dst[k] = ghost_value(dst[k], in, h_km[k]);
+            }
         }
     };
     auto load_y0 = [&](int p, T* dst) {
         if (A.use_y0) {
-            const __amdgpu_buffer_rsrc_t rb = make_srd(y0 + (long long)p * A.stride0, plane_bytes);
+            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load(ry0, own_g[r], so, T());
         }
     };
     const int p_last = p_end - 1;
@@ -275,11 +301,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     for (int r = 0; r < R; ++r) { y0X[r] = T(0); y0Y[r] = T(0); }
     load_halo(p_begin, halX);
     load_y0(p_begin, y0X);
-    plX = HAM::plane(A.ham, p_begin);
+    plX = HAM::plane(A.ham, p_begin, A.sc);
     load_own(min(p_begin + 4, p_end + 2), ownX);          // plane p+4 enters the queue after plane p
     load_halo(min(p_begin + 1, p_last), halY);
     load_y0(min(p_begin + 1, p_last), y0Y);
-    plY = HAM::plane(A.ham, min(p_begin + 1, p_last));
+    plY = HAM::plane(A.ham, min(p_begin + 1, p_last), A.sc);
 
     double amax[ND];
 #pragma unroll
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         for (int d = 0; d < ND; ++d) pz[d] = T(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            HAM::eval(A.ham, hcell[r], plX, pz, Hz, az);
+            HAM::eval(A.ham, hcell[r], plX, A.sc, pz, Hz, az);
 #pragma unroll
             for (int d = 0; d < ND; ++d)
                 if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
@@ -311,9 +337,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         __syncthreads();
         const int p2 = min(p + 2, p_last);
         load_halo(p2, hal_c);
-        const __amdgpu_buffer_rsrc_t ro = make_srd(out + (long long)p * A.stride0, plane_bytes);
+        const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
-        pl_c = HAM::plane(A.ham, p2);
+        pl_c = HAM::plane(A.ham, p2, A.sc);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             T pc[ND], hd[ND];
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
                 upwind_cd<SCHEME, T>(v, A.K[d], eps[d], pc[d], hd[d]);
             }
             T H, alpha[ND];
-            HAM::eval(A.ham, hcell[r], pl_use, pc, H, alpha);
+            HAM::eval(A.ham, hcell[r], pl_use, A.sc, pc, H, alpha);
             T diss = T(0);
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             T o;
             if (A.ydot_only) o = ydot;
             else o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
-            buf_store(o, ro, own_g[r]);
+            buf_store(o, rout, own_g[r], so_out);
         }
         load_y0(p2, y0_c);
         // rotate the queue: own_c was loaded two iterations ago
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-        const double m = wave_max(amax[d]);
+        const double m = wave_max(amax[d]) / (double)A.sc[d];   // alpha_s = sc*alpha
         if (lane == 0) red[wv][d] = m;
     }
     __syncthreads();

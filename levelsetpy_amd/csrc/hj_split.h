@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G
         T p[ND], H, a[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) p[d] = T(0);
-        HAM::eval(P, HAM::cell(P, idx), HAM::plane(P, idx[0]), p, H, a);
+        T one[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) one[d] = T(1);
+        HAM::eval(P, HAM::cell(P, idx, one), HAM::plane(P, idx[0], one), one, p, H, a);
 #pragma unroll
         for (int d = 0; d < ND; ++d) m[d] = fmax(m[d], (double)a[d]);
     }
@@ -214,6 +217,7 @@ template <typename T, int ND> struct DirectArgs {
     long long cell_begin, cell_end;   // linear cell range (whole axis-0 planes)
     int stage, restrict_sign;
     T dt;
+    T sc[ND];                     // costate scale (see hj_device.h): 1/(60dx) as-shipped WENO5, else 1
     HamTables<T> ham;
 };
 
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
             upwind_cd<SCHEME, T>(v, A.G.K[d], eps[d], pc[d], hd[d]);
         }
         T H, alpha[ND];
-        HAM::eval(A.ham, HAM::cell(A.ham, idx), HAM::plane(A.ham, idx[0]), pc, H, alpha);
+        HAM::eval(A.ham, HAM::cell(A.ham, idx, A.sc), HAM::plane(A.ham, idx[0], A.sc), A.sc, pc, H, alpha);
         T diss = T(0);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
     if (threadIdx.x < ND) {
         const int d = threadIdx.x;
         const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        if (w > -1e299) atomicMax(A.bound + d, max_key(w));
+        if (w > -1e299) atomicMax(A.bound + d, max_key(w / (double)A.sc[d]));
     }
 }
 
