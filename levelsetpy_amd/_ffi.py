@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libhj_mi355x.so")
+LIB_PATH = os.environ.get("HJ_LIB") or os.path.join(HERE, "csrc", "libhj_mi355x.so")   # HJ_LIB: tuning builds
 
 # enums of include/hj_mi355x.h
 BC_EXTRAPOLATE, BC_PERIODIC = 0, 1

@@ -76,7 +76,7 @@ struct hj_ctx {
     int internal_slot;
     // tuning
     KernelCfg cfg;
-    int force_direct, debug, full_rows;
+    int force_direct, debug, full_rows, num_cus, pd, occ_hint;
     int target_blocks, min_chunk;
     size_t lds_limit;
 };
@@ -156,21 +156,37 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
         }
         if (d >= nd) break;
     }
-    if (!best.ok) return best;
+    return best;
+}
+
+// Axis-0 chunking: blocks = ntiles * nchunks should fill the GPU in whole "rounds" of resident
+// workgroups (capacity = CUs * workgroups per CU for this kernel), and every chunk pays 6 warm-up
+// planes of loads.  Pick the chunk count that minimises  rounds * (chunk + warm-up cost).
+void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu) {
     const int64_t planes = p1 - p0;
-    int64_t want = std::max<int64_t>(1, c->target_blocks / best.ntiles);
-    int64_t max_chunks = std::max<int64_t>(1, planes / c->min_chunk);
-    int64_t nch = std::min(want, max_chunks);
-    best.chunk = (int)((planes + nch - 1) / nch);
+    const int64_t capacity = (int64_t)c->num_cus * std::max(1, blocks_per_cu);
     // one buffer descriptor spans a chunk plus 3 planes either side: keep it below 4 GiB
     const double plane_bytes = (double)(c->total / c->N[0]) * (double)c->esz;
-    const int64_t chunk_cap = (int64_t)(4294967295.0 / plane_bytes) - 2 * HJ_STENCIL;
-    if (chunk_cap < 1) { best.ok = false; return best; }
-    if (best.chunk > chunk_cap) best.chunk = (int)chunk_cap;
-    best.nchunks = (int)((planes + best.chunk - 1) / best.chunk);
-    best.nblocks = best.nchunks * best.ntiles;
-    best.bpx = (best.nblocks + 7) / 8;
-    return best;
+    int64_t chunk_cap = (int64_t)(4294967295.0 / plane_bytes) - 2 * HJ_STENCIL;
+    if (chunk_cap < 1) { t.ok = false; return; }
+    int64_t best_nch = 1;
+    double best_cost = 1e300;
+    const int64_t max_nch = c->target_blocks > 0 ? std::max<int64_t>(1, c->target_blocks / t.ntiles)
+                                                 : std::max<int64_t>(1, planes / c->min_chunk);
+    for (int64_t nch = 1; nch <= std::min<int64_t>(planes, std::max<int64_t>(max_nch, 1)); ++nch) {
+        const int64_t chunk = (planes + nch - 1) / nch;
+        if (chunk > chunk_cap) continue;
+        const int64_t nchunks = (planes + chunk - 1) / chunk;
+        const int64_t blocks = nchunks * t.ntiles;
+        const int64_t rounds = (blocks + capacity - 1) / capacity;
+        const double cost = (double)rounds * ((double)chunk + 4.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_nch = nch; }
+    }
+    if (c->target_blocks > 0) best_nch = std::max<int64_t>(1, std::min<int64_t>(planes / std::max(1, c->min_chunk), c->target_blocks / t.ntiles));
+    t.chunk = (int)std::min<int64_t>((planes + best_nch - 1) / best_nch, chunk_cap);
+    t.nchunks = (int)((planes + t.chunk - 1) / t.chunk);
+    t.nblocks = t.nchunks * t.ntiles;
+    t.bpx = (t.nblocks + 7) / 8;
 }
 
 template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
@@ -222,9 +238,28 @@ struct SubstepCall {
     int64_t p0, p1;
 };
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
-int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
+int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
     constexpr int ND = HAM::ND;
+    {
+        auto kern0 = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD>;
+        static int occ_lds = -1, occ_blocks = 1;          // per instantiation
+        if (occ_lds != (int)t.lds_bytes) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern0), NT,
+                                                             t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+            occ_blocks = nb;
+            occ_lds = (int)t.lds_bytes;
+        }
+        choose_chunks(c, t, s.p0, s.p1, occ_blocks);
+        if (!t.ok) return fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
+        if (c->debug) {
+            fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
+                    NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.ntiles, t.chunk,
+                    t.nchunks, t.nblocks, occ_blocks, t.lds_bytes, t.score);
+            c->debug = 0;
+        }
+    }
     FusedArgs<T, ND> A;
     memset(&A, 0, sizeof(A));
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
@@ -264,7 +299,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
     A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
     fill_ham<T>(c, s.par, A.ham);
-    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
+    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD>;
     if (t.lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
@@ -305,12 +340,13 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
 
 // (threads per workgroup, cells per thread, halo slots per thread) instantiated for the tiled kernel
 #ifndef HJ_CONFIGS
-#define HJ_CONFIGS(X) X(512, 4, 2, 2) X(1024, 2, 1, 4) X(512, 2, 1, 4) X(256, 4, 3, 2) X(256, 2, 2, 4) \
-                      X(512, 1, 1, 4) X(256, 1, 2, 6) X(1024, 1, 1, 4)
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(1024, 2, 1, 4, 2) X(512, 2, 1, 4, 2) X(256, 4, 3, 2, 2) X(256, 2, 2, 4, 2) \
+                      X(512, 1, 1, 4, 2) X(256, 1, 2, 6, 2) X(1024, 1, 1, 4, 2) \
+                      X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2)
 #endif
 
 int cfg_kh(int nt, int r) {
-#define X(NT_, R_, KH_, OCC_) if (nt == NT_ && r == R_) return KH_;
+#define X(NT_, R_, KH_, OCC_, PD_) if (nt == NT_ && r == R_) return KH_;
     HJ_CONFIGS(X)
 #undef X
     return -1;
@@ -329,14 +365,8 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
         if (!c->force_direct) {
             const KernelCfg k = c->cfg;
             Tiling t = make_tiling(c, k, s.p0, s.p1);
-            if (c->debug) {
-                fprintf(stderr, "[hj] tiling ok=%d NT=%d R=%d KH=%d E=(%d,%d,%d) ntiles=%d chunk=%d nchunks=%d blocks=%d lds=%zu score=%.3f\n",
-                        (int)t.ok, k.NT, k.R, k.KH, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0,
-                        t.ntiles, t.chunk, t.nchunks, t.nblocks, t.lds_bytes, t.score);
-                c->debug = 0;
-            }
             if (t.ok) {
-#define X(NT_, R_, KH_, OCC_) if (k.NT == NT_ && k.R == R_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_>(c, s, t);
+#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && c->pd == PD_ && c->occ_hint == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
                 HJ_CONFIGS(X)
 #undef X
             }
@@ -587,10 +617,22 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->force_direct = env_int("HJ_FORCE_DIRECT", 0);
     c->debug = env_int("HJ_DEBUG", 0);
     c->full_rows = env_int("HJ_FULL_ROWS", 0);
-    c->target_blocks = env_int("HJ_TARGET_BLOCKS", 1024);
-    c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 8));
+    c->target_blocks = env_int("HJ_TARGET_BLOCKS", 0);   // 0 = choose from the GPU's capacity
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu < 1) ncu = 256;
+        c->num_cus = ncu;
+    }
+    c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 4));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
     c->cfg.KH = cfg_kh(c->cfg.NT, c->cfg.R);
+    c->pd = env_int("HJ_PD", 2);
+    c->occ_hint = env_int("HJ_OCC", -1);
+    if (c->occ_hint < 0) {   // default waves/SIMD hint = first table entry of this (NT, R, PD)
+#define X(NT_, R_, KH_, OCC_, PD_) if (c->occ_hint < 0 && c->cfg.NT == NT_ && c->cfg.R == R_ && c->pd == PD_) c->occ_hint = OCC_;
+        HJ_CONFIGS(X)
+#undef X
+    }
     if (c->cfg.KH < 0) {
         const int nt = c->cfg.NT, r = c->cfg.R;
         delete c;

@@ -319,20 +319,25 @@ template <typename T>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const T* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, /*stride*/ 0, (int)bytes, 0x00020000);
 }
-// off: per-lane byte offset (VGPR); soff: wave-uniform byte offset (SGPR), e.g. the plane
+// off: per-lane byte offset (VGPR); soff: wave-uniform byte offset (SGPR), e.g. the plane;
+// AUX: cache policy (gfx940+ encoding: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, double) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, float) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
     using V = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(V, v), r, off, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(V, v), r, off, soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
     using V = decltype(__builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(V, v), r, off, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(V, v), r, off, soff, AUX);
 }
 
 // order-preserving map double -> uint64 so atomicMax on the key is max on the value

@@ -13,16 +13,16 @@
 //     (double buffered: one s_barrier per plane); in-plane stencils are read from LDS.
 //     Halo cells outside the domain are ghost cells computed at load time.
 //   * software pipeline: the HBM loads a plane needs (its own cells for the queue, the halo ring,
-//     the RK operand y0, the plane's Hamiltonian scalars) are issued TWO planes before they are
-//     consumed, into alternating register sets (the loop body is instantiated twice with the
-//     sets swapped, so in-flight data is never moved): a full plane of arithmetic always covers
+//     the RK operand y0, the plane's Hamiltonian scalars) are issued PD (2 or 3) planes before they
+//     are consumed, into rotating register sets (the loop body is instantiated PD times with the
+//     sets permuted, so in-flight data is never moved): a full plane of arithmetic always covers
 //     the memory latency and the memory queue does not drain at the barrier.
 //   * thread <-> cell: the tile's cells are numbered linearly (last axis fastest) and dealt
 //     round-robin to the NT threads, R cells per thread: consecutive lanes touch consecutive
 //     addresses in HBM (coalesced, full 64-lane waves even when N is not a multiple of 64) and
 //     consecutive 8-byte LDS words (bank-conflict free for ds_read_b64).  Threads beyond the
-//     tile's cell count shadow its last cell (identical values, duplicate stores): the hot loop
-//     has no per-lane validity branches.
+//     tile's cell count shadow its last cell (they compute, only their LDS/HBM writes are
+//     predicated off): no per-lane validity branches around the arithmetic.
 //   * blockIdx -> (chunk, tile) is XCD-aware: the 8 XCDs get contiguous ranges of the logical
 //     block order, so tiles sharing halo rows share an L2.
 //   * per-dim max(alpha) is reduced with wavefront shuffles, then LDS, then one 64-bit
@@ -31,6 +31,17 @@
 #include "hj_device.h"
 
 namespace hj {
+
+// cache policies of the streams (tuning macros): y0 and the output are touched once
+#ifndef HJ_AUX_Y0
+#define HJ_AUX_Y0 0
+#endif
+#ifndef HJ_AUX_ST
+#define HJ_AUX_ST 0
+#endif
+#ifndef HJ_AUX_OWN
+#define HJ_AUX_OWN 0
+#endif
 
 template <typename T, int ND> struct FusedArgs {
     const T* max_d1sq;            // ND values (HJ_WENO5 only)
@@ -90,7 +101,7 @@ __device__ __forceinline__ PlaneSrc<T> plane_src(const FusedArgs<T, ND>& A, int 
     return s;
 }
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
 __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restrict__ y,
                                                            const T* __restrict__ y0,
                                                            T* __restrict__ out,
@@ -137,6 +148,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     int own_lds[R];
     unsigned own_g[R];
     typename HAM::Cell hcell[R];
+    // only the last round of the deal can run past the tile: shadows compute but do not write
+    const bool last_real = (tid + (R - 1) * NT) < tile_cells;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int c = min(tid + r * NT, tile_cells - 1);
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     int h_lds[KH], h_dlt[KH];
     unsigned h_src[KH];
     T h_km[KH];
+    bool h_real[KH];
     {
         int area[ND], base[ND + 1];
         base[1] = 0;
@@ -174,7 +188,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
         for (int k = 0; k < KH; ++k) {
             int h = tid + k * NT;
-            if (h >= base[ND]) h = 0;
+            h_real[k] = h < base[ND];
+            if (!h_real[k]) h = 0;                    // shadow of slot 0: loads it, never writes LDS
             h_lds[k] = 0; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
             // static loop over the axis the slot belongs to (runtime-indexed local arrays
             // would be demoted to scratch)
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         if (direct) {
             const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load(ry, own_g[r], so, T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_OWN>(ry, own_g[r], so, T());
         } else {
             const PlaneSrc<T> s = plane_src<T, ND>(A, p);
             const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         if (A.use_y0) {
             const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load(ry0, own_g[r], so, T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_Y0>(ry0, own_g[r], so, T());
         }
     };
     const int p_last = p_end - 1;
@@ -292,20 +307,24 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
         for (int r = 0; r < R; ++r) q[r][j] = tmp[r];
     }
-    // register sets of the pipeline: X is consumed by even iterations, Y by odd ones
-    T ownX[R], ownY[R], halX[KH], halY[KH], y0X[R], y0Y[R];
+    // register sets of the pipeline: set s = (p - p_begin) % PD serves plane p
+    T own[PD][R], hal[PD][KH], y0s[PD][R];
+    typename HAM::Plane pls[PD];
 #pragma unroll
-    for (int k = 0; k < KH; ++k) { halX[k] = T(0); halY[k] = T(0); }
-    typename HAM::Plane plX, plY;
+    for (int s = 0; s < PD; ++s) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { y0X[r] = T(0); y0Y[r] = T(0); }
-    load_halo(p_begin, halX);
-    load_y0(p_begin, y0X);
-    plX = HAM::plane(A.ham, p_begin, A.sc);
-    load_own(min(p_begin + 4, p_end + 2), ownX);          // plane p+4 enters the queue after plane p
-    load_halo(min(p_begin + 1, p_last), halY);
-    load_y0(min(p_begin + 1, p_last), y0Y);
-    plY = HAM::plane(A.ham, min(p_begin + 1, p_last), A.sc);
+        for (int k = 0; k < KH; ++k) hal[s][k] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { y0s[s][r] = T(0); own[s][r] = T(0); }
+        const int ps = min(p_begin + s, p_last);
+        load_halo(ps, hal[s]);
+        load_y0(ps, y0s[s]);
+        pls[s] = HAM::plane(A.ham, ps, A.sc);
+        // own[s] holds plane p+4 for the iteration of plane p = p_begin+s; the last set is filled
+        // by the first iteration
+        if (s < PD - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+    }
+    const typename HAM::Plane& plX = pls[0];
 
     double amax[ND];
 #pragma unroll
@@ -324,18 +343,20 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     }
 
     // one plane.  own_c holds plane p+4 (joins the queue at the end); own_n is refilled with plane
-    // p+5; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
-    // are refilled for plane p+2 once consumed.
+    // p+3+PD; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
+    // are refilled for plane p+PD once consumed.
     auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* y0_c, typename HAM::Plane& pl_c) {
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
-        load_own(min(p + 5, p_end + 2), own_n);
+        load_own(min(p + 3 + PD, p_end + 2), own_n);
         // stage the centre plane
 #pragma unroll
-        for (int r = 0; r < R; ++r) buf[own_lds[r]] = q[r][3];
+        for (int r = 0; r < R; ++r)
+            if (r < R - 1 || last_real) buf[own_lds[r]] = q[r][3];
 #pragma unroll
-        for (int k = 0; k < KH; ++k) buf[h_lds[k]] = hal_c[k];
+        for (int k = 0; k < KH; ++k)
+            if (h_real[k]) buf[h_lds[k]] = hal_c[k];
         __syncthreads();
-        const int p2 = min(p + 2, p_last);
+        const int p2 = min(p + PD, p_last);
         load_halo(p2, hal_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
@@ -343,14 +364,32 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             T pc[ND], hd[ND];
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 1)
+            // timing experiment: keep every operand alive, skip the arithmetic
+            pc[0] = q[r][0]; hd[0] = q[r][6];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(q[r][j]));
+#else
             upwind_cd<SCHEME, T>(q[r], A.K[0], eps[0], pc[0], hd[0]);
+#endif
 #pragma unroll
             for (int d = 1; d < ND; ++d) {
                 T v[7];
                 const T* c = buf + own_lds[r];
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 2)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) v[j] = q[r][j];
+#else
 #pragma unroll
                 for (int j = 0; j < 7; ++j) v[j] = (j == 3) ? q[r][3] : c[(j - 3) * ls[d]];
+#endif
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 1)
+                pc[d] = v[0]; hd[d] = v[6];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(v[j]));
+#else
                 upwind_cd<SCHEME, T>(v, A.K[d], eps[d], pc[d], hd[d]);
+#endif
             }
             T H, alpha[ND];
             HAM::eval(A.ham, hcell[r], pl_use, A.sc, pc, H, alpha);
@@ -369,7 +408,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             T o;
             if (A.ydot_only) o = ydot;
             else o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
-            buf_store(o, rout, own_g[r], so_out);
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 4)
+            asm volatile("" ::"v"(o));
+#else
+            if (r < R - 1 || last_real) buf_store<HJ_AUX_ST>(o, rout, own_g[r], so_out);
+#endif
         }
         load_y0(p2, y0_c);
         // rotate the queue: own_c was loaded two iterations ago
@@ -381,9 +424,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
     };
 
-    for (int p = p_begin; p < p_end; p += 2) {
-        body(p, ownX, ownY, halX, y0X, plX);
-        if (p + 1 < p_end) body(p + 1, ownY, ownX, halY, y0Y, plY);
+    for (int p = p_begin; p < p_end; p += PD) {
+        body(p, own[0], own[PD - 1], hal[0], y0s[0], pls[0]);
+        if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], y0s[1], pls[1]);
+        if constexpr (PD > 2) {
+            if (p + 2 < p_end) body(p + 2, own[2], own[1], hal[2], y0s[2], pls[2]);
+        }
     }
 
     // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim

@@ -39,7 +39,7 @@ def shapeSphere(grid, center=None, radius=1):
     center = _center(grid, center)
     data = (grid.xs[0] - center[0]) ** 2
     for i in range(1, grid.dim):
-        data += (grid.xs[i] - center[i]) ** 2
+        data = data + (grid.xs[i] - center[i]) ** 2      # not in place: xs may be sparse (low_mem grids)
     data = np.sqrt(data) - radius
     _check(data)
     return data
