@@ -76,7 +76,7 @@ struct hj_ctx {
     int internal_slot;
     // tuning
     KernelCfg cfg;
-    int force_direct, debug, full_rows, num_cus, pd, occ_hint;
+    int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env;
     int target_blocks, min_chunk;
     size_t lds_limit;
 };
@@ -228,6 +228,13 @@ template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G
     G.total = c->total;
 }
 
+// costate scale the scheme's stencil leaves out (hj_device.h, scaling note)
+template <typename T> T scheme_scale(int scheme, double dx) {
+    if (scheme == HJ_WENO5_ASSHIPPED) return (T)((1.0 / dx) * (1.0 / 60.0));
+    if (scheme == HJ_WENO5) return (T)((1.0 / dx) * (1.0 / 12.0));
+    return T(1);
+}
+
 struct SubstepCall {
     int scheme, ham, stage, restrict_sign;
     const double* par;
@@ -270,7 +277,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
         A.bc[d] = c->bc[d];
         A.km[d] = c->tz[d] ? T(-1) : T(1);
         fill_stencil_constants<T>(c->dx[d], A.K[d]);
-        A.sc[d] = (SCHEME == HJ_WENO5_ASSHIPPED) ? (T)((1.0 / c->dx[d]) * (1.0 / 60.0)) : T(1);
+        A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
         A.pstride[d] = (d >= 1) ? (int)st : 0;
         if (d == 0) A.stride0 = st;
         st *= c->N[d];
@@ -321,8 +328,7 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
     A.bound = s.bound;
     fill_grid<T, ND>(c, A.G);
-    for (int d = 0; d < ND; ++d)
-        A.sc[d] = (SCHEME == HJ_WENO5_ASSHIPPED) ? (T)((1.0 / c->dx[d]) * (1.0 / 60.0)) : T(1);
+    for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
     const long long plane = c->total / c->N[0];
     A.cell_begin = s.p0 * plane;
     A.cell_end = s.p1 * plane;
@@ -342,7 +348,8 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
 #ifndef HJ_CONFIGS
 #define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(1024, 2, 1, 4, 2) X(512, 2, 1, 4, 2) X(256, 4, 3, 2, 2) X(256, 2, 2, 4, 2) \
                       X(512, 1, 1, 4, 2) X(256, 1, 2, 6, 2) X(1024, 1, 1, 4, 2) \
-                      X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2)
+                      X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
+                      X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
 #endif
 
 int cfg_kh(int nt, int r) {
@@ -363,10 +370,18 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
 #endif
     if constexpr (tiled_ok) {
         if (!c->force_direct) {
-            const KernelCfg k = c->cfg;
+            KernelCfg k = c->cfg;
+            int pd = c->pd, occ = c->occ_hint;
+            if (!c->cfg_from_env) {
+                // round-1 sweeps (profiles/): the heavier the per-cell arithmetic, the fewer cells per
+                // thread fit in the 256-VGPR budget without scratch
+                if (SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
+                else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
+                k.KH = cfg_kh(k.NT, k.R);
+            }
             Tiling t = make_tiling(c, k, s.p0, s.p1);
             if (t.ok) {
-#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && c->pd == PD_ && c->occ_hint == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
+#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
                 HJ_CONFIGS(X)
 #undef X
             }
@@ -466,7 +481,7 @@ double key_to_double(unsigned long long k) {
 
 int weno_eps_pass(hj_ctx* c, const void* y) {
     HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
-    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 8);
+    const int blocks = (int)std::min<int64_t>(c->total / c->N[c->ndim - 1], 256 * 16);   // rows
 #define HJ_MAXD1(T, ND)                                                                          \
     {                                                                                            \
         GridArgs<T, ND> G;                                                                       \
@@ -611,6 +626,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         c->N[d] = N[d]; c->xmin[d] = xmin[d]; c->dx[d] = dx[d]; c->bc[d] = bc[d];
         c->tz[d] = toward_zero ? (toward_zero[d] != 0) : 0;
     }
+    c->cfg_from_env = (getenv("HJ_NT") != nullptr) || (getenv("HJ_R") != nullptr);
     c->cfg.NT = env_int("HJ_NT", 512);   // defaults: best of the round-1 sweep (profiles/r01_cfgsweep.txt)
     c->cfg.R = env_int("HJ_R", 4);
     c->cfg.KH = 0;

@@ -162,8 +162,22 @@ __device__ __forceinline__ void upwind(const T* v, const T* K, T eps, T& L, T& R
 // phi, so both are short fixed stencils on the undivided differences u_j = v[j+1]-v[j]:
 //   L = (2u0 - 13u1 + 47u2 + 27u3 - 3u4)/(60dx),  R = (-3u1 + 27u2 + 47u3 - 13u4 + 2u5)/(60dx)
 // (SURVEY Appendix B), which collapse to the stencils below.  Nonlinear schemes go through upwind<>.
+// per-dimension constants of the intended WENO5 that depend on the (device-side) epsilon
+template <typename T> struct WenoK {
+    T c13, c4;
+};
+template <typename T>
+__device__ __forceinline__ WenoK<T> weno_consts(T eps, const T* K) {
+    WenoK<T> w;
+    const T e2 = eps * K[4];            // epsilon in undivided units: eps*dx^2
+    const T ie = T(1) / e2;
+    w.c13 = (T(13) / T(12)) * ie;
+    w.c4 = T(0.25) * ie;
+    return w;
+}
+
 template <int SCHEME, typename T>
-__device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, T& pc, T& hd) {
+__device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const WenoK<T>& wk, T& pc, T& hd) {
     if constexpr (SCHEME == HJ_WENO5_ASSHIPPED) {
         // in terms of phi: with D_k = phi[i+k]-phi[i-k], S_k = phi[i+k]+phi[i-k]
         //   pc = (45 D1 - 9 D2 + D3)/(60dx)            (6th-order central difference)
@@ -174,6 +188,51 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, T& pc, 
         const T S1 = v[4] + v[2], S2 = v[5] + v[1], S3 = v[6] + v[0];
         pc = T(45) * D1 + (T(-9) * D2 + D3);
         hd = T(15) * S1 + (T(-6) * S2 + (S3 + T(-20) * v[3]));
+    } else if constexpr (SCHEME == HJ_WENO5) {
+        // Intended WENO5 (O&F 3.32-3.41; ENO3bHelper.py:135-160) on UNDIVIDED differences
+        // u_j = v[j+1]-v[j]: candidates x6, smoothness x dx^2 (so is epsilon: wk.e2), weights x10,
+        // the two quotients L' = N_L/D_L, R' = N_R/D_R brought over one reciprocal.  Returns
+        // pc' = L'+R', hd' = R'-L' with p = pc'/(12dx), (R-L)/2 = hd'/(12dx)  (sc[d] = 1/(12dx)).
+        const T u0 = v[1] - v[0], u1 = v[2] - v[1], u2 = v[3] - v[2];
+        const T u3 = v[4] - v[3], u4 = v[5] - v[4], u5 = v[6] - v[5];
+        // candidates (x6): left phi1..3 = F1,F2,F3; right psi1 = G1, psi2 = F3, psi3 = F2
+        const T F1 = T(2) * u0 + (T(-7) * u1 + T(11) * u2);
+        const T F2 = T(5) * u2 + (T(2) * u3 - u1);
+        const T F3 = T(2) * u2 + (T(5) * u3 - u4);
+        const T G1 = T(2) * u5 + (T(-7) * u4 + T(11) * u3);
+        // second differences shared by both sides
+        const T t0 = (u0 + u2) - T(2) * u1, t1 = (u1 + u3) - T(2) * u2;
+        const T t2 = (u2 + u4) - T(2) * u3, t3 = (u3 + u5) - T(2) * u4;
+        const T bl1 = u0 + (T(3) * u2 - T(4) * u1), bl2 = u1 - u3, bl3 = u4 + (T(3) * u2 - T(4) * u3);
+        const T br1 = u5 + (T(3) * u3 - T(4) * u4), br2 = u4 - u2, br3 = u1 + (T(3) * u3 - T(4) * u2);
+        // q = (S + eps)/eps = c13*t^2 + c4*b^2 + 1   with c13 = (13/12)/eps', c4 = (1/4)/eps'
+        const T c13 = wk.c13, c4 = wk.c4;
+        T l1 = c13 * (t0 * t0) + (c4 * (bl1 * bl1) + T(1));
+        T l2 = c13 * (t1 * t1) + (c4 * (bl2 * bl2) + T(1));
+        T l3 = c13 * (t2 * t2) + (c4 * (bl3 * bl3) + T(1));
+        T r1 = c13 * (t3 * t3) + (c4 * (br1 * br1) + T(1));
+        T r2 = c13 * (t2 * t2) + (c4 * (br2 * br2) + T(1));
+        T r3 = c13 * (t1 * t1) + (c4 * (br3 * br3) + T(1));
+        l1 *= l1; l2 *= l2; l3 *= l3; r1 *= r1; r2 *= r2; r3 *= r3;
+        // weights x10: (.1,.6,.3)/q_k^2 multiplied through by q1^2 q2^2 q3^2
+        const T A1 = l2 * l3, A2 = T(6) * (l1 * l3), A3 = T(3) * (l1 * l2);
+        const T B1 = r2 * r3, B2 = T(6) * (r1 * r3), B3 = T(3) * (r1 * r2);
+        const T NL = A1 * F1 + (A2 * F2 + A3 * F3), DL = A1 + (A2 + A3);
+        const T NR = B1 * G1 + (B2 * F3 + B3 * F2), DR = B1 + (B2 + B3);
+        if constexpr (sizeof(T) == 8) {
+            // one reciprocal for both quotients (products stay < 1e62 in fp64): rcp + 2 Newton steps
+            const T den = DL * DR;
+            T rc = __builtin_amdgcn_rcp(den);
+            rc = rc + rc * (T(1) - den * rc);
+            rc = rc + rc * (T(1) - den * rc);
+            const T a = NL * DR, b = NR * DL;
+            pc = (a + b) * rc;
+            hd = (b - a) * rc;
+        } else {
+            const T Lq = NL / DL, Rq = NR / DR;
+            pc = Lq + Rq;
+            hd = Rq - Lq;
+        }
     } else {
         T L, R;
         upwind<SCHEME, T>(v, K, eps, L, R);

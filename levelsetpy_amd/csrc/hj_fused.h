@@ -240,9 +240,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     T eps[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) eps[d] = T(0);
+    WenoK<T> wk[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { wk[d].c13 = T(0); wk[d].c4 = T(0); }
     if constexpr (SCHEME == HJ_WENO5) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+        for (int d = 0; d < ND; ++d) {
+            eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            wk[d] = weno_consts<T>(eps[d], A.K[d]);
+        }
     }
 
     // ---- loaders.  p is wave-uniform and clamped by the callers to planes that exist.  One buffer
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
             for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(q[r][j]));
 #else
-            upwind_cd<SCHEME, T>(q[r], A.K[0], eps[0], pc[0], hd[0]);
+            upwind_cd<SCHEME, T>(q[r], A.K[0], eps[0], wk[0], pc[0], hd[0]);
 #endif
 #pragma unroll
             for (int d = 1; d < ND; ++d) {
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
                 for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(v[j]));
 #else
-                upwind_cd<SCHEME, T>(v, A.K[d], eps[d], pc[d], hd[d]);
+                upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pc[d], hd[d]);
 #endif
             }
             T H, alpha[ND];

@@ -120,26 +120,47 @@ __device__ __forceinline__ void decode(const GridArgs<T, ND>& G, long long t, in
 template <typename T, int ND>
 __global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, GridArgs<T, ND> G,
                                                        unsigned long long* keys) {
+    // one row of the last axis per loop trip: the row index is decoded once (wave-uniform), lanes
+    // stride along the contiguous axis
     double m[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) m[d] = -1e300;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < G.total;
-         t += (long long)gridDim.x * blockDim.x) {
+    const int nl = G.n[ND - 1];
+    const long long rows = G.total / nl;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         int idx[ND];
-        decode<T, ND>(G, t, idx);
-        const T c = y[t];
+        long long t = row;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            T nb;
-            bool have = true;
-            if (idx[d] + 1 < G.n[d]) nb = y[t + G.stride[d]];
-            else if (d == 0 && G.halo_hi) nb = y[t + G.stride[d]];
-            else if (G.bc[d] == HJ_BC_PERIODIC) nb = y[t - (long long)(G.n[d] - 1) * G.stride[d]];
-            else { nb = c; have = false; }
-            if (have) { const T D1 = G.inv_dx[d] * (nb - c); m[d] = fmax(m[d], (double)(D1 * D1)); }
-            if (d == 0 && G.halo_lo && idx[0] == 0) {
-                const T D1 = G.inv_dx[0] * (c - y[t - G.stride[0]]);
-                m[0] = fmax(m[0], (double)(D1 * D1));
+        for (int d = ND - 2; d >= 0; --d) {
+            const long long q = t / G.n[d];
+            idx[d] = (int)(t - q * G.n[d]);
+            t = q;
+        }
+        const T* line = y + row * nl;
+        for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+            const T c = line[i];
+            // last axis
+            {
+                T nb = c;
+                bool have = true;
+                if (i + 1 < nl) nb = line[i + 1];
+                else if (G.bc[ND - 1] == HJ_BC_PERIODIC) nb = line[0];
+                else have = false;
+                if (have) { const T D1 = G.inv_dx[ND - 1] * (nb - c); m[ND - 1] = fmax(m[ND - 1], (double)(D1 * D1)); }
+            }
+#pragma unroll
+            for (int d = 0; d < ND - 1; ++d) {
+                T nb = c;
+                bool have = true;
+                if (idx[d] + 1 < G.n[d]) nb = line[i + G.stride[d]];
+                else if (d == 0 && G.halo_hi) nb = line[i + G.stride[d]];
+                else if (G.bc[d] == HJ_BC_PERIODIC) nb = line[i - (long long)(G.n[d] - 1) * G.stride[d]];
+                else have = false;
+                if (have) { const T D1 = G.inv_dx[d] * (nb - c); m[d] = fmax(m[d], (double)(D1 * D1)); }
+                if (d == 0 && G.halo_lo && idx[0] == 0) {
+                    const T D1 = G.inv_dx[0] * (c - line[i - G.stride[0]]);
+                    m[0] = fmax(m[0], (double)(D1 * D1));
+                }
             }
         }
     }
@@ -226,11 +247,16 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
     constexpr int ND = HAM::ND;
     double amax[ND];
     T eps[ND];
+    WenoK<T> wk[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
         amax[d] = -1e300;
         eps[d] = T(0);
-        if constexpr (SCHEME == HJ_WENO5) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+        wk[d].c13 = T(0); wk[d].c4 = T(0);
+        if constexpr (SCHEME == HJ_WENO5) {
+            eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            wk[d] = weno_consts<T>(eps[d], A.G.K[d]);
+        }
     }
     for (long long t = A.cell_begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
          t < A.cell_end; t += (long long)gridDim.x * blockDim.x) {
@@ -245,7 +271,7 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
             for (int k = 0; k < 7; ++k)
                 v[k] = line_value(line, A.G.stride[d], idx[d] + k - 3, A.G.n[d], A.G.bc[d],
                                   A.G.km[d], d == 0 ? A.G.halo_lo : 0, d == 0 ? A.G.halo_hi : 0);
-            upwind_cd<SCHEME, T>(v, A.G.K[d], eps[d], pc[d], hd[d]);
+            upwind_cd<SCHEME, T>(v, A.G.K[d], eps[d], wk[d], pc[d], hd[d]);
         }
         T H, alpha[ND];
         HAM::eval(A.ham, HAM::cell(A.ham, idx, A.sc), HAM::plane(A.ham, idx[0], A.sc), A.sc, pc, H, alpha);
