@@ -25,6 +25,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the slab stepper uses three streams (+ RCCL's): give each its own hardware queue, otherwise streams
+# that share a queue serialise (must be set before HIP initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SUBSTEP = {"float64": 64.0 / 3.0, "float32": 32.0 / 3.0}   # 8 words / RK3 step

@@ -156,6 +156,32 @@ int hj_minmax_with(hj_ctx* ctx, int op, void* y, const void* other, int64_t n);
 /* NaN guard of HJIPDE_solve (hji_solver.py:544-545): *has_nan_host = 1 if any NaN.  Synchronises. */
 int hj_any_nan(hj_ctx* ctx, const void* y, int64_t n, int* has_nan_host);
 
+/* ---- multi-GPU slab stepping in native code: RCCL halo exchange over xGMI on a second HIP stream,
+ * overlapped with the interior stencil compute (no reference counterpart).
+ *   hj_comm_unique_id   rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it.
+ *   hj_comm_init        one communicator per ctx.  rccl_path: the librccl.so to dlopen (NULL =
+ *                       "librccl.so.1"); lo_rank / hi_rank: neighbour ranks on axis 0 (-1 = physical
+ *                       boundary).  Must be called by all ranks.
+ *   hj_halo_exchange    fill the HJ_STENCIL pad planes of `buf` (pointer to the first interior plane)
+ *                       from the neighbours' edge planes; stream-ordered on the ctx stream.
+ *   hj_slab_rk_step     one odeCFL{1,2,3} step with a given dt on padded slab buffers (pointers to
+ *                       the first interior plane).  Per substep: the edge plane ranges [0,3) and
+ *                       [n-3,n) run on an edge stream, their exchange on a comm stream, the interior
+ *                       planes on the ctx stream; the next substep waits for all three.  With
+ *                       HJ_WENO5 the per-dimension max(D1^2) is all-reduced (ncclMax) first.
+ *                       Result is left in y_out; cur is preserved.  The exchange of the last substep
+ *                       is left in flight on return (it overlaps the next step's interior):
+ *   hj_slab_join        makes the ctx stream wait for the outstanding edge/comm work; call it
+ *                       before anything else reads the slab buffers. */
+int hj_comm_unique_id(const char* rccl_path, void* uid128_host);
+int hj_comm_init(hj_ctx* ctx, const char* rccl_path, int rank, int nranks, const void* uid128_host,
+                 int lo_rank, int hi_rank);
+int hj_comm_destroy(hj_ctx* ctx);
+int hj_halo_exchange(hj_ctx* ctx, void* buf);
+int hj_slab_join(hj_ctx* ctx);
+int hj_slab_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double dt,
+                    int restrict_sign, const void* cur, void* y_out, void* work0, void* work1);
+
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);
 const char* hj_version(void);

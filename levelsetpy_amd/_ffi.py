@@ -43,6 +43,12 @@ SIGNATURES = {
     "hj_ctx_set_weno_eps_source": (_i, [_vp, _vp]),
     "hj_minmax_with": (_i, [_vp, _i, _vp, _vp, _i64]),
     "hj_any_nan": (_i, [_vp, _vp, _i64, _pi]),
+    "hj_comm_unique_id": (_i, [C.c_char_p, _vp]),
+    "hj_comm_init": (_i, [_vp, C.c_char_p, _i, _i, _vp, _i, _i]),
+    "hj_comm_destroy": (_i, [_vp]),
+    "hj_halo_exchange": (_i, [_vp, _vp]),
+    "hj_slab_join": (_i, [_vp]),
+    "hj_slab_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _i, _vp, _vp, _vp, _vp]),
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
     "hj_version": (C.c_char_p, []),

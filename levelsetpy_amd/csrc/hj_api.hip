@@ -1,5 +1,7 @@
 // C ABI of libhj_mi355x.so (see include/hj_mi355x.h).  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is dlopen'ed (hj_comm_*), so libhj loads without RCCL
 
 #include <algorithm>
 #include <cmath>
@@ -39,7 +41,7 @@ constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys
 
 struct Tiling {
     int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
-    int ntiles, chunk, nchunks, nblocks, bpx;
+    int ntiles, chunk, nchunks, nchunks1, nblocks, bpx;
     size_t lds_bytes;
     double score;
     bool ok;
@@ -74,6 +76,12 @@ struct hj_ctx {
     double sb_par[4], sb_val, sb_alpha[HJ_MAX_DIM];
     bool sb_valid;
     int internal_slot;
+    // slab communication (hj_comm_*)
+    ncclComm_t comm;
+    int comm_rank, comm_size, lo_rank, hi_rank;
+    hipStream_t comm_stream, edge_stream, edge_stream2;
+    hipEvent_t ev_start, ev_edge, ev_edge2, ev_comm;
+    int slab_pending;
     // tuning
     KernelCfg cfg;
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env;
@@ -243,6 +251,7 @@ struct SubstepCall {
     void* out;
     unsigned long long* bound;
     int64_t p0, p1;
+    int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
 };
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
@@ -260,6 +269,12 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
         }
         choose_chunks(c, t, s.p0, s.p1, occ_blocks);
         if (!t.ok) return fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
+        t.nchunks1 = t.nchunks;
+        if (s.q1 > s.q0) {     // second range: same chunk length
+            t.nchunks += (int)((s.q1 - s.q0 + t.chunk - 1) / t.chunk);
+            t.nblocks = t.nchunks * t.ntiles;
+            t.bpx = (t.nblocks + 7) / 8;
+        }
         if (c->debug) {
             fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
                     NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.ntiles, t.chunk,
@@ -291,6 +306,9 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.nchunks = t.nchunks;
     A.plane_begin = (int)s.p0;
     A.plane_end = (int)s.p1;
+    A.plane_begin2 = (int)s.q0;
+    A.plane_end2 = (int)s.q1;
+    A.nchunks1 = t.nchunks1;
     A.nblocks = t.nblocks;
     A.blocks_per_xcd = t.bpx;
     A.ydot_only = (s.stage == HJ_STAGE_YDOT);
@@ -336,11 +354,18 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.restrict_sign = s.restrict_sign;
     A.dt = (T)s.dt;
     fill_ham<T>(c, s.par, A.ham);
-    const long long cells = A.cell_end - A.cell_begin;
-    if (cells <= 0) return HJ_OK;
-    int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, c->stream, A);
-    HIP_TRY(hipGetLastError());
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (s.q1 <= s.q0) break;
+            A.cell_begin = s.q0 * plane;
+            A.cell_end = s.q1 * plane;
+        }
+        const long long cells = A.cell_end - A.cell_begin;
+        if (cells <= 0) continue;
+        int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, c->stream, A);
+        HIP_TRY(hipGetLastError());
+    }
     return HJ_OK;
 }
 
@@ -592,6 +617,147 @@ template <typename T> static int upwind_launch(hj_ctx* c, int scheme, int dim, c
     return HJ_OK;
 }
 
+// ------------------------------------------------------------------------------------ RCCL (dlopen)
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load(const char* path) {
+    if (g_rccl.handle) return HJ_OK;
+    const char* names[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(HJ_ESTATE, "cannot dlopen RCCL: %s", dlerror());
+#define HJ_SYM(field, name)                                                        \
+    *(void**)(&g_rccl.field) = dlsym(h, name);                                     \
+    if (!g_rccl.field) return fail(HJ_ESTATE, "RCCL symbol %s missing", name);
+    HJ_SYM(GetUniqueId, "ncclGetUniqueId")
+    HJ_SYM(CommInitRank, "ncclCommInitRank")
+    HJ_SYM(CommDestroy, "ncclCommDestroy")
+    HJ_SYM(GroupStart, "ncclGroupStart")
+    HJ_SYM(GroupEnd, "ncclGroupEnd")
+    HJ_SYM(Send, "ncclSend")
+    HJ_SYM(Recv, "ncclRecv")
+    HJ_SYM(AllReduce, "ncclAllReduce")
+    HJ_SYM(GetErrorString, "ncclGetErrorString")
+#undef HJ_SYM
+    g_rccl.handle = h;
+    return HJ_OK;
+}
+
+#define NCCL_TRY(expr)                                                                       \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess)                                                               \
+            return fail(HJ_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));         \
+    } while (0)
+
+// post the halo sends/receives of `buf` (first interior plane) on `st`.  Order per peer is fixed so
+// that lo == hi (two ranks, periodic axis, or the single-rank self ring) pairs up: sends
+// [low planes -> lo, high planes -> hi], receives [hi pad <- hi, lo pad <- lo].
+int post_halo(hj_ctx* c, void* buf, hipStream_t st) {
+    if (!c->comm) return fail(HJ_ESTATE, "hj_comm_init has not been called");
+    const size_t plane = (size_t)(c->total / c->N[0]);
+    const size_t cnt = plane * HJ_STENCIL;
+    const ncclDataType_t dt = c->dtype == HJ_F64 ? ncclDouble : ncclFloat;
+    char* b = (char*)buf;
+    const size_t pb = plane * c->esz;
+    const int64_t n = c->N[0];
+    NCCL_TRY(g_rccl.GroupStart());
+    if (c->lo_rank >= 0) NCCL_TRY(g_rccl.Send(b, cnt, dt, c->lo_rank, c->comm, st));
+    if (c->hi_rank >= 0) NCCL_TRY(g_rccl.Send(b + (size_t)(n - HJ_STENCIL) * pb, cnt, dt, c->hi_rank, c->comm, st));
+    if (c->hi_rank >= 0) NCCL_TRY(g_rccl.Recv(b + (size_t)n * pb, cnt, dt, c->hi_rank, c->comm, st));
+    if (c->lo_rank >= 0) NCCL_TRY(g_rccl.Recv(b - (size_t)HJ_STENCIL * pb, cnt, dt, c->lo_rank, c->comm, st));
+    NCCL_TRY(g_rccl.GroupEnd());
+    return HJ_OK;
+}
+
+// One substep on a slab.  Streams: `main` (ctx stream) runs the interior planes, edge streams A/B run
+// the low/high edge plane ranges, the comm stream the RCCL exchange of the freshly written edges.
+// Dependencies (s = this substep, s-1 = the previous one, possibly of the previous RK step):
+//   edges_s     need  interior_{s-1}, edges_{s-1}, comm_{s-1}   (they read y's pads)
+//   comm_s      needs edges_s
+//   interior_s  needs interior_{s-1} (stream order), edges_{s-1}  -- NOT comm_{s-1}: it never reads pads
+// so the exchange of substep s-1 overlaps the interior of substep s as well, and the only serial chain
+// is comm -> edges -> comm.  hj_slab_join() makes the ctx stream wait for everything outstanding.
+int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, double dt, int rs,
+                 const void* y, const void* y0, void* out) {
+    int rc;
+    const int64_t n = c->N[0];
+    hipStream_t main = c->stream;
+    const bool talk = (c->lo_rank >= 0 || c->hi_rank >= 0);
+    if (scheme == HJ_WENO5) {
+        // global max(D1^2) per dim: needs y complete incl. pads -> join first; then all-reduce(MAX)
+        if (talk && c->slab_pending) {
+            HIP_TRY(hipStreamWaitEvent(main, c->ev_edge, 0));
+            HIP_TRY(hipStreamWaitEvent(main, c->ev_comm, 0));
+        }
+        if ((rc = weno_eps_pass(c, y))) return rc;
+        if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+        if (c->comm_size > 1)
+            NCCL_TRY(g_rccl.AllReduce(c->weno_vals, c->weno_vals, (size_t)c->ndim,
+                                      c->dtype == HJ_F64 ? ncclDouble : ncclFloat, ncclMax, c->comm, main));
+        c->weno_src = c->weno_vals;
+    }
+    const int64_t lo_e = c->halo_lo ? std::min<int64_t>(HJ_STENCIL, n) : 0;
+    const int64_t hi_b = c->halo_hi ? std::max<int64_t>(n - HJ_STENCIL, lo_e) : n;
+    if (!talk) {
+        SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, 0, n};
+        rc = do_substep(c, s, -1);
+        if (scheme == HJ_WENO5) c->weno_src = nullptr;
+        return rc;
+    }
+    // everything launched on main so far (interior_{s-1}, eps pass) gates the edges
+    HIP_TRY(hipEventRecord(c->ev_start, main));
+    HIP_TRY(hipStreamWaitEvent(c->edge_stream, c->ev_start, 0));
+    if (c->slab_pending && c->comm_stream != c->edge_stream) HIP_TRY(hipStreamWaitEvent(c->edge_stream, c->ev_comm, 0));
+    // interior_s reads the edges written by substep s-1
+    if (c->slab_pending) HIP_TRY(hipStreamWaitEvent(main, c->ev_edge, 0));
+    {   // both edge ranges in ONE launch on the edge stream
+        SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, 0, 0};
+        if (lo_e > 0) { s.p0 = 0; s.p1 = lo_e; if (hi_b < n) { s.q0 = hi_b; s.q1 = n; } }
+        else { s.p0 = hi_b; s.p1 = n; }
+        c->stream = c->edge_stream;
+        rc = do_substep(c, s, -1);
+        c->stream = main;
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(c->ev_edge, c->edge_stream));
+    if (c->comm_stream != c->edge_stream) HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
+    if ((rc = post_halo(c, out, c->comm_stream))) return rc;
+    HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+    c->slab_pending = 1;
+    if (hi_b > lo_e) {
+        SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, lo_e, hi_b};
+        if ((rc = do_substep(c, s, -1))) return rc;
+    }
+    if (scheme == HJ_WENO5) c->weno_src = nullptr;
+    return HJ_OK;
+}
+
+int slab_join(hj_ctx* c) {
+    if (c->slab_pending) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_edge, 0));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        c->slab_pending = 0;
+    }
+    return HJ_OK;
+}
+
 // =========================================================================================== ABI
 extern "C" {
 
@@ -622,6 +788,9 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     for (int s = 0; s < 4; ++s) { c->aux[s] = nullptr; c->aux_n[s] = 0; }
     c->ring = nullptr; c->keys = nullptr; c->weno_vals = nullptr; c->weno_src = nullptr; c->flag = nullptr;
     c->sb_valid = false; c->internal_slot = 0;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->lo_rank = c->hi_rank = -1;
+    c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
+    c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr; c->slab_pending = 0;
     for (int d = 0; d < ndim; ++d) {
         c->N[d] = N[d]; c->xmin[d] = xmin[d]; c->dx[d] = dx[d]; c->bc[d] = bc[d];
         c->tz[d] = toward_zero ? (toward_zero[d] != 0) : 0;
@@ -676,6 +845,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
 
 void hj_ctx_destroy(hj_ctx* c) {
     if (!c) return;
+    (void)hj_comm_destroy(c);
     for (int d = 0; d < HJ_MAX_DIM; ++d) if (c->coord[d]) (void)hipFree(c->coord[d]);
     for (int s = 0; s < 4; ++s) if (c->aux[s]) (void)hipFree(c->aux[s]);
     if (c->ring) (void)hipFree(c->ring);
@@ -923,6 +1093,87 @@ int hj_any_nan(hj_ctx* c, const void* y, int64_t n, int* has) {
     HIP_TRY(hipMemcpyAsync(has, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HJ_OK;
+}
+
+int hj_comm_unique_id(const char* rccl_path, void* uid) {
+    if (!uid) return fail(HJ_EINVAL, "null argument");
+    int rc = rccl_load(rccl_path);
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    NCCL_TRY(g_rccl.GetUniqueId((ncclUniqueId*)uid));
+    return HJ_OK;
+}
+
+int hj_comm_init(hj_ctx* c, const char* rccl_path, int rank, int nranks, const void* uid, int lo, int hi) {
+    if (!c || !uid) return fail(HJ_EINVAL, "null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(HJ_EINVAL, "bad rank/nranks");
+    if (lo >= nranks || hi >= nranks) return fail(HJ_EINVAL, "neighbour rank out of range");
+    int rc = rccl_load(rccl_path);
+    if (rc) return rc;
+    if (c->comm) (void)hj_comm_destroy(c);
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, uid, sizeof(id));
+    NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->comm_rank = rank; c->comm_size = nranks; c->lo_rank = lo; c->hi_rank = hi;
+    {   // the exchange and the edge planes sit on the critical path: highest priority, so their (few)
+        // workgroups are dispatched ahead of the interior kernel's when both are ready
+        int lo_p = 0, hi_p = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        // ONE auxiliary stream carries the chain  edges_s -> exchange_s -> edges_{s+1} -> ...  in stream
+        // order: every cross-stream event hop costs 10-15 us of dispatch latency on this platform
+        // (profiles/r01_slab_timeline.txt), and this chain is the critical path at 201^3 per rank
+        HIP_TRY(hipStreamCreateWithPriority(&c->edge_stream, hipStreamNonBlocking, hi_p));
+        c->comm_stream = c->edge_stream;
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    return HJ_OK;
+}
+
+int hj_comm_destroy(hj_ctx* c) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);   // comm_stream aliases it
+    if (c->edge_stream2) (void)hipStreamDestroy(c->edge_stream2);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
+    if (c->ev_edge2) (void)hipEventDestroy(c->ev_edge2);
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
+    c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr;
+    c->slab_pending = 0;
+    return HJ_OK;
+}
+
+int hj_halo_exchange(hj_ctx* c, void* buf) {
+    if (!c || !buf) return fail(HJ_EINVAL, "null argument");
+    if (c->lo_rank < 0 && c->hi_rank < 0) return HJ_OK;
+    int rc = slab_join(c);
+    if (rc) return rc;
+    return post_halo(c, buf, c->stream);
+}
+
+int hj_slab_join(hj_ctx* c) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    return slab_join(c);
+}
+
+int hj_slab_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, double dt, int rs,
+                    const void* cur, void* y_out, void* w0, void* w1) {
+    if (!c || !cur || !y_out) return fail(HJ_EINVAL, "null argument");
+    if (order < 1 || order > 3) return fail(HJ_EINVAL, "order must be 1, 2 or 3");
+    if (order >= 2 && !w0) return fail(HJ_EINVAL, "work0 required for order >= 2");
+    if (order == 3 && !w1) return fail(HJ_EINVAL, "work1 required for order 3");
+    if ((c->lo_rank >= 0 || c->hi_rank >= 0) && !c->comm) return fail(HJ_ESTATE, "hj_comm_init has not been called");
+    int rc;
+    if (order == 1) return slab_substep(c, scheme, ham, par, HJ_STAGE_EULER, dt, rs, cur, nullptr, y_out);
+    if ((rc = slab_substep(c, scheme, ham, par, HJ_STAGE_EULER, dt, rs, cur, nullptr, w0))) return rc;
+    if (order == 2) return slab_substep(c, scheme, ham, par, HJ_STAGE_RK2_FULL, dt, rs, w0, cur, y_out);
+    if ((rc = slab_substep(c, scheme, ham, par, HJ_STAGE_RK3_HALF, dt, rs, w0, cur, w1))) return rc;
+    return slab_substep(c, scheme, ham, par, HJ_STAGE_RK3_FULL, dt, rs, w1, cur, y_out);
 }
 
 int hj_sync(hj_ctx* c) {

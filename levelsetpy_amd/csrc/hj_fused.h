@@ -59,6 +59,7 @@ template <typename T, int ND> struct FusedArgs {
     int ntiles;
     int chunk, nchunks;
     int plane_begin, plane_end;
+    int plane_begin2, plane_end2, nchunks1;   // optional second plane range (slab edges): chunks >= nchunks1
     int nblocks, blocks_per_xcd;
     // out = ydot                                   (ydot_only)
     //     = ca*y0 + cb*(y + dt*ydot)               otherwise; y0 is read iff use_y0
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         org[d] = min((rem - q * A.ntile[d]) * A.E[d], A.n[d] - A.E[d]);
         rem = q;
     }
-    const int p_begin = A.plane_begin + chunk_id * A.chunk;
-    const int p_end = min(p_begin + A.chunk, A.plane_end);
+    // two plane ranges may share a launch (the low and high edge planes of a slab)
+    const bool second = chunk_id >= A.nchunks1;
+    const int p_begin = second ? A.plane_begin2 + (chunk_id - A.nchunks1) * A.chunk : A.plane_begin + chunk_id * A.chunk;
+    const int p_end = min(p_begin + A.chunk, second ? A.plane_end2 : A.plane_end);
 
     // ---- LDS geometry: halo'd box, last axis contiguous
     int ls[ND];

@@ -34,7 +34,10 @@ class SlabDecomposition(object):
     """Planes [begin, end) of axis 0 owned by `rank`; the remainder is spread over the low ranks
     (513 = 8*64+1 -> rank 0 gets 65 planes)."""
 
-    def __init__(self, n0, world, rank, periodic0=False):
+    def __init__(self, n0, world, rank, periodic0=False, self_exchange=False):
+        """self_exchange: with ONE rank and a periodic axis 0, close the ring through the transport
+        (rank 0 <-> rank 0) instead of wrapping inside the kernel -- exercises the RCCL path on a
+        single GPU (tests / tools); results are identical."""
         if world < 1 or not (0 <= rank < world):
             raise ValueError("bad rank/world")
         base, rem = divmod(int(n0), world)
@@ -46,8 +49,9 @@ class SlabDecomposition(object):
         self.end = self.begin + self.counts[rank]
         self.n_local = self.counts[rank]
         # neighbours (None on a physical boundary)
-        self.lo = rank - 1 if rank > 0 else (world - 1 if (periodic0 and world > 1) else None)
-        self.hi = rank + 1 if rank < world - 1 else (0 if (periodic0 and world > 1) else None)
+        ring = periodic0 and (world > 1 or self_exchange)
+        self.lo = rank - 1 if rank > 0 else (world - 1 if ring else None)
+        self.hi = rank + 1 if rank < world - 1 else (0 if ring else None)
 
     @property
     def halo_lo(self):
@@ -255,6 +259,91 @@ class HipSlabBackend(object):
         self.torch.cuda.synchronize(self.device)
 
 
+def rccl_library_path():
+    """The librccl.so this process already has loaded (torch's), so the native stepper shares it."""
+    import os
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else None
+
+
+class NativeSlabStepper(object):
+    """Slab time stepping with the halo exchange in native code: hj_slab_rk_step posts
+    ncclSend/ncclRecv (RCCL over xGMI) on a comm stream between the edge-plane and interior-plane
+    launches -- one C call per RK step, no Python on the critical path.  torch.distributed is used
+    once, to broadcast the ncclUniqueId.  Same buffers / semantics as SlabIntegrator."""
+
+    def __init__(self, grid, slab, scheme_id, ham_id, ham_params, dx, dtype="float64", order=3,
+                 factor_cfl=0.8, group=None):
+        import torch
+        import torch.distributed as dist
+        from .context import DeviceGrid
+        self.torch = torch
+        self.slab, self.order, self.factor_cfl = slab, order, factor_cfl
+        self.dg = dg = DeviceGrid(grid, dtype, None, (slab.begin, slab.end, slab.halo_lo, slab.halo_hi))
+        self.device = dg.device
+        self.sid, self.ham, self.par = scheme_id, ham_id, _ffi.darr(ham_params)
+        self.n = slab.n_local
+        lib = dg.lib
+        path = rccl_library_path()
+        cpath = path.encode() if path else None
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if slab.rank == 0:
+            buf = (C.c_char * 128)()
+            _ffi.check(lib.hj_comm_unique_id(cpath, buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if slab.world > 1:
+            if dist.get_backend(group) == "nccl":
+                uid = uid.to(self.device)
+            dist.broadcast(uid, src=0, group=group)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        dg.bind_stream()
+        _ffi.check(lib.hj_comm_init(dg.ctx, cpath, slab.rank, slab.world, raw,
+                                    -1 if slab.lo is None else slab.lo, -1 if slab.hi is None else slab.hi))
+        shape = (self.n + 2 * HALO,) + tuple(dg.shape[1:])
+        self.buf = {k: torch.zeros(shape, dtype=dg.tdtype, device=self.device) for k in ("cur", "w1", "nxt")}
+        # stepBound from the all-reduced per-dimension alpha maxima (artificial_diss_glf.py:101-109)
+        sb, am = C.c_double(), (C.c_double * 4)()
+        _ffi.check(lib.hj_static_step_bound(dg.ctx, self.ham, self.par, C.byref(sb), am))
+        amax = torch.tensor([am[d] for d in range(dg.dim)], dtype=torch.float64, device=self.device)
+        if slab.world > 1:
+            dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+        self.alpha_max = [float(v) for v in amax.cpu()]
+        self.step_bound = 1.0 / sum(a / d for a, d in zip(self.alpha_max, dx))
+
+    @staticmethod
+    def _ip(buf):
+        return C.c_void_p(buf[HALO:].data_ptr())
+
+    def set_state(self, local_planes):
+        self.buf["cur"][HALO:HALO + self.n].copy_(local_planes)
+        self.dg.bind_stream()
+        _ffi.check(self.dg.lib.hj_halo_exchange(self.dg.ctx, self._ip(self.buf["cur"])))
+        self.torch.cuda.synchronize(self.device)
+
+    def state(self):
+        _ffi.check(self.dg.lib.hj_slab_join(self.dg.ctx))     # the last exchange may still be in flight
+        return self.buf["cur"][HALO:HALO + self.n]
+
+    def step(self, t, tf=float("inf"), max_step=float("inf")):
+        dt = min(self.factor_cfl * self.step_bound, tf - t, max_step)
+        b = self.buf
+        # three arrays: the first stage buffer doubles as the output (see bench.py)
+        _ffi.check(self.dg.lib.hj_slab_rk_step(self.dg.ctx, self.order, self.sid, self.ham, self.par, float(dt), 0,
+                                               self._ip(b["cur"]), self._ip(b["nxt"]), self._ip(b["nxt"]),
+                                               self._ip(b["w1"])))
+        b["cur"], b["nxt"] = b["nxt"], b["cur"]
+        if self.order == 1:
+            return t + dt, dt
+        t2 = (t + dt) + dt
+        if self.order == 2:
+            return 0.5 * (t + t2), dt
+        return (1.0 / 3.0) * (t + 2 * (0.25 * (3 * t + t2) + dt)), dt
+
+    def close(self):
+        _ffi.check(self.dg.lib.hj_comm_destroy(self.dg.ctx))
+
+
 def bench_slab(args, rank, world):
     """bench.py's N > 1 leg: every rank owns an n^3 slab of an (N*n) x n x n Dubins grid."""
     import time
@@ -266,15 +355,24 @@ def bench_slab(args, rank, world):
     gmin = np.array([[-.75, -1.25, -np.pi]]).T
     gmax = np.array([[-.75 + dx0 * (world * n - 1), 1.25, np.pi * (1 - 2 / n)]]).T
     g = L.createGrid(gmin, gmax, np.array([[world * n], [n], [n]], dtype=np.int64), 2, low_mem=True)
+    import os
     slab = SlabDecomposition(world * n, world, rank, False)
-    be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS[args.scheme], _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], args.dtype)
-    integ = SlabIntegrator(slab, be, [float(v) for v in np.asarray(g.dx).ravel()], 3, 0.8,
-                           needs_eps=(args.scheme == "WENO5"))
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    if os.environ.get("HJ_SLAB_TRANSPORT", "native") == "torch":
+        be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS[args.scheme], _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], args.dtype)
+        integ = SlabIntegrator(slab, be, dxs, 3, 0.8, needs_eps=(args.scheme == "WENO5"))
+        transport = "torch.distributed P2P"
+    else:
+        integ = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[args.scheme], _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0],
+                                  dxs, args.dtype, 3, 0.8)
+        be = integ
+        transport = "native ncclSend/ncclRecv"
     # cylinder initial data for this slab only (sparse xs: broadcasting)
     x0 = np.asarray(g.vs[0]).ravel()[slab.begin:slab.end].reshape(-1, 1, 1)
     x1 = np.asarray(g.vs[1]).ravel().reshape(1, -1, 1)
     d0 = np.sqrt(x0 ** 2 + x1 ** 2) - 0.5 + np.zeros((1, 1, n))
     integ.set_state(torch.as_tensor(d0, dtype=be.dg.tdtype, device=be.device))
+    dist.barrier()
     t = 0.0
     for _ in range(args.warmup):
         t, _dt = integ.step(t)
@@ -292,4 +390,4 @@ def bench_slab(args, rank, world):
     wall = time.perf_counter() - t0
     assert bool(torch.isfinite(integ.state()).all())
     return {"wall": wall, "dev_ms": e0.elapsed_time(e1), "cells": n ** 3,
-            "parallelism": "slab%d (axis-0 slabs, 3-plane halo exchange over RCCL, edge-first overlap)" % world}
+            "parallelism": "slab%d (axis-0 slabs, 3-plane halo exchange over RCCL [%s], edge-first overlap)" % (world, transport)}

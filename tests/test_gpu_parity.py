@@ -675,3 +675,42 @@ def test_slab_integrator_hip_backend_two_virtual_ranks(scheme, periodic0):
         got[b:e] = ys
         assert abs(t - t_ref) <= 1e-14
     (close if scheme.startswith("WENO") else close_eno)(got, y.reshape(n), 1e-12)
+
+
+def test_native_rccl_slab_stepper_self_ring():
+    """hj_slab_rk_step (ncclSend/ncclRecv inside the C library, edge planes + exchange on a second
+    stream) on ONE GPU: a periodic axis 0 closed through a self send/recv must reproduce the
+    in-kernel periodic wrap.  Exercises the real RCCL transport, streams and events."""
+    import torch.distributed as dist
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29591")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        n = (40, 18, 16)
+        g, og = mk([-2., -1.25, -np.pi], [2. * (1 - 2 / n[0]), 1.25, np.pi * (1 - 2 / n[2])], n, (0, 2))
+        data = O.shape_cylinder(og, 2, None, .5) + 0.1 * np.sin(3 * og.xs[0])
+        for scheme in ("WENO5_ASSHIPPED", "WENO5", "ENO3"):
+            sys_ = L.DubinsVehicleRel(g, 1, 1)
+            sd = sdata(g, sys_, DERIV[scheme])
+            op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+            y, t_ref = data.reshape(-1, 1), 0.
+            for _ in range(4):
+                t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
+            slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
+            nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
+                                    [float(v) for v in np.asarray(g.dx).ravel()])
+            nat.set_state(torch.as_tensor(data, device="cuda"))
+            t = 0.
+            for _ in range(4):
+                t, _dt = nat.step(t)
+            got = nat.state().cpu().numpy()
+            nat.close()
+            assert abs(t - t_ref) <= 1e-14
+            (close if scheme.startswith("WENO") else close_eno)(got, y.reshape(n), 1e-12, what=scheme)
+    finally:
+        if created:
+            dist.destroy_process_group()
