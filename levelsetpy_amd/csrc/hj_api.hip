@@ -67,10 +67,12 @@ struct hj_ctx {
     unsigned long long* ring;          // RING_SLOTS * HJ_MAX_DIM keys
     int ring_pos;
     int slot_ring[HJ_BOUND_SLOTS];     // user slot -> ring index (-1 = none)
-    unsigned long long* keys;          // scratch keys (upwind min/max, weno eps): 8
+    unsigned long long* keys;          // scratch keys: [0,32) weno eps (8 groups x 4 dims), [32,36) upwind min/max
     void* weno_vals;                   // HJ_MAX_DIM values of dtype
     const void* weno_src;              // caller-provided eps source or null
     int* flag;                         // nan flag
+    double* partials;                  // per-workgroup partial maxima of max_d1sq_kernel
+    int partials_cap;
     // static step bound cache
     int sb_ham;
     double sb_par[4], sb_val, sb_alpha[HJ_MAX_DIM];
@@ -504,15 +506,28 @@ double key_to_double(unsigned long long k) {
     return v;
 }
 
-int weno_eps_pass(hj_ctx* c, const void* y) {
-    HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
-    const int blocks = (int)std::min<int64_t>(c->total / c->N[c->ndim - 1], 256 * 16);   // rows
+// max(D1^2) per dim of `y` -> `out` (ndim values of the ctx dtype, device), stream-ordered
+int weno_eps_to(hj_ctx* c, const void* y, void* out) {
+    const int64_t S = c->total / c->N[0];
+    const int bx = (int)((S + 255) / 256);
+    // enough workgroups to fill the GPU a few times over, chunks of at least 8 planes
+    int by = (int)std::max<int64_t>(1, std::min<int64_t>((c->N[0] + 7) / 8, (256 * 8 + bx - 1) / bx));
+    const int chunk = (int)((c->N[0] + by - 1) / by);
+    by = (int)((c->N[0] + chunk - 1) / chunk);
+    const int nblocks = bx * by;
+    if (nblocks > c->partials_cap) {
+        if (c->partials) { HIP_TRY(hipFree(c->partials)); c->partials = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c->partials, sizeof(double) * HJ_MAX_DIM * (size_t)nblocks));
+        c->partials_cap = nblocks;
+    }
 #define HJ_MAXD1(T, ND)                                                                          \
     {                                                                                            \
         GridArgs<T, ND> G;                                                                       \
         fill_grid<T, ND>(c, G);                                                                  \
-        hipLaunchKernelGGL((max_d1sq_kernel<T, ND>), dim3(blocks), dim3(256), 0, c->stream,      \
-                           (const T*)y, G, c->keys);                                             \
+        hipLaunchKernelGGL((max_d1sq_kernel<T, ND>), dim3(bx, by), dim3(256), 0, c->stream,      \
+                           (const T*)y, G, c->partials, chunk);                                  \
+        hipLaunchKernelGGL((partials_to_values_kernel<T>), dim3(1), dim3(256), 0, c->stream,     \
+                           c->partials, nblocks, (T*)out, c->ndim);                              \
     }
     if (c->dtype == HJ_F64) {
         if (c->ndim == 2) HJ_MAXD1(double, 2) else if (c->ndim == 3) HJ_MAXD1(double, 3) else HJ_MAXD1(double, 4)
@@ -524,12 +539,12 @@ int weno_eps_pass(hj_ctx* c, const void* y) {
     return HJ_OK;
 }
 
+int weno_eps_pass(hj_ctx* c, const void* y) { return weno_eps_to(c, y, c->weno_vals); }
+
+// kept for call sites that used the two-step form: the values are already in place
 int keys_to_vals(hj_ctx* c, void* out) {
-    if (c->dtype == HJ_F64)
-        hipLaunchKernelGGL((keys_to_values_kernel<double>), dim3(1), dim3(64), 0, c->stream, c->keys, (double*)out, c->ndim);
-    else
-        hipLaunchKernelGGL((keys_to_values_kernel<float>), dim3(1), dim3(64), 0, c->stream, c->keys, (float*)out, c->ndim);
-    HIP_TRY(hipGetLastError());
+    if (out != c->weno_vals)
+        HIP_TRY(hipMemcpyAsync(out, c->weno_vals, c->esz * (size_t)c->ndim, hipMemcpyDeviceToDevice, c->stream));
     return HJ_OK;
 }
 
@@ -787,6 +802,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     for (int d = 0; d < HJ_MAX_DIM; ++d) { c->coord[d] = nullptr; c->N[d] = 1; c->bc[d] = 0; c->tz[d] = 0; c->dx[d] = 1; c->xmin[d] = 0; }
     for (int s = 0; s < 4; ++s) { c->aux[s] = nullptr; c->aux_n[s] = 0; }
     c->ring = nullptr; c->keys = nullptr; c->weno_vals = nullptr; c->weno_src = nullptr; c->flag = nullptr;
+    c->partials = nullptr; c->partials_cap = 0;
     c->sb_valid = false; c->internal_slot = 0;
     c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->lo_rank = c->hi_rank = -1;
     c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
@@ -834,7 +850,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     if ((rc = default_aux(c))) return bail(rc);
     hipError_t e;
     if ((e = hipMalloc((void**)&c->ring, sizeof(unsigned long long) * RING_SLOTS * HJ_MAX_DIM)) != hipSuccess ||
-        (e = hipMalloc((void**)&c->keys, sizeof(unsigned long long) * 8)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->keys, sizeof(unsigned long long) * 40)) != hipSuccess ||
         (e = hipMalloc(&c->weno_vals, 8 * HJ_MAX_DIM)) != hipSuccess ||
         (e = hipMalloc((void**)&c->flag, sizeof(int))) != hipSuccess)
         return bail(fail(HJ_EHIP, "hipMalloc: %s", hipGetErrorString(e)));
@@ -852,6 +868,7 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->keys) (void)hipFree(c->keys);
     if (c->weno_vals) (void)hipFree(c->weno_vals);
     if (c->flag) (void)hipFree(c->flag);
+    if (c->partials) (void)hipFree(c->partials);
     delete c;
 }
 
@@ -914,7 +931,7 @@ int hj_upwind(hj_ctx* c, int scheme, int dim, const void* phi, void* dL, void* d
     }
     unsigned long long* keys = nullptr;
     if (mm) {
-        keys = c->keys + 4;
+        keys = c->keys + 32;
         HIP_TRY(hipMemsetAsync(keys, 0, 4 * sizeof(unsigned long long), c->stream));
     }
     rc = c->dtype == HJ_F64 ? upwind_launch<double>(c, scheme, dim, phi, dL, dR, keys, (const double*)epsv)
@@ -970,7 +987,7 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         return HJ_OK;
     }
     HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
-    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 8);
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 2);
 #define HJ_AB(T, HAM)                                                                            \
     {                                                                                            \
         GridArgs<T, HAM<T>::ND> G;                                                               \
@@ -1055,9 +1072,7 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
 
 int hj_max_d1sq(hj_ctx* c, const void* y, void* out_dev) {
     if (!c || !y || !out_dev) return fail(HJ_EINVAL, "null argument");
-    int rc = weno_eps_pass(c, y);
-    if (rc) return rc;
-    return keys_to_vals(c, out_dev);
+    return weno_eps_to(c, y, out_dev);
 }
 
 int hj_ctx_set_weno_eps_source(hj_ctx* c, const void* src) {

@@ -105,6 +105,16 @@ template <typename T, int ND> struct GridArgs {
 
 template <typename T, int ND>
 __device__ __forceinline__ void decode(const GridArgs<T, ND>& G, long long t, int* idx) {
+    if (G.total < (1ll << 31)) {       // 32-bit divisions: ~4x cheaper than 64-bit ones (uniform branch)
+        unsigned u = (unsigned)t;
+#pragma unroll
+        for (int d = ND - 1; d >= 0; --d) {
+            const unsigned q = u / (unsigned)G.n[d];
+            idx[d] = (int)(u - q * (unsigned)G.n[d]);
+            u = q;
+        }
+        return;
+    }
 #pragma unroll
     for (int d = ND - 1; d >= 0; --d) {
         const long long q = t / G.n[d];
@@ -117,51 +127,60 @@ __device__ __forceinline__ void decode(const GridArgs<T, ND>& G, long long t, in
 // Ghost-to-ghost differences repeat the first interior one (extrapolation) or interior ones
 // (periodic), so the max runs over forward differences of interior cells, the periodic wrap
 // pair, and -- on a slab face -- the pair reaching into the lower halo plane.
+// Plane march: a thread owns one column (fixed indices on axes 1..ND-1, decoded once) and walks a
+// chunk of axis-0 planes, carrying the next plane's value in a register: per cell one streamed load
+// plus ND-1 neighbour loads that adjacent lanes / rows also issue (L1/L2 hits), no divisions in the
+// loop.  Every workgroup leaves its ND partial maxima in partials[block][d] (no contended atomics);
+// partials_to_values_kernel folds them.
 template <typename T, int ND>
 __global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, GridArgs<T, ND> G,
-                                                       unsigned long long* keys) {
-    // one row of the last axis per loop trip: the row index is decoded once (wave-uniform), lanes
-    // stride along the contiguous axis
+                                                       double* __restrict__ partials, int chunk) {
     double m[ND];
 #pragma unroll
-    for (int d = 0; d < ND; ++d) m[d] = -1e300;
-    const int nl = G.n[ND - 1];
-    const long long rows = G.total / nl;
-    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    for (int d = 0; d < ND; ++d) m[d] = 0.0;
+    const long long S = G.stride[0];
+    const long long col = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int pb = blockIdx.y * chunk, pe = min(pb + chunk, G.n[0]);
+    if (col < S && pb < pe) {
         int idx[ND];
-        long long t = row;
+        {
+            unsigned u = (unsigned)col;      // plane size < 2^31 (checked at ctx creation)
 #pragma unroll
-        for (int d = ND - 2; d >= 0; --d) {
-            const long long q = t / G.n[d];
-            idx[d] = (int)(t - q * G.n[d]);
-            t = q;
-        }
-        const T* line = y + row * nl;
-        for (int i = threadIdx.x; i < nl; i += blockDim.x) {
-            const T c = line[i];
-            // last axis
-            {
-                T nb = c;
-                bool have = true;
-                if (i + 1 < nl) nb = line[i + 1];
-                else if (G.bc[ND - 1] == HJ_BC_PERIODIC) nb = line[0];
-                else have = false;
-                if (have) { const T D1 = G.inv_dx[ND - 1] * (nb - c); m[ND - 1] = fmax(m[ND - 1], (double)(D1 * D1)); }
+            for (int d = ND - 1; d >= 1; --d) {
+                const unsigned q = u / (unsigned)G.n[d];
+                idx[d] = (int)(u - q * (unsigned)G.n[d]);
+                u = q;
             }
+        }
+        long long off[ND];       // offset of the forward neighbour on axes >= 1; 0 = none
 #pragma unroll
-            for (int d = 0; d < ND - 1; ++d) {
-                T nb = c;
-                bool have = true;
-                if (idx[d] + 1 < G.n[d]) nb = line[i + G.stride[d]];
-                else if (d == 0 && G.halo_hi) nb = line[i + G.stride[d]];
-                else if (G.bc[d] == HJ_BC_PERIODIC) nb = line[i - (long long)(G.n[d] - 1) * G.stride[d]];
-                else have = false;
-                if (have) { const T D1 = G.inv_dx[d] * (nb - c); m[d] = fmax(m[d], (double)(D1 * D1)); }
-                if (d == 0 && G.halo_lo && idx[0] == 0) {
-                    const T D1 = G.inv_dx[0] * (c - line[i - G.stride[0]]);
-                    m[0] = fmax(m[0], (double)(D1 * D1));
+        for (int d = 1; d < ND; ++d) {
+            off[d] = 0;
+            if (idx[d] + 1 < G.n[d]) off[d] = G.stride[d];
+            else if (G.bc[d] == HJ_BC_PERIODIC) off[d] = -(long long)(G.n[d] - 1) * G.stride[d];
+        }
+        const T* p0 = y + col;
+        T c = p0[(long long)pb * S];
+        if (pb == 0 && G.halo_lo) {      // the pair reaching into the lower halo plane
+            const T D1 = G.inv_dx[0] * (c - p0[-S]);
+            m[0] = fmax(m[0], (double)(D1 * D1));
+        }
+        for (int p = pb; p < pe; ++p) {
+            const T* row = p0 + (long long)p * S;
+            T nx = c;
+            bool have0 = true;
+            if (p + 1 < G.n[0] || G.halo_hi) nx = row[S];
+            else if (G.bc[0] == HJ_BC_PERIODIC) nx = p0[0];
+            else have0 = false;
+            if (have0) { const T D1 = G.inv_dx[0] * (nx - c); m[0] = fmax(m[0], (double)(D1 * D1)); }
+#pragma unroll
+            for (int d = 1; d < ND; ++d) {
+                if (off[d] != 0) {
+                    const T D1 = G.inv_dx[d] * (row[off[d]] - c);
+                    m[d] = fmax(m[d], (double)(D1 * D1));
                 }
             }
+            c = nx;
         }
     }
     __shared__ double red[4][ND];
@@ -175,7 +194,30 @@ __global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, 
     if (threadIdx.x < ND) {
         const int d = threadIdx.x;
         const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        atomicMax(keys + d, max_key(fmax(w, 0.0)));
+        partials[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * HJ_MAX_DIM + d] = w;
+    }
+}
+
+// max over the per-workgroup partials -> ND values of dtype T (one workgroup)
+template <typename T>
+__global__ __launch_bounds__(256) void partials_to_values_kernel(const double* __restrict__ partials, int nblocks,
+                                                                 T* __restrict__ out, int nd) {
+    __shared__ double red[4][HJ_MAX_DIM];
+    double m[HJ_MAX_DIM] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+        for (int d = 0; d < HJ_MAX_DIM; ++d)
+            if (d < nd) m[d] = fmax(m[d], partials[(size_t)b * HJ_MAX_DIM + d]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < HJ_MAX_DIM; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nd) {
+        const int d = threadIdx.x;
+        out[d] = (T)fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
     }
 }
 

@@ -388,6 +388,9 @@ def bench_slab(args, rank, world):
     torch.cuda.synchronize()
     dist.barrier()
     wall = time.perf_counter() - t0
-    assert bool(torch.isfinite(integ.state()).all())
+    ok = bool(torch.isfinite(integ.state()).all())
+    if hasattr(integ, "close"):
+        integ.close()
+    assert ok, "non-finite state after the timed steps"
     return {"wall": wall, "dev_ms": e0.elapsed_time(e1), "cells": n ** 3,
             "parallelism": "slab%d (axis-0 slabs, 3-plane halo exchange over RCCL [%s], edge-first overlap)" % (world, transport)}
