@@ -41,7 +41,7 @@ constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys
 
 struct Tiling {
     int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
-    int ntiles, chunk, nchunks, nchunks1, nblocks, bpx;
+    int ntiles, chunk, nchunks, nchunks1, nblocks, bpx, lpitch;
     size_t lds_bytes;
     double score;
     bool ok;
@@ -86,7 +86,7 @@ struct hj_ctx {
     int slab_pending;
     // tuning
     KernelCfg cfg;
-    int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env;
+    int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
     int target_blocks, min_chunk;
     size_t lds_limit;
 };
@@ -135,6 +135,11 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
             cells *= E[1];
             long long halo = 0, box = 1;
             for (int d = 1; d < nd; ++d) { halo += 6 * (cells / E[d]); box *= (E[d] + 6); }
+            // bank-friendly row pitch (E + 32) when it fits, else the minimal E + 6
+            const long long rows = box / (E[nd - 1] + 6);
+            int pitch = E[nd - 1] + 6;
+            if (c->lds_pad && nd >= 3 && 512 + 2 * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= c->lds_limit) pitch = E[nd - 1] + 32;
+            box = rows * pitch;
             size_t lds = 512 + 2 * (size_t)box * c->esz;
             if (halo <= (long long)k.KH * k.NT && lds <= c->lds_limit) {
                 double util = (double)cells / (double)(((cells + k.NT - 1) / k.NT) * k.NT);
@@ -149,6 +154,7 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
                     best.ok = true;
                     best.score = score;
                     best.lds_bytes = lds;
+                    best.lpitch = pitch;
                     best.ntiles = 1;
                     for (int d = 1; d < nd; ++d) {
                         best.E[d] = E[d];
@@ -278,8 +284,8 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
             t.bpx = (t.nblocks + 7) / 8;
         }
         if (c->debug) {
-            fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
-                    NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.ntiles, t.chunk,
+            fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
+                    NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.lpitch, t.ntiles, t.chunk,
                     t.nchunks, t.nblocks, occ_blocks, t.lds_bytes, t.score);
             c->debug = 0;
         }
@@ -304,6 +310,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.halo_lo = c->halo_lo;
     A.halo_hi = c->halo_hi;
     A.ntiles = t.ntiles;
+    A.lpitch = t.lpitch;
     A.chunk = t.chunk;
     A.nchunks = t.nchunks;
     A.plane_begin = (int)s.p0;
@@ -818,6 +825,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->force_direct = env_int("HJ_FORCE_DIRECT", 0);
     c->debug = env_int("HJ_DEBUG", 0);
     c->full_rows = env_int("HJ_FULL_ROWS", 0);
+    c->lds_pad = env_int("HJ_LDS_PAD", 0);   // bank-friendly row pitch: measured +0.5 % only, off by default
     c->target_blocks = env_int("HJ_TARGET_BLOCKS", 0);   // 0 = choose from the GPU's capacity
     {
         int ncu = 0;

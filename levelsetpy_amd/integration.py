@@ -177,12 +177,16 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
         raise ValueError('y0 does not agree in size with grid')
     dg.bind_stream()
     shape0 = tuple(y0.shape)
+    # the input is only ever read (hj_rk_step never writes y_in), so it is used in place; results go
+    # to buffers allocated here (A/B ping-pong for multi-step spans), so nothing is cloned and the
+    # caller's array is never mutated
     cur = dg.to_device(y0).reshape(dg.shape)
-    if is_tensor(y0) and cur.data_ptr() == y0.data_ptr():
-        cur = cur.clone()                                 # inputs are never mutated
-    nxt, w0, w1 = dg.work('rk_out'), dg.work('rk_w0'), (dg.work('rk_w1') if order == 3 else None)
-    if nxt.data_ptr() == cur.data_ptr():
-        nxt = dg.work('rk_out2')
+    nxt = dg.empty()
+    spare = None
+    # RK3: the first stage buffer doubles as the output (stage 3 reads w1 and y_in only); RK2's second
+    # stage reads the first stage buffer as its stencil input, so it needs its own
+    w0_own = dg.work('rk_w0') if order == 2 else None
+    w1 = dg.work('rk_w1') if order == 3 else None
     parv = _ffi.darr(par)
     t = float(tspan[0])
     tf = float(tspan[1])
@@ -194,17 +198,22 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     while tf - t >= small * abs(tf):
         tOld = t
         _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
-                                     float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0),
+                                     float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt),
+                                     dg.ptr(nxt if order == 3 else w0_own),
                                      dg.ptr(w1), C.byref(tout), C.byref(dtout)))
         yOld = cur
-        cur, nxt = nxt, cur
+        prev = cur
+        cur = nxt
+        # next output buffer: recycle the one two steps back if it is ours, never the caller's input
+        nxt = spare if spare is not None else dg.empty()
+        spare = prev if steps >= 1 else None
         t = float(tout.value)
         steps += 1
         if post:
             yv = dg.like(cur.reshape(shape0), y0)
             yv, schemeData = odeCFLcallPostTimestep(t, yv, schemeData, options)
             cur = dg.to_device(yv).reshape(dg.shape)
-            if cur.data_ptr() in (nxt.data_ptr(),):
+            if cur.data_ptr() == nxt.data_ptr() or (spare is not None and cur.data_ptr() == spare.data_ptr()):
                 cur = cur.clone()
         if strcmp(options.singleStep, 'on'):
             break
@@ -219,8 +228,8 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
         dg.sync()
         info('%d steps in %.2g seconds from  %.2f to %.2f.' % (steps, cputime() - startTime, tspan[0], t))
     out = cur.reshape(shape0)
-    if is_tensor(y0):
-        out = out.clone()          # `cur` is ctx scratch that the next call reuses
+    if is_tensor(y0) and steps == 0:
+        out = out.clone()          # zero steps taken: do not hand the caller's own tensor back
     return np.float64(t), dg.like(out, y0), schemeData
 
 
