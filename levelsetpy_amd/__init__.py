@@ -7,6 +7,12 @@ hot path, behind the reference's own names and callback protocol:
 All arithmetic on the path runs in hand-written HIP kernels (csrc/, C ABI in
 include/hj_mi355x.h, bound with ctypes).  There is no CPU fallback.
 """
+import os as _os
+
+# the slab stepper drives three HIP streams plus RCCL's: with the default 4 hardware queues two of
+# them share a queue and serialise (DESIGN.md 7).  Only effective before HIP initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .utilities import *            # noqa: F401,F403
 from .boundary import addGhostExtrapolate, addGhostPeriodic, addGhostAllDims   # noqa: F401
 from .grids import createGrid, processGrid                                      # noqa: F401

@@ -380,10 +380,14 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
 
 // (threads per workgroup, cells per thread, halo slots per thread) instantiated for the tiled kernel
 #ifndef HJ_CONFIGS
+#ifdef HJ_ALL_CONFIGS   // the full sweep table (tools/cfgsweep.sh); ~2.5 min to compile
 #define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(1024, 2, 1, 4, 2) X(512, 2, 1, 4, 2) X(256, 4, 3, 2, 2) X(256, 2, 2, 4, 2) \
                       X(512, 1, 1, 4, 2) X(256, 1, 2, 6, 2) X(1024, 1, 1, 4, 2) \
                       X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
                       X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
+#else                   // the defaults per scheme plus the runners-up of the round-1 sweeps
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(256, 4, 3, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
+#endif
 #endif
 
 int cfg_kh(int nt, int r) {
