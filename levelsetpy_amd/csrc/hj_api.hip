@@ -386,7 +386,8 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
                       X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
                       X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
 #else                   // the defaults per scheme plus the runners-up of the round-1 sweeps
-#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(256, 4, 3, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(256, 4, 3, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2) \
+                      X(512, 4, 2, 2, 241) X(512, 4, 2, 2, 221) X(512, 4, 3, 2, 2) X(512, 4, 3, 2, 231) X(512, 4, 3, 2, 241) X(512, 4, 3, 2, 221)
 #endif
 #endif
 
@@ -419,7 +420,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             }
             Tiling t = make_tiling(c, k, s.p0, s.p1);
             if (t.ok) {
-#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
+#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
                 HJ_CONFIGS(X)
 #undef X
             }
@@ -839,6 +840,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 4));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
     c->cfg.KH = cfg_kh(c->cfg.NT, c->cfg.R);
+    if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);
     c->occ_hint = env_int("HJ_OCC", -1);
     if (c->occ_hint < 0) {   // default waves/SIMD hint = first table entry of this (NT, R, PD)

@@ -333,22 +333,36 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
         for (int r = 0; r < R; ++r) q[r][j] = tmp[r];
     }
-    // register sets of the pipeline: set s = (p - p_begin) % PD serves plane p
-    T own[PD][R], hal[PD][KH], y0s[PD][R];
-    typename HAM::Plane pls[PD];
+    // register sets of the pipeline.  PD < 10: one depth for everything; else PD = 100*y0 + 10*halo + own
+    // (e.g. 241: own cells 1 plane ahead, halo ring 4, y0 2 -- the halo ring of plane P is then
+    // requested in the same iteration in which the neighbouring tiles request P as their own cells,
+    // so the second requester finds the lines in L2).  Set (p - p_begin) % depth serves plane p.
+    constexpr int PDO = PD < 10 ? PD : PD % 10;
+    constexpr int PDH = PD < 10 ? PD : (PD / 10) % 10;
+    constexpr int PDY = PD < 10 ? PD : PD / 100;
+    T own[PDO][R], hal[PDH][KH], y0s[PDY][R];
+    typename HAM::Plane pls[PDY];
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
+    for (int s = 0; s < PDO; ++s) {
 #pragma unroll
-        for (int k = 0; k < KH; ++k) hal[s][k] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) { y0s[s][r] = T(0); own[s][r] = T(0); }
-        const int ps = min(p_begin + s, p_last);
-        load_halo(ps, hal[s]);
-        load_y0(ps, y0s[s]);
-        pls[s] = HAM::plane(A.ham, ps, A.sc);
+        for (int r = 0; r < R; ++r) own[s][r] = T(0);
         // own[s] holds plane p+4 for the iteration of plane p = p_begin+s; the last set is filled
         // by the first iteration
-        if (s < PD - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+        if (s < PDO - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < PDH; ++s) {
+#pragma unroll
+        for (int k = 0; k < KH; ++k) hal[s][k] = T(0);
+        load_halo(min(p_begin + s, p_last), hal[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < PDY; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) y0s[s][r] = T(0);
+        const int ps = min(p_begin + s, p_last);
+        load_y0(ps, y0s[s]);
+        pls[s] = HAM::plane(A.ham, ps, A.sc);
     }
     const typename HAM::Plane& plX = pls[0];
 
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // are refilled for plane p+PD once consumed.
     auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* y0_c, typename HAM::Plane& pl_c) {
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
-        load_own(min(p + 3 + PD, p_end + 2), own_n);
+        load_own(min(p + 3 + PDO, p_end + 2), own_n);
         // stage the centre plane
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -382,8 +396,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         for (int k = 0; k < KH; ++k)
             if (h_real[k]) buf[h_lds[k]] = hal_c[k];
         __syncthreads();
-        const int p2 = min(p + PD, p_last);
-        load_halo(p2, hal_c);
+        const int p2 = min(p + PDY, p_last);
+        load_halo(min(p + PDH, p_last), hal_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
         pl_c = HAM::plane(A.ham, p2, A.sc);
@@ -450,13 +464,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
     };
 
-    for (int p = p_begin; p < p_end; p += PD) {
-        body(p, own[0], own[PD - 1], hal[0], y0s[0], pls[0]);
-        if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], y0s[1], pls[1]);
-        if constexpr (PD > 2) {
-            if (p + 2 < p_end) body(p + 2, own[2], own[1], hal[2], y0s[2], pls[2]);
-        }
+    constexpr int L1 = PDO * PDH / (PDO % PDH == 0 ? PDH : (PDH % PDO == 0 ? PDO : 1));   // lcm for 1..4
+    constexpr int UNR = L1 * PDY / (L1 % PDY == 0 ? PDY : (PDY % L1 == 0 ? L1 : 1));
+    static_assert(UNR <= 6 && UNR % PDO == 0 && UNR % PDH == 0 && UNR % PDY == 0, "unsupported depth mix");
+#define HJ_BODY(u)                                                                                   \
+    if constexpr (UNR > (u)) {                                                                       \
+        if (p + (u) < p_end)                                                                         \
+            body(p + (u), own[(u) % PDO], own[((u) + PDO - 1) % PDO], hal[(u) % PDH], y0s[(u) % PDY], \
+                 pls[(u) % PDY]);                                                                    \
     }
+    for (int p = p_begin; p < p_end; p += UNR) {
+        HJ_BODY(0) HJ_BODY(1) HJ_BODY(2) HJ_BODY(3) HJ_BODY(4) HJ_BODY(5)
+    }
+#undef HJ_BODY
 
     // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim
     const int lane = tid & 63, wv = tid >> 6;
