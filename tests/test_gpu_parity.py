@@ -714,3 +714,81 @@ def test_native_rccl_slab_stepper_self_ring():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ BASELINE sizes: properties
+def _substep(dg, scheme, ham, par, stage, dt, y, y0, out, p0=0, p1=None, slot=3):
+    p1 = dg.shape[0] if p1 is None else p1
+    _ffi.check(dg.lib.hj_rk_substep(dg.ctx, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), 0., stage, dt, 0,
+                                    dg.ptr(y), dg.ptr(y0) if y0 is not None else None, dg.ptr(out), slot, p0, p1))
+
+
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "WENO5"])
+def test_full_size_201_cubed_properties(scheme, monkeypatch):
+    """BASELINE C2 (201^3 Dubins, fp64), too big for the NumPy oracle in a test: size-independent
+    properties instead.  (1) the tiled kernel and the independent direct kernel agree to rounding;
+    (2) computing the grid as two plane ranges equals one launch bitwise; (3) after 3 RK3 steps from
+    the z-invariant cylinder the state is still z-invariant wherever the Hamiltonian is (it is not: the
+    dynamics depend on x3) -- instead check the reflection symmetry x2 -> -x2, x3 -> -x3 of the Dubins
+    problem on the symmetric grid rows; (4) stepBound equals the closed form 1/sum(max alpha/dx)."""
+    n = 201
+    g, og = dubins(n)
+    d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+    par = [1., 1., 1., 2.]
+    outs = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        y = dg.to_device(d0)
+        a, b, c = dg.empty(), dg.empty(), dg.empty()
+        _substep(dg, scheme, _ffi.HAM_DUBINS_REL, par, _ffi.STAGE_EULER, 2e-3, y, None, a)
+        _substep(dg, scheme, _ffi.HAM_DUBINS_REL, par, _ffi.STAGE_RK3_HALF, 2e-3, a, y, b)
+        _substep(dg, scheme, _ffi.HAM_DUBINS_REL, par, _ffi.STAGE_RK3_FULL, 2e-3, b, y, c)
+        if force == "0":
+            # (2) plane-range split of the last substep
+            c2 = torch.zeros_like(c)
+            _substep(dg, scheme, _ffi.HAM_DUBINS_REL, par, _ffi.STAGE_RK3_FULL, 2e-3, b, y, c2, 0, 77, slot=4)
+            _substep(dg, scheme, _ffi.HAM_DUBINS_REL, par, _ffi.STAGE_RK3_FULL, 2e-3, b, y, c2, 77, n, slot=5)
+            dg.sync()
+            assert torch.equal(c, c2), float((c - c2).abs().max())
+            sb, am = C.c_double(), (C.c_double * 4)()
+            _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 3, C.byref(sb), am))
+            x0, x1, x2 = (np.asarray(v).ravel() for v in g.vs)
+            a0 = np.max(np.abs(1 - np.cos(x2))) + np.max(np.abs(x1))
+            a1 = np.max(np.abs(np.sin(x2))) + np.max(np.abs(x0))
+            dx = np.asarray(g.dx).ravel()
+            assert abs(sb.value - 1 / (a0 / dx[0] + a1 / dx[1] + 2 / dx[2])) <= 1e-13 * sb.value
+        dg.sync()
+        outs[force] = c.cpu().numpy()
+    err = np.max(np.abs(outs["0"] - outs["1"]))
+    assert err <= 1e-12, err
+    assert np.isfinite(outs["0"]).all()
+    # (3) H(x1, -x2, -x3; p1, -p2, -p3) = H(x; p) and the cylinder is even in x2: the solution stays
+    # even under (x2, x3) -> (-x2, -x3).  x2 nodes are symmetric; x3 = -pi + k*dx3 maps k -> n-k (mod n).
+    u = outs["0"]
+    k = np.arange(n)
+    mirror = u[:, ::-1, :][:, :, (n - k) % n]
+    assert np.max(np.abs(u - mirror)) <= 1e-10
+
+
+def test_full_size_4096_squared_tiled_vs_direct(monkeypatch):
+    """BASELINE C3 (double integrator, 4096^2, ENO3): tiled vs direct kernel on one substep, and the
+    CFL bound against its closed form 1/(max|x2|/dx1 + u/dx2)."""
+    n = 4096
+    g = L.createGrid(-np.ones((2, 1)), np.ones((2, 1)), n * np.ones((2, 1), dtype=np.int64), None, low_mem=True)
+    d0 = L.shapeSphere(g, np.zeros((2, 1)), .25) + 0.01 * np.random.default_rng(0).standard_normal((n, n))
+    outs = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        y = dg.to_device(d0)
+        a = dg.empty()
+        _substep(dg, "ENO3", _ffi.HAM_DOUBLE_INTEGRATOR, [1.5, 0, 0, 0], _ffi.STAGE_EULER, 1e-4, y, None, a)
+        sb = C.c_double()
+        _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 3, C.byref(sb), None))
+        dx = np.asarray(g.dx).ravel()
+        assert abs(sb.value - 1 / (1.0 / dx[0] + 1.5 / dx[1])) <= 1e-13 * sb.value
+        outs[force] = a.cpu().numpy()
+    assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-11
