@@ -129,6 +129,11 @@ def measured_traffic(n, scheme, dtype, world):
 
 def main():
     a = parse()
+    # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version header at
+    # communicator creation, for one) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,11 +149,16 @@ def main():
     from levelsetpy_amd.context import DeviceGrid
 
     n = a.n
-    if world > 1:
+    if world > 1 or os.environ.get("HJ_BENCH_FORCE_SLAB"):
         from levelsetpy_amd import dist as hjdist
+        if world == 1:      # rehearsal of the N > 1 leg on one GPU (a single slab, no neighbours)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         result = hjdist.bench_slab(a, rank, world)
         wall, dev_ms, cells, sched = result["wall"], result["dev_ms"], result["cells"], result["parallelism"]
-        also = {}
+        also = {"slab_check_max_abs_diff": result.get("slab_check_max_abs_diff")}
     else:
         g, gmin, gmax = dubins_grid(L, n, n)
         dg = DeviceGrid(g, a.dtype)
@@ -205,8 +215,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.scheme)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or os.environ.get("HJ_BENCH_FORCE_SLAB"):
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -120,8 +120,10 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
             if (e == 1) break;
         }
     }
-    if (c->full_rows) {   // tuning knob: the last axis is never split (contiguous tile planes)
+    if (c->full_rows == 1) {   // tuning knob: the last axis is never split (contiguous tile planes)
         cand[nd - 1].assign(1, n[nd - 1]);
+    } else if (c->full_rows > 1) {   // tuning knob: force the last-axis extent
+        cand[nd - 1].assign(1, std::min(c->full_rows, n[nd - 1]));
     }
     int E[HJ_MAX_DIM] = {1, 1, 1, 1};
     // enumerate extents of all plane axes except the first, which takes what is left
@@ -149,7 +151,10 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
                     int nt = (n[d] + E[d] - 1) / E[d];
                     waste *= (double)nt * E[d] / (double)n[d];
                 }
-                double score = ((double)(cells + halo) / (double)cells) * waste / util;
+                // every row of the tile (own and halo) drags in partial cache lines at both ends:
+                // ~48 B per row, calibrated on the 401^3 fp64 and 129^4 fp32 tile-shape sweeps
+                const double row_cost = 1.0 + (48.0 / (double)c->esz) / (double)E[nd - 1];
+                double score = ((double)(cells + halo) / (double)cells) * row_cost * waste / util;
                 if (score < best.score) {
                     best.ok = true;
                     best.score = score;
@@ -390,9 +395,15 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
 #endif
 #endif
 
-int cfg_kh(int nt, int r) {
+// 4-D grids tile three plane axes: the halo cross is ~2x the tile, so more halo slots per thread
+#ifndef HJ_CONFIGS_4D
+#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2) X(1024, 1, 2, 2, 2)
+#endif
+
+int cfg_kh(int nd, int nt, int r) {
 #define X(NT_, R_, KH_, OCC_, PD_) if (nt == NT_ && r == R_) return KH_;
-    HJ_CONFIGS(X)
+    if (nd == 4) { HJ_CONFIGS_4D(X) }
+    else { HJ_CONFIGS(X) }
 #undef X
     return -1;
 }
@@ -404,7 +415,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
     constexpr bool tiled_ok = std::is_same<T, double>::value && HAM::ID == HJ_HAM_DUBINS_REL &&
                               (SCHEME == HJ_WENO5 || SCHEME == HJ_WENO5_ASSHIPPED);
 #else
-    constexpr bool tiled_ok = HAM::ND <= 3;
+    constexpr bool tiled_ok = true;
 #endif
     if constexpr (tiled_ok) {
         if (!c->force_direct) {
@@ -413,14 +424,16 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             if (!c->cfg_from_env) {
                 // round-1 sweeps (profiles/): the heavier the per-cell arithmetic, the fewer cells per
                 // thread fit in the 256-VGPR budget without scratch
-                if (SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
+                if (HAM::ND == 4) { k.NT = sizeof(T) == 4 ? 1024 : 512; k.R = sizeof(T) == 4 ? 1 : 2; pd = 2; occ = 2; }
+                else if (SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
                 else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
-                k.KH = cfg_kh(k.NT, k.R);
+                k.KH = cfg_kh(HAM::ND, k.NT, k.R);
             }
             Tiling t = make_tiling(c, k, s.p0, s.p1);
             if (t.ok) {
 #define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
-                HJ_CONFIGS(X)
+                if constexpr (HAM::ND == 4) { HJ_CONFIGS_4D(X) }
+                else { HJ_CONFIGS(X) }
 #undef X
             }
         }
@@ -838,16 +851,17 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     }
     c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 4));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
-    c->cfg.KH = cfg_kh(c->cfg.NT, c->cfg.R);
+    c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);
     c->occ_hint = env_int("HJ_OCC", -1);
     if (c->occ_hint < 0) {   // default waves/SIMD hint = first table entry of this (NT, R, PD)
 #define X(NT_, R_, KH_, OCC_, PD_) if (c->occ_hint < 0 && c->cfg.NT == NT_ && c->cfg.R == R_ && c->pd == PD_) c->occ_hint = OCC_;
-        HJ_CONFIGS(X)
+        if (ndim == 4) { HJ_CONFIGS_4D(X) }
+        else { HJ_CONFIGS(X) }
 #undef X
     }
-    if (c->cfg.KH < 0) {
+    if (c->cfg.KH < 0 && c->cfg_from_env) {
         const int nt = c->cfg.NT, r = c->cfg.R;
         delete c;
         return fail(HJ_EINVAL, "unsupported HJ_NT/HJ_R combination %d/%d", nt, r);

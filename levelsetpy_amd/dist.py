@@ -344,6 +344,41 @@ class NativeSlabStepper(object):
         _ffi.check(self.dg.lib.hj_comm_destroy(self.dg.ctx))
 
 
+def _slab_self_check(L, g, slab, integ, args, tdtype, device, steps=2):
+    """max |slab result - single-domain result| over this rank's planes after `steps` RK3 steps."""
+    import torch
+    from .context import DeviceGrid
+    t = 0.0
+    for _ in range(steps):
+        t, _dt = integ.step(t)
+    mine = integ.state().clone()
+    torch.cuda.synchronize(device)
+    n0 = slab.n0
+    x0 = np.asarray(g.vs[0]).ravel().reshape(-1, 1, 1)
+    x1 = np.asarray(g.vs[1]).ravel().reshape(1, -1, 1)
+    full0 = np.sqrt(x0 ** 2 + x1 ** 2) - 0.5 + np.zeros((1, 1, int(np.asarray(g.N).ravel()[2])))
+    dg = DeviceGrid(g, args.dtype)
+    dg.bind_stream()
+    cur = torch.as_tensor(full0, dtype=tdtype, device=device)
+    assert cur.shape[0] == n0
+    nxt, w1 = torch.empty_like(cur), torch.empty_like(cur)
+    tout, dtout = C.c_double(), C.c_double()
+    par = _ffi.darr([1.0, 1.0, 1.0, 2.0])
+    ts = 0.0
+    for _ in range(steps):
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, _ffi.SCHEME_IDS[args.scheme], _ffi.HAM_DUBINS_REL, par, ts, 1e9, 0.8,
+                                     1e300, 0, dg.ptr(cur), dg.ptr(nxt), dg.ptr(nxt), dg.ptr(w1),
+                                     C.byref(tout), C.byref(dtout)))
+        cur, nxt = nxt, cur
+        ts = float(tout.value)
+    torch.cuda.synchronize(device)
+    diff = float((cur[slab.begin:slab.end] - mine).abs().max())
+    if abs(ts - t) > 1e-14 * max(1.0, abs(t)):
+        diff = max(diff, abs(ts - t))
+    del cur, nxt, w1
+    return diff
+
+
 def bench_slab(args, rank, world):
     """bench.py's N > 1 leg: every rank owns an n^3 slab of an (N*n) x n x n Dubins grid."""
     import time
@@ -371,8 +406,21 @@ def bench_slab(args, rank, world):
     x0 = np.asarray(g.vs[0]).ravel()[slab.begin:slab.end].reshape(-1, 1, 1)
     x1 = np.asarray(g.vs[1]).ravel().reshape(1, -1, 1)
     d0 = np.sqrt(x0 ** 2 + x1 ** 2) - 0.5 + np.zeros((1, 1, n))
-    integ.set_state(torch.as_tensor(d0, dtype=be.dg.tdtype, device=be.device))
+    y_init = torch.as_tensor(d0, dtype=be.dg.tdtype, device=be.device)
+    integ.set_state(y_init)
     dist.barrier()
+    # self-check (untimed): two slab steps against the same two steps of the WHOLE (N*n) x n x n grid
+    # computed single-domain on this GPU -- the decomposition must not change the numbers
+    check = None
+    if os.environ.get("HJ_BENCH_SLAB_CHECK", "1") != "0":
+        check = _slab_self_check(L, g, slab, integ, args, be.dg.tdtype, be.device)
+        worst = torch.tensor([check], dtype=torch.float64, device=be.device)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        check = float(worst.item())
+        if not check <= 1e-12:
+            raise RuntimeError("slab decomposition changed the result: max |slab - single domain| = %g" % check)
+        integ.set_state(y_init)
+        dist.barrier()
     t = 0.0
     for _ in range(args.warmup):
         t, _dt = integ.step(t)
@@ -392,5 +440,5 @@ def bench_slab(args, rank, world):
     if hasattr(integ, "close"):
         integ.close()
     assert ok, "non-finite state after the timed steps"
-    return {"wall": wall, "dev_ms": e0.elapsed_time(e1), "cells": n ** 3,
+    return {"wall": wall, "dev_ms": e0.elapsed_time(e1), "cells": n ** 3, "slab_check_max_abs_diff": check,
             "parallelism": "slab%d (axis-0 slabs, 3-plane halo exchange over RCCL [%s], edge-first overlap)" % (world, transport)}

@@ -195,6 +195,12 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     post = _post_hook(options)
     tout, dtout = C.c_double(), C.c_double()
     eventValueOld = None
+    # the native Hamiltonians have a data-independent alpha, so stepBound is the same at every
+    # substep: the reference's CFL warning (ode_cfl_3.py:173-175,215-217) can only fire when
+    # factorCFL > min(1, 1.2 factorCFL), and it is decided on the host without a device read
+    safetyFactorCFL = min(1.0, 1.2 * float(options.factorCFL))
+    sb_static = C.c_double()
+    _ffi.check(dg.lib.hj_static_step_bound(dg.ctx, ham, parv, C.byref(sb_static), None))
     while tf - t >= small * abs(tf):
         tOld = t
         _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
@@ -209,6 +215,9 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
         spare = prev if steps >= 1 else None
         t = float(tout.value)
         steps += 1
+        if order > 1 and dtout.value > safetyFactorCFL * sb_static.value:
+            for which in ('Second', 'Third')[:order - 1]:
+                warn('%s substep violated CFL effective number %s' % (which, dtout.value / sb_static.value))
         if post:
             yv = dg.like(cur.reshape(shape0), y0)
             yv, schemeData = odeCFLcallPostTimestep(t, yv, schemeData, options)

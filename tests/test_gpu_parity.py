@@ -254,6 +254,24 @@ def test_term_4d_pendulum_vs_oracle(scheme):
     assert abs(sb - sbo) <= 1e-12 * sbo
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((14, 13, 17, 15), (0, 2)), ((8, 25, 9, 30), (1, 3)), ((21, 7, 8, 33), None)])
+def test_term_tiled_and_direct_vs_oracle_4d(scheme, n, pd, monkeypatch):
+    """4-D grids tile three plane axes (halo cross on each): periodic and extrapolated axes mixed,
+    extents that are not multiples of the tile, several tiles per axis."""
+    gmin = [-np.pi, -8, -np.pi, -8]
+    gmax = [np.pi * (1 - 2 / n[0]), 8 * (1 - 2 / n[1]), np.pi * (1 - 2 / n[2]), 8 * (1 - 2 / n[3])]
+    g, og = mk(gmin, gmax, n, pd)
+    data = O.shape_sphere(og, None, 1.5) + 0.02 * np.random.default_rng(12).standard_normal(n)
+    y = data.reshape(-1, 1)
+    (yt, sbt, _), (yd, sbd, _) = _term_both_kernels(g, L.DoublePendulum4D(g, 1.0), scheme, y, monkeypatch)
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), scheme, 0., y)
+    close(yt, yo, 1e-10, what="tiled")
+    close(yd, yo, 1e-10, what="direct")
+    close(yt, yd, 1e-12, what="tiled vs direct")
+    assert abs(sbt - sbo) <= 1e-12 * sbo and abs(sbd - sbo) <= 1e-12 * sbo
+
+
 def test_term_split_path_with_foreign_callbacks_matches_fused():
     """A user hamFunc/partialFunc (plain functions -> split path) gives the fused result."""
     g, og = dubins([14, 13, 12])
@@ -387,6 +405,21 @@ def test_ode_generic_path_equals_device_path_and_hooks():
     assert tt.shape == (3, 1) and yy.shape == (3, y0.size)
     # inputs are never mutated
     assert np.array_equal(y0, O.shape_cylinder(og, 2, None, .5).reshape(-1, 1))
+
+
+def test_cfl_violation_warning_on_device_and_generic_paths(caplog):
+    # ode_cfl_3.py:173-175,215-217: warn when deltaT > min(1, 1.2 factorCFL)*stepBound at substeps 2, 3
+    import logging
+    g, og = dubins([13, 12, 11])
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstENO3)
+    y0 = O.shape_cylinder(og, 2, None, .5).reshape(-1, 1)
+    for fn in (L.termLaxFriedrichs, lambda t, y, s: L.termLaxFriedrichs(t, y, s)):
+        for factor, expect in ((0.8, 0), (1.5, 2)):
+            caplog.clear()
+            with caplog.at_level(logging.WARNING):
+                L.odeCFL3(fn, [0., 1.], y0, L.odeCFLset(L.Bundle(dict(factorCFL=factor, singleStep='on'))), sd)
+            n = sum('violated CFL' in r.getMessage() for r in caplog.records)
+            assert n == expect, (factor, n)
 
 
 def test_known_answers_51cubed_all_schemes():
