@@ -36,8 +36,8 @@ BYTES_PER_SUBSTEP = {"float64": 64.0 / 3.0, "float32": 32.0 / 3.0}   # SURVEY 8(
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=201, help="grid points per axis (per rank along axis 0)")
     ap.add_argument("--scheme", default="WENO5_ASSHIPPED", choices=["WENO5", "WENO5_ASSHIPPED", "ENO3", "ENO2"],
                     help="WENO5_ASSHIPPED = what the reference's upwindFirstWENO5 computes (parity-pinned; "

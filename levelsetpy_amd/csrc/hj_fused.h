@@ -302,17 +302,18 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             }
         }
     };
-    auto load_halo = [&](int p, T* dst) {
+    // the halo ring of a tile that touches an extrapolated edge needs two loads per slot (edge and
+    // inner cell).  Both are only ISSUED here; the ghost arithmetic is done when the slot is
+    // consumed, PD planes later -- forming the ghost value at load time would make the wave wait
+    // out the full memory latency every plane (measured: 21 % of the 401^3 launch, since the
+    // edge tiles then set the duration of the single round of workgroups).
+    auto load_halo = [&](int p, T* dst, T* dst_in) {
         const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
         for (int k = 0; k < KH; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
         if (tile_ghost) {
 #pragma unroll
-            for (int k = 0; k < KH; ++k) {
-                // h_km = 0 for in-domain slots: edge + 0*slope = edge
-                const T in = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
-                dst[k] = ghost_value(dst[k], in, h_km[k]);
-            }
+            for (int k = 0; k < KH; ++k) dst_in[k] = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
         }
     };
     auto load_y0 = [&](int p, T* dst) {
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     constexpr int PDO = PD < 10 ? PD : PD % 10;
     constexpr int PDH = PD < 10 ? PD : (PD / 10) % 10;
     constexpr int PDY = PD < 10 ? PD : PD / 100;
-    T own[PDO][R], hal[PDH][KH], y0s[PDY][R];
+    T own[PDO][R], hal[PDH][KH], hin[PDH][KH], y0s[PDY][R];
     typename HAM::Plane pls[PDY];
 #pragma unroll
     for (int s = 0; s < PDO; ++s) {
@@ -353,8 +354,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
     for (int s = 0; s < PDH; ++s) {
 #pragma unroll
-        for (int k = 0; k < KH; ++k) hal[s][k] = T(0);
-        load_halo(min(p_begin + s, p_last), hal[s]);
+        for (int k = 0; k < KH; ++k) { hal[s][k] = T(0); hin[s][k] = T(0); }
+        load_halo(min(p_begin + s, p_last), hal[s], hin[s]);
     }
 #pragma unroll
     for (int s = 0; s < PDY; ++s) {
@@ -385,19 +386,26 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // one plane.  own_c holds plane p+4 (joins the queue at the end); own_n is refilled with plane
     // p+3+PD; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
     // are refilled for plane p+PD once consumed.
-    auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* y0_c, typename HAM::Plane& pl_c) {
+    auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* hin_c, T* y0_c, typename HAM::Plane& pl_c) {
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
         load_own(min(p + 3 + PDO, p_end + 2), own_n);
         // stage the centre plane
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (r < R - 1 || last_real) buf[own_lds[r]] = q[r][3];
+        if (tile_ghost) {
+            // h_km = 0 for in-domain slots: edge + 0*slope = edge
 #pragma unroll
-        for (int k = 0; k < KH; ++k)
-            if (h_real[k]) buf[h_lds[k]] = hal_c[k];
+            for (int k = 0; k < KH; ++k)
+                if (h_real[k]) buf[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KH; ++k)
+                if (h_real[k]) buf[h_lds[k]] = hal_c[k];
+        }
         __syncthreads();
         const int p2 = min(p + PDY, p_last);
-        load_halo(min(p + PDH, p_last), hal_c);
+        load_halo(min(p + PDH, p_last), hal_c, hin_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
         pl_c = HAM::plane(A.ham, p2, A.sc);
@@ -470,8 +478,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #define HJ_BODY(u)                                                                                   \
     if constexpr (UNR > (u)) {                                                                       \
         if (p + (u) < p_end)                                                                         \
-            body(p + (u), own[(u) % PDO], own[((u) + PDO - 1) % PDO], hal[(u) % PDH], y0s[(u) % PDY], \
-                 pls[(u) % PDY]);                                                                    \
+            body(p + (u), own[(u) % PDO], own[((u) + PDO - 1) % PDO], hal[(u) % PDH], hin[(u) % PDH],  \
+                 y0s[(u) % PDY], pls[(u) % PDY]);                                                                    \
     }
     for (int p = p_begin; p < p_end; p += UNR) {
         HJ_BODY(0) HJ_BODY(1) HJ_BODY(2) HJ_BODY(3) HJ_BODY(4) HJ_BODY(5)

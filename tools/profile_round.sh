@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu-baseline --steps 20 --warmup 3 > $out/stats_bench.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
 for n in 201 401; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
     name=$(echo $ctr | cut -d' ' -f1)
