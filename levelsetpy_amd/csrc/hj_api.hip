@@ -343,9 +343,28 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     }
+    const char* dump = getenv("HJ_TIMING_DUMP");    // debug: per-workgroup start/end clocks of every launch
+    unsigned long long* tbuf = nullptr;
+    if (dump && *dump) {
+        HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), c->stream));
+        A.timing = tbuf;
+    }
     hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (const T*)s.y0,
                        (T*)s.out, A);
     HIP_TRY(hipGetLastError());
+    if (tbuf) {
+        std::vector<unsigned long long> h((size_t)t.nblocks * 4);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(h.data(), tbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(tbuf));
+        if (FILE* f = fopen(dump, "a")) {
+            fprintf(f, "# launch nblocks=%d ntiles=%d chunk=%d stage=%d\n", t.nblocks, t.ntiles, t.chunk, s.stage);
+            for (int i = 0; i < t.nblocks; ++i)
+                fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+            fclose(f);
+        }
+    }
     return HJ_OK;
 }
 

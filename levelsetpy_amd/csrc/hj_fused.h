@@ -82,6 +82,8 @@ template <typename T, int ND> struct FusedArgs {
     int do_clamp;                 // termRestrictUpdate: ydot clamped to [lo, hi]
     T clamp_lo, clamp_hi;
     HamTables<T> ham;
+    // debug (HJ_TIMING_DUMP): per logical block {start, end} of the constant 100 MHz clock, {xcc id, chunk}
+    unsigned long long* timing;
 };
 
 // where the values of axis-0 plane `p` (possibly a ghost plane) come from: wave-uniform
@@ -133,8 +135,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const int b = blockIdx.x;
     const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
     if (L >= A.nblocks) return;
+    const int prio_cls = (b >> 3) / 32;
     const int chunk_id = L / A.ntiles;
     int rem = L - chunk_id * A.ntiles;
+    if (A.timing && threadIdx.x == 0) {
+        A.timing[4 * L + 0] = wall_clock64();
+        A.timing[4 * L + 2] = (unsigned long long)(b & 7);
+        A.timing[4 * L + 3] = (unsigned long long)chunk_id;
+    }
     int org[ND];
 #pragma unroll
     for (int d = ND - 1; d >= 1; --d) {
@@ -313,7 +321,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         for (int k = 0; k < KH; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
         if (tile_ghost) {
 #pragma unroll
-            for (int k = 0; k < KH; ++k) dst_in[k] = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
+            for (int k = 0; k < KH; ++k) {
+                // only the slots that really are ghost cells fetch their inner neighbour (exec-masked
+                // load): the other lanes would just re-request the line of their first load
+                dst_in[k] = T(0);
+                if (h_dlt[k] != 0) dst_in[k] = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
+            }
         }
     };
     auto load_y0 = [&](int p, T* dst) {
@@ -388,6 +401,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // are refilled for plane p+PD once consumed.
     auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* hin_c, T* y0_c, typename HAM::Plane& pl_c) {
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
+#ifdef HJ_ROTATE_PRIO
+        // experiment: rotate the wave priority so that co-resident workgroups share the CU evenly
+        switch ((prio_cls + (p - p_begin)) % 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(2); break;
+        }
+#endif
         load_own(min(p + 3 + PDO, p_end + 2), own_n);
         // stage the centre plane
 #pragma unroll
@@ -499,6 +520,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
         if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
     }
+    if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
 }
 
 }  // namespace hj
