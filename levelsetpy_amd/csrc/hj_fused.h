@@ -135,7 +135,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const int b = blockIdx.x;
     const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
     if (L >= A.nblocks) return;
-    const int prio_cls = (b >> 3) / 32;
     const int chunk_id = L / A.ntiles;
     int rem = L - chunk_id * A.ntiles;
     if (A.timing && threadIdx.x == 0) {
@@ -401,14 +400,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // are refilled for plane p+PD once consumed.
     auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* hin_c, T* y0_c, typename HAM::Plane& pl_c) {
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
-#ifdef HJ_ROTATE_PRIO
-        // experiment: rotate the wave priority so that co-resident workgroups share the CU evenly
-        switch ((prio_cls + (p - p_begin)) % 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(2); break;
-        }
-#endif
         load_own(min(p + 3 + PDO, p_end + 2), own_n);
         // stage the centre plane
 #pragma unroll
