@@ -182,6 +182,25 @@ int hj_slab_join(hj_ctx* ctx);
 int hj_slab_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double dt,
                     int restrict_sign, const void* cur, void* y_out, void* work0, void* work1);
 
+/* ---- deep-halo slab stepping: ONE exchange per odeCFLn step instead of one per substep.
+ * The slab buffers carry D = HJ_STENCIL*order pad planes on every side that has a neighbour.  Stage s
+ * also computes HJ_STENCIL*(order-s) planes beyond the slab (redundantly with the neighbour), so
+ * the next stage finds its stencil inputs locally; only the final result's D edge planes are exchanged,
+ * overlapped with the last interior launch of this step and the first of the next.  Needs a dt known
+ * in advance (data-independent alpha: every native Hamiltonian) and n_local >= 2*D.
+ *   hj_ctx_set_axis0_pad   axis-0 tables for the pad planes: vs0_ext (and, for Hamiltonians whose
+ *                          aux slots 0/1 are indexed by the axis-0 node, aux0_ext/aux1_ext; else NULL)
+ *                          hold N[0]+2*pad values, entry `pad` being the slab's first plane.
+ *   hj_comm_init_external  like hj_comm_init but WITHOUT a communicator: the caller moves the pad planes
+ *                          itself (MPI, torch.distributed, a test harness) after hj_slab_join + sync.
+ *   hj_halo_exchange_depth hj_halo_exchange for `depth` planes.
+ *   hj_slab_rk_step_deep   one step; same buffers/semantics as hj_slab_rk_step (pads D deep). */
+int hj_ctx_set_axis0_pad(hj_ctx* ctx, int pad, const double* vs0_ext, const double* aux0_ext, const double* aux1_ext);
+int hj_comm_init_external(hj_ctx* ctx, int rank, int nranks, int lo_rank, int hi_rank);
+int hj_halo_exchange_depth(hj_ctx* ctx, void* buf, int depth);
+int hj_slab_rk_step_deep(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double dt,
+                         int restrict_sign, const void* cur, void* y_out, void* work0, void* work1);
+
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);
 const char* hj_version(void);

@@ -49,6 +49,10 @@ SIGNATURES = {
     "hj_halo_exchange": (_i, [_vp, _vp]),
     "hj_slab_join": (_i, [_vp]),
     "hj_slab_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _i, _vp, _vp, _vp, _vp]),
+    "hj_ctx_set_axis0_pad": (_i, [_vp, _i, _pd, _pd, _pd]),
+    "hj_comm_init_external": (_i, [_vp, _i, _i, _i, _i]),
+    "hj_halo_exchange_depth": (_i, [_vp, _vp, _i]),
+    "hj_slab_rk_step_deep": (_i, [_vp, _i, _i, _i, _pd, _d, _i, _vp, _vp, _vp, _vp]),
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
     "hj_version": (C.c_char_p, []),

@@ -52,7 +52,7 @@ def grid_bc(grid):
 class DeviceGrid(object):
     """hj_ctx + array marshalling for one (grid, dtype, device[, slab])."""
 
-    def __init__(self, grid, dtype="float64", device=None, slab=None):
+    def __init__(self, grid, dtype="float64", device=None, slab=None, pad=0):
         torch = require_gpu()
         self.torch = torch
         self.lib = _ffi.lib()
@@ -68,9 +68,17 @@ class DeviceGrid(object):
         vs = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()) for v in grid.vs]
         # slab = (plane_begin, plane_end, halo_lo, halo_hi): this rank owns planes [b, e) of axis 0
         self.slab = slab
+        vs0_ext = None
         if slab is not None:
             b, e, hlo, hhi = slab
             self.shape = (e - b,) + self.shape[1:]
+            if pad:
+                # coordinates of the pad planes (deep-halo stepper computes on them): the neighbour's
+                # nodes, wrapped on a periodic axis; clamped where there is no neighbour (never read)
+                n0 = vs[0].size
+                ids = np.arange(b - pad, e + pad)
+                ids = ids % n0 if bc[0] == _ffi.BC_PERIODIC else np.clip(ids, 0, n0 - 1)
+                vs0_ext = np.ascontiguousarray(vs[0][ids])
             vs[0] = np.ascontiguousarray(vs[0][b:e])
             xmin[0] = float(vs[0][0])
         self.numel = int(np.prod(self.shape))
@@ -96,6 +104,12 @@ class DeviceGrid(object):
             self._aux(3, np.cos(vs[2]))
         if slab is not None:
             _ffi.check(self.lib.hj_ctx_set_slab(ctx, int(slab[2]), int(slab[3])))
+            if vs0_ext is not None:
+                a0 = a1 = None
+                if self.dim == 4:       # aux slots 0/1 are sin/cos of the axis-0 node
+                    t0, t1 = np.ascontiguousarray(np.sin(vs0_ext)), np.ascontiguousarray(np.cos(vs0_ext))
+                    a0, a1 = t0.ctypes.data_as(_ffi._pd), t1.ctypes.data_as(_ffi._pd)
+                _ffi.check(self.lib.hj_ctx_set_axis0_pad(ctx, int(pad), vs0_ext.ctypes.data_as(_ffi._pd), a0, a1))
         self._work = {}
 
     def _aux(self, slot, tab):

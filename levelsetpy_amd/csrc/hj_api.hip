@@ -1,5 +1,6 @@
 // C ABI of libhj_mi355x.so (see include/hj_mi355x.h).  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types only: the library is dlopen'ed (hj_comm_*), so libhj loads without RCCL
 
@@ -83,7 +84,15 @@ struct hj_ctx {
     int comm_rank, comm_size, lo_rank, hi_rank;
     hipStream_t comm_stream, edge_stream, edge_stream2;
     hipEvent_t ev_start, ev_edge, ev_edge2, ev_comm;
+    hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
     int slab_pending;
+    int external_exchange;             // hj_comm_init_external: the caller fills the pad planes itself
+    hipEvent_t launch_stop;            // if set, the next tiled launch signals this event on completion
+    int ext_events;                    // HJ_EXT_EVENTS (default 1): use that instead of hipEventRecord
+    // axis-0 tables extended by pad0 planes either side (deep-halo stepper computes on pad planes)
+    int pad0;
+    void* coord0_ext;
+    void* aux_ext[2];
     // tuning
     KernelCfg cfg;
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
@@ -213,6 +222,9 @@ void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int block
 template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
     for (int d = 0; d < HJ_MAX_DIM; ++d) H.coord[d] = (const T*)c->coord[d];
     for (int s = 0; s < 4; ++s) H.aux[s] = (const T*)c->aux[s];
+    if (c->coord0_ext) H.coord[0] = (const T*)c->coord0_ext + c->pad0;
+    for (int s = 0; s < 2; ++s)
+        if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
     for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
 }
 
@@ -350,8 +362,16 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
         HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), c->stream));
         A.timing = tbuf;
     }
-    hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (const T*)s.y0,
-                       (T*)s.out, A);
+    if (c->launch_stop) {
+        // completion signal attached to the dispatch packet itself: a separate hipEventRecord costs a
+        // marker packet and ~6 us of bubble before the next kernel of the stream (slab timeline)
+        hipExtLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), (unsigned)t.lds_bytes, c->stream, nullptr, c->launch_stop, 0,
+                              (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
+        c->launch_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (const T*)s.y0,
+                           (T*)s.out, A);
+    }
     HIP_TRY(hipGetLastError());
     if (tbuf) {
         std::vector<unsigned long long> h((size_t)t.nblocks * 4);
@@ -380,6 +400,8 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.bound = s.bound;
     fill_grid<T, ND>(c, A.G);
     for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
+    if (s.p0 < 0 || s.p1 > c->N[0] || (s.q1 > s.q0 && (s.q0 < 0 || s.q1 > c->N[0])))
+        return fail(HJ_EUNSUPPORTED, "pad planes need the tiled kernel");
     const long long plane = c->total / c->N[0];
     A.cell_begin = s.p0 * plane;
     A.cell_end = s.p1 * plane;
@@ -598,7 +620,11 @@ int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
     int rc = check_ham(c, s.ham, s.par);
     if (rc) return rc;
     if (s.scheme < 0 || s.scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
-    if (s.p0 < 0 || s.p1 > c->N[0] || s.p0 > s.p1) return fail(HJ_EINVAL, "bad plane range [%lld,%lld)", (long long)s.p0, (long long)s.p1);
+    {   // pad planes may be computed too when the tables cover them (deep-halo stepper)
+        const int64_t lo = c->halo_lo ? -(int64_t)c->pad0 : 0, hi = c->N[0] + (c->halo_hi ? c->pad0 : 0);
+        if (s.p0 < lo || s.p1 > hi || s.p0 > s.p1 || (s.q1 > s.q0 && (s.q0 < lo || s.q1 > hi)))
+            return fail(HJ_EINVAL, "bad plane range [%lld,%lld)", (long long)s.p0, (long long)s.p1);
+    }
     if (!s.y || !s.out) return fail(HJ_EINVAL, "null array argument");
     if (s.y == s.out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
     if (s.stage >= HJ_STAGE_RK3_HALF && !s.y0) return fail(HJ_EINVAL, "stage %d needs y0", s.stage);
@@ -730,19 +756,20 @@ int rccl_load(const char* path) {
 // post the halo sends/receives of `buf` (first interior plane) on `st`.  Order per peer is fixed so
 // that lo == hi (two ranks, periodic axis, or the single-rank self ring) pairs up: sends
 // [low planes -> lo, high planes -> hi], receives [hi pad <- hi, lo pad <- lo].
-int post_halo(hj_ctx* c, void* buf, hipStream_t st) {
+int post_halo(hj_ctx* c, void* buf, hipStream_t st, int depth = HJ_STENCIL) {
+    if (c->external_exchange) return HJ_OK;      // the caller moves the planes (hj_comm_init_external)
     if (!c->comm) return fail(HJ_ESTATE, "hj_comm_init has not been called");
     const size_t plane = (size_t)(c->total / c->N[0]);
-    const size_t cnt = plane * HJ_STENCIL;
+    const size_t cnt = plane * (size_t)depth;
     const ncclDataType_t dt = c->dtype == HJ_F64 ? ncclDouble : ncclFloat;
     char* b = (char*)buf;
     const size_t pb = plane * c->esz;
     const int64_t n = c->N[0];
     NCCL_TRY(g_rccl.GroupStart());
     if (c->lo_rank >= 0) NCCL_TRY(g_rccl.Send(b, cnt, dt, c->lo_rank, c->comm, st));
-    if (c->hi_rank >= 0) NCCL_TRY(g_rccl.Send(b + (size_t)(n - HJ_STENCIL) * pb, cnt, dt, c->hi_rank, c->comm, st));
+    if (c->hi_rank >= 0) NCCL_TRY(g_rccl.Send(b + (size_t)(n - depth) * pb, cnt, dt, c->hi_rank, c->comm, st));
     if (c->hi_rank >= 0) NCCL_TRY(g_rccl.Recv(b + (size_t)n * pb, cnt, dt, c->hi_rank, c->comm, st));
-    if (c->lo_rank >= 0) NCCL_TRY(g_rccl.Recv(b - (size_t)HJ_STENCIL * pb, cnt, dt, c->lo_rank, c->comm, st));
+    if (c->lo_rank >= 0) NCCL_TRY(g_rccl.Recv(b - (size_t)depth * pb, cnt, dt, c->lo_rank, c->comm, st));
     NCCL_TRY(g_rccl.GroupEnd());
     return HJ_OK;
 }
@@ -810,6 +837,119 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
     return HJ_OK;
 }
 
+int slab_streams_create(hj_ctx* c) {
+    // the exchange and the edge planes sit on the critical path: highest priority, so their (few)
+    // workgroups are dispatched ahead of the interior kernel's when both are ready
+    int lo_p = 0, hi_p = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+    // ONE auxiliary stream carries the chain  edges -> exchange -> edges -> ...  in stream order: every
+    // cross-stream event hop costs 10-15 us of dispatch latency on this platform
+    // (profiles/r01_slab_timeline.txt)
+    HIP_TRY(hipStreamCreateWithPriority(&c->edge_stream, hipStreamNonBlocking, hi_p));
+    c->comm_stream = c->edge_stream;
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_edge2, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_int[i], hipEventDisableTiming));
+    return HJ_OK;
+}
+
+// One odeCFL{1,2,3} step on a slab with ONE exchange per step ("deep halo").  The pads are
+// D = 3*order planes deep.  Stage s (1..order) computes, on every side that has a neighbour, 3*(order-s)
+// planes BEYOND the slab (redundantly with the neighbour: 3 % more plane updates for RK3 at 201 planes),
+// so stage s+1 finds its stencil inputs locally and only the final result is exchanged (D planes).
+//   main stream:  interior_s = [3s, n-3s)              needs interior_{s-1} only (stream order)
+//   aux stream:   edges_s    = [-3(order-s), 3s) and [n-3s, n+3(order-s))
+//                            needs edges_{s-1} (stream order) and interior_{s-1} (event)
+//                 after the last stage: exchange of the D edge planes of y_out
+// Across steps: interior_1 of the next step needs edges_order of this one (event); edges_1 of the next
+// step needs the exchange (stream order).  The two streams never wait for each other inside a step
+// except for the (already satisfied) interior events, and the exchange overlaps interior_order of this
+// step and interior_1 of the next.  Requires a static dt (all native Hamiltonians) and n >= 6*order.
+int slab_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par, double dt, int rs,
+                   const void* cur, void* y_out, void* w0, void* w1) {
+    int rc;
+    const int64_t n = c->N[0];
+    const int W = HJ_STENCIL, D = W * order;
+    const bool lo = c->halo_lo, hi = c->halo_hi;
+    hipStream_t main = c->stream, aux = c->edge_stream;
+    if (!lo && !hi) {   // a single slab without neighbours: plain substeps on the ctx stream
+        const void* src1[3] = {cur, w0, w1};
+        void* dst1[3] = {order == 1 ? y_out : w0, order == 2 ? y_out : w1, y_out};
+        const int kind1[3] = {HJ_STAGE_EULER, order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF, HJ_STAGE_RK3_FULL};
+        for (int st = 1; st <= order; ++st) {
+            SubstepCall s{scheme, ham, kind1[st - 1], rs, par, dt, src1[st - 1], st == 1 ? nullptr : cur, dst1[st - 1], nullptr, 0, n};
+            if ((rc = do_substep(c, s, -1))) return rc;
+        }
+        return HJ_OK;
+    }
+    if (!aux) return fail(HJ_ESTATE, "hj_comm_init / hj_comm_init_external has not been called");
+    if (c->pad0 < D) return fail(HJ_ESTATE, "axis-0 tables cover %d pad planes, order %d needs %d (hj_ctx_set_axis0_pad)", c->pad0, order, D);
+    if (n < 2 * D) return fail(HJ_EUNSUPPORTED, "slab of %lld planes is too thin for the deep-halo stepper (needs %d)", (long long)n, 2 * D);
+    const void* src[3] = {cur, w0, w1};
+    void* dst[3] = {order == 1 ? y_out : w0, order == 2 ? y_out : w1, y_out};
+    const int kind[3] = {HJ_STAGE_EULER, order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF, HJ_STAGE_RK3_FULL};
+    bool edge_signalled = false;
+    if (!c->slab_pending) {     // first step after set-up: aux joins whatever main did to the buffers
+        HIP_TRY(hipEventRecord(c->ev_start, main));
+        HIP_TRY(hipStreamWaitEvent(aux, c->ev_start, 0));
+    } else {
+        HIP_TRY(hipStreamWaitEvent(main, c->ev_edge, 0));   // edges_order of the previous step
+    }
+    for (int st = 1; st <= order; ++st) {
+        const int ext = W * (order - st);
+        const int64_t i0 = lo ? W * st : 0, i1 = hi ? n - W * st : n;
+        const void* y0 = st == 1 ? nullptr : cur;
+        if (scheme == HJ_WENO5) {
+            // global max(D1^2) of this stage's input: needs the edges of the previous stage -> join,
+            // reduce over the slab, all-reduce, and hand the result to both streams
+            if (st > 1 || c->slab_pending) {
+                HIP_TRY(hipEventRecord(c->ev_edge2, aux));
+                HIP_TRY(hipStreamWaitEvent(main, c->ev_edge2, 0));
+            }
+            if ((rc = weno_eps_pass(c, src[st - 1]))) return rc;
+            if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+            if (c->comm_size > 1 && c->comm)
+                NCCL_TRY(g_rccl.AllReduce(c->weno_vals, c->weno_vals, (size_t)c->ndim,
+                                          c->dtype == HJ_F64 ? ncclDouble : ncclFloat, ncclMax, c->comm, main));
+            c->weno_src = c->weno_vals;
+            HIP_TRY(hipEventRecord(c->ev_start, main));
+            HIP_TRY(hipStreamWaitEvent(aux, c->ev_start, 0));
+        }
+        if (i1 > i0) {
+            SubstepCall s{scheme, ham, kind[st - 1], rs, par, dt, src[st - 1], y0, dst[st - 1], nullptr, i0, i1};
+            c->launch_stop = c->ext_events ? c->ev_int[st - 1] : nullptr;
+            rc = do_substep(c, s, -1);
+            const bool signalled = c->ext_events && c->launch_stop == nullptr;   // consumed by the tiled launch
+            c->launch_stop = nullptr;
+            if (rc) { c->weno_src = nullptr; return rc; }
+            if (!signalled) HIP_TRY(hipEventRecord(c->ev_int[st - 1], main));
+        } else {
+            HIP_TRY(hipEventRecord(c->ev_int[st - 1], main));
+        }
+        if (st > 1) HIP_TRY(hipStreamWaitEvent(aux, c->ev_int[st - 2], 0));
+        {
+            SubstepCall s{scheme, ham, kind[st - 1], rs, par, dt, src[st - 1], y0, dst[st - 1], nullptr, 0, 0};
+            if (lo) { s.p0 = -ext; s.p1 = W * st; if (hi) { s.q0 = n - W * st; s.q1 = n + ext; } }
+            else { s.p0 = n - W * st; s.p1 = n + ext; }
+            c->stream = aux;
+            c->launch_stop = (c->ext_events && st == order) ? c->ev_edge : nullptr;
+            rc = do_substep(c, s, -1);
+            edge_signalled = c->ext_events && st == order && c->launch_stop == nullptr;
+            c->launch_stop = nullptr;
+            c->stream = main;
+            if (rc) { c->weno_src = nullptr; return rc; }
+        }
+        if (scheme == HJ_WENO5) c->weno_src = nullptr;
+    }
+    if (!edge_signalled) HIP_TRY(hipEventRecord(c->ev_edge, aux));
+    if ((rc = post_halo(c, y_out, aux, D))) return rc;
+    HIP_TRY(hipEventRecord(c->ev_comm, aux));
+    c->slab_pending = 1;
+    return HJ_OK;
+}
+
 int slab_join(hj_ctx* c) {
     if (c->slab_pending) {
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_edge, 0));
@@ -853,6 +993,9 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->lo_rank = c->hi_rank = -1;
     c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr; c->slab_pending = 0;
+    c->ev_int[0] = c->ev_int[1] = c->ev_int[2] = nullptr;
+    c->launch_stop = nullptr; c->ext_events = env_int("HJ_EXT_EVENTS", 1);
+    c->external_exchange = 0; c->pad0 = 0; c->coord0_ext = nullptr; c->aux_ext[0] = c->aux_ext[1] = nullptr;
     for (int d = 0; d < ndim; ++d) {
         c->N[d] = N[d]; c->xmin[d] = xmin[d]; c->dx[d] = dx[d]; c->bc[d] = bc[d];
         c->tz[d] = toward_zero ? (toward_zero[d] != 0) : 0;
@@ -913,6 +1056,8 @@ void hj_ctx_destroy(hj_ctx* c) {
     (void)hj_comm_destroy(c);
     for (int d = 0; d < HJ_MAX_DIM; ++d) if (c->coord[d]) (void)hipFree(c->coord[d]);
     for (int s = 0; s < 4; ++s) if (c->aux[s]) (void)hipFree(c->aux[s]);
+    if (c->coord0_ext) (void)hipFree(c->coord0_ext);
+    for (int s = 0; s < 2; ++s) if (c->aux_ext[s]) (void)hipFree(c->aux_ext[s]);
     if (c->ring) (void)hipFree(c->ring);
     if (c->keys) (void)hipFree(c->keys);
     if (c->weno_vals) (void)hipFree(c->weno_vals);
@@ -1180,20 +1325,20 @@ int hj_comm_init(hj_ctx* c, const char* rccl_path, int rank, int nranks, const v
     memcpy(&id, uid, sizeof(id));
     NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
     c->comm_rank = rank; c->comm_size = nranks; c->lo_rank = lo; c->hi_rank = hi;
-    {   // the exchange and the edge planes sit on the critical path: highest priority, so their (few)
-        // workgroups are dispatched ahead of the interior kernel's when both are ready
-        int lo_p = 0, hi_p = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-        // ONE auxiliary stream carries the chain  edges_s -> exchange_s -> edges_{s+1} -> ...  in stream
-        // order: every cross-stream event hop costs 10-15 us of dispatch latency on this platform
-        // (profiles/r01_slab_timeline.txt), and this chain is the critical path at 201^3 per rank
-        HIP_TRY(hipStreamCreateWithPriority(&c->edge_stream, hipStreamNonBlocking, hi_p));
-        c->comm_stream = c->edge_stream;
-    }
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
-    return HJ_OK;
+    c->external_exchange = 0;
+    return slab_streams_create(c);
+}
+
+int hj_comm_init_external(hj_ctx* c, int rank, int nranks, int lo, int hi) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(HJ_EINVAL, "bad rank/nranks");
+    if (lo >= nranks || hi >= nranks) return fail(HJ_EINVAL, "neighbour rank out of range");
+    if (c->comm || c->edge_stream) (void)hj_comm_destroy(c);
+    HIP_TRY(hipSetDevice(c->device));
+    c->comm = nullptr;
+    c->comm_rank = rank; c->comm_size = nranks; c->lo_rank = lo; c->hi_rank = hi;
+    c->external_exchange = 1;
+    return slab_streams_create(c);
 }
 
 int hj_comm_destroy(hj_ctx* c) {
@@ -1206,9 +1351,11 @@ int hj_comm_destroy(hj_ctx* c) {
     if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
     if (c->ev_edge2) (void)hipEventDestroy(c->ev_edge2);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    for (int i = 0; i < 3; ++i) { if (c->ev_int[i]) (void)hipEventDestroy(c->ev_int[i]); c->ev_int[i] = nullptr; }
     c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr;
     c->slab_pending = 0;
+    c->external_exchange = 0;
     return HJ_OK;
 }
 
@@ -1220,9 +1367,42 @@ int hj_halo_exchange(hj_ctx* c, void* buf) {
     return post_halo(c, buf, c->stream);
 }
 
+int hj_halo_exchange_depth(hj_ctx* c, void* buf, int depth) {
+    if (!c || !buf) return fail(HJ_EINVAL, "null argument");
+    if (depth < 1 || depth > c->N[0]) return fail(HJ_EINVAL, "bad halo depth %d", depth);
+    if (c->lo_rank < 0 && c->hi_rank < 0) return HJ_OK;
+    int rc = slab_join(c);
+    if (rc) return rc;
+    return post_halo(c, buf, c->stream, depth);
+}
+
 int hj_slab_join(hj_ctx* c) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
     return slab_join(c);
+}
+
+int hj_ctx_set_axis0_pad(hj_ctx* c, int pad, const double* vs0_ext, const double* aux0_ext, const double* aux1_ext) {
+    if (!c || !vs0_ext) return fail(HJ_EINVAL, "null argument");
+    if (pad < 0 || pad > 64) return fail(HJ_EINVAL, "bad pad %d", pad);
+    const int64_t n = c->N[0] + 2 * (int64_t)pad;
+    int rc;
+    if ((rc = upload(c, &c->coord0_ext, vs0_ext, n))) return rc;
+    const double* tabs[2] = {aux0_ext, aux1_ext};
+    for (int s = 0; s < 2; ++s) {
+        if (tabs[s]) { if ((rc = upload(c, &c->aux_ext[s], tabs[s], n))) return rc; }
+        else if (c->aux_ext[s]) { HIP_TRY(hipFree(c->aux_ext[s])); c->aux_ext[s] = nullptr; }
+    }
+    c->pad0 = pad;
+    return HJ_OK;
+}
+
+int hj_slab_rk_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par, double dt, int rs,
+                         const void* cur, void* y_out, void* w0, void* w1) {
+    if (!c || !cur || !y_out) return fail(HJ_EINVAL, "null argument");
+    if (order < 1 || order > 3) return fail(HJ_EINVAL, "order must be 1, 2 or 3");
+    if (order >= 2 && !w0) return fail(HJ_EINVAL, "work0 required for order >= 2");
+    if (order == 3 && !w1) return fail(HJ_EINVAL, "work1 required for order 3");
+    return slab_step_deep(c, order, scheme, ham, par, dt, rs, cur, y_out, w0, w1);
 }
 
 int hj_slab_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, double dt, int rs,
@@ -1231,7 +1411,7 @@ int hj_slab_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par
     if (order < 1 || order > 3) return fail(HJ_EINVAL, "order must be 1, 2 or 3");
     if (order >= 2 && !w0) return fail(HJ_EINVAL, "work0 required for order >= 2");
     if (order == 3 && !w1) return fail(HJ_EINVAL, "work1 required for order 3");
-    if ((c->lo_rank >= 0 || c->hi_rank >= 0) && !c->comm) return fail(HJ_ESTATE, "hj_comm_init has not been called");
+    if ((c->lo_rank >= 0 || c->hi_rank >= 0) && !c->comm && !c->external_exchange) return fail(HJ_ESTATE, "hj_comm_init has not been called");
     int rc;
     if (order == 1) return slab_substep(c, scheme, ham, par, HJ_STAGE_EULER, dt, rs, cur, nullptr, y_out);
     if ((rc = slab_substep(c, scheme, ham, par, HJ_STAGE_EULER, dt, rs, cur, nullptr, w0))) return rc;

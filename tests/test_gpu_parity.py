@@ -733,20 +733,88 @@ def test_native_rccl_slab_stepper_self_ring():
             y, t_ref = data.reshape(-1, 1), 0.
             for _ in range(4):
                 t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
-            slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
-            nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
-                                    [float(v) for v in np.asarray(g.dx).ravel()])
-            nat.set_state(torch.as_tensor(data, device="cuda"))
-            t = 0.
-            for _ in range(4):
-                t, _dt = nat.step(t)
-            got = nat.state().cpu().numpy()
-            nat.close()
-            assert abs(t - t_ref) <= 1e-14
-            (close if scheme.startswith("WENO") else close_eno)(got, y.reshape(n), 1e-12, what=scheme)
+            for deep in (True, False):      # one 9-plane exchange per step / one 3-plane exchange per substep
+                slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
+                nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
+                                        [float(v) for v in np.asarray(g.dx).ravel()], deep=deep)
+                nat.set_state(torch.as_tensor(data, device="cuda"))
+                t = 0.
+                for _ in range(4):
+                    t, _dt = nat.step(t)
+                got = nat.state().cpu().numpy()
+                nat.close()
+                assert abs(t - t_ref) <= 1e-14
+                (close if scheme.startswith("WENO") else close_eno)(got, y.reshape(n), 1e-12, what="%s deep=%s" % (scheme, deep))
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("scheme,periodic0,world", [("WENO5_ASSHIPPED", False, 3), ("ENO3", False, 2),
+                                                    ("WENO5_ASSHIPPED", True, 3), ("ENO2", True, 2)])
+def test_deep_halo_stepper_virtual_ranks_bitwise(scheme, periodic0, world, order):
+    """hj_slab_rk_step_deep with `world` virtual ranks in ONE process (hj_comm_init_external: the test moves
+    the pad planes itself): end ranks with a single neighbour, middle ranks with two, the periodic ring.
+    Stages recompute planes beyond the slab; the result must equal the undivided grid BITWISE."""
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    n = (61, 18, 16)
+    pd = (0, 2) if periodic0 else 2
+    gmax0 = 2. * (1 - 2 / n[0]) if periodic0 else 2.
+    g, og = mk([-2., -1.25, -np.pi], [gmax0, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+    rng = np.random.default_rng(5)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.1 * np.sin(3 * og.xs[0]) + 0.01 * rng.standard_normal(n)
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    par = [1., 1., 1., 2.]
+    sid = _ffi.SCHEME_IDS[scheme]
+    # undivided reference: the same fused kernels, whole grid, same dt
+    dg = DeviceGrid(g)
+    dg.bind_stream()
+    steppers = []
+    for r in range(world):
+        slab = SlabDecomposition(n[0], world, r, periodic0)
+        steppers.append(NativeSlabStepper(g, slab, sid, _ffi.HAM_DUBINS_REL, par, dxs, order=order,
+                                          external=lambda st: None))
+    amax = [max(st.alpha_local[d] for st in steppers) for d in range(3)]
+    for st in steppers:
+        st.set_alpha_max(amax)
+
+    def move_pads():
+        torch.cuda.synchronize()
+        for st in steppers:
+            D, nl, sl = st.pad, st.n, st.slab
+            if sl.hi is not None:
+                nb = steppers[sl.hi]
+                st.buf["cur"][D + nl:D + nl + D].copy_(nb.buf["cur"][nb.pad:nb.pad + D])
+            if sl.lo is not None:
+                nb = steppers[sl.lo]
+                st.buf["cur"][0:D].copy_(nb.buf["cur"][nb.pad + nb.n - D:nb.pad + nb.n])
+        torch.cuda.synchronize()
+
+    full = torch.as_tensor(data, device="cuda")
+    for st in steppers:
+        st.set_state(full[st.slab.begin:st.slab.end])
+    move_pads()
+    cur, nxt, w0, w1 = full.clone(), torch.empty_like(full), torch.empty_like(full), torch.empty_like(full)
+    tout, dtout = C.c_double(), C.c_double()
+    t = t_ref = 0.
+    for _ in range(3):
+        ts = [st.step(t) for st in steppers]
+        move_pads()
+        assert all(abs(a[0] - ts[0][0]) == 0 for a in ts)
+        dt = ts[0][1]
+        t = ts[0][0]
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, _ffi.HAM_DUBINS_REL, _ffi.darr(par), t_ref, 1e9, 0.8, dt, 0,
+                                     dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+        cur, nxt = nxt, cur
+        t_ref = float(tout.value)
+        assert dtout.value == dt and abs(t_ref - t) <= 1e-15
+    torch.cuda.synchronize()
+    for st in steppers:
+        got = st.state()
+        ref = cur[st.slab.begin:st.slab.end]
+        assert torch.equal(got, ref), "rank %d differs by %g" % (st.slab.rank, float((got - ref).abs().max()))
+        st.close()
 
 
 # ------------------------------------------------------------------------------ BASELINE sizes: properties

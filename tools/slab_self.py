@@ -39,21 +39,27 @@ for self_ex in (False, True):
         print("max |rccl-ring - in-kernel wrap| = %.3e" % float((res - ref).abs().max()))
     else:
         ref = res
-# native stepper (hj_slab_rk_step: ncclSend/ncclRecv inside the C library), same self ring
+# native steppers (ncclSend/ncclRecv inside the C library), same self ring: per-substep 3-plane exchange
+# and the deep-halo variant (one 9-plane exchange per step)
 from levelsetpy_amd.dist import NativeSlabStepper
-slab = SlabDecomposition(n, 1, 0, True, self_exchange=True)
-nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
-                        [float(v) for v in np.asarray(g.dx).ravel()])
-nat.set_state(torch.as_tensor(d0, device="cuda"))
-t = 0.
-for _ in range(3):
-    t, _ = nat.step(t)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps):
-    t, _ = nat.step(t)
-enq = time.perf_counter() - t0
-torch.cuda.synchronize(); sec = time.perf_counter() - t0
-print("native self ring: %.3f ms/step (%.3e cell-substeps/s), CPU enqueue %.3f ms/step" % (1e3 * sec / steps, n ** 3 * 3 * steps / sec, 1e3 * enq / steps))
-print("max |native-ring - in-kernel wrap| = %.3e" % float((nat.state() - ref).abs().max()))
-nat.close()
+steps = 100
+for deep in (False, True):
+    slab = SlabDecomposition(n, 1, 0, True, self_exchange=True)
+    nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
+                            [float(v) for v in np.asarray(g.dx).ravel()], deep=deep)
+    nat.set_state(torch.as_tensor(d0, device="cuda"))
+    t = 0.
+    for _ in range(23):
+        t, _ = nat.step(t)
+    chk = nat.state().clone()
+    for _ in range(10):
+        t, _ = nat.step(t)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        t, _ = nat.step(t)
+    enq = time.perf_counter() - t0
+    torch.cuda.synchronize(); sec = time.perf_counter() - t0
+    print("native self ring deep=%s: %.3f ms/step (%.3e cell-substeps/s), CPU enqueue %.3f ms/step" % (deep, 1e3 * sec / steps, n ** 3 * 3 * steps / sec, 1e3 * enq / steps))
+    print("   max |native-ring - in-kernel wrap| after 23 steps = %.3e" % float((chk - ref).abs().max()))
+    nat.close()
 dist.destroy_process_group()
