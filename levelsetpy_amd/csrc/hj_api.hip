@@ -265,7 +265,7 @@ template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G
 template <typename T> T scheme_scale(int scheme, double dx) {
     if (scheme == HJ_WENO5_ASSHIPPED) return (T)((1.0 / dx) * (1.0 / 60.0));
     if (scheme == HJ_WENO5) return (T)((1.0 / dx) * (1.0 / 12.0));
-    return T(1);
+    return (T)((1.0 / dx) * 0.5);     // ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
 }
 
 struct SubstepCall {

@@ -233,6 +233,38 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
             pc = Lq + Rq;
             hd = Rq - Lq;
         }
+    } else if constexpr (SCHEME == HJ_ENO3) {
+        // ENO3 (upwind_first_eno3a.py:105-141, ENO3aHelper.py:116-189) on UNDIVIDED differences
+        // u_j = v[j+1]-v[j], s_j = u_{j+1}-u_j, t_j = s_{j+1}-s_j  (D1 = u/dx, D2 = s/(2dx^2), D3 = t/(6dx^3);
+        // the |D2| / |D3| comparisons are comparisons of |s| / |t|), select FIRST, then form the one
+        // candidate that was chosen:  dx*L = u2 + s/2 + {t/3 | -t/6},  dx*R = u3 - s/2 + {-t/6 | t/3}.
+        // Returns pc' = L'+R', hd' = R'-L' with p = pc'/(2dx)  (sc[d] = 1/(2dx)).
+        const T u0 = v[1] - v[0], u1 = v[2] - v[1], u2 = v[3] - v[2];
+        const T u3 = v[4] - v[3], u4 = v[5] - v[4], u5 = v[6] - v[5];
+        const T s0 = u1 - u0, s1 = u2 - u1, s2 = u3 - u2, s3 = u4 - u3, s4 = u5 - u4;
+        const T t0 = s1 - s0, t1 = s2 - s1, t2 = s3 - s2, t3 = s4 - s3;
+        const bool sL0 = t_abs(s1) < t_abs(s2), sL1 = t_abs(s2) < t_abs(s3);          // strict '<': ties go right
+        const bool sT0 = t_abs(t0) < t_abs(t1), sT1 = t_abs(t1) < t_abs(t2), sT2 = t_abs(t2) < t_abs(t3);
+        const T third = T(1) / T(3), sixth = T(1) / T(6);
+        const T a1 = third * t1, b1 = -sixth * t1, b2 = -sixth * t2;
+        // left:  sL0 ? (sT0 ? t0/3 : t1/3) : (sT1 ? t1/3 : -t2/6)      with s1 resp. s2
+        const T tl = sL0 ? (sT0 ? third * t0 : a1) : (sT1 ? a1 : b2);
+        // (the middle candidate is written with the LEFT second difference on the left side and the
+        // right one's mirror on the right side, as ENO3aHelper.py:132-168 does)
+        const T Lq = u2 + (T(0.5) * ((sL0 || sT1) ? s1 : s2) + tl);
+        // right: sL1 ? (sT1 ? -t1/6 : -t2/6) : (sT2 ? -t2/6 : t3/3)    with -s2 resp. -s3
+        const T tr = sL1 ? (sT1 ? b1 : b2) : (sT2 ? b2 : third * t3);
+        const T Rq = u3 + (T(-0.5) * ((sL1 || sT2) ? s2 : s3) + tr);
+        pc = Lq + Rq;
+        hd = Rq - Lq;
+    } else if constexpr (SCHEME == HJ_ENO2) {
+        // ENO2 (upwind_first_eno2.py:97-148): dx*L = u2 + sel(|s1|<|s2|, s1, s2)/2, dx*R = u3 - sel(|s2|<|s3|, s2, s3)/2
+        const T u1 = v[2] - v[1], u2 = v[3] - v[2], u3 = v[4] - v[3], u4 = v[5] - v[4];
+        const T s1 = u2 - u1, s2 = u3 - u2, s3 = u4 - u3;
+        const T Lq = u2 + T(0.5) * ((t_abs(s1) < t_abs(s2)) ? s1 : s2);
+        const T Rq = u3 + T(-0.5) * ((t_abs(s2) < t_abs(s3)) ? s2 : s3);
+        pc = Lq + Rq;
+        hd = Rq - Lq;
     } else {
         T L, R;
         upwind<SCHEME, T>(v, K, eps, L, R);
