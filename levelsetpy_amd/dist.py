@@ -293,7 +293,8 @@ class NativeSlabStepper(object):
             # where the redundant planes cost more than the dependency bubbles they remove
             env = os.environ.get("HJ_SLAB_DEEP")
             cells = slab.n_local * int(np.prod([int(v) for v in np.asarray(grid.N).ravel()[1:]]))
-            deep = (env != "0") if env is not None else (cells < 20e6 and slab.n_local >= 2 * HALO * order)
+            # (and not on thin slabs: the 6*order redundant planes are a fixed cost per slab)
+            deep = (env != "0") if env is not None else (cells < 20e6 and slab.n_local >= 128)
         self.deep = bool(deep)
         self.pad = HALO * order if self.deep else HALO
         self.external = external
