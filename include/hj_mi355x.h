@@ -136,6 +136,16 @@ int hj_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham
                double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
                void* y_out, void* work0, void* work1, double* t_out, double* dt_out);
 
+/* The whole odeCFLn loop of a time span in one call (ode_cfl_3.py:125-251 with singleStep off and no
+ * postTimeStep / terminalEvent callbacks): steps from t0 until tf - t < 100*eps*|tf| (or max_steps > 0
+ * steps).  y_in is never written; results alternate between buf_a and buf_b, `work` is stage scratch
+ * (all of y's size, all distinct).  *result_in = 0 (no step taken: y_in), 1 (buf_a) or 2 (buf_b).
+ * No host synchronisation for Hamiltonians with a static stepBound: one call enqueues the span. */
+int hj_rk_integrate(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double t0,
+                    double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
+                    void* buf_a, void* buf_b, void* work, int64_t max_steps, double* t_out,
+                    int64_t* steps_out, int* result_in);
+
 /* stepBound of a native Hamiltonian on this grid (alpha is data-independent for all HJ_HAM_*);
  * computed once per (ham_id, params) and cached.  Synchronises on the first call.
  * alpha_max_host (nullable): the ndim per-dimension maxima of alpha (a slab-decomposed run

@@ -38,6 +38,7 @@ SIGNATURES = {
     "hj_rk_substep": (_i, [_vp, _i, _i, _pd, _d, _i, _d, _i, _vp, _vp, _vp, _i, _i64, _i64]),
     "hj_read_step_bound": (_i, [_vp, _i, _pd, _pd]),
     "hj_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _pd, _pd]),
+    "hj_rk_integrate": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _i64, _pd, _pi64, _pi]),
     "hj_static_step_bound": (_i, [_vp, _i, _pd, _pd, _pd]),
     "hj_max_d1sq": (_i, [_vp, _vp, _vp]),
     "hj_ctx_set_weno_eps_source": (_i, [_vp, _vp]),

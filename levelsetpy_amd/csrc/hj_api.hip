@@ -1264,6 +1264,40 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     return HJ_OK;
 }
 
+int hj_rk_integrate(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf,
+                    double factor_cfl, double max_step, int restrict_sign, const void* y_in, void* buf_a,
+                    void* buf_b, void* work, int64_t max_steps, double* t_out, int64_t* steps_out,
+                    int* result_in) {
+    if (!c || !y_in || !buf_a || !buf_b) return fail(HJ_EINVAL, "null argument");
+    if (order >= 2 && !work) return fail(HJ_EINVAL, "work buffer required for order >= 2");
+    if (buf_a == buf_b || buf_a == y_in || buf_b == y_in || work == y_in || work == buf_a || work == buf_b)
+        return fail(HJ_EINVAL, "buffers must be distinct");
+    // the loop of odeCFLn (ode_cfl_3.py:125): while tf - t >= small*|tf|, small = 100*eps (:81)
+    const double small = 100.0 * 2.220446049250313e-16;
+    const void* cur = y_in;
+    void* outs[2] = {buf_a, buf_b};
+    int which = 0;          // 0: y_in holds the state, 1: buf_a, 2: buf_b
+    double t = t0;
+    int64_t steps = 0;
+    while (tf - t >= small * std::fabs(tf) && (max_steps <= 0 || steps < max_steps)) {
+        void* nxt = outs[steps & 1];
+        double tn = t, dt = 0;
+        // RK3: the first stage buffer doubles as the output; RK2: `work` is the first stage buffer
+        int rc = hj_rk_step(c, order, scheme, ham, par, t, tf, factor_cfl, max_step, restrict_sign, cur, nxt,
+                            order == 3 ? nxt : work, work, &tn, &dt);
+        if (rc) return rc;
+        if (!(tn > t)) return fail(HJ_ESTATE, "time step underflow at t=%g (dt=%g)", t, dt);
+        cur = nxt;
+        which = 1 + (int)(steps & 1);
+        t = tn;
+        ++steps;
+    }
+    if (t_out) *t_out = t;
+    if (steps_out) *steps_out = steps;
+    if (result_in) *result_in = which;
+    return HJ_OK;
+}
+
 int hj_max_d1sq(hj_ctx* c, const void* y, void* out_dev) {
     if (!c || !y || !out_dev) return fail(HJ_EINVAL, "null argument");
     return weno_eps_to(c, y, out_dev);

@@ -296,6 +296,8 @@ class NativeSlabStepper(object):
             # (and not on thin slabs: the 6*order redundant planes are a fixed cost per slab)
             deep = (env != "0") if env is not None else (cells < 20e6 and slab.n_local >= 128)
         self.deep = bool(deep)
+        if external is not None and not self.deep:
+            raise ValueError("an external transport can only serve the deep-halo schedule (one exchange per step)")
         self.pad = HALO * order if self.deep else HALO
         self.external = external
         if self.deep and slab.n_local < 2 * self.pad and (slab.halo_lo or slab.halo_hi):

@@ -201,6 +201,19 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     safetyFactorCFL = min(1.0, 1.2 * float(options.factorCFL))
     sb_static = C.c_double()
     _ffi.check(dg.lib.hj_static_step_bound(dg.ctx, ham, parv, C.byref(sb_static), None))
+    # no per-step callbacks and nothing to warn about: the whole span is one native call
+    # (hj_rk_integrate runs the same loop in C; no Python and no host synchronisation per step)
+    if (not post and not getattr(options, 'terminalEvent', None) and not strcmp(options.singleStep, 'on')
+            and float(options.factorCFL) <= safetyFactorCFL and tf - t >= small * abs(tf)):
+        buf_b = dg.empty()
+        work = dg.work('rk_w1')
+        nsteps, where = C.c_int64(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
+                                          float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt), dg.ptr(buf_b),
+                                          dg.ptr(work), 0, C.byref(tout), C.byref(nsteps), C.byref(where)))
+        cur = (cur, nxt, buf_b)[where.value]
+        t = float(tout.value)
+        steps = int(nsteps.value)
     while tf - t >= small * abs(tf):
         tOld = t
         _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),

@@ -773,7 +773,7 @@ def test_deep_halo_stepper_virtual_ranks_bitwise(scheme, periodic0, world, order
     steppers = []
     for r in range(world):
         slab = SlabDecomposition(n[0], world, r, periodic0)
-        steppers.append(NativeSlabStepper(g, slab, sid, _ffi.HAM_DUBINS_REL, par, dxs, order=order,
+        steppers.append(NativeSlabStepper(g, slab, sid, _ffi.HAM_DUBINS_REL, par, dxs, order=order, deep=True,
                                           external=lambda st: None))
     amax = [max(st.alpha_local[d] for st in steppers) for d in range(3)]
     for st in steppers:
@@ -893,3 +893,22 @@ def test_full_size_4096_squared_tiled_vs_direct(monkeypatch):
         assert abs(sb.value - 1 / (1.0 / dx[0] + 1.5 / dx[1])) <= 1e-13 * sb.value
         outs[force] = a.cpu().numpy()
     assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-11
+
+
+def test_native_integrate_loop_equals_stepwise():
+    """hj_rk_integrate (the odeCFLn loop of a whole span in one C call) against the same span stepped
+    through Python with a no-op postTimeStep hook: identical t and state, inputs untouched."""
+    g, og = dubins([24, 20, 18])
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+    y0 = (O.shape_cylinder(og, 2, None, .5) + 0.01 * np.random.default_rng(3).standard_normal(g.shape)).reshape(-1, 1)
+    keep = y0.copy()
+    for order, fn in ((3, L.odeCFL3), (2, L.odeCFL2), (1, L.odeCFL1)):
+        a = fn(L.termLaxFriedrichs, [0., 0.07], y0, L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off'))), sd)
+        b = fn(L.termLaxFriedrichs, [0., 0.07], y0,
+               L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off', postTimeStep=lambda t, y, s: (y, s)))), sd)
+        assert a[0] == b[0] and abs(a[0] - 0.07) <= 100 * L.eps * 0.07
+        assert np.array_equal(a[1], b[1]), order
+    assert np.array_equal(y0, keep)
+    # a span that is already over takes no step and hands back a copy of the input
+    t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0.5, 0.5], y0, L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off'))), sd)
+    assert t == 0.5 and np.array_equal(y, y0)
