@@ -912,3 +912,47 @@ def test_native_integrate_loop_equals_stepwise():
     # a span that is already over takes no step and hands back a copy of the input
     t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0.5, 0.5], y0, L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off'))), sd)
     assert t == 0.5 and np.array_equal(y, y0)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n", [(3, 3, 3), (4, 3, 6), (5, 7, 3), (3, 40, 4), (6, 5, 33)])
+def test_term_tiny_extents_vs_oracle(scheme, n, monkeypatch):
+    """Extents down to the stencil width (3 nodes): every stencil then reaches ghost cells on both sides
+    (extrapolated: ghosts built from the same two edge nodes; periodic: wrapped more than once is not
+    needed since width 3 <= N)."""
+    g, og = dubins(n)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * np.random.default_rng(21).standard_normal(g.shape)
+    y = data.reshape(-1, 1)
+    (yt, sbt, _), (yd, sbd, _) = _term_both_kernels(g, L.DubinsVehicleRel(g, 1, 2), scheme, y, monkeypatch)
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 2), scheme, 0., y)
+    close(yt, yo, what="tiled")
+    close(yd, yo, what="direct")
+    assert abs(sbt - sbo) <= 1e-13 * sbo and abs(sbd - sbo) <= 1e-13 * sbo
+
+
+def test_grid_below_stencil_width_is_rejected():
+    g, og = dubins((2, 5, 5))
+    y = np.zeros((50, 1))
+    with pytest.raises(ValueError):
+        L.termLaxFriedrichs(0., y, sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5))
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "WENO5_ASSHIPPED", "WENO5"])
+def test_term_toward_zero_ghost_data_in_fused_path(scheme, monkeypatch):
+    """grid.bdryData[i].towardZero (add_ghost_extrapolate.py:60-64) must reach the fused kernels' ghost
+    synthesis: slopes point towards zero on axes 0 and 1."""
+    n = (17, 14, 12)
+    g, _ = dubins(n)
+    g.bdryData[0] = L.Bundle(dict(towardZero=True))
+    g.bdryData[1] = L.Bundle(dict(towardZero=True))
+    og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, [2], toward_zero=[True, True, False])
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * np.random.default_rng(4).standard_normal(n)
+    y = data.reshape(-1, 1)
+    (yt, sbt, _), (yd, sbd, _) = _term_both_kernels(g, L.DubinsVehicleRel(g, 1, 1), scheme, y, monkeypatch)
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), scheme, 0., y)
+    close(yt, yo, what="tiled")
+    close(yd, yo, what="direct")
+    # and it differs from the default (away-from-zero) ghosts, i.e. the flag is not ignored
+    g2, og2 = dubins(n)
+    y2, _, _ = L.termLaxFriedrichs(0., y, sdata(g2, L.DubinsVehicleRel(g2, 1, 1), DERIV[scheme]))
+    assert np.max(np.abs(np.asarray(y2) - np.asarray(yt))) > 1e-6
