@@ -165,22 +165,39 @@ __global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, 
             const T D1 = G.inv_dx[0] * (c - p0[-S]);
             m[0] = fmax(m[0], (double)(D1 * D1));
         }
-        for (int p = pb; p < pe; ++p) {
-            const T* row = p0 + (long long)p * S;
-            T nx = c;
-            bool have0 = true;
-            if (p + 1 < G.n[0] || G.halo_hi) nx = row[S];
-            else if (G.bc[0] == HJ_BC_PERIODIC) nx = p0[0];
-            else have0 = false;
-            if (have0) { const T D1 = G.inv_dx[0] * (nx - c); m[0] = fmax(m[0], (double)(D1 * D1)); }
+        // every load is unconditional (a missing neighbour is the cell itself: D1 = 0 cannot raise the
+        // max) and U planes are requested before any is used: U*ND loads in flight per thread instead of
+        // a full memory round trip per plane
+        constexpr int U = 4;
+        const int n0 = G.n[0];
+        for (int p = pb; p < pe; p += U) {
+            T nx[U], nb[ND][U];
 #pragma unroll
-            for (int d = 1; d < ND; ++d) {
-                if (off[d] != 0) {
-                    const T D1 = G.inv_dx[d] * (row[off[d]] - c);
-                    m[d] = fmax(m[d], (double)(D1 * D1));
+            for (int k = 0; k < U; ++k) {
+                const int pp = min(p + k, pe - 1);
+                int pn = pp;                                   // forward neighbour plane on axis 0
+                if (pp + 1 < n0 || G.halo_hi) pn = pp + 1;
+                else if (G.bc[0] == HJ_BC_PERIODIC) pn = 0;
+                const T* row = p0 + (long long)pp * S;
+                nx[k] = p0[(long long)pn * S];
+#pragma unroll
+                for (int d = 1; d < ND; ++d) nb[d][k] = row[off[d]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (p + k < pe) {
+                    {
+                        const T D1 = G.inv_dx[0] * (nx[k] - c);
+                        m[0] = fmax(m[0], (double)(D1 * D1));
+                    }
+#pragma unroll
+                    for (int d = 1; d < ND; ++d) {
+                        const T D1 = G.inv_dx[d] * (nb[d][k] - c);
+                        m[d] = fmax(m[d], (double)(D1 * D1));
+                    }
+                    if (p + k + 1 < pe) c = nx[k];     // inside the chunk the forward plane is the next own plane
                 }
             }
-            c = nx;
         }
     }
     __shared__ double red[4][ND];
