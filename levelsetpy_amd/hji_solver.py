@@ -5,20 +5,27 @@ ValueFuncs/hji_solver.py:24; core loop :509-656).
 The value function stays on the GPU for the whole tau loop when the problem can run fused
 (native Hamiltonian): RK3 steps are hj_rk_step launches, the post-step operators (min/max with the
 previous step, data0, targets; obstacle masking) are hj_minmax_with, the NaN guard is hj_any_nan.
-Visualisation, trajectory extraction and the other front-end extras are outside the path.
+Stopping conditions (stopInit via multilinear point evaluation, stopSetInclude / stopSetIntersect with
+stopLevel, stopConverge with ignoreBoundary) and the discounting steps (default and 'Kene' mode,
+discountAnneal) are applied to the device-resident state as well; flipOutput reverses the stored time
+axis.  Visualisation, noise injection (addGaussianNoiseStandardDeviation) and trajectory extraction are
+outside the path.
 
 Deviations from the shipped reference, all listed in SURVEY Appendix D: the integrator honours
 the schemeFunc that was built (minWithZero -> termRestrictUpdate; the reference ignores it,
 hji_solver.py:542); store-all-times mode keeps time on axis 0 and works (the reference crashes,
 :483-484); obstacle masking is elementwise (omax returns a scalar in the reference);
-schemeData.CoStateCalc or .derivFunc is honoured if the caller set it, else upwindFirstWENO5.
+schemeData.CoStateCalc or .derivFunc is honoured if the caller set it, else upwindFirstWENO5;
+the stop set is the region where stopSet < 0 (the reference extracts the VALUES there, :260, and its
+truncation `tau[i+1:] = []` is not valid NumPy); discounting runs (the reference calls an undefined
+`eisfield`, :603) with the toolbox's intended meaning: default mode unless discountMode == 'Kene'.
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _ffi
-from .context import device_grid, is_tensor
+from .context import device_grid, grid_bc, is_tensor
 from .dissipation import artificialDissipationGLF
 from .integration import odeCFL3, odeCFLset
 from .spatial import upwindFirstWENO5
@@ -65,6 +72,56 @@ class _Ops(object):
         return bool(np.any(np.isnan(y)))
 
 
+def _eval_point(g, data, x):
+    """eval_u(g, data, x) for ONE state (ValueFuncs/evaluate_u.py:15,64: multilinear interpolation,
+    periodic axes augmented by one wrapped node and the state wrapped into the period).  `data` may
+    live on the GPU: only the 2^dim corner values are read.  Outside an extrapolated axis -> NaN."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    if x.size != g.dim:
+        error('stopInit must be a vector of length g.dim!')
+    bc, _ = grid_bc(g)
+    N = [int(v) for v in np.asarray(g.N).ravel()]
+    lo, w = [], []
+    for d in range(g.dim):
+        vs = np.asarray(g.vs[d], dtype=np.float64).ravel()
+        dx = float(np.asarray(g.dx).ravel()[d])
+        xd = float(x[d])
+        if bc[d] == _ffi.BC_PERIODIC:
+            period = N[d] * dx
+            xd = vs[0] + ((xd - vs[0]) % period)
+            i = min(int(np.floor((xd - vs[0]) / dx)), N[d] - 1)
+        else:
+            if xd < vs[0] or xd > vs[-1]:
+                return float('nan')
+            i = min(int(np.floor((xd - vs[0]) / dx)), N[d] - 2)
+        lo.append(i)
+        w.append((xd - (vs[0] + i * dx)) / dx)
+    v = 0.0
+    for corner in range(1 << g.dim):
+        idx, wt = [], 1.0
+        for d in range(g.dim):
+            up = (corner >> d) & 1
+            j = lo[d] + up
+            if bc[d] == _ffi.BC_PERIODIC:
+                j %= N[d]
+            idx.append(j)
+            wt *= w[d] if up else (1.0 - w[d])
+        if wt != 0.0:
+            v += wt * float(data[tuple(idx)])
+    return v
+
+
+def _trim(g, a):
+    """truncateGrid(g, a, g.min + 4 dx, g.max - 4 dx) (Grids/truncate.py:8): nodes strictly inside."""
+    sl = []
+    for d in range(g.dim):
+        vs = np.asarray(g.vs[d], dtype=np.float64).ravel()
+        dx = float(np.asarray(g.dx).ravel()[d])
+        keep = np.nonzero((vs > vs[0] + 4 * dx) & (vs < vs[-1] - 4 * dx))[0]
+        sl.append(slice(int(keep[0]), int(keep[-1]) + 1) if keep.size else slice(0, 0))
+    return a[tuple(sl)]
+
+
 def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
     extraArgs = extraArgs if extraArgs is not None else Bundle({})
     extraOuts = Bundle({})
@@ -92,6 +149,28 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
 
     stopConverge = bool(_get(extraArgs, 'stopConverge', False))
     convergeThreshold = _get(extraArgs, 'convergeThreshold', 1e-5)
+    ignoreBoundary = bool(_get(extraArgs, 'ignoreBoundary', False))
+    flipOutput = bool(_get(extraArgs, 'flipOutput', False))
+    # stopping sets (hji_solver.py:250-266,686-704)
+    stopInit = _get(extraArgs, 'stopInit')
+    if stopInit is not None and np.asarray(stopInit).size != gDim:
+        error('stopInit must be a vector of length g.dim!')
+    stopSet = _get(extraArgs, 'stopSetInclude')
+    stopSetAll = stopSet is not None
+    if stopSet is None:
+        stopSet = _get(extraArgs, 'stopSetIntersect')
+    stopLevel = float(_get(extraArgs, 'stopLevel', 0))
+    if stopSet is not None:
+        stopSet = np.asarray(stopSet.detach().cpu().numpy() if is_tensor(stopSet) else stopSet)
+        if stopSet.ndim != gDim or tuple(stopSet.shape) != tuple(g.shape):
+            error('Inconsistent stopSet dimensions!')
+    # discounting (hji_solver.py:603-638,708-719)
+    discountFactor = _get(extraArgs, 'discountFactor')
+    discountFactor = float(discountFactor) if discountFactor else None
+    discountKene = _get(extraArgs, 'discountMode') == 'Kene'
+    discountAnneal = _get(extraArgs, 'discountAnneal')
+    if discountFactor is not None and discountKene and targets is None:
+        error('Need to define target function l(x)!')
 
     # ---- scheme (hji_solver.py:424-446)
     schemeFunc = termLaxFriedrichs
@@ -159,8 +238,10 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
             tNow, y, _ = odeCFL3(schemeFunc, [tNow, tau[i]], y, integratorOptions, sd_run)
             if ops.has_nan(y):
                 error('Nans encountered in the integrated result of HJI PDE data')   # :544-545
-            # ---- compMethod (hji_solver.py:566-599)
-            if compMethod in (None, 'zero', 'set', 'none', 'minWithZero'):
+            # ---- compMethod (hji_solver.py:566-599); in 'Kene' discount mode the min/max with the target
+            # happens inside the discount step instead (:613-636)
+            kene = discountFactor is not None and discountKene
+            if kene or compMethod in (None, 'zero', 'set', 'none', 'minWithZero'):
                 pass
             elif compMethod == 'minVOverTime':
                 y = ops.minmax(_ffi.OP_MIN, y, yLast)
@@ -180,23 +261,57 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
                 y = ops.minmax(_ffi.OP_MIN, y, target_i)
             else:
                 error('Check which compMethod you are using')
+            if discountFactor is not None:
+                y = _discount(ops, y, discountFactor, discountKene, compMethod, target_i, y_init)
             if obstacle_i is not None:                         # "mask" using obstacles (:641-644)
                 y = ops.minmax(_ffi.OP_MAX_NEG, y, obstacle_i)
         cur = y.reshape(g.shape)
-        if store_all or stopConverge or isfield(extraArgs, 'stopInit') or isfield(extraArgs, 'SDModFunc'):
+        if store_all or isfield(extraArgs, 'SDModFunc'):
             cur_np = cur.detach().cpu().numpy() if is_tensor(cur) else np.asarray(cur)
         if store_all:
             data[i] = cur_np
-        if stopConverge:
-            ys = y_start.detach().cpu().numpy() if is_tensor(y_start) else y_start
-            change = float(np.max(np.abs(cur_np.reshape(-1) - ys.reshape(-1))))
+
+        def stop_here():
+            extraOuts.stoptau = tau[i]
+            return tau[:i + 1], (data[:i + 1] if store_all else None)
+
+        change = None
+        if stopConverge:                                       # hji_solver.py:661-672
+            a, b = cur, y_start.reshape(g.shape)
+            if ignoreBoundary:
+                a, b = _trim(g, a), _trim(g, b)
+            count = a.numel() if is_tensor(a) else a.size
+            change = float(abs(a - b).max()) if count else 0.0
             if not quiet:
                 info('Max change since last iteration: %s' % change)
-            if change < convergeThreshold:
-                extraOuts.stoptau = tau[i]
-                tau = tau[:i + 1]
-                if store_all:
-                    data = data[:i + 1]
+        if stopInit is not None:                               # :676-684
+            initValue = _eval_point(g, cur, stopInit)
+            if not np.isnan(initValue) and initValue <= 0:
+                tau, d2 = stop_here()
+                data = d2 if store_all else data
+                break
+        if stopSet is not None:                                # :686-704 (indices where stopSet < 0)
+            inside = cur <= stopLevel
+            inside = inside.detach().cpu().numpy() if is_tensor(inside) else np.asarray(inside)
+            sel = inside[stopSet < 0]
+            hit = bool(sel.all()) if stopSetAll else bool(sel.any())
+            if sel.size and hit:
+                tau, d2 = stop_here()
+                data = d2 if store_all else data
+                break
+        if stopConverge and change < convergeThreshold:        # :706-722
+            if discountFactor is not None and discountAnneal and discountFactor != 1:
+                if discountAnneal == 'soft':
+                    discountFactor = 1 - (1 - discountFactor) / 2
+                    if abs(1 - discountFactor) < .00005:
+                        discountFactor = 1.0
+                else:                                          # 'hard' or 1
+                    discountFactor = 1.0
+                if not quiet:
+                    info('Discount factor: %s' % discountFactor)
+            else:
+                tau, d2 = stop_here()
+                data = d2 if store_all else data
                 break
     if not store_all:
         data = cur = y.reshape(g.shape)
@@ -204,7 +319,31 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
     elif is_tensor(data0):
         import torch
         data = torch.as_tensor(data, device=data0.device)
+    if flipOutput and store_all:
+        data = data.flip(0) if is_tensor(data) else np.flip(data, 0).copy()
     endTime = cputime()
     if not quiet:
         info('Total execution time %s seconds' % (endTime - startTime))
     return data, tau, extraOuts
+
+
+def _discount(ops, y, gamma, kene, compMethod, target_i, y_init):
+    """Discounted value iteration steps of HJIPDE_solve (hji_solver.py:603-638).
+    Default ('Jaime', ICRA 2019): y <- gamma*y + (1-gamma)*l with l the target (or data0).
+    'Kene' (minimum discounted rewards): shift everything below zero by max|l|, discount, take the
+    min/max with the shifted target, shift back."""
+    if not kene:
+        other = target_i if target_i is not None else y_init
+        return y * gamma + other * (1.0 - gamma)
+    if target_i is None:
+        error('Need to define target function l(x)!')
+    maxVal = float(abs(target_i).max())
+    ytemp = (y - maxVal) * gamma
+    ttemp = target_i - maxVal
+    if compMethod in ('minVWithL', 'minVwithL', 'minVWithTarget'):
+        ytemp = ops.minmax(_ffi.OP_MIN, ytemp, ttemp)
+    elif compMethod in ('maxVWithL', 'maxVwithL', 'maxVWithTarget'):
+        ytemp = ops.minmax(_ffi.OP_MAX, ytemp, ttemp)
+    else:
+        error('check your compMethod!')
+    return ytemp + maxVal

@@ -956,3 +956,88 @@ def test_term_toward_zero_ghost_data_in_fused_path(scheme, monkeypatch):
     g2, og2 = dubins(n)
     y2, _, _ = L.termLaxFriedrichs(0., y, sdata(g2, L.DubinsVehicleRel(g2, 1, 1), DERIV[scheme]))
     assert np.max(np.abs(np.asarray(y2) - np.asarray(yt))) > 1e-6
+
+
+# ------------------------------------------------------------------------------ HJIPDE_solve: stopping sets, discounting
+def _solve_setup(n=(21, 19, 16)):
+    g, og = dubins(n)
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, accuracy='high',
+                       dissFunc=L.artificialDissipationGLF, CoStateCalc=L.upwindFirstENO2))
+    data0 = O.shape_cylinder(og, 2, None, .5)
+    return g, og, sd, data0
+
+
+def test_hjipde_solve_stop_init_and_stop_sets():
+    from levelsetpy_amd.hji_solver import _eval_point
+    g, og, sd, data0 = _solve_setup()
+    tau = np.linspace(0, 0.6, 13)
+    ex = L.Bundle(dict(quiet=True))
+    full, _, _ = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', ex)
+    # a state outside the initial set that the backward reachable tube swallows (picked from the run)
+    swallowed = (full[0] > 0.02) & (full[-1] < -0.02)
+    assert swallowed.any(), "the tube did not grow: min change %g" % float((full[-1] - full[0]).min())
+    node = np.unravel_index(int(np.argmax(np.where(swallowed, full[0], -np.inf))), g.shape)
+    x = np.array([float(np.asarray(g.vs[d]).ravel()[node[d]]) for d in range(3)])
+    vals = [_eval_point(g, full[i], x) for i in range(len(tau))]
+    assert vals[0] > 0 and vals[-1] < 0
+    first = next(i for i, v in enumerate(vals) if v <= 0)
+    d, t, out = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, stopInit=x)))
+    assert out.stoptau == tau[first] and len(t) == first + 1 and d.shape[0] == first + 1
+    assert np.array_equal(d, full[:first + 1])
+    # stop sets: the tube at tau[6] as the set; 'intersect' fires as soon as one of its nodes is inside
+    # (at once: it contains the initial set), 'include' when all are (the tube is monotone: at tau[6])
+    ball = np.where(full[6] <= 0, -1., 1.)
+    di, ti, oi = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, stopSetIntersect=ball)))
+    da, ta, oa = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, stopSetInclude=ball)))
+    ki = next(i for i in range(1, len(tau)) if np.any((full[i] <= 0)[ball < 0]))
+    ka = next(i for i in range(1, len(tau)) if np.all((full[i] <= 0)[ball < 0]))
+    assert (ki, ka) == (1, 6)
+    assert len(ti) == ki + 1 and len(ta) == ka + 1 and oi.stoptau == tau[ki] and oa.stoptau == tau[ka]
+    assert np.array_equal(da, full[:ka + 1])
+    # stopLevel moves the level that is tested
+    kl = next(i for i in range(1, len(tau)) if np.all((full[i] <= 0.2)[ball < 0]))
+    dl, tl, ol = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, stopSetInclude=ball, stopLevel=0.2)))
+    assert len(tl) == kl + 1 and kl < ka
+    with pytest.raises(ValueError):
+        L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, stopSetInclude=ball[:-1])))
+    with pytest.raises(ValueError):
+        L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, stopInit=[0., 0.])))
+
+
+def test_hjipde_solve_discounting_flip_and_anneal():
+    g, og, sd, data0 = _solve_setup()
+    target = data0 + 0.1 * np.sin(2 * og.xs[0])
+    # tau steps shorter than one CFL step: exactly one integrator step (and one discount) per interval
+    tau = np.array([0., 0.002, 0.004])
+    plain, _, _ = L.HJIPDE_solve(data0, tau[:2], sd, 'set', L.Bundle(dict(quiet=True, keepLast=True)))
+    gam = 0.9
+    # default ('Jaime') mode: y <- gamma*y + (1-gamma)*data0, or the target when one is given
+    d1, _, _ = L.HJIPDE_solve(data0, tau[:2], sd, 'set', L.Bundle(dict(quiet=True, keepLast=True, discountFactor=gam)))
+    close(d1, gam * plain + (1 - gam) * data0, 1e-13)
+    pl, _, _ = L.HJIPDE_solve(data0, tau[:2], sd, 'minVWithL', L.Bundle(dict(quiet=True, keepLast=True, targetFunction=target)))
+    d2, _, _ = L.HJIPDE_solve(data0, tau[:2], sd, 'minVWithL',
+                              L.Bundle(dict(quiet=True, keepLast=True, targetFunction=target, discountFactor=gam)))
+    close(d2, gam * pl + (1 - gam) * target, 1e-13)
+    # 'Kene' mode: shift below zero by max|l|, discount, min with the shifted target, shift back
+    d3, _, _ = L.HJIPDE_solve(data0, tau[:2], sd, 'minVWithL',
+                              L.Bundle(dict(quiet=True, keepLast=True, targetFunction=target, discountFactor=gam, discountMode='Kene')))
+    M = np.max(np.abs(target))
+    close(d3, np.minimum(gam * (plain - M), target - M) + M, 1e-13)
+    with pytest.raises(ValueError):
+        L.HJIPDE_solve(data0, tau[:2], sd, 'set', L.Bundle(dict(quiet=True, discountFactor=gam, discountMode='Kene')))
+    # flipOutput reverses the stored time axis
+    fa, _, _ = L.HJIPDE_solve(data0, tau, sd, 'set', L.Bundle(dict(quiet=True)))
+    fb, _, _ = L.HJIPDE_solve(data0, tau, sd, 'set', L.Bundle(dict(quiet=True, flipOutput=True)))
+    assert np.array_equal(fb, fa[::-1])
+    # convergence stop; with annealing the first "convergence" only raises the discount factor
+    big = L.Bundle(dict(quiet=True, stopConverge=True, convergeThreshold=1e9, discountFactor=gam))
+    _, t1, o1 = L.HJIPDE_solve(data0, tau, sd, 'set', big)
+    assert len(t1) == 2 and o1.stoptau == tau[1]
+    big.discountAnneal = 'hard'
+    _, t2, o2 = L.HJIPDE_solve(data0, tau, sd, 'set', big)
+    assert len(t2) == 3 and o2.stoptau == tau[2]
+    # ignoreBoundary: the change is measured 4 cells inside the grid
+    ib = L.Bundle(dict(quiet=True, stopConverge=True, convergeThreshold=1e9, ignoreBoundary=True))
+    _, t3, _ = L.HJIPDE_solve(data0, tau, sd, 'set', ib)
+    assert len(t3) == 2
