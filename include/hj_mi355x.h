@@ -153,6 +153,14 @@ int hj_rk_integrate(hj_ctx* ctx, int order, int scheme, int ham_id, const double
 int hj_static_step_bound(hj_ctx* ctx, int ham_id, const double* ham_params, double* step_bound_host,
                          double* alpha_max_host);
 
+/* Which artificial dissipation's CFL bound hj_lf_term / hj_rk_step / hj_static_step_bound report.  For a
+ * Hamiltonian whose alpha ignores the data the dissipation TERM of all three Lax-Friedrichs variants is
+ * the same array, only the bound differs: global LF 1/sum_d max_x alpha_d/dx_d
+ * (artificial_diss_glf.py:101-109), local variants 1/max_x sum_d alpha_d(x)/dx_d
+ * (diss_local_laxfried.py:116-121, diss_localsq_laxfried.py:99-104, with the reduction the toolbox intends). */
+enum { HJ_DISS_GLF = 0, HJ_DISS_LOCAL = 1 };
+int hj_ctx_set_dissipation(hj_ctx* ctx, int kind);
+
 /* max over the (unstripped) first-divided-difference table of D1^2, per dim: the 'maxOverGrid'
  * epsilon of true WENO5 (upwind_first_weno5a.py:69-70,153-156).  out_dev: ndim values of the ctx
  * dtype on the device.  hj_rk_substep/hj_lf_term with HJ_WENO5 run this themselves unless

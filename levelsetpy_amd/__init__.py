@@ -20,7 +20,8 @@ from .init_conds import shapeCylinder, shapeSphere                              
 from .spatial import (upwindFirstENO2, upwindFirstENO3, upwindFirstENO3a, upwindFirstWENO5,   # noqa: F401
                       upwindFirstWENO5a, upwindFirstWENO5Intended, upwindFirstENO3aHelper,
                       set_weno5_mode, get_weno5_mode)
-from .dissipation import artificialDissipationGLF                               # noqa: F401
+from .dissipation import (artificialDissipationGLF, artificialDissipationLLF,      # noqa: F401
+                          artificialDissipationLLLF)
 from .dynamics import DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D      # noqa: F401
 from .term import termLaxFriedrichs, termRestrictUpdate                         # noqa: F401
 from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      # noqa: F401

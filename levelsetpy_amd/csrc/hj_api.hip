@@ -76,7 +76,8 @@ struct hj_ctx {
     int partials_cap;
     // static step bound cache
     int sb_ham;
-    double sb_par[4], sb_val, sb_alpha[HJ_MAX_DIM];
+    double sb_par[4], sb_val, sb_local, sb_alpha[HJ_MAX_DIM];
+    int diss_local;                    // hj_ctx_set_dissipation: step bound of the local LF variants
     bool sb_valid;
     int internal_slot;
     // slab communication (hj_comm_*)
@@ -989,7 +990,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     for (int s = 0; s < 4; ++s) { c->aux[s] = nullptr; c->aux_n[s] = 0; }
     c->ring = nullptr; c->keys = nullptr; c->weno_vals = nullptr; c->weno_src = nullptr; c->flag = nullptr;
     c->partials = nullptr; c->partials_cap = 0;
-    c->sb_valid = false; c->internal_slot = 0;
+    c->sb_valid = false; c->internal_slot = 0; c->diss_local = 0; c->sb_local = 0;
     c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->lo_rank = c->hi_rank = -1;
     c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr; c->slab_pending = 0;
@@ -1166,7 +1167,12 @@ int hj_lf_term(hj_ctx* c, int scheme, int ham, const double* par, double t, int 
     SubstepCall s{scheme, ham, HJ_STAGE_YDOT, restrict_sign, par, 0.0, y, nullptr, ydot, nullptr, 0, c->N[0]};
     int rc = do_substep(c, s, slot);
     if (rc) return rc;
-    if (sb) return read_ring(c, c->slot_ring[slot], sb, nullptr);
+    if (sb) {
+        // local LF variants: alpha of a native Hamiltonian does not depend on the data, so the bound
+        // 1/max_x sum_d alpha_d(x)/dx_d is a static property of the grid
+        if (c->diss_local) return hj_static_step_bound(c, ham, par, sb, nullptr);
+        return read_ring(c, c->slot_ring[slot], sb, nullptr);
+    }
     return HJ_OK;
 }
 
@@ -1176,7 +1182,7 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
     if (rc) return rc;
     const int np = ham_npar(ham);
     if (c->sb_valid && c->sb_ham == ham && memcmp(c->sb_par, par, sizeof(double) * np) == 0) {
-        *sb = c->sb_val;
+        *sb = c->diss_local ? c->sb_local : c->sb_val;
         if (amax) for (int d = 0; d < c->ndim; ++d) amax[d] = c->sb_alpha[d];
         return HJ_OK;
     }
@@ -1188,8 +1194,10 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         fill_grid<T, HAM<T>::ND>(c, G);                                                          \
         HamTables<T> P;                                                                          \
         fill_ham<T>(c, par, P);                                                                  \
+        DxArgs DX;                                                                               \
+        for (int d = 0; d < HJ_MAX_DIM; ++d) DX.dx[d] = c->dx[d];                                \
         hipLaunchKernelGGL((alpha_bound_kernel<T, HAM<T>>), dim3(blocks), dim3(256), 0,          \
-                           c->stream, G, P, c->keys);                                            \
+                           c->stream, G, P, c->keys, DX);                                        \
     }
     if (c->dtype == HJ_F64) {
         if (ham == HJ_HAM_DUBINS_REL) HJ_AB(double, HamDubinsRel)
@@ -1202,7 +1210,7 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
     }
 #undef HJ_AB
     HIP_TRY(hipGetLastError());
-    unsigned long long k[HJ_MAX_DIM];
+    unsigned long long k[HJ_MAX_DIM + 1];
     HIP_TRY(hipMemcpyAsync(k, c->keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double inv = 0.0;
@@ -1211,12 +1219,20 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         inv += c->sb_alpha[d] / c->dx[d];
     }
     c->sb_val = 1.0 / inv;
+    c->sb_local = 1.0 / key_to_double(k[HJ_MAX_DIM]);   // 1 / max_x sum_d alpha_d(x)/dx_d
     c->sb_ham = ham;
     memset(c->sb_par, 0, sizeof(c->sb_par));
     memcpy(c->sb_par, par, sizeof(double) * np);
     c->sb_valid = true;
-    *sb = c->sb_val;
+    *sb = c->diss_local ? c->sb_local : c->sb_val;
     if (amax) for (int d = 0; d < c->ndim; ++d) amax[d] = c->sb_alpha[d];
+    return HJ_OK;
+}
+
+int hj_ctx_set_dissipation(hj_ctx* c, int kind) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (kind != HJ_DISS_GLF && kind != HJ_DISS_LOCAL) return fail(HJ_EINVAL, "unknown dissipation kind %d", kind);
+    c->diss_local = (kind == HJ_DISS_LOCAL);
     return HJ_OK;
 }
 

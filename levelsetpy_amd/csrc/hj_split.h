@@ -249,13 +249,16 @@ __global__ void keys_to_values_kernel(const unsigned long long* keys, T* out, in
 }
 
 // ---- max alpha per dim with p = 0: stepBound of a Hamiltonian whose alpha ignores the data
+struct DxArgs { double dx[HJ_MAX_DIM]; };
 template <typename T, typename HAM>
 __global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G, HamTables<T> P,
-                                                          unsigned long long* keys) {
+                                                          unsigned long long* keys, DxArgs DX) {
     constexpr int ND = HAM::ND;
-    double m[ND];
+    const double* dx = DX.dx;
+    // m[0..ND): max alpha_d (global LF);  m[ND]: max over nodes of sum_d alpha_d/dx_d (local LF variants)
+    double m[ND + 1];
 #pragma unroll
-    for (int d = 0; d < ND; ++d) m[d] = -1e300;
+    for (int d = 0; d <= ND; ++d) m[d] = -1e300;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < G.total;
          t += (long long)gridDim.x * blockDim.x) {
         int idx[ND];
@@ -267,21 +270,27 @@ __global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G
 #pragma unroll
         for (int d = 0; d < ND; ++d) one[d] = T(1);
         HAM::eval(P, HAM::cell(P, idx, one), HAM::plane(P, idx[0], one), one, p, H, a);
+        double inv = 0.0;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) m[d] = fmax(m[d], (double)a[d]);
+        for (int d = 0; d < ND; ++d) {
+            m[d] = fmax(m[d], (double)a[d]);
+            inv += (double)a[d] / dx[d];
+        }
+        m[ND] = fmax(m[ND], inv);
     }
-    __shared__ double red[4][ND];
+    __shared__ double red[4][ND + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
+    for (int d = 0; d <= ND; ++d) {
         const double w = wave_max(m[d]);
         if (lane == 0) red[wv][d] = w;
     }
     __syncthreads();
-    if (threadIdx.x < ND) {
+    if (threadIdx.x <= ND) {
         const int d = threadIdx.x;
         const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        if (w > -1e299) atomicMax(keys + d, max_key(w));
+        // the sum goes to keys[HJ_MAX_DIM], whatever ND is
+        if (w > -1e299) atomicMax(keys + (d == ND ? HJ_MAX_DIM : d), max_key(w));
     }
 }
 

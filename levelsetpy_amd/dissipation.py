@@ -8,7 +8,7 @@ import numpy as np
 from .context import is_tensor
 from .utilities import isfield, cell
 
-__all__ = ["artificialDissipationGLF"]
+__all__ = ["artificialDissipationGLF", "artificialDissipationLLF", "artificialDissipationLLLF"]
 
 
 def _amin(a):
@@ -49,3 +49,55 @@ def artificialDissipationGLF(t, data, derivL, derivR, schemeData):
         stepBoundInv += (float(alpha) / float(np.asarray(grid.dx).item(i)))         # :107
     stepBound = float(1 / stepBoundInv)                           # :109
     return diss, stepBound
+
+
+def _minimum(a, b):
+    return a.minimum(b) if is_tensor(a) else np.minimum(a, b)
+
+
+def _maximum(a, b):
+    return a.maximum(b) if is_tensor(a) else np.maximum(a, b)
+
+
+def _local(t, data, derivL, derivR, schemeData, every_dim_local):
+    if not isfield(schemeData, 'grid'):
+        raise ValueError('grid is not a structure')
+    if not isfield(schemeData, 'partialFunc'):
+        raise ValueError('partialFunc is not a structure')
+    grid = schemeData.grid
+    dim = grid.dim
+    nodeMin = [_minimum(derivL[i], derivR[i]) for i in range(dim)]
+    nodeMax = [_maximum(derivL[i], derivR[i]) for i in range(dim)]
+    if every_dim_local:
+        gMin, gMax = nodeMin, nodeMax
+    else:
+        gMin = [min(_amin(derivL[i]), _amin(derivR[i])) for i in range(dim)]
+        gMax = [max(_amax(derivL[i]), _amax(derivR[i])) for i in range(dim)]
+    diss = 0
+    stepBoundInv = 0
+    for i in range(dim):
+        derivMin, derivMax = list(gMin), list(gMax)
+        derivMin[i], derivMax[i] = nodeMin[i], nodeMax[i]
+        alpha = schemeData.partialFunc(t, data, derivMin, derivMax, schemeData, i)
+        diss = diss + (0.5 * (derivR[i] - derivL[i]) * alpha)
+        stepBoundInv = stepBoundInv + alpha / float(np.asarray(grid.dx).item(i))
+    if is_tensor(stepBoundInv) or isinstance(stepBoundInv, np.ndarray):
+        stepBoundInv = _amax(stepBoundInv)
+    return diss, float(1 / float(stepBoundInv))
+
+
+def artificialDissipationLLF(t, data, derivL, derivR, schemeData):
+    """Local Lax-Friedrichs (reference ExplicitIntegration/Dissipation/diss_local_laxfried.py:8): alpha_i is
+    evaluated with the costate of dimension i restricted, at every node, to [min(p_i^-, p_i^+),
+    max(p_i^-, p_i^+)] (:108-111) and the global range in the other dimensions (:84-99);
+    diss = sum_i (p_i^+ - p_i^-)/2 alpha_i (:117).  stepBound = 1 / max_x sum_i alpha_i(x)/dx_i: the
+    shipped code calls .item() on that array (:121), which only works for a scalar alpha -- the
+    reduction over the grid is what the level-set toolbox it ports does."""
+    return _local(t, data, derivL, derivR, schemeData, False)
+
+
+def artificialDissipationLLLF(t, data, derivL, derivR, schemeData):
+    """Local local Lax-Friedrichs (reference .../diss_localsq_laxfried.py:7): per-node costate ranges in
+    EVERY dimension (:87-90; the shipped code applies Python's scalar min/max to the arrays there, which
+    raises), diss and stepBound as for LLF (:99-104, reduced over the grid)."""
+    return _local(t, data, derivL, derivR, schemeData, True)

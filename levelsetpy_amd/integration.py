@@ -170,12 +170,14 @@ def _integrate(order, schemeFunc, tspan, y0, options, schemeData):
 
 
 def _integrate_device(order, dev, tspan, y0, options, schemeData):
-    (grid, sid, ham, par), rs = dev
+    plan, rs = dev
+    grid, sid, ham, par = plan
     small = 100 * eps
     dg = device_grid(grid, array_dtype_name(y0))
     if int(np.prod(y0.shape)) != dg.numel:
         raise ValueError('y0 does not agree in size with grid')
     dg.bind_stream()
+    plan.bind(dg)
     shape0 = tuple(y0.shape)
     # the input is only ever read (hj_rk_step never writes y_in), so it is used in place; results go
     # to buffers allocated here (A/B ping-pong for multi-step spans), so nothing is cloned and the

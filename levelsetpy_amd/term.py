@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _ffi
 from .context import device_grid, array_dtype_name, is_tensor
-from .dissipation import artificialDissipationGLF
+from .dissipation import artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF
 from .dynamics import native_of
 from .spatial import scheme_id_of
 from .utilities import isfield, iscell
@@ -32,6 +32,18 @@ def _deriv_func(sd):
     return None
 
 
+class _Plan(tuple):
+    """(grid, scheme_id, ham_id, params) plus .diss, the hj_ctx_set_dissipation kind."""
+
+    def __new__(cls, items, diss):
+        self = super(_Plan, cls).__new__(cls, items)
+        self.diss = diss
+        return self
+
+    def bind(self, dg):
+        _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, self.diss))
+
+
 def native_plan(schemeData):
     """(grid, scheme_id, ham_id, params) if this LF schemeData can run fused, else None."""
     sd = schemeData[0] if iscell(schemeData) else schemeData
@@ -40,7 +52,9 @@ def native_plan(schemeData):
             return None
     fn = _deriv_func(sd)
     sid = scheme_id_of(fn) if fn is not None else None
-    if sid is None or sd.dissFunc is not artificialDissipationGLF:
+    # all three Lax-Friedrichs variants run fused: a native Hamiltonian's alpha ignores the costate range, so
+    # their dissipation terms coincide and only the CFL bound differs (hj_ctx_set_dissipation)
+    if sid is None or sd.dissFunc not in (artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF):
         return None
     nat = native_of(sd.hamFunc, sd.partialFunc)
     if nat is None or nat[0].grid is not sd.grid:
@@ -50,7 +64,8 @@ def native_plan(schemeData):
         grid_bc(sd.grid)
     except ValueError:
         return None
-    return sd.grid, sid, nat[1], nat[2]
+    return _Plan((sd.grid, sid, nat[1], nat[2]),
+                 _ffi.DISS_GLF if sd.dissFunc is artificialDissipationGLF else _ffi.DISS_LOCAL)
 
 
 def _fused_term(plan, t, y, restrict_sign):
@@ -59,6 +74,7 @@ def _fused_term(plan, t, y, restrict_sign):
     if int(np.prod(y.shape)) != dg.numel:
         raise ValueError('y does not agree in size with grid')
     dg.bind_stream()
+    plan.bind(dg)
     yd = dg.to_device(y)
     out = dg.empty()
     sb = C.c_double()

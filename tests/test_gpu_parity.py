@@ -1041,3 +1041,67 @@ def test_hjipde_solve_discounting_flip_and_anneal():
     ib = L.Bundle(dict(quiet=True, stopConverge=True, convergeThreshold=1e9, ignoreBoundary=True))
     _, t3, _ = L.HJIPDE_solve(data0, tau, sd, 'set', ib)
     assert len(t3) == 2
+
+
+# ------------------------------------------------------------------------------ local Lax-Friedrichs variants
+class _BurgersLike(object):
+    """H = sum p_i^2 / 2 with alpha_i = max(|p_i| over the costate range handed in): a DATA-DEPENDENT
+    alpha, so the three Lax-Friedrichs variants really differ (plain callbacks -> split path)."""
+
+    @staticmethod
+    def hamiltonian(t, data, derivs, sd):
+        return sum(0.5 * p * p for p in derivs)
+
+    @staticmethod
+    def dissipation(t, data, derivMin, derivMax, sd, dim):
+        lo, hi = derivMin[dim], derivMax[dim]
+        if torch.is_tensor(lo) or torch.is_tensor(hi):
+            lo = lo if torch.is_tensor(lo) else torch.full_like(hi, float(lo))
+            hi = hi if torch.is_tensor(hi) else torch.full_like(lo, float(hi))
+            return torch.maximum(lo.abs(), hi.abs())
+        return np.maximum(np.abs(lo), np.abs(hi))
+
+
+@pytest.mark.parametrize("kind", ["llf", "lllf"])
+@pytest.mark.parametrize("scheme", ["ENO2", "WENO5_ASSHIPPED"])
+def test_local_lax_friedrichs_split_path_vs_oracle(kind, scheme):
+    g, og = dubins((19, 17, 15))
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * np.random.default_rng(9).standard_normal(g.shape)
+    y = data.reshape(-1, 1)
+    fn = {"llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sd = L.Bundle(dict(grid=g, hamFunc=_BurgersLike.hamiltonian, partialFunc=_BurgersLike.dissipation,
+                       dissFunc=fn, CoStateCalc=DERIV[scheme]))
+    yd, sb, _ = L.termLaxFriedrichs(0., y, sd)
+    yo, sbo = O.term_lax_friedrichs(og, _BurgersLike, scheme, 0., y, diss=kind)
+    close(yd, yo)
+    assert abs(sb - sbo) <= 1e-13 * sbo
+    # and they are not the global variant in disguise
+    yg, sbg = O.term_lax_friedrichs(og, _BurgersLike, scheme, 0., y)
+    assert np.max(np.abs(yg - yo)) > 1e-6 and sbo > sbg
+
+
+@pytest.mark.parametrize("kind", ["llf", "lllf"])
+def test_local_lax_friedrichs_fused_native(kind):
+    """Native Hamiltonian: alpha ignores the costate range, so the term equals the GLF one and only the CFL
+    bound changes (1/max_x sum_i alpha_i/dx_i); the integrator steps with it."""
+    g, og = dubins((18, 16, 14))
+    data = O.shape_cylinder(og, 2, None, .5) + 0.02 * np.random.default_rng(10).standard_normal(g.shape)
+    y = data.reshape(-1, 1)
+    fn = {"llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sys_ = L.DubinsVehicleRel(g, 1, 2)
+    sd = sdata(g, sys_, L.upwindFirstWENO5)
+    sd.dissFunc = fn
+    yd, sb, _ = L.termLaxFriedrichs(0., y, sd)
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 2), "WENO5_ASSHIPPED", 0., y, diss=kind)
+    _, sbg = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 2), "WENO5_ASSHIPPED", 0., y)
+    close(yd, yo)
+    assert abs(sb - sbo) <= 1e-13 * sbo and sbo > sbg
+    term = lambda tt, yy: O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 2), "WENO5_ASSHIPPED", tt, yy, diss=kind)  # noqa: E731
+    to, yo3 = O.ode_cfl_3(term, [0., 0.05], y, 0.8)
+    t3, y3, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 0.05], y, L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off'))), sd)
+    assert abs(t3 - to) <= 1e-14
+    close(y3, yo3)
+    # the ctx goes back to the global bound for a GLF problem on the same grid
+    sd2 = sdata(g, sys_, L.upwindFirstWENO5)
+    _, sb2, _ = L.termLaxFriedrichs(0., y, sd2)
+    assert abs(sb2 - sbg) <= 1e-13 * sbg
