@@ -27,5 +27,6 @@ from .term import termLaxFriedrichs, termRestrictUpdate                         
 from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      # noqa: F401
                           odeCFLmultipleSteps, odeCFLcallPostTimestep)
 from .hji_solver import HJIPDE_solve                                            # noqa: F401
+from .gradients import computeGradients                                         # noqa: F401
 
 __version__ = "0.1.0"

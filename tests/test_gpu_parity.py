@@ -1105,3 +1105,37 @@ def test_local_lax_friedrichs_fused_native(kind):
     sd2 = sdata(g, sys_, L.upwindFirstWENO5)
     _, sb2, _ = L.termLaxFriedrichs(0., y, sd2)
     assert abs(sb2 - sbg) <= 1e-13 * sbg
+
+
+def test_compute_gradients_vs_oracle():
+    """computeGradients (compute_gradients.py:11): central/left/right costates of a stored value function,
+    single time and time-stacked, NaN/inf kept where they were, dims mask, NumPy and device input."""
+    g, og = dubins((14, 13, 12))
+    rng = np.random.default_rng(6)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * rng.standard_normal(g.shape)
+    dC, dL, dR = L.computeGradients(g, data)
+    for i in range(3):
+        oL, oR = O.upwind_first_weno5(og, data, i)
+        close(dL[i], oL)
+        close(dR[i], oR)
+        close(dC[i], 0.5 * (oL + oR))
+    # another scheme, a dims mask, a device tensor in -> tensors out
+    dC2, dL2, dR2 = L.computeGradients(g, torch.as_tensor(data, device="cuda"), dims=[True, False, True],
+                                       derivFunc=L.upwindFirstENO3)
+    assert np.ndim(dC2[1]) == 0 and torch.is_tensor(dC2[0]) and dC2[0].is_cuda   # skipped dims stay empty cells
+    oL, oR = O.upwind_first_eno3(og, data, 2)
+    close(dC2[2].cpu().numpy(), 0.5 * (oL + oR))
+    # time-stacked (time first), with a NaN and an inf: they come back in place, neighbours are finite
+    stack = np.stack([data, data + 0.1, data * 1.5])
+    stack[1, 3, 4, 5] = np.nan
+    stack[2, 6, 7, 8] = np.inf
+    keep = stack.copy()
+    sC, sL, sR = L.computeGradients(g, stack)
+    assert np.array_equal(np.isnan(stack), np.isnan(keep)) and np.array_equal(stack[np.isfinite(keep)], keep[np.isfinite(keep)])
+    assert sC[0].shape == stack.shape
+    assert np.isnan(sC[0][1, 3, 4, 5]) and np.isinf(sC[2][2, 6, 7, 8])
+    assert np.isfinite(sC[0][1, 4, 4, 5]) and np.isfinite(sC[0][0]).all()
+    oL, oR = O.upwind_first_weno5(og, stack[0], 1)
+    close(sC[1][0], 0.5 * (oL + oR))
+    with pytest.raises(ValueError):
+        L.computeGradients(g, data[0])
