@@ -28,5 +28,6 @@ from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      
                           odeCFLmultipleSteps, odeCFLcallPostTimestep)
 from .hji_solver import HJIPDE_solve                                            # noqa: F401
 from .gradients import computeGradients                                         # noqa: F401
+from .convection import termConvection                                          # noqa: F401
 
 __version__ = "0.1.0"

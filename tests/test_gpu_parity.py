@@ -1139,3 +1139,36 @@ def test_compute_gradients_vs_oracle():
     close(sC[1][0], 0.5 * (oL + oR))
     with pytest.raises(ValueError):
         L.computeGradients(g, data[0])
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_term_convection_vs_oracle_and_integration(scheme):
+    """termConvection (term_convection.py:7): -V.grad(phi) upwinded by the sign of each component; scalar and
+    array components, exact zeros, NumPy and device input; integrates through odeCFL3.  The shipped
+    reference raises, so the oracle restates the documented formula (parity unpinned for this term)."""
+    g, og = dubins((15, 14, 12))
+    rng = np.random.default_rng(13)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * rng.standard_normal(g.shape)
+    v2 = np.sin(2 * og.xs[0]) * np.cos(og.xs[2]) + 0.3
+    v2[np.abs(v2) < 0.05] = 0.0
+    vel = [0.7, -0.4 * np.ones(g.shape), v2]
+    y = data.reshape(-1, 1)
+    sd = L.Bundle(dict(grid=g, velocity=vel, derivFunc=DERIV[scheme]))
+    yd, sb, _ = L.termConvection(0., y, sd)
+    yo, sbo = O.term_convection(og, vel, scheme, 0., y)
+    assert yd.shape == y.shape and isinstance(sb, float)
+    close(yd, yo)
+    assert abs(sb - sbo) <= 1e-14 * sbo
+    # device tensor in -> device tensor out; a callable velocity
+    sd2 = L.Bundle(dict(grid=g, velocity=lambda t, d, s: vel, derivFunc=DERIV[scheme]))
+    yd2, sb2, _ = L.termConvection(0., torch.as_tensor(y, device="cuda"), sd2)
+    assert torch.is_tensor(yd2) and yd2.is_cuda and sb2 == sb
+    close(yd2.cpu().numpy(), yo)
+    # a few RK3 steps through the generic integrator loop
+    term = lambda tt, yy: O.term_convection(og, vel, scheme, tt, yy)  # noqa: E731
+    to, y3o = O.ode_cfl_3(term, [0., 0.05], y, 0.5)
+    t3, y3, _ = L.odeCFL3(L.termConvection, [0., 0.05], y, L.odeCFLset(L.Bundle(dict(factorCFL=.5, singleStep='off'))), sd)
+    assert abs(t3 - to) <= 1e-14
+    (close if scheme.startswith("WENO") else close_eno)(y3, y3o, 1e-11)
+    with pytest.raises(ValueError):
+        L.termConvection(0., y, L.Bundle(dict(grid=g, velocity=[1., 2.], derivFunc=DERIV[scheme])))
