@@ -72,6 +72,13 @@ def lib():
             raise RuntimeError(
                 "levelsetpy_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `make -C levelsetpy_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        # torch first: its wheel bundles the HIP/HSA runtime the process must share.  Loaded the other way
+        # round, the library would bring in /opt/rocm's copy and torch a second one, and the later of the
+        # two runtimes to initialise finds "no ROCm-capable device" (seen with build() followed by smoke()).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
