@@ -1172,3 +1172,49 @@ def test_term_convection_vs_oracle_and_integration(scheme):
     (close if scheme.startswith("WENO") else close_eno)(y3, y3o, 1e-11)
     with pytest.raises(ValueError):
         L.termConvection(0., y, L.Bundle(dict(grid=g, velocity=[1., 2.], derivFunc=DERIV[scheme])))
+
+
+# ------------------------------------------------------------------------------ randomized shapes / boundary mixes
+def _fuzz_cases():
+    rng = np.random.default_rng(2024)
+    cases = []
+    for k in range(28):
+        dim = int(rng.choice([2, 3, 3, 3, 4]))
+        hi = {2: 400, 3: 70, 4: 20}[dim]
+        n = tuple(int(v) for v in rng.integers(3, hi, size=dim))
+        if dim == 2 and k % 2:
+            n = (int(rng.integers(3, 40)), int(rng.integers(200, 2500)))
+        pd = tuple(int(d) for d in range(dim) if rng.random() < 0.4)
+        tz = tuple(bool(rng.random() < 0.3) for _ in range(dim))
+        scheme = SCHEMES[int(rng.integers(0, 4))]
+        cases.append((k, dim, n, pd, tz, scheme))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "%d-%dd-%s-%s" % (c[0], c[1], "x".join(map(str, c[2])), c[5]))
+def test_fuzz_shapes_boundaries_schemes(case, monkeypatch):
+    """Random extents (down to the stencil width, primes, long thin grids), random periodic / extrapolated
+    / towardZero mixes, every scheme and Hamiltonian: tiled kernel = direct kernel = oracle."""
+    k, dim, n, pd, tz, scheme = case
+    rng = np.random.default_rng(1000 + k)
+    gmin = [-1.0 - 0.1 * d for d in range(dim)]
+    gmax = [1.0 + 0.2 * d for d in range(dim)]
+    g, _ = mk(gmin, gmax, n, list(pd) if pd else None)
+    for d in range(dim):
+        if tz[d] and d not in pd:
+            g.bdryData[d] = L.Bundle(dict(towardZero=True))
+    og = O.Grid(gmin, gmax, n, list(pd), toward_zero=[tz[d] and d not in pd for d in range(dim)])
+    data = O.shape_sphere(og, None, .6) + 0.05 * rng.standard_normal(n)
+    y = data.reshape(-1, 1)
+    if dim == 2:
+        sys_, osys = L.DoubleIntegrator(g, 1.3), O.DoubleIntegrator(og, 1.3)
+    elif dim == 3:
+        sys_, osys = L.DubinsVehicleRel(g, 1.5, 0.7), O.DubinsRel(og, 1.5, 0.7)
+    else:
+        sys_, osys = L.DoublePendulum4D(g, 1.0), O.DoublePendulum4D(og, 1.0)
+    (yt, sbt, _), (yd, sbd, _) = _term_both_kernels(g, sys_, scheme, y, monkeypatch)
+    yo, sbo = O.term_lax_friedrichs(og, osys, scheme, 0., y)
+    tol = 1e-10 if dim == 4 else 1e-11
+    close(yt, yo, tol, what="tiled")
+    close(yd, yo, tol, what="direct")
+    assert abs(sbt - sbo) <= 1e-12 * sbo and abs(sbd - sbo) <= 1e-12 * sbo
