@@ -752,13 +752,14 @@ def test_native_rccl_slab_stepper_self_ring():
 
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("scheme,periodic0,world", [("WENO5_ASSHIPPED", False, 3), ("ENO3", False, 2),
-                                                    ("WENO5_ASSHIPPED", True, 3), ("ENO2", True, 2)])
+                                                    ("WENO5_ASSHIPPED", True, 3), ("ENO2", True, 2),
+                                                    ("ENO3", True, 5), ("WENO5_ASSHIPPED", False, 5)])
 def test_deep_halo_stepper_virtual_ranks_bitwise(scheme, periodic0, world, order):
     """hj_slab_rk_step_deep with `world` virtual ranks in ONE process (hj_comm_init_external: the test moves
     the pad planes itself): end ranks with a single neighbour, middle ranks with two, the periodic ring.
     Stages recompute planes beyond the slab; the result must equal the undivided grid BITWISE."""
     from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
-    n = (61, 18, 16)
+    n = (61 if world <= 3 else 97, 18, 16)      # 97 = 5*19 + 2: uneven slabs of 20 and 19 planes
     pd = (0, 2) if periodic0 else 2
     gmax0 = 2. * (1 - 2 / n[0]) if periodic0 else 2.
     g, og = mk([-2., -1.25, -np.pi], [gmax0, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
