@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 # that share a queue serialise (must be set before HIP initialises)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+SPINUP_STEPS = int(os.environ.get("HJ_BENCH_SPINUP", "300"))   # untimed clock ramp before the W warm-up steps
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SUBSTEP = {"float64": 64.0 / 3.0, "float32": 32.0 / 3.0}   # 8 words / RK3 step
 
@@ -77,6 +78,10 @@ def time_steps(torch, dg, lib, sid, ham, par, bufs, steps, warmup, world):
             raise RuntimeError(lib.hj_last_error().decode())
         return nxt, cur, float(tout.value)
 
+    # device spin-up (untimed, reported as config.spinup_steps): the GPU's clocks need a few tens of
+    # milliseconds of load to reach their steady state; without it a short --steps run measures the ramp
+    for _ in range(SPINUP_STEPS):
+        cur, nxt, t = one(cur, nxt, t)
     for _ in range(warmup):
         cur, nxt, t = one(cur, nxt, t)
     torch.cuda.synchronize()
@@ -203,7 +208,8 @@ def main():
         "config": {"workload": "Dubins-relative (air3D) 3-D HJI, %s x %d x %d grid, %s + GLF, odeCFL3 "
                                "(factorCFL 0.8), cylinder r=0.5 initial data" %
                                (("%d" % n) if world == 1 else ("%dx%d" % (world, n)), n, n, a.scheme),
-                   "scheme": a.scheme, "parallelism": sched, "substeps_per_step": 3},
+                   "scheme": a.scheme, "parallelism": sched, "substeps_per_step": 3,
+                   "spinup_steps": SPINUP_STEPS},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, a.scheme, a.dtype, world),
                      "kernel": "fused_substep_kernel", "kernel_ms": kern_ms,

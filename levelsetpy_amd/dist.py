@@ -492,7 +492,8 @@ def bench_slab(args, rank, world):
         raise RuntimeError("no slab transport reproduced the single-domain result (last diff %g)" % check)
     transport = how
     t = 0.0
-    for _ in range(args.warmup):
+    # untimed device spin-up (clock ramp), as in bench.py's single-GPU leg
+    for _ in range(int(os.environ.get("HJ_BENCH_SPINUP", "300")) + args.warmup):
         t, _dt = integ.step(t)
     torch.cuda.synchronize()
     dist.barrier()
