@@ -246,15 +246,15 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
         const bool sL0 = t_abs(s1) < t_abs(s2), sL1 = t_abs(s2) < t_abs(s3);          // strict '<': ties go right
         const bool sT0 = t_abs(t0) < t_abs(t1), sT1 = t_abs(t1) < t_abs(t2), sT2 = t_abs(t2) < t_abs(t3);
         const T third = T(1) / T(3), sixth = T(1) / T(6);
-        const T a1 = third * t1, b1 = -sixth * t1, b2 = -sixth * t2;
-        // left:  sL0 ? (sT0 ? t0/3 : t1/3) : (sT1 ? t1/3 : -t2/6)      with s1 resp. s2
-        const T tl = sL0 ? (sT0 ? third * t0 : a1) : (sT1 ? a1 : b2);
-        // (the middle candidate is written with the LEFT second difference on the left side and the
-        // right one's mirror on the right side, as ENO3aHelper.py:132-168 does)
-        const T Lq = u2 + (T(0.5) * ((sL0 || sT1) ? s1 : s2) + tl);
-        // right: sL1 ? (sT1 ? -t1/6 : -t2/6) : (sT2 ? -t2/6 : t3/3)    with -s2 resp. -s3
-        const T tr = sL1 ? (sT1 ? b1 : b2) : (sT2 ? b2 : third * t3);
-        const T Rq = u3 + (T(-0.5) * ((sL1 || sT2) ? s2 : s3) + tr);
+        // the three corrections per side, then TWO levels of selection (a 64-bit select is two
+        // v_cndmask): the middle candidate is written with the left second difference on the left side
+        // and its mirror on the right side, as ENO3aHelper.py:132-168 does
+        const T h1 = T(0.5) * s1, h2 = T(0.5) * s2, h3 = T(0.5) * s3;
+        const T qL0 = third * t0 + h1, qL1 = third * t1 + h1, qL2 = h2 - sixth * t2;
+        const T qR0 = -sixth * t1 - h2, qR1 = -sixth * t2 - h2, qR2 = third * t3 - h3;
+        // left:  sL0 ? (sT0 ? c0 : c1) : (sT1 ? c1 : c2);   right: sL1 ? (sT1 ? c0 : c1) : (sT2 ? c1 : c2)
+        const T Lq = u2 + (sL0 ? (sT0 ? qL0 : qL1) : (sT1 ? qL1 : qL2));
+        const T Rq = u3 + (sL1 ? (sT1 ? qR0 : qR1) : (sT2 ? qR1 : qR2));
         pc = Lq + Rq;
         hd = Rq - Lq;
     } else if constexpr (SCHEME == HJ_ENO2) {
