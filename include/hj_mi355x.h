@@ -138,13 +138,21 @@ int hj_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham
 
 /* The whole odeCFLn loop of a time span in one call (ode_cfl_3.py:125-251 with singleStep off and no
  * postTimeStep / terminalEvent callbacks): steps from t0 until tf - t < 100*eps*|tf| (or max_steps > 0
- * steps).  y_in is never written; results alternate between buf_a and buf_b, `work` is stage scratch
+ * steps; stop_tol >= 0 replaces the stopping test by HJIPDE_solve's `t < tf - stop_tol`,
+ * hji_solver.py:536).  y_in is never written; results alternate between buf_a and buf_b, `work` is stage scratch
  * (all of y's size, all distinct).  *result_in = 0 (no step taken: y_in), 1 (buf_a) or 2 (buf_b).
  * No host synchronisation for Hamiltonians with a static stepBound: one call enqueues the span. */
 int hj_rk_integrate(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double t0,
                     double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
-                    void* buf_a, void* buf_b, void* work, int64_t max_steps, double* t_out,
-                    int64_t* steps_out, int* result_in);
+                    void* buf_a, void* buf_b, void* work, int64_t max_steps, double stop_tol,
+                    double* t_out, int64_t* steps_out, int* result_in);
+
+/* Post-step operator of HJIPDE_solve fused into the LAST stage of every hj_rk_step / hj_rk_integrate step
+ * (hji_solver.py:566-580): HJ_POST_MIN_PREV / HJ_POST_MAX_PREV = min / max of the new state with the
+ * state the step started from ('minVOverTime' / 'maxVOverTime'; NaN propagates as in NumPy).  That
+ * state is an operand of the last stage anyway, so the operator costs no extra pass over memory. */
+enum { HJ_POST_NONE = 0, HJ_POST_MIN_PREV = 1, HJ_POST_MAX_PREV = 2 };
+int hj_ctx_set_post_step(hj_ctx* ctx, int op);
 
 /* stepBound of a native Hamiltonian on this grid (alpha is data-independent for all HJ_HAM_*);
  * computed once per (ham_id, params) and cached.  Synchronises on the first call.

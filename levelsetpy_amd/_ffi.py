@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("HJ_LIB") or os.path.join(HERE, "csrc", "libhj_mi355x.
 # enums of include/hj_mi355x.h
 BC_EXTRAPOLATE, BC_PERIODIC = 0, 1
 DISS_GLF, DISS_LOCAL = 0, 1
+POST_NONE, POST_MIN_PREV, POST_MAX_PREV = 0, 1, 2
 ENO2, ENO3, WENO5, WENO5_ASSHIPPED = 0, 1, 2, 3
 HAM_DUBINS_REL, HAM_DOUBLE_INTEGRATOR, HAM_DOUBLE_PENDULUM = 0, 1, 2
 F64, F32 = 0, 1
@@ -39,7 +40,8 @@ SIGNATURES = {
     "hj_rk_substep": (_i, [_vp, _i, _i, _pd, _d, _i, _d, _i, _vp, _vp, _vp, _i, _i64, _i64]),
     "hj_read_step_bound": (_i, [_vp, _i, _pd, _pd]),
     "hj_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _pd, _pd]),
-    "hj_rk_integrate": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _i64, _pd, _pi64, _pi]),
+    "hj_rk_integrate": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _i64, _d, _pd, _pi64, _pi]),
+    "hj_ctx_set_post_step": (_i, [_vp, _i]),
     "hj_static_step_bound": (_i, [_vp, _i, _pd, _pd, _pd]),
     "hj_ctx_set_dissipation": (_i, [_vp, _i]),
     "hj_max_d1sq": (_i, [_vp, _vp, _vp]),

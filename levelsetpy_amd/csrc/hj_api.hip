@@ -78,6 +78,7 @@ struct hj_ctx {
     int sb_ham;
     double sb_par[4], sb_val, sb_local, sb_alpha[HJ_MAX_DIM];
     int diss_local;                    // hj_ctx_set_dissipation: step bound of the local LF variants
+    int post_step_op;                  // hj_ctx_set_post_step: fused into the last stage of hj_rk_step
     bool sb_valid;
     int internal_slot;
     // slab communication (hj_comm_*)
@@ -278,6 +279,7 @@ struct SubstepCall {
     unsigned long long* bound;
     int64_t p0, p1;
     int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
+    int post_op = 0;          // fused post-step min/max with the state the step started from
 };
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
@@ -347,6 +349,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
         default: A.ca = T(0); A.cb = T(1); break;
     }
     A.dt = (T)s.dt;
+    A.post_op = s.post_op;
     A.do_clamp = s.restrict_sign != 0;
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
     A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
@@ -407,6 +410,7 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.cell_begin = s.p0 * plane;
     A.cell_end = s.p1 * plane;
     A.stage = s.stage;
+    A.post_op = s.post_op;
     A.restrict_sign = s.restrict_sign;
     A.dt = (T)s.dt;
     fill_ham<T>(c, s.par, A.ham);
@@ -990,7 +994,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     for (int s = 0; s < 4; ++s) { c->aux[s] = nullptr; c->aux_n[s] = 0; }
     c->ring = nullptr; c->keys = nullptr; c->weno_vals = nullptr; c->weno_src = nullptr; c->flag = nullptr;
     c->partials = nullptr; c->partials_cap = 0;
-    c->sb_valid = false; c->internal_slot = 0; c->diss_local = 0; c->sb_local = 0;
+    c->sb_valid = false; c->internal_slot = 0; c->diss_local = 0; c->sb_local = 0; c->post_step_op = 0;
     c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->lo_rank = c->hi_rank = -1;
     c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr; c->slab_pending = 0;
@@ -1229,6 +1233,13 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
     return HJ_OK;
 }
 
+int hj_ctx_set_post_step(hj_ctx* c, int op) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (op < 0 || op > 2) return fail(HJ_EINVAL, "unknown post-step operator %d", op);
+    c->post_step_op = op;
+    return HJ_OK;
+}
+
 int hj_ctx_set_dissipation(hj_ctx* c, int kind) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
     if (kind != HJ_DISS_GLF && kind != HJ_DISS_LOCAL) return fail(HJ_EINVAL, "unknown dissipation kind %d", kind);
@@ -1254,12 +1265,14 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     double t = t0;
     if (order == 1) {
         SubstepCall s{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, y_out, nullptr, 0, n0};
+        s.post_op = c->post_step_op;
         if ((rc = do_substep(c, s, slot()))) return rc;
         t = t0 + dt;
     } else if (order == 2) {
         SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, work0, nullptr, 0, n0};
         if ((rc = do_substep(c, a, slot()))) return rc;
         SubstepCall b{scheme, ham, HJ_STAGE_RK2_FULL, restrict_sign, par, dt, work0, y_in, y_out, nullptr, 0, n0};
+        b.post_op = c->post_step_op;
         if ((rc = do_substep(c, b, slot()))) return rc;
         const double t1 = t0 + dt, t2 = t1 + dt;
         t = 0.5 * (t0 + t2);  // ode_cfl_2.py:200
@@ -1269,6 +1282,7 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
         SubstepCall b{scheme, ham, HJ_STAGE_RK3_HALF, restrict_sign, par, dt, work0, y_in, work1, nullptr, 0, n0};
         if ((rc = do_substep(c, b, slot()))) return rc;
         SubstepCall d{scheme, ham, HJ_STAGE_RK3_FULL, restrict_sign, par, dt, work1, y_in, y_out, nullptr, 0, n0};
+        d.post_op = c->post_step_op;
         if ((rc = do_substep(c, d, slot()))) return rc;
         const double t1 = t0 + dt, t2 = t1 + dt;
         const double tHalf = 0.25 * (3 * t0 + t2);       // ode_cfl_3.py:188
@@ -1282,8 +1296,8 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
 
 int hj_rk_integrate(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf,
                     double factor_cfl, double max_step, int restrict_sign, const void* y_in, void* buf_a,
-                    void* buf_b, void* work, int64_t max_steps, double* t_out, int64_t* steps_out,
-                    int* result_in) {
+                    void* buf_b, void* work, int64_t max_steps, double stop_tol, double* t_out,
+                    int64_t* steps_out, int* result_in) {
     if (!c || !y_in || !buf_a || !buf_b) return fail(HJ_EINVAL, "null argument");
     if (order >= 2 && !work) return fail(HJ_EINVAL, "work buffer required for order >= 2");
     if (buf_a == buf_b || buf_a == y_in || buf_b == y_in || work == y_in || work == buf_a || work == buf_b)
@@ -1295,7 +1309,9 @@ int hj_rk_integrate(hj_ctx* c, int order, int scheme, int ham, const double* par
     int which = 0;          // 0: y_in holds the state, 1: buf_a, 2: buf_b
     double t = t0;
     int64_t steps = 0;
-    while (tf - t >= small * std::fabs(tf) && (max_steps <= 0 || steps < max_steps)) {
+    // stop_tol < 0: the integrators' own test; stop_tol >= 0: HJIPDE_solve's `while tNow < tau[i] - small`
+    auto more = [&]() { return stop_tol < 0 ? (tf - t >= small * std::fabs(tf)) : (t < tf - stop_tol); };
+    while (more() && (max_steps <= 0 || steps < max_steps)) {
         void* nxt = outs[steps & 1];
         double tn = t, dt = 0;
         // RK3: the first stage buffer doubles as the output; RK2: `work` is the first stage buffer

@@ -40,6 +40,19 @@ __device__ __forceinline__ T ghost_value(T edge, T inner, T km) {
     return edge + ks;
 }
 
+// post-step operator of HJIPDE_solve fused into the last RK stage (hji_solver.py:566-580):
+// 1: min(new, previous state), 2: max(new, previous state); NaN propagates like NumPy's minimum/maximum
+template <typename T>
+__device__ __forceinline__ T post_step(int op, T a, T b) {
+    if (op == 0) return a;
+    T r;
+    if (a != a) r = a;
+    else if (b != b) r = b;
+    else if (op == 1) r = a < b ? a : b;
+    else r = a > b ? a : b;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // v[0..6] = phi at i-3 .. i+3 along the differentiated axis.
 // local tables: D1[j] = (v[j+1]-v[j])/dx (j=0..5), D2[j] = (D1[j+1]-D1[j])/(2dx) (j=0..4),

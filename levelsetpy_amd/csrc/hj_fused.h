@@ -79,6 +79,7 @@ template <typename T, int ND> struct FusedArgs {
     //     = ca*y0 + cb*(y + dt*ydot)               otherwise; y0 is read iff use_y0
     int ydot_only, use_y0;
     T ca, cb, dt;
+    int post_op;                  // 0 none, 1/2: out = min/max(out, state at the start of the step)
     int do_clamp;                 // termRestrictUpdate: ydot clamped to [lo, hi]
     T clamp_lo, clamp_hi;
     HamTables<T> ham;
@@ -467,7 +468,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             }
             T o;
             if (A.ydot_only) o = ydot;
-            else o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
+            else {
+                o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
+                // the step started from y0 (stages that read it) or from y itself (Euler step)
+                if (A.post_op) o = post_step(A.post_op, o, A.use_y0 ? y0_c[r] : q[r][3]);
+            }
 #if defined(HJ_ABLATE) && (HJ_ABLATE & 4)
             asm volatile("" ::"v"(o));
 #else

@@ -304,7 +304,7 @@ template <typename T, int ND> struct DirectArgs {
     unsigned long long* bound;
     GridArgs<T, ND> G;
     long long cell_begin, cell_end;   // linear cell range (whole axis-0 planes)
-    int stage, restrict_sign;
+    int stage, restrict_sign, post_op;
     T dt;
     T sc[ND];                     // costate scale (see hj_device.h): 1/(60dx) as-shipped WENO5, else 1
     HamTables<T> ham;
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
             else if (A.stage == HJ_STAGE_RK3_HALF) o = T(0.25) * (T(3) * A.y0[t] + ye);
             else if (A.stage == HJ_STAGE_RK3_FULL) o = (T(1) / T(3)) * (A.y0[t] + T(2) * ye);
             else o = T(0.5) * (A.y0[t] + ye);
+            if (A.post_op) o = post_step(A.post_op, o, A.stage == HJ_STAGE_EULER ? A.y[t] : A.y0[t]);
         }
         A.out[t] = o;
     }

@@ -27,7 +27,7 @@ import numpy as np
 from . import _ffi
 from .context import device_grid, grid_bc, is_tensor
 from .dissipation import artificialDissipationGLF
-from .integration import odeCFL3, odeCFLset
+from .integration import odeCFL3, odeCFLset, integrate_span_device
 from .spatial import upwindFirstWENO5
 from .term import termLaxFriedrichs, termRestrictUpdate, native_plan
 from .utilities import Bundle, isfield, error, info, cputime, expand
@@ -230,9 +230,20 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
         tNow = tau[i - 1]
         target_i = ops.prep(targets[i] if targ_tv else targets, y)
         obstacle_i = ops.prep(obstacles[i] if obs_tv else obstacles, y)
+        # Fast path: nothing has to happen between the steps of this interval except (possibly) the
+        # min/max with the previous step, which the last RK stage applies itself -> the whole interval is
+        # one native call and the NaN guard runs once, at its end (same error, raised a few steps later).
+        post = {'minVOverTime': _ffi.POST_MIN_PREV, 'maxVOverTime': _ffi.POST_MAX_PREV}.get(compMethod, _ffi.POST_NONE)
+        plain = compMethod in (None, 'zero', 'set', 'none', 'minWithZero', 'minVOverTime', 'maxVOverTime')
+        if dg is not None and plain and obstacle_i is None and discountFactor is None and tNow < tau[i] - small:
+            res = integrate_span_device(schemeFunc, sd_run, y, tNow, tau[i], integratorOptions, small, post)
+            if res is not None:
+                tNow, y = res
+                if ops.has_nan(y):
+                    error('Nans encountered in the integrated result of HJI PDE data')   # :544-545
         while tNow < tau[i] - small:                           # hji_solver.py:536
             if compMethod in ('minVOverTime', 'maxVOverTime'):
-                yLast = y.clone() if is_tensor(y) else y
+                yLast = y          # the integrators never write their input: no copy needed
             if not quiet:
                 info('Cur Time %s bound: %s' % (tNow, tau[i] - small))
             tNow, y, _ = odeCFL3(schemeFunc, [tNow, tau[i]], y, integratorOptions, sd_run)

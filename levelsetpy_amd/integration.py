@@ -212,7 +212,7 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
         nsteps, where = C.c_int64(), C.c_int()
         _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
                                           float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt), dg.ptr(buf_b),
-                                          dg.ptr(work), 0, C.byref(tout), C.byref(nsteps), C.byref(where)))
+                                          dg.ptr(work), 0, -1.0, C.byref(tout), C.byref(nsteps), C.byref(where)))
         cur = (cur, nxt, buf_b)[where.value]
         t = float(tout.value)
         steps = int(nsteps.value)
@@ -255,6 +255,35 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     if is_tensor(y0) and steps == 0:
         out = out.clone()          # zero steps taken: do not hand the caller's own tensor back
     return np.float64(t), dg.like(out, y0), schemeData
+
+
+def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, post_op=0, order=3):
+    """HJIPDE_solve's inner loop for one tau interval in ONE native call (hji_solver.py:536-543 plus the
+    min/max-over-time operator of :571-575 fused into the last RK stage): steps while t < tf - stop_tol.
+    `y` is a device tensor; returns (t, new device tensor), or None if the problem cannot run fused."""
+    dev = _device_plan(schemeFunc, schemeData, y)
+    if dev is None:
+        return None
+    plan, rs = dev
+    grid, sid, ham, par = plan
+    dg = device_grid(grid, array_dtype_name(y))
+    dg.bind_stream()
+    plan.bind(dg, post_op)
+    try:
+        cur = dg.to_device(y).reshape(dg.shape)
+        a, b, w = dg.empty(), dg.empty(), dg.work('rk_w1')
+        tout, nsteps, where = C.c_double(), C.c_int64(), C.c_int()
+        options = _options(options)
+        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, sid, ham, _ffi.darr(par), float(t0), float(tf),
+                                          float(options.factorCFL), float(options.maxStep), rs, dg.ptr(cur),
+                                          dg.ptr(a), dg.ptr(b), dg.ptr(w), 0, float(stop_tol),
+                                          C.byref(tout), C.byref(nsteps), C.byref(where)))
+    finally:
+        plan.bind(dg, 0)
+    out = (cur, a, b)[where.value]
+    if where.value == 0:
+        out = out.clone()
+    return float(tout.value), out.reshape(y.shape)
 
 
 def _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small, safetyFactorCFL):

@@ -40,8 +40,10 @@ class _Plan(tuple):
         self.diss = diss
         return self
 
-    def bind(self, dg):
+    def bind(self, dg, post_op=0):
+        # per-call state of the (cached, shared) ctx: which CFL bound, which fused post-step operator
         _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, self.diss))
+        _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, post_op))
 
 
 def native_plan(schemeData):
