@@ -153,6 +153,11 @@ int hj_rk_integrate(hj_ctx* ctx, int order, int scheme, int ham_id, const double
  * state is an operand of the last stage anyway, so the operator costs no extra pass over memory. */
 enum { HJ_POST_NONE = 0, HJ_POST_MIN_PREV = 1, HJ_POST_MAX_PREV = 2 };
 int hj_ctx_set_post_step(hj_ctx* ctx, int op);
+/* ... and, after the step, up to two operators against caller arrays of the state's size (device pointers,
+ * NULL = none; applied by separate elementwise launches inside hj_rk_step, so that a whole tau interval
+ * still is one hj_rk_integrate call): op 1 = min, 2 = max, 3 = max with the NEGATED array.  'minVWithV0'/'maxVWithV0' and
+ * 'min/maxVWithL' use the first (hji_solver.py:576-597), the obstacle mask the second (:641-644). */
+int hj_ctx_set_post_arrays(hj_ctx* ctx, int op_a, const void* a, int op_b, const void* b);
 
 /* stepBound of a native Hamiltonian on this grid (alpha is data-independent for all HJ_HAM_*);
  * computed once per (ham_id, params) and cached.  Synchronises on the first call.

@@ -42,6 +42,7 @@ SIGNATURES = {
     "hj_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _pd, _pd]),
     "hj_rk_integrate": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _i64, _d, _pd, _pi64, _pi]),
     "hj_ctx_set_post_step": (_i, [_vp, _i]),
+    "hj_ctx_set_post_arrays": (_i, [_vp, _i, _vp, _i, _vp]),
     "hj_static_step_bound": (_i, [_vp, _i, _pd, _pd, _pd]),
     "hj_ctx_set_dissipation": (_i, [_vp, _i]),
     "hj_max_d1sq": (_i, [_vp, _vp, _vp]),

@@ -21,6 +21,7 @@ truncation `tau[i+1:] = []` is not valid NumPy); discounting runs (the reference
 `eisfield`, :603) with the toolbox's intended meaning: default mode unless discountMode == 'Kene'.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -230,13 +231,30 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
         tNow = tau[i - 1]
         target_i = ops.prep(targets[i] if targ_tv else targets, y)
         obstacle_i = ops.prep(obstacles[i] if obs_tv else obstacles, y)
-        # Fast path: nothing has to happen between the steps of this interval except (possibly) the
-        # min/max with the previous step, which the last RK stage applies itself -> the whole interval is
-        # one native call and the NaN guard runs once, at its end (same error, raised a few steps later).
-        post = {'minVOverTime': _ffi.POST_MIN_PREV, 'maxVOverTime': _ffi.POST_MAX_PREV}.get(compMethod, _ffi.POST_NONE)
-        plain = compMethod in (None, 'zero', 'set', 'none', 'minWithZero', 'minVOverTime', 'maxVOverTime')
-        if dg is not None and plain and obstacle_i is None and discountFactor is None and tNow < tau[i] - small:
-            res = integrate_span_device(schemeFunc, sd_run, y, tNow, tau[i], integratorOptions, small, post)
+        # Fast path: everything that happens between the steps of this interval -- the compMethod min/max
+        # (with the previous step, data0 or the target) and the obstacle mask -- is applied by the last RK
+        # stage itself, so the whole interval is ONE native call and the NaN guard runs once, at its end
+        # (same error, raised a few steps later).  Discounting keeps the step-by-step loop below.
+        post, post_a, known = _ffi.POST_NONE, None, True
+        if compMethod in (None, 'zero', 'set', 'none', 'minWithZero'):
+            pass
+        elif compMethod == 'minVOverTime':
+            post = _ffi.POST_MIN_PREV
+        elif compMethod == 'maxVOverTime':
+            post = _ffi.POST_MAX_PREV
+        elif compMethod in ('minVWithV0', 'maxVWithV0'):
+            post_a = (1 if compMethod == 'minVWithV0' else 2, y_init)
+        elif compMethod in ('minVWithL', 'minVwithL', 'minVWithTarget', 'maxVWithL', 'maxVwithL', 'maxVWithTarget'):
+            if target_i is None:
+                error('Need to define target function l(x)!')
+            post_a = (1 if compMethod.startswith('min') else 2, target_i)
+        else:
+            known = False
+        post_b = (3, obstacle_i) if obstacle_i is not None else None
+        stepwise = os.environ.get("HJ_HJIPDE_STEPWISE") == "1"     # test knob: force the loop below
+        if dg is not None and known and discountFactor is None and not stepwise and tNow < tau[i] - small:
+            res = integrate_span_device(schemeFunc, sd_run, y, tNow, tau[i], integratorOptions, small, post,
+                                        post_a=post_a, post_b=post_b)
             if res is not None:
                 tNow, y = res
                 if ops.has_nan(y):

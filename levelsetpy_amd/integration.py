@@ -257,7 +257,8 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     return np.float64(t), dg.like(out, y0), schemeData
 
 
-def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, post_op=0, order=3):
+def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, post_op=0, order=3,
+                          post_a=None, post_b=None):
     """HJIPDE_solve's inner loop for one tau interval in ONE native call (hji_solver.py:536-543 plus the
     min/max-over-time operator of :571-575 fused into the last RK stage): steps while t < tf - stop_tol.
     `y` is a device tensor; returns (t, new device tensor), or None if the problem cannot run fused."""
@@ -268,7 +269,7 @@ def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, 
     grid, sid, ham, par = plan
     dg = device_grid(grid, array_dtype_name(y))
     dg.bind_stream()
-    plan.bind(dg, post_op)
+    plan.bind(dg, post_op, post_a, post_b)
     try:
         cur = dg.to_device(y).reshape(dg.shape)
         a, b, w = dg.empty(), dg.empty(), dg.work('rk_w1')

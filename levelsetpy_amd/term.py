@@ -40,10 +40,13 @@ class _Plan(tuple):
         self.diss = diss
         return self
 
-    def bind(self, dg, post_op=0):
-        # per-call state of the (cached, shared) ctx: which CFL bound, which fused post-step operator
+    def bind(self, dg, post_op=0, post_a=None, post_b=None):
+        # per-call state of the (cached, shared) ctx: which CFL bound, which fused post-step operators
+        # (post_a / post_b: (op, device tensor) or None)
         _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, self.diss))
         _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, post_op))
+        _ffi.check(dg.lib.hj_ctx_set_post_arrays(dg.ctx, post_a[0] if post_a else 0, dg.ptr(post_a[1]) if post_a else None,
+                                                 post_b[0] if post_b else 0, dg.ptr(post_b[1]) if post_b else None))
 
 
 def native_plan(schemeData):

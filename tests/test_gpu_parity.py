@@ -1219,3 +1219,30 @@ def test_fuzz_shapes_boundaries_schemes(case, monkeypatch):
     close(yt, yo, tol, what="tiled")
     close(yd, yo, tol, what="direct")
     assert abs(sbt - sbo) <= 1e-12 * sbo and abs(sbd - sbo) <= 1e-12 * sbo
+
+
+@pytest.mark.parametrize("comp,with_target,with_obstacle", [
+    ("minVOverTime", False, False), ("maxVOverTime", False, True), ("minVWithV0", False, False),
+    ("maxVWithV0", False, True), ("minVWithL", True, False), ("maxVWithL", True, True), ("set", False, True),
+    ("minWithZero", False, False)])
+def test_hjipde_solve_interval_at_once_equals_stepwise(comp, with_target, with_obstacle, monkeypatch):
+    """The one-call-per-interval path (post-step operators fused into the last RK stage) against the
+    step-by-step loop with separate min/max kernels: bitwise the same tube, time-varying obstacle included."""
+    g, og, sd, data0 = _solve_setup((19, 17, 15))
+    tau = np.linspace(0, 0.12, 5)
+    ex = dict(quiet=True)
+    if with_target:
+        ex["targetFunction"] = data0 + 0.1 * np.cos(2 * og.xs[1])
+    if with_obstacle:
+        obs = np.sqrt((og.xs[0] - 1.5) ** 2 + og.xs[1] ** 2) - 0.4
+        ex["obstacleFunction"] = np.stack([obs + 0.02 * k for k in range(len(tau))])
+    outs = []
+    for stepwise in ("1", "0"):
+        monkeypatch.setenv("HJ_HJIPDE_STEPWISE", stepwise)
+        sdk = L.Bundle(dict(grid=g, hamFunc=sd.hamFunc, partialFunc=sd.partialFunc, dissFunc=sd.dissFunc,
+                            CoStateCalc=sd.CoStateCalc))
+        d, t, _ = L.HJIPDE_solve(data0, tau, sdk, comp, L.Bundle(dict(ex)))
+        outs.append(d)
+    assert outs[0].shape == outs[1].shape == (len(tau),) + tuple(g.shape)
+    assert np.array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0][-1], outs[0][0])
