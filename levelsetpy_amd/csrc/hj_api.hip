@@ -86,7 +86,7 @@ struct hj_ctx {
     // slab communication (hj_comm_*)
     ncclComm_t comm;
     int comm_rank, comm_size, lo_rank, hi_rank;
-    hipStream_t comm_stream, edge_stream, edge_stream2;
+    hipStream_t comm_stream, edge_stream;
     hipEvent_t ev_start, ev_edge, ev_edge2, ev_comm;
     hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
     int slab_pending;
@@ -999,7 +999,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->sb_valid = false; c->internal_slot = 0; c->diss_local = 0; c->sb_local = 0; c->post_step_op = 0;
     c->post_arr[0] = c->post_arr[1] = nullptr; c->post_arr_op[0] = c->post_arr_op[1] = 0;
     c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->lo_rank = c->hi_rank = -1;
-    c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
+    c->comm_stream = c->edge_stream = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr; c->slab_pending = 0;
     c->ev_int[0] = c->ev_int[1] = c->ev_int[2] = nullptr;
     c->launch_stop = nullptr; c->ext_events = env_int("HJ_EXT_EVENTS", 1);
@@ -1431,13 +1431,12 @@ int hj_comm_destroy(hj_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     c->comm = nullptr;
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);   // comm_stream aliases it
-    if (c->edge_stream2) (void)hipStreamDestroy(c->edge_stream2);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
     if (c->ev_edge2) (void)hipEventDestroy(c->ev_edge2);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     for (int i = 0; i < 3; ++i) { if (c->ev_int[i]) (void)hipEventDestroy(c->ev_int[i]); c->ev_int[i] = nullptr; }
-    c->comm_stream = c->edge_stream = c->edge_stream2 = nullptr;
+    c->comm_stream = c->edge_stream = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr;
     c->slab_pending = 0;
     c->external_exchange = 0;
