@@ -477,6 +477,9 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // (201^3 = 8.1 M: 32 k cells per CU) three small independent workgroups per CU with longer
                 // chunks win (sweeps at 101^3 ... 401^3 after the deferred-ghost fix)
                 else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total >= 12000000) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
+                // tiny grids (<= ~135^3) run one wave per SIMD and a launch is a chain of ~10 plane
+                // iterations: one cell per thread shortens every iteration (7-10 % at 51^3 ... 129^3)
+                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total < 2500000) { k.NT = 512; k.R = 1; pd = 2; occ = 4; }
                 else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
                 k.KH = cfg_kh(HAM::ND, k.NT, k.R);
             }
