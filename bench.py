@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: grid-cell RK-substep updates / second of the HJI hot path
 (odeCFL3 -> termLaxFriedrichs -> upwindFirstWENO5 -> artificialDissipationGLF -> ghost cells)
-on the Dubins-relative 3-D problem, fp64 (BASELINE.json configs[1]).
+on the Dubins-relative 3-D problem, fp64 (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one odeCFL3 time step = 3 fused RK substeps over the whole grid.  Inputs are
-resident in HBM before the timed region.  N > 1 (launched by torch.distributed.run): the grid is
-slab-decomposed along axis 0, every rank owns an n^3 slab of an (N*n) x n x n grid ("weak"
-scaling) and exchanges 3 ghost planes with its neighbours per substep over RCCL.
+One "step" = one odeCFL3 time step = 3 RK substeps over the whole grid; inputs are resident in HBM
+before the timed region; K steps are timed between synchronisations, R times (--repeats, default 5),
+and `value` is the MEDIAN repeat (the spread is reported in "repeats").
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (algorithmic bytes / measured kernel
-time vs the 8 TB/s HBM peak) and "cpu_baseline" (the NumPy oracle timed on this host's cores on a
-bounded sample of the same workload).
+N = 1 (default): BASELINE C2, the 201^3 grid.  The same run also times, each with its own spin-up and
+reported under "also" with its own roofline fraction: the intended WENO5 arithmetic at 201^3, the
+single-GPU 513^3 grid (C4's N = 1 point), C3 (double integrator 4096^2, ENO3) and C5 (double
+pendulum 129^4 fp32, all axes periodic).
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE C4 -- the 513^3 grid
+slab-decomposed along axis 0 over the N ranks (65/64-plane slabs at N = 8), halo planes exchanged with
+ncclSend/ncclRecv over RCCL, STRONG scaling (`--global-n 513`, the default for N > 1; every N
+integrates the same grid, so N = 1 with `--global-n 513` is the single-domain 513^3 number).
+`--global-n 0` selects the weak-scaling leg instead (every rank owns a 201^3 slab of an (N*201) x 201 x 201
+grid).  Before it is timed, a decomposition has to reproduce the single-domain result on the hardware
+it runs on ("slab_check_max_abs_diff").
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (algorithmic bytes / measured kernel time vs
+the 8 TB/s HBM peak) and "cpu_baseline" (the NumPy oracle timed on this host's cores on a bounded sample
+of the same workload; N = 1 only).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,6 +46,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 SPINUP_STEPS = int(os.environ.get("HJ_BENCH_SPINUP", "300"))   # untimed clock ramp before the W warm-up steps
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SUBSTEP = {"float64": 64.0 / 3.0, "float32": 32.0 / 3.0}   # 8 words / RK3 step
+REF_IMPORT = "reference import (BASELINE.md s2, build container, 1 core): 6.6e5 at 51^3, 3.7e5 at 101^3, 1.57e5 at 201^3"
 
 
 def parse():
@@ -39,110 +54,263 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=201, help="grid points per axis (per rank along axis 0)")
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated this many times; value = median")
+    ap.add_argument("--n", type=int, default=201, help="grid points per axis of the single-GPU / weak-scaling leg")
+    ap.add_argument("--global-n", type=int, default=None,
+                    help="strong scaling: an n^3 grid slab-decomposed over the ranks (default 513 when N > 1; "
+                         "0 = weak scaling with --n planes per rank)")
     ap.add_argument("--scheme", default="WENO5_ASSHIPPED", choices=["WENO5", "WENO5_ASSHIPPED", "ENO3", "ENO2"],
                     help="WENO5_ASSHIPPED = what the reference's upwindFirstWENO5 computes (parity-pinned; "
                          "headline); WENO5 = the intended nonlinear scheme (reported in 'also')")
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=101, help="grid size of the CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=16)
-    ap.add_argument("--extra-schemes", default="WENO5",
-                    help="comma list of further schemes timed after the headline (reported in 'also')")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported under 'also'")
+    ap.add_argument("--also", default="WENO5,513,C3,C5", help="comma list of the extra workloads to time")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def dubins_grid(L, n0, n):
-    """C2 geometry; n0 planes along axis 0 (dx kept, max extended for slabs)."""
-    dx0 = 4.0 / (n - 1)
-    gmin = np.array([[-.75, -1.25, -np.pi]]).T
-    gmax = np.array([[-.75 + dx0 * (n0 - 1), 1.25, np.pi * (1 - 2 / n)]]).T
-    N = np.array([[n0], [n], [n]], dtype=np.int64)
-    return L.createGrid(gmin, gmax, N, 2, low_mem=True), gmin, gmax
-
-
-def time_steps(torch, dg, lib, sid, ham, par, bufs, steps, warmup, world):
-    import torch.distributed as dist
-    cur, nxt, w0, w1 = bufs
-    tout, dtout = C.c_double(), C.c_double()
-    parv = (C.c_double * 4)(*par)
-    t = 0.0
-
-    def one(cur, nxt, t):
-        # three arrays are enough for RK3: the first stage buffer doubles as the output (stage 3
-        # reads w1 and y0=cur only), which keeps the 201^3 working set (195 MB) inside the 256 MB
-        # Infinity Cache
-        rc = lib.hj_rk_step(dg.ctx, 3, sid, ham, parv, t, 1e9, 0.8, 1e300, 0, dg.ptr(cur), dg.ptr(nxt),
-                            dg.ptr(nxt if w0 is None else w0), dg.ptr(w1), C.byref(tout), C.byref(dtout))
-        if rc != 0:
-            raise RuntimeError(lib.hj_last_error().decode())
-        return nxt, cur, float(tout.value)
-
-    # device spin-up (untimed, reported as config.spinup_steps): the GPU's clocks need a few tens of
-    # milliseconds of load to reach their steady state; without it a short --steps run measures the ramp
-    for _ in range(SPINUP_STEPS):
-        cur, nxt, t = one(cur, nxt, t)
-    for _ in range(warmup):
-        cur, nxt, t = one(cur, nxt, t)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        cur, nxt, t = one(cur, nxt, t)
-    e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    return wall, dev_ms, cur, t
-
-
-def cpu_baseline(n, steps, scheme):
-    """The NumPy oracle (a port of the reference's array path) on one core of this host."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+# Workers are started BEFORE the GPU is initialised (a process that holds the GPU must not fork/exec
+# on this pool) and sit blocked on stdin until the GPU legs are over, so they do not disturb the timing.
+def cpu_worker(spec):
+    """Child process: the NumPy oracle (a port of the reference's array path; 18x faster than the reference
+    import itself, which materialises 519 fancy-index gathers per step) on n^3 for `steps` RK3 steps."""
+    n, steps, scheme = spec.split(":")
+    n, steps = int(n), int(steps)
     from oracle import hj_oracle as O
     og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n)], [n] * 3, [2])
     osys = O.DubinsRel(og, 1, 1)
     y = O.shape_cylinder(og, 2, None, .5).reshape(-1, 1)
     term = lambda tt, yy: O.term_lax_friedrichs(og, osys, scheme, tt, yy)  # noqa: E731
+    sys.stdout.write("ready\n")
+    sys.stdout.flush()
+    if not sys.stdin.readline().startswith("go"):
+        return
     t = 0.
     t0 = time.perf_counter()
     for _ in range(steps):
         t, y = O.ode_cfl_3(term, [t, 10.], y, 0.8, single_step=True)
     sec = time.perf_counter() - t0
-    return {"value": n ** 3 * 3 * steps / sec, "unit": "cell-substeps/s", "cores": 1, "kind": "port",
-            "sample": "%d RK3 steps of Dubins-relative %d^3 %s+GLF fp64 with oracle/hj_oracle.py (NumPy, "
-                      "single-threaded) in %.1f s; host has %d cores" % (steps, n, scheme, sec, os.cpu_count())}
+    sys.stdout.write(json.dumps({"n": n, "steps": steps, "sec": sec, "finite": bool(np.isfinite(y).all())}) + "\n")
+    sys.stdout.flush()
 
 
-def measured_traffic(n, scheme, dtype, world):
-    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE
-    doubled per MI355X_MICROARCH.md's gfx950 correction); None when no pass exists for this workload."""
+class CpuBaseline(object):
+    def __init__(self, scheme):
+        self.scheme = scheme
+        try:
+            self.cores_avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            self.cores_avail = os.cpu_count() or 1
+        self.pool_size = max(1, min(self.cores_avail, 16))
+        self.specs = [("c2", "201:2:%s" % scheme), ("c1", "51:10:%s" % scheme)] + \
+                     [("all%d" % i, "101:4:%s" % scheme) for i in range(self.pool_size)]
+        self.procs = []
+        for name, spec in self.specs:
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec],
+                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+            self.procs.append((name, p))
+
+    def _go(self, items):
+        for _, p in items:
+            assert p.stdout.readline().strip() == "ready"
+        t0 = time.perf_counter()
+        for _, p in items:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for _, p in items]
+        wall = time.perf_counter() - t0
+        for _, p in items:
+            p.wait()
+        return res, wall
+
+    def run(self):
+        (c2,), _ = self._go(self.procs[0:1])
+        (c1,), _ = self._go(self.procs[1:2])
+        allr, wall = self._go(self.procs[2:])
+        rate = lambda r: r["n"] ** 3 * 3 * r["steps"] / r["sec"]  # noqa: E731
+        units = sum(r["n"] ** 3 * 3 * r["steps"] for r in allr)
+        try:
+            model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except Exception:  # noqa: BLE001
+            model = "?"
+        return {"value": rate(c2), "unit": "cell-substeps/s", "cores": 1, "kind": "port",
+                "sample": "%d RK3 steps of Dubins-relative 201^3 %s+GLF fp64 (the GPU workload itself) with "
+                          "oracle/hj_oracle.py (NumPy restatement pinned to the reference's outputs, single-threaded) "
+                          "in %.1f s on one core of %s (%d cores visible, %d in this process's affinity); %s"
+                          % (c2["steps"], self.scheme, c2["sec"], model, os.cpu_count(), self.cores_avail, REF_IMPORT),
+                "c1_51cubed": {"value": rate(c1), "cores": 1, "sample": "%d RK3 steps at 51^3 in %.2f s" % (c1["steps"], c1["sec"])},
+                "all_cores": {"value": units / wall, "cores": len(allr),
+                              "sample": "%d processes, each %d RK3 steps at 101^3 on its own grid, wall %.1f s"
+                                        % (len(allr), allr[0]["steps"], wall)}}
+
+    def abort(self):
+        for _, p in self.procs:
+            if p.poll() is None:
+                p.kill()
+
+
+# ------------------------------------------------------------------------------------------ workloads
+def dubins_grid(L, n0, n):
+    """C2/C4 geometry; n0 planes along axis 0 (dx kept, max extended for weak-scaling slabs)."""
+    dx0 = 4.0 / (n - 1)
+    gmin = np.array([[-.75, -1.25, -np.pi]]).T
+    gmax = np.array([[-.75 + dx0 * (n0 - 1), 1.25, np.pi * (1 - 2 / n)]]).T
+    N = np.array([[n0], [n], [n]], dtype=np.int64)
+    return L.createGrid(gmin, gmax, N, 2, low_mem=True)
+
+
+def device_sdf(torch, g, radius, ignore=(), dtype=None):
+    """shapeCylinder / shapeSphere of a low-memory grid built on the device: sqrt(sum_i x_i^2) - r over the
+    axes not in `ignore` (cylinder.py:55-59, sphere.py:50-57)."""
+    shape = [int(v) for v in np.asarray(g.N).ravel()]
+    acc = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    for i, v in enumerate(g.vs):
+        if i in ignore:
+            continue
+        view = [1] * len(shape)
+        view[i] = -1
+        acc += torch.as_tensor(np.asarray(v).ravel(), device="cuda").reshape(view) ** 2
+    return (acc.sqrt_() - radius).to(dtype or torch.float64).contiguous()
+
+
+def workload(L, _ffi, torch, name, scheme, dtype, n):
+    """(description, grid, ham id, params, scheme, dtype, initial data on the device)."""
+    if name == "dubins":
+        g = dubins_grid(L, n, n)
+        d0 = device_sdf(torch, g, 0.5, ignore=(2,), dtype=torch.float64 if dtype == "float64" else torch.float32)
+        return ("Dubins-relative (air3D) 3-D HJI, %d x %d x %d grid, %s + GLF, odeCFL3 (factorCFL 0.8), cylinder r=0.5 "
+                "initial data" % (n, n, n, scheme)), g, _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], scheme, dtype, d0
+    if name == "C3":
+        n = 4096
+        g = L.createGrid(-np.ones((2, 1)), np.ones((2, 1)), n * np.ones((2, 1), dtype=np.int64), None, low_mem=True)
+        return ("double integrator 2-D, 4096 x 4096 grid, ENO3 + GLF, odeCFL3 (factorCFL 0.8), sphere r=0.25 (BASELINE C3)",
+                g, _ffi.HAM_DOUBLE_INTEGRATOR, [1.0, 0, 0, 0], "ENO3", "float64", device_sdf(torch, g, 0.25))
+    if name == "C5":
+        n = int(os.environ.get("HJ_BENCH_C5_N", "129"))
+        gmin = np.array([[-np.pi, -8, -np.pi, -8]]).T
+        gmax = np.array([[np.pi * (1 - 2 / n), 8 * (1 - 2 / n), np.pi * (1 - 2 / n), 8 * (1 - 2 / n)]]).T
+        g = L.createGrid(gmin, gmax, n * np.ones((4, 1), dtype=np.int64), [0, 1, 2, 3], low_mem=True)
+        return ("double pendulum 4-D, %d^4 grid fp32, all axes periodic, WENO5_ASSHIPPED + GLF, odeCFL3, sphere r=0.5 "
+                "(BASELINE C5 on one GPU)" % n, g, _ffi.HAM_DOUBLE_PENDULUM, [1.0, 0, 0, 0], "WENO5_ASSHIPPED", "float32",
+                device_sdf(torch, g, 0.5, dtype=torch.float32))
+    raise ValueError(name)
+
+
+def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
+    """R repeats of K odeCFL3 steps (hj_rk_step: 3 launches, three arrays) on one GPU.  Returns a dict with
+    the wall seconds and HIP-event milliseconds of every repeat."""
+    desc, g, ham, par, scheme, dtype, d0 = wl
+    dg = DeviceGrid(g, dtype)
+    dg.bind_stream()
+    lib = dg.lib
+    sid = _ffi.SCHEME_IDS[scheme]
+    cur, nxt, w1 = d0.clone(), dg.empty(), dg.empty()
+    tout, dtout = C.c_double(), C.c_double()
+    parv = (C.c_double * 4)(*par)
+    state = {"cur": cur, "nxt": nxt, "t": 0.0}
+
+    def one():
+        # three arrays are enough for RK3: the first stage buffer doubles as the output (stage 3 reads w1
+        # and y0 = cur only), which keeps the 201^3 working set (195 MB) inside the 256 MB Infinity Cache
+        rc = lib.hj_rk_step(dg.ctx, 3, sid, ham, parv, state["t"], 1e9, 0.8, 1e300, 0, dg.ptr(state["cur"]),
+                            dg.ptr(state["nxt"]), dg.ptr(state["nxt"]), dg.ptr(w1), C.byref(tout), C.byref(dtout))
+        if rc != 0:
+            raise RuntimeError(lib.hj_last_error().decode())
+        state["cur"], state["nxt"], state["t"] = state["nxt"], state["cur"], float(tout.value)
+
+    # device spin-up (untimed, reported as config.spinup_steps): the GPU's clocks need a few tens of
+    # milliseconds of load to reach their steady state; without it a short --steps run measures the ramp
+    for _ in range(spinup + warmup):
+        one()
+    walls, devs = [], []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        devs.append(e0.elapsed_time(e1))
+    assert bool(torch.isfinite(state["cur"]).all()), "non-finite state after the timed steps (%s)" % desc
+    launches = lib.hj_launches_per_step(dg.ctx, 3, sid) if hasattr(lib, "hj_launches_per_step") else 3
+    return {"desc": desc, "cells": dg.numel, "dtype": dtype, "scheme": scheme, "walls": walls, "devs": devs,
+            "launches_per_step": int(launches)}
+
+
+def summarize(r, steps):
+    """value from the MEDIAN repeat, spread, and the roofline numbers of the step's launches."""
+    med = statistics.median(r["walls"])
+    k = r["walls"].index(sorted(r["walls"])[len(r["walls"]) // 2])
+    per_s = lambda w: r["cells"] * 3 * steps / w  # noqa: E731
+    bps = BYTES_PER_SUBSTEP[r["dtype"]]
+    dev_step_ms = r["devs"][k] / steps
+    achieved = r["cells"] * 3 * bps / (dev_step_ms * 1e-3) / 1e9
+    return {"value": per_s(med), "ms_per_step": 1e3 * med / steps,
+            "repeats": {"n": len(r["walls"]), "value_min": per_s(max(r["walls"])), "value_max": per_s(min(r["walls"])),
+                        "spread": (max(r["walls"]) - min(r["walls"])) / med},
+            "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "dev_step_ms": dev_step_ms}
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in ("hj_api.hip", "hj_device.h", "hj_fused.h", "hj_split.h"):
+        with open(os.path.join(ROOT, "levelsetpy_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(n, scheme, dtype):
+    """HBM bytes per RK3 step from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs by tools/profile_round.sh, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction).  Counters cannot be read from inside this process, so the
+    figure is only reported when the pass was taken on THIS kernel source (hash of csrc/ recorded with it);
+    otherwise null."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tab = json.load(f)
         rec = tab.get("%d/%s/%s" % (n, scheme, dtype))
-        return rec["bytes_per_launch"] if (rec and world == 1) else None
+        if rec and rec.get("source_hash") == source_hash():
+            return rec
     except Exception:  # noqa: BLE001
-        return None
+        pass
+    return None
 
 
 def main():
     a = parse()
+    if a.cpu_worker:
+        cpu_worker(a.cpu_worker)
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    slab_leg = world > 1 or bool(os.environ.get("HJ_BENCH_FORCE_SLAB")) or (a.global_n not in (None, 0))
+    cpu = None
+    if rank == 0 and world == 1 and not slab_leg and not a.no_cpu_baseline:
+        cpu = CpuBaseline(a.scheme)          # before the GPU is touched; idle until the GPU legs are done
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version header at
     # communicator creation, for one) are sent to stderr for the duration of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    try:
+        out = run(a, rank, world, local, slab_leg, cpu)
+    except BaseException:
+        if cpu is not None:
+            cpu.abort()
+        raise
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+def run(a, rank, world, local, slab_leg, cpu):
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -153,79 +321,103 @@ def main():
     from levelsetpy_amd import _ffi
     from levelsetpy_amd.context import DeviceGrid
 
-    n = a.n
-    if world > 1 or os.environ.get("HJ_BENCH_FORCE_SLAB"):
+    bps = BYTES_PER_SUBSTEP[a.dtype]
+    dt_tag = "f64" if a.dtype == "float64" else "f32"
+    if slab_leg:
         from levelsetpy_amd import dist as hjdist
+        import torch.distributed as dist
         if world == 1:      # rehearsal of the N > 1 leg on one GPU (a single slab, no neighbours)
-            import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
-        result = hjdist.bench_slab(a, rank, world)
-        wall, dev_ms, cells, sched = result["wall"], result["dev_ms"], result["cells"], result["parallelism"]
-        also = {"slab_check_max_abs_diff": result.get("slab_check_max_abs_diff")}
-    else:
-        g, gmin, gmax = dubins_grid(L, n, n)
-        dg = DeviceGrid(g, a.dtype)
-        dg.bind_stream()
-        lib = dg.lib
-        d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
-        par = [1.0, 1.0, 1.0, 2.0]
-        ham = _ffi.HAM_DUBINS_REL
+        gn = 513 if a.global_n is None else a.global_n
+        res = hjdist.bench_slab(a, rank, world, global_n=gn)
+        walls = res["walls"]
+        tw = torch.tensor(walls, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)           # per repeat: the slowest rank
+        walls = [float(v) for v in tw.cpu()]
+        med = statistics.median(walls)
+        k = walls.index(sorted(walls)[len(walls) // 2])
+        total_cells = res["total_cells"]
+        value = total_cells * 3 * a.steps / med
+        dev_step_ms = res["devs"][k] / a.steps
+        # roofline of the step's launches on THIS rank (rank 0): its own cells over its own device time
+        achieved = res["local_cells"] * 3 * bps / (dev_step_ms * 1e-3) / 1e9
+        strong = gn > 0
+        grid_txt = ("%d x %d x %d" % (gn, gn, gn)) if strong else ("%dx%d x %d x %d" % (world, a.n, a.n, a.n))
+        out = {
+            "metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI %s %s, slab-decomposed over %d MI355X"
+                      % ("%d^3" % gn if strong else "%d^3 per GPU" % a.n, "fp64" if a.dtype == "float64" else "fp32", world),
+            "value": value, "unit": "cell-substeps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * med / a.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": dt_tag, "data": "synthetic",
+            "config": {"workload": "Dubins-relative (air3D) 3-D HJI, %s grid slab-decomposed over %d along axis 0 (%s planes "
+                                   "per rank), %s + GLF, odeCFL3 (factorCFL 0.8), cylinder r=0.5 initial data"
+                                   % (grid_txt, world, res["planes"], a.scheme),
+                       "scheme": a.scheme, "parallelism": res["parallelism"], "substeps_per_step": 3,
+                       "spinup_steps": SPINUP_STEPS, "rccl_nranks": res.get("nranks")},
+            "repeats": {"n": len(walls), "value_min": total_cells * 3 * a.steps / max(walls),
+                        "value_max": total_cells * 3 * a.steps / min(walls), "spread": (max(walls) - min(walls)) / med},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fused_substep_kernel (rank 0's launches of one RK3 step: interior + edge planes)",
+                         "kernel_ms": dev_step_ms, "algorithmic_bytes_per_launch": res["local_cells"] * 3 * bps},
+            "per_gpu_value": value / world,
+            "also": {"slab_check_max_abs_diff": res.get("slab_check_max_abs_diff")},
+        }
+        dist.destroy_process_group()
+        return out
 
-        def run(scheme):
-            bufs = [dg.to_device(d0).clone(), dg.empty(), (dg.empty() if os.environ.get("HJ_BENCH_4BUF") else None), dg.empty()]
-            return time_steps(torch, dg, lib, _ffi.SCHEME_IDS[scheme], ham, par, bufs, a.steps, a.warmup, 1)
-
-        wall, dev_ms, cur, t_end = run(a.scheme)
-        assert bool(torch.isfinite(cur).all()), "non-finite state after the timed steps"
-        cells = n ** 3
-        sched = "single"
-        also = {}
-        for s in [x for x in a.extra_schemes.split(",") if x and x != a.scheme]:
-            w2, d2, _, _ = run(s)
-            also[s] = {"value": cells * 3 * a.steps / w2, "ms_per_step": 1e3 * w2 / a.steps,
-                       "roofline_frac": cells * 3 * a.steps / w2 * BYTES_PER_SUBSTEP[a.dtype] / 1e9 / HBM_PEAK_GBS}
-
-    if world > 1:
-        import torch.distributed as dist
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-    value = cells * world * 3 * a.steps / wall
-    per_gpu = value / world
-    bps = BYTES_PER_SUBSTEP[a.dtype]
-    # dominant kernel = the fused substep; its mean launch duration from HIP events over the timed
-    # region (3 launches per step, back to back on the ctx stream)
-    kern_ms = dev_ms / (a.steps * 3)
-    achieved = cells * bps / (kern_ms * 1e-3) / 1e9
+    # ---------------------------------------------------------------- single GPU: BASELINE C2 (+ also)
+    wl = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n)
+    r = time_single(torch, _ffi, DeviceGrid, wl, a.steps, a.warmup, a.repeats, SPINUP_STEPS)
+    s = summarize(r, a.steps)
+    cells = r["cells"]
+    tr = measured_traffic(a.n, a.scheme, a.dtype)
     out = {
-        "metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI %d^3 fp64" % n if a.dtype == "float64"
-                  else "grid-cell RK-substep updates/sec, Dubins-3D HJI %d^3 fp32" % n,
-        "value": value, "unit": "cell-substeps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * wall / a.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64" if a.dtype == "float64" else "f32", "data": "synthetic",
-        "config": {"workload": "Dubins-relative (air3D) 3-D HJI, %s x %d x %d grid, %s + GLF, odeCFL3 "
-                               "(factorCFL 0.8), cylinder r=0.5 initial data" %
-                               (("%d" % n) if world == 1 else ("%dx%d" % (world, n)), n, n, a.scheme),
-                   "scheme": a.scheme, "parallelism": sched, "substeps_per_step": 3,
-                   "spinup_steps": SPINUP_STEPS},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, a.scheme, a.dtype, world),
-                     "kernel": "fused_substep_kernel", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": cells * bps},
-        "per_gpu_value": per_gpu,
+        "metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI %d^3 %s" % (a.n, "fp64" if a.dtype == "float64" else "fp32"),
+        "value": s["value"], "unit": "cell-substeps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dt_tag, "data": "synthetic",
+        "config": {"workload": r["desc"], "scheme": a.scheme, "parallelism": "single", "substeps_per_step": 3,
+                   "launches_per_step": r["launches_per_step"], "spinup_steps": SPINUP_STEPS},
+        "repeats": s["repeats"],
+        # the step's launches as one unit: algorithmic bytes of an RK3 step (8 words per cell) over the HIP-event
+        # time of a step's launches, back to back on the ctx stream (median repeat)
+        "roofline": {"bound": "hbm", "achieved": s["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s["frac"],
+                     "traffic": tr["bytes_per_step"] if tr else None,
+                     "kernel": "fused_substep_kernel x %d launches = one RK3 step" % r["launches_per_step"],
+                     "kernel_ms": s["dev_step_ms"] / r["launches_per_step"], "step_ms": s["dev_step_ms"],
+                     "algorithmic_bytes_per_launch": cells * 3 * bps / r["launches_per_step"],
+                     "algorithmic_bytes_per_step": cells * 3 * bps},
+        "per_gpu_value": s["value"],
     }
+    also = {}
+    if not a.no_also:
+        for name in [x for x in a.also.split(",") if x]:
+            try:
+                if name in ("WENO5", "ENO3", "ENO2", "WENO5_ASSHIPPED"):
+                    if name == a.scheme:
+                        continue
+                    wl2, st, key = workload(L, _ffi, torch, "dubins", name, a.dtype, a.n), a.steps, "%d^3 %s" % (a.n, name)
+                elif name.isdigit():
+                    wl2, st, key = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, int(name)), max(10, a.steps // 4), "%s^3 %s" % (name, a.scheme)
+                else:
+                    wl2, st, key = workload(L, _ffi, torch, name, None, None, 0), max(10, a.steps // 4), name
+                r2 = time_single(torch, _ffi, DeviceGrid, wl2, st, max(2, a.warmup // 2), min(3, a.repeats), max(20, SPINUP_STEPS // 3))
+                s2 = summarize(r2, st)
+                also[key] = {"workload": r2["desc"], "dtype": "f64" if r2["dtype"] == "float64" else "f32", "steps": st,
+                             "value": s2["value"], "ms_per_step": s2["ms_per_step"], "roofline_frac": s2["frac"],
+                             "achieved_GBps": s2["achieved"], "repeats": s2["repeats"]}
+                del r2, wl2
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001 -- an extra workload must not take the headline down
+                also[name] = {"error": repr(e)}
     if also:
         out["also"] = also
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps, a.scheme)
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or os.environ.get("HJ_BENCH_FORCE_SLAB"):
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if cpu is not None:
+        out["cpu_baseline"] = cpu.run()
+    return out
 
 
 if __name__ == "__main__":

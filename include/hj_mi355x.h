@@ -208,6 +208,9 @@ int hj_comm_unique_id(const char* rccl_path, void* uid128_host);
 int hj_comm_init(hj_ctx* ctx, const char* rccl_path, int rank, int nranks, const void* uid128_host,
                  int lo_rank, int hi_rank);
 int hj_comm_destroy(hj_ctx* ctx);
+/* rank / size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount; the
+ * caller-supplied values for hj_comm_init_external) and the neighbour ranks; any pointer may be NULL. */
+int hj_comm_info(hj_ctx* ctx, int* rank, int* nranks, int* lo_rank, int* hi_rank);
 int hj_halo_exchange(hj_ctx* ctx, void* buf);
 int hj_slab_join(hj_ctx* ctx);
 int hj_slab_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double dt,

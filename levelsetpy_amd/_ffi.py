@@ -52,6 +52,7 @@ SIGNATURES = {
     "hj_comm_unique_id": (_i, [C.c_char_p, _vp]),
     "hj_comm_init": (_i, [_vp, C.c_char_p, _i, _i, _vp, _i, _i]),
     "hj_comm_destroy": (_i, [_vp]),
+    "hj_comm_info": (_i, [_vp, _pi, _pi, _pi, _pi]),
     "hj_halo_exchange": (_i, [_vp, _vp]),
     "hj_slab_join": (_i, [_vp]),
     "hj_slab_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _i, _vp, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <type_traits>
 #include <vector>
 
@@ -100,8 +101,10 @@ struct hj_ctx {
     // tuning
     KernelCfg cfg;
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
-    int target_blocks, min_chunk;
+    int target_blocks, min_chunk, warmup_cost;
     size_t lds_limit;
+    // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
+    std::map<std::pair<const void*, size_t>, int> occ_cache;
 };
 
 namespace {
@@ -213,7 +216,7 @@ void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int block
         const int64_t nchunks = (planes + chunk - 1) / chunk;
         const int64_t blocks = nchunks * t.ntiles;
         const int64_t rounds = (blocks + capacity - 1) / capacity;
-        const double cost = (double)rounds * ((double)chunk + 4.0);
+        const double cost = (double)rounds * ((double)chunk + (double)c->warmup_cost);
         if (cost < best_cost - 1e-9) { best_cost = cost; best_nch = nch; }
     }
     if (c->target_blocks > 0) best_nch = std::max<int64_t>(1, std::min<int64_t>(planes / std::max(1, c->min_chunk), c->target_blocks / t.ntiles));
@@ -282,21 +285,24 @@ struct SubstepCall {
     int64_t p0, p1;
     int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
     int post_op = 0;          // fused post-step min/max with the state the step started from
+    bool on_aux = false;      // launch on the ctx's auxiliary (edge) stream instead of the ctx stream
 };
+
+inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s.on_aux ? c->edge_stream : c->stream; }
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
 int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
     constexpr int ND = HAM::ND;
     {
         auto kern0 = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD>;
-        static int occ_lds = -1, occ_blocks = 1;          // per instantiation
-        if (occ_lds != (int)t.lds_bytes) {
+        const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
+        auto it = c->occ_cache.find(key);
+        if (it == c->occ_cache.end()) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern0), NT,
-                                                             t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
-            occ_blocks = nb;
-            occ_lds = (int)t.lds_bytes;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+            it = c->occ_cache.emplace(key, nb).first;
         }
+        const int occ_blocks = it->second;
         choose_chunks(c, t, s.p0, s.p1, occ_blocks);
         if (!t.ok) return fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
         t.nchunks1 = t.nchunks;
@@ -365,23 +371,23 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
     unsigned long long* tbuf = nullptr;
     if (dump && *dump) {
         HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), call_stream(c, s)));
         A.timing = tbuf;
     }
     if (c->launch_stop) {
         // completion signal attached to the dispatch packet itself: a separate hipEventRecord costs a
         // marker packet and ~6 us of bubble before the next kernel of the stream (slab timeline)
-        hipExtLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), (unsigned)t.lds_bytes, c->stream, nullptr, c->launch_stop, 0,
+        hipExtLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
                               (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
         c->launch_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (const T*)s.y0,
+        hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0,
                            (T*)s.out, A);
     }
     HIP_TRY(hipGetLastError());
     if (tbuf) {
         std::vector<unsigned long long> h((size_t)t.nblocks * 4);
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(call_stream(c, s)));
         HIP_TRY(hipMemcpy(h.data(), tbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipFree(tbuf));
         if (FILE* f = fopen(dump, "a")) {
@@ -425,7 +431,7 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
         const long long cells = A.cell_end - A.cell_begin;
         if (cells <= 0) continue;
         int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, c->stream, A);
+        hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, call_stream(c, s), A);
         HIP_TRY(hipGetLastError());
     }
     return HJ_OK;
@@ -567,8 +573,14 @@ int default_aux(hj_ctx* c) {
 unsigned long long* next_ring(hj_ctx* c, int user_slot, int* rc) {
     *rc = HJ_OK;
     if (c->ring_pos >= RING_SLOTS) {
-        hipError_t e = hipMemsetAsync(c->ring, 0, sizeof(unsigned long long) * RING_SLOTS * HJ_MAX_DIM, c->stream);
-        if (e != hipSuccess) { *rc = fail(HJ_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e)); return nullptr; }
+        // wrap-around (once per RING_SLOTS launches): kernels on EITHER stream may still be reducing into
+        // their slots, so drain both before the whole ring is zeroed, and finish the memset before any
+        // stream can launch into it again
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && c->edge_stream) e = hipStreamSynchronize(c->edge_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->ring, 0, sizeof(unsigned long long) * RING_SLOTS * HJ_MAX_DIM, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { *rc = fail(HJ_EHIP, "bound ring reset: %s", hipGetErrorString(e)); return nullptr; }
         c->ring_pos = 0;
         for (int i = 0; i < HJ_BOUND_SLOTS; ++i) c->slot_ring[i] = -1;
     }
@@ -726,6 +738,8 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -751,6 +765,8 @@ int rccl_load(const char* path) {
     HJ_SYM(Recv, "ncclRecv")
     HJ_SYM(AllReduce, "ncclAllReduce")
     HJ_SYM(GetErrorString, "ncclGetErrorString")
+    HJ_SYM(CommCount, "ncclCommCount")
+    HJ_SYM(CommUserRank, "ncclCommUserRank")
 #undef HJ_SYM
     g_rccl.handle = h;
     return HJ_OK;
@@ -829,10 +845,8 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
         SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, 0, 0};
         if (lo_e > 0) { s.p0 = 0; s.p1 = lo_e; if (hi_b < n) { s.q0 = hi_b; s.q1 = n; } }
         else { s.p0 = hi_b; s.p1 = n; }
-        c->stream = c->edge_stream;
-        rc = do_substep(c, s, -1);
-        c->stream = main;
-        if (rc) return rc;
+        s.on_aux = true;
+        if ((rc = do_substep(c, s, -1))) return rc;
     }
     HIP_TRY(hipEventRecord(c->ev_edge, c->edge_stream));
     if (c->comm_stream != c->edge_stream) HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
@@ -943,12 +957,11 @@ int slab_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par,
             SubstepCall s{scheme, ham, kind[st - 1], rs, par, dt, src[st - 1], y0, dst[st - 1], nullptr, 0, 0};
             if (lo) { s.p0 = -ext; s.p1 = W * st; if (hi) { s.q0 = n - W * st; s.q1 = n + ext; } }
             else { s.p0 = n - W * st; s.p1 = n + ext; }
-            c->stream = aux;
+            s.on_aux = true;
             c->launch_stop = (c->ext_events && st == order) ? c->ev_edge : nullptr;
             rc = do_substep(c, s, -1);
             edge_signalled = c->ext_events && st == order && c->launch_stop == nullptr;
             c->launch_stop = nullptr;
-            c->stream = main;
             if (rc) { c->weno_src = nullptr; return rc; }
         }
         if (scheme == HJ_WENO5) c->weno_src = nullptr;
@@ -1026,6 +1039,8 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         c->num_cus = ncu;
     }
     c->min_chunk = std::max(1, env_int("HJ_MIN_CHUNK", 4));
+    // planes of loads a chunk pays before its first result: 2*HJ_STENCIL = 6 (HJ_WARMUP_COST: sweep knob)
+    c->warmup_cost = std::max(0, env_int("HJ_WARMUP_COST", 2 * HJ_STENCIL));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
@@ -1431,6 +1446,13 @@ int hj_comm_init_external(hj_ctx* c, int rank, int nranks, int lo, int hi) {
 
 int hj_comm_destroy(hj_ctx* c) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
+    // sends/receives or edge kernels may still be in flight (also when reached from hj_ctx_destroy at
+    // interpreter teardown): drain the auxiliary stream and the ctx stream before anything is destroyed
+    if (c->edge_stream) {
+        (void)slab_join(c);
+        (void)hipStreamSynchronize(c->edge_stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     c->comm = nullptr;
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);   // comm_stream aliases it
@@ -1443,6 +1465,20 @@ int hj_comm_destroy(hj_ctx* c) {
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr;
     c->slab_pending = 0;
     c->external_exchange = 0;
+    return HJ_OK;
+}
+
+int hj_comm_info(hj_ctx* c, int* rank, int* nranks, int* lo, int* hi) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    int r = c->comm_rank, n = c->comm_size;
+    if (c->comm) {
+        NCCL_TRY(g_rccl.CommCount(c->comm, &n));
+        NCCL_TRY(g_rccl.CommUserRank(c->comm, &r));
+    }
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    if (lo) *lo = c->lo_rank;
+    if (hi) *hi = c->hi_rank;
     return HJ_OK;
 }
 

@@ -27,14 +27,9 @@ def artificialDissipationGLF(t, data, derivL, derivR, schemeData):
     grid = schemeData.grid
     dim = grid.dim
     derivMin, derivMax, derivDiff = cell(dim), cell(dim), cell(dim)
-    cache = None
-    dgs = grid.__dict__.get("_hj_device") or {}
-    for dg in dgs.values():
-        cache = getattr(dg, "minmax", None) or cache
+    from .spatial import cached_minmax
     for i in range(dim):
-        mm = None
-        if cache is not None and is_tensor(derivL[i]):
-            mm = cache.get((derivL[i].data_ptr(), derivR[i].data_ptr()))
+        mm = cached_minmax(derivL[i], derivR[i])
         if mm is None:
             mm = (min(_amin(derivL[i]), _amin(derivR[i])), max(_amax(derivL[i]), _amax(derivR[i])))
         derivMin[i], derivMax[i] = mm                             # :80-88

@@ -385,6 +385,13 @@ class NativeSlabStepper(object):
             return 0.5 * (t + t2), dt
         return (1.0 / 3.0) * (t + 2 * (0.25 * (3 * t + t2) + dt)), dt
 
+    @property
+    def nranks(self):
+        """size of the communicator as RCCL reports it (ncclCommCount)."""
+        n = C.c_int()
+        _ffi.check(self.dg.lib.hj_comm_info(self.dg.ctx, None, C.byref(n), None, None))
+        return int(n.value)
+
     def close(self):
         _ffi.check(self.dg.lib.hj_comm_destroy(self.dg.ctx))
 
@@ -399,12 +406,9 @@ def _slab_self_check(L, g, slab, integ, args, tdtype, device, steps=2):
     mine = integ.state().clone()
     torch.cuda.synchronize(device)
     n0 = slab.n0
-    x0 = np.asarray(g.vs[0]).ravel().reshape(-1, 1, 1)
-    x1 = np.asarray(g.vs[1]).ravel().reshape(1, -1, 1)
-    full0 = np.sqrt(x0 ** 2 + x1 ** 2) - 0.5 + np.zeros((1, 1, int(np.asarray(g.N).ravel()[2])))
     dg = DeviceGrid(g, args.dtype)
     dg.bind_stream()
-    cur = torch.as_tensor(full0, dtype=tdtype, device=device)
+    cur = _cylinder_planes(torch, g, 0, n0, tdtype, device)
     assert cur.shape[0] == n0
     nxt, w1 = torch.empty_like(cur), torch.empty_like(cur)
     tout, dtout = C.c_double(), C.c_double()
@@ -424,25 +428,50 @@ def _slab_self_check(L, g, slab, integ, args, tdtype, device, steps=2):
     return diff
 
 
-def bench_slab(args, rank, world):
-    """bench.py's N > 1 leg: every rank owns an n^3 slab of an (N*n) x n x n Dubins grid."""
+def _cylinder_planes(torch, g, b, e, tdtype, device):
+    """shapeCylinder(g, 2, 0, .5) restricted to axis-0 planes [b, e), built on the device (cylinder.py:55-59)."""
+    x0 = torch.as_tensor(np.asarray(g.vs[0]).ravel()[b:e], device=device).reshape(-1, 1, 1)
+    x1 = torch.as_tensor(np.asarray(g.vs[1]).ravel(), device=device).reshape(1, -1, 1)
+    n2 = int(np.asarray(g.N).ravel()[2])
+    d = (x0 * x0 + x1 * x1).sqrt() - 0.5
+    return d.expand(e - b, x1.shape[1], n2).to(tdtype).contiguous()
+
+
+def slab_grid(L, world, n, global_n):
+    """The bench grid: strong scaling (global_n > 0) integrates the global_n^3 Dubins grid of BASELINE C4
+    whatever the rank count; weak scaling gives every rank an n^3 slab of an (world*n) x n x n grid."""
+    if global_n > 0:
+        n = n0 = int(global_n)
+        gmax0 = 3.25
+    else:
+        n0 = world * n
+        gmax0 = -.75 + 4.0 / (n - 1) * (n0 - 1)
+    gmin = np.array([[-.75, -1.25, -np.pi]]).T
+    gmax = np.array([[gmax0, 1.25, np.pi * (1 - 2 / n)]]).T
+    return L.createGrid(gmin, gmax, np.array([[n0], [n], [n]], dtype=np.int64), 2, low_mem=True), n0, n
+
+
+def _agree(dist, ok, device):
+    """Collective decision: True only if EVERY rank reports ok (a rank that failed locally must not leave
+    the others inside a different collective: ADVICE r01)."""
+    import torch
+    flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return float(flag.item()) == 0.0
+
+
+def bench_slab(args, rank, world, global_n=513):
+    """bench.py's slab leg.  global_n > 0: STRONG scaling of the global_n^3 grid (BASELINE C4: 513^3, slabs of
+    65/64 planes at 8 ranks); global_n == 0: weak scaling, every rank owns an n^3 slab."""
     import time
     import torch
     import torch.distributed as dist
     import levelsetpy_amd as L
-    n = args.n
-    dx0 = 4.0 / (n - 1)
-    gmin = np.array([[-.75, -1.25, -np.pi]]).T
-    gmax = np.array([[-.75 + dx0 * (world * n - 1), 1.25, np.pi * (1 - 2 / n)]]).T
-    g = L.createGrid(gmin, gmax, np.array([[world * n], [n], [n]], dtype=np.int64), 2, low_mem=True)
-    import os
-    slab = SlabDecomposition(world * n, world, rank, False)
+    g, n0, n = slab_grid(L, world, args.n, global_n)
+    slab = SlabDecomposition(n0, world, rank, False)
     dxs = [float(v) for v in np.asarray(g.dx).ravel()]
-    # cylinder initial data for this slab only (sparse xs: broadcasting)
-    x0 = np.asarray(g.vs[0]).ravel()[slab.begin:slab.end].reshape(-1, 1, 1)
-    x1 = np.asarray(g.vs[1]).ravel().reshape(1, -1, 1)
-    d0 = np.sqrt(x0 ** 2 + x1 ** 2) - 0.5 + np.zeros((1, 1, n))
     sid, par = _ffi.SCHEME_IDS[args.scheme], [1.0, 1.0, 1.0, 2.0]
+    device = torch.device("cuda", torch.cuda.current_device())
 
     def make(kind):
         if kind == "torch":
@@ -455,25 +484,38 @@ def bench_slab(args, rank, world):
                else "3-plane exchange per substep, edge-first overlap")
         return it, it, how + ", ncclSend/ncclRecv over RCCL inside the C library"
 
-    # transports in order of preference; each one has to reproduce the single-domain result ON THIS
-    # HARDWARE before it is timed (two RK3 steps of the whole (N*n) x n x n grid on every rank, untimed);
-    # a transport that fails the check (or cannot be set up) is reported on stderr and the next is tried
+    # Transports in order of preference; each one has to reproduce the single-domain result ON THIS HARDWARE
+    # before it is timed (two RK3 steps of the whole grid on every rank, untimed).  Every stage ends in a
+    # collective agreement: a rank whose set-up raised reports it there instead of skipping ahead, so the
+    # ranks never sit in different collectives.  Set-up failures inside a transport's own collectives
+    # (communicator creation) cannot be recovered from and abort the run with a non-zero exit.
     want = os.environ.get("HJ_SLAB_TRANSPORT")
-    order = [want] if want else ["native-deep", "native", "torch"]
-    integ = be = how = check = None
+    # the deep-halo schedule pays 18 redundant planes per slab and step: only worth it on thick slabs
+    thick = min(slab.counts) >= 128
+    order = [want] if want else ((["native-deep"] if thick else []) + ["native", "torch"])
+    integ = be = how = None
+    check = float("inf")
+    y_init = None
     for kind in order:
+        ok, err = True, None
         try:
             integ, be, how = make(kind)
-            y_init = torch.as_tensor(d0, dtype=be.dg.tdtype, device=be.device)
+            y_init = _cylinder_planes(torch, g, slab.begin, slab.end, be.dg.tdtype, be.device)
             integ.set_state(y_init)
-            dist.barrier()
-            bad = 0.0
-            if os.environ.get("HJ_BENCH_SLAB_CHECK", "1") != "0":
-                bad = _slab_self_check(L, g, slab, integ, args, be.dg.tdtype, be.device)
         except Exception as e:  # noqa: BLE001 -- decided collectively below
-            sys.stderr.write("[bench_slab] rank %d: transport %s failed: %r\n" % (rank, kind, e))
-            bad = float("inf")
-        worst = torch.tensor([bad], dtype=torch.float64, device="cuda")
+            ok, err = False, e
+            sys.stderr.write("[bench_slab] rank %d: transport %s failed to set up: %r\n" % (rank, kind, e))
+        if not _agree(dist, ok, device):
+            # a rank that got past its communicator while another did not cannot be re-synchronised safely
+            raise RuntimeError("slab transport %s could not be set up on every rank (%r)" % (kind, err))
+        bad = 0.0
+        if os.environ.get("HJ_BENCH_SLAB_CHECK", "1") != "0":
+            try:
+                bad = _slab_self_check(L, g, slab, integ, args, be.dg.tdtype, be.device)
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("[bench_slab] rank %d: self check of %s raised: %r\n" % (rank, kind, e))
+                bad = float("inf")
+        worst = torch.tensor([bad], dtype=torch.float64, device=device)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         check = float(worst.item())
         if check <= 1e-12:
@@ -482,7 +524,7 @@ def bench_slab(args, rank, world):
             break
         if rank == 0:
             sys.stderr.write("[bench_slab] transport %s rejected: max |slab - single domain| = %g\n" % (kind, check))
-        if integ is not None and hasattr(integ, "close"):
+        if hasattr(integ, "close"):
             try:
                 integ.close()
             except Exception:  # noqa: BLE001
@@ -490,26 +532,32 @@ def bench_slab(args, rank, world):
         integ = None
     if integ is None:
         raise RuntimeError("no slab transport reproduced the single-domain result (last diff %g)" % check)
-    transport = how
     t = 0.0
     # untimed device spin-up (clock ramp), as in bench.py's single-GPU leg
     for _ in range(int(os.environ.get("HJ_BENCH_SPINUP", "300")) + args.warmup):
         t, _dt = integ.step(t)
-    torch.cuda.synchronize()
-    dist.barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        t, _dt = integ.step(t)
-    e1.record()
-    torch.cuda.synchronize()
-    dist.barrier()
-    wall = time.perf_counter() - t0
+    walls, devs = [], []
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            t, _dt = integ.step(t)
+        e1.record()
+        torch.cuda.synchronize()
+        dist.barrier()
+        walls.append(time.perf_counter() - t0)
+        devs.append(e0.elapsed_time(e1))
     ok = bool(torch.isfinite(integ.state()).all())
+    nranks = getattr(integ, "nranks", world)
     if hasattr(integ, "close"):
         integ.close()
     assert ok, "non-finite state after the timed steps"
-    return {"wall": wall, "dev_ms": e0.elapsed_time(e1), "cells": n ** 3, "slab_check_max_abs_diff": check,
-            "parallelism": "slab%d (axis-0 slabs; %s)" % (world, transport)}
+    plane = n * n
+    return {"walls": walls, "devs": devs, "total_cells": n0 * plane, "local_cells": slab.n_local * plane,
+            "planes": "/".join(str(c) for c in sorted(set(slab.counts), reverse=True)),
+            "slab_check_max_abs_diff": check, "nranks": nranks,
+            "parallelism": "slab%d (axis-0 slabs; %s)" % (world, how)}

@@ -161,14 +161,21 @@ class DoublePendulum4D(object):
 
 def native_of(hamFunc, partialFunc):
     """(system, ham_id, params) when hamFunc/partialFunc are the bound methods of ONE of the
-    systems above (so the fused kernel computes exactly what the callbacks would), else None."""
+    systems above (so the fused kernel computes exactly what the callbacks would), else None.
+    A subclass that overrides hamiltonian() / dissipation() / native() is NOT native: the methods are
+    compared with the ones of the class that owns the kernel, not with type(self)'s."""
     sys_h = getattr(hamFunc, "__self__", None)
     sys_p = getattr(partialFunc, "__self__", None)
-    if sys_h is None or sys_h is not sys_p or not hasattr(sys_h, "native"):
+    if sys_h is None or sys_h is not sys_p:
         return None
-    if getattr(hamFunc, "__func__", None) is not type(sys_h).hamiltonian:
+    owner = next((k for k in (DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D) if isinstance(sys_h, k)), None)
+    if owner is None:
         return None
-    if getattr(partialFunc, "__func__", None) is not type(sys_h).dissipation:
+    if getattr(hamFunc, "__func__", None) is not owner.hamiltonian:
+        return None
+    if getattr(partialFunc, "__func__", None) is not owner.dissipation:
+        return None
+    if type(sys_h).native is not owner.native:
         return None
     nat = sys_h.native()
     if nat is None:

@@ -227,6 +227,30 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
         if isfield(extraArgs, 'SDModFunc'):
             paramsIn = _get(extraArgs, 'SDModParams', [])
             schemeData = extraArgs.SDModFunc(schemeData, i, tau, cur_np, obstacles, paramsIn)
+            # the reference hands the reassigned Bundle straight to the integrator (hji_solver.py:512-542):
+            # re-apply the defaults and rebuild what was derived from the old Bundle
+            schemeData.dissFunc = artificialDissipationGLF
+            if not isfield(schemeData, 'CoStateCalc') and not isfield(schemeData, 'derivFunc'):
+                schemeData.derivFunc = upwindFirstWENO5
+            if schemeFunc is termRestrictUpdate:
+                sd_run = Bundle(dict(innerFunc=termLaxFriedrichs, innerData=schemeData, positive=0))
+            else:
+                sd_run = schemeData
+            if schemeData.grid is not g:
+                error('SDModFunc must keep schemeData.grid (the stored arrays live on it)')
+            new_plan = native_plan(schemeData)
+            if (new_plan is None) != (plan is None):
+                # the state changes sides (device tensor <-> NumPy) with the execution path
+                if new_plan is None:
+                    y = y.detach().cpu().numpy() if is_tensor(y) else y
+                    y_init = y_init.detach().cpu().numpy() if is_tensor(y_init) else y_init
+                    dg = None
+                else:
+                    dg = device_grid(g, "float64")
+                    y = dg.to_device(y).reshape(col).clone()
+                    y_init = dg.to_device(y_init).reshape(col).clone() if y_init is not None else None
+                ops = _Ops(dg)
+            plan = new_plan
         y_start = y.clone() if is_tensor(y) else y.copy()
         tNow = tau[i - 1]
         target_i = ops.prep(targets[i] if targ_tv else targets, y)

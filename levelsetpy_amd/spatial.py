@@ -9,6 +9,7 @@ reproduces the reference's results ('asshipped', the drop-in default); the inten
 Osher-Fedkiw scheme is `upwindFirstWENO5Intended` or `set_weno5_mode('weno5')`.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -57,12 +58,19 @@ def _upwind(scheme_name, grid, data, dim):
     _ffi.check(dg.lib.hj_upwind(dg.ctx, _ffi.SCHEME_IDS[scheme_name], int(dim), dg.ptr(phi),
                                 dg.ptr(dL), dg.ptr(dR), mm))
     # the four reductions artificialDissipationGLF needs (artificial_diss_glf.py:80-88) came out of
-    # the same kernel: remember them so the dissipation does not re-reduce
-    dg.minmax = getattr(dg, "minmax", {})
-    if len(dg.minmax) > 64:
-        dg.minmax.clear()
-    dg.minmax[(dL.data_ptr(), dR.data_ptr())] = (min(mm[0], mm[2]), max(mm[1], mm[3]))
+    # the same kernel: they ride on the returned tensor itself (tagged with its partner and both
+    # in-place version counters), so they die with it and an edited or foreign array never matches
+    if is_tensor(data):
+        dL._hj_minmax = (weakref.ref(dR), dL._version, dR._version, min(mm[0], mm[2]), max(mm[1], mm[3]))
     return dg.like(dL, data), dg.like(dR, data)
+
+
+def cached_minmax(dL, dR):
+    """(min, max) over derivL and derivR if this exact, unmodified pair came out of hj_upwind, else None."""
+    tag = getattr(dL, "_hj_minmax", None) if is_tensor(dL) else None
+    if tag is None or tag[0]() is not dR or tag[1] != dL._version or tag[2] != dR._version:
+        return None
+    return tag[3], tag[4]
 
 
 def _candidates(grid, data, dim, order):

@@ -99,12 +99,13 @@ def _data(og):
     return O.shape_cylinder(og, 2, None, .5) + 0.05 * np.random.default_rng(3).standard_normal(og.shape)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cases=None, N=N):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        for ci, (scheme, periodic0, order) in enumerate(CASES):
+        for ci, (scheme, periodic0, order) in enumerate(cases or CASES):
             pd = [0, 2] if periodic0 else [2]
             og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / N[2])], N, pd)
             data = _data(og)
@@ -121,7 +122,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _reference(scheme, periodic0, order):
+def _reference(scheme, periodic0, order, N=N):
     pd = [0, 2] if periodic0 else [2]
     og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / N[2])], N, pd)
     data = _data(og)
@@ -157,6 +158,37 @@ def test_two_rank_slab_runs_equal_single_domain():
             got[b:e] = y
             assert abs(t - t_ref) <= 1e-14
             assert abs(sb - sb_ref) <= 1e-14 * sb_ref        # all-reduced alpha maxima
+        assert np.max(np.abs(got - y_ref)) <= 1e-12, (scheme, periodic0, order)
+
+
+CASES8 = [("WENO5_ASSHIPPED", False, 3), ("ENO3", True, 3), ("WENO5", False, 2)]
+N8 = (41, 7, 8)       # 41 = 8*5 + 1: slabs of 6, 5, 5, ... planes (BASELINE C4's 513 = 8*64 + 1 pattern)
+
+
+def test_eight_rank_uneven_slabs_equal_single_domain():
+    """World size 8 (the node size BASELINE C4 names) over gloo with uneven slabs: interior ranks with two
+    neighbours, end ranks with one, the periodic ring closed 7 <-> 0, all-reduced alpha maxima and WENO
+    epsilon over 8 ranks."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, CASES8, N8)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world * len(CASES8))]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for ci, (scheme, periodic0, order) in enumerate(CASES8):
+        t_ref, y_ref, sb_ref = _reference(scheme, periodic0, order, N8)
+        got = np.full(N8, np.nan)
+        parts = [r for r in res if r[0] == ci]
+        assert sorted(e - b for (_c, _r, b, e, _t, _s, _y) in parts) == [5] * 7 + [6]
+        for (_ci, _rank, b, e, t, sb, y) in parts:
+            got[b:e] = y
+            assert abs(t - t_ref) <= 1e-14
+            assert abs(sb - sb_ref) <= 1e-14 * sb_ref
         assert np.max(np.abs(got - y_ref)) <= 1e-12, (scheme, periodic0, order)
 
 

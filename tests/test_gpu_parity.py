@@ -35,19 +35,29 @@ def close(a, ref, tol=1e-11, what=""):
     assert err <= tol * scale, "%s err %.3e > %.1e*%.3g" % (what, err, tol, scale)
 
 
-def close_eno(a, ref, tol=1e-11, loose=1e-4, what=""):
+ENO_STATS = []      # (what, fraction of cells beyond the strict tolerance, max error / scale): read by the report test
+
+
+def close_eno(a, ref, tol=1e-11, loose=1e-4, what="", frac=None):
     """Multi-step ENO2/ENO3 on TIE-PRONE data.  The signed-distance cylinder is
     symmetric, so many |D2| / |D3| comparisons are exact ties in exact arithmetic; which of the two
     equally valid stencils wins is decided by rounding noise -- in the reference too -- and a
     flipped choice propagates to neighbours over the following substeps.  Any implementation whose
     rounding differs (FMA contraction here) therefore agrees only to the candidates' O(dx^3 D^4 phi)
-    difference on such data.  The strict 1e-11 comparisons use the `*n_*` goldens, whose initial
-    data carry 1e-2 noise and have no exact ties."""
+    difference at the cells a flipped tie reaches.  Masked comparison: every cell within `loose`, and
+    -- when `frac` is given -- at most that fraction of the cells beyond the strict `tol` (the cells
+    downstream of a flipped tie).  The strict all-cells 1e-11 comparisons use the `*n_*` goldens, whose
+    initial data carry 1e-2 noise and have no exact ties."""
     a, ref = np.asarray(a), np.asarray(ref)
     assert a.shape == ref.shape
     scale = max(1.0, float(np.max(np.abs(ref))))
-    err = float(np.max(np.abs(a - ref)))
+    diff = np.abs(a - ref)
+    err = float(np.max(diff))
+    beyond = float(np.mean(diff > tol * scale))
+    ENO_STATS.append((what, beyond, err / scale))
     assert err <= loose * scale, "%s max err %.3e" % (what, err)
+    if frac is not None:
+        assert beyond <= frac, "%s: %.3e of the cells differ by more than %.1e (allowed %.1e)" % (what, beyond, tol, frac)
 
 
 def mk(gmin, gmax, N, pd):
@@ -1246,3 +1256,13 @@ def test_hjipde_solve_interval_at_once_equals_stepwise(comp, with_target, with_o
     assert outs[0].shape == outs[1].shape == (len(tau),) + tuple(g.shape)
     assert np.array_equal(outs[0], outs[1])
     assert not np.array_equal(outs[0][-1], outs[0][0])
+
+
+def test_zz_report_eno_tie_statistics():
+    """Not a check: writes what the masked ENO comparisons saw (fraction of cells beyond the strict
+    tolerance, max error) to gpurun_out/eno_tie_stats.txt so the bound quoted in DESIGN.md is measured."""
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "eno_tie_stats.txt"), "w") as f:
+        for what, beyond, err in ENO_STATS:
+            f.write("%-40s beyond_strict=%.3e max_err/scale=%.3e\n" % (what or "-", beyond, err))
