@@ -1,25 +1,9 @@
 // C ABI of libhj_mi355x.so (see include/hj_mi355x.h).  gfx950 only.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types only: the library is dlopen'ed (hj_comm_*), so libhj loads without RCCL
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <map>
-#include <type_traits>
-#include <vector>
+#include "hj_host.h"
 
-#include "../../include/hj_mi355x.h"
-#include "hj_fused.h"
-#include "hj_split.h"
-
-namespace {
+namespace hjh {
 
 thread_local char g_err[512] = "";
 
@@ -30,86 +14,6 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                    \
-    do {                                                                                 \
-        hipError_t e_ = (expr);                                                          \
-        if (e_ != hipSuccess)                                                            \
-            return fail(HJ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
-                        __FILE__, __LINE__);                                             \
-    } while (0)
-
-constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys)
-
-struct Tiling {
-    int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
-    int ntiles, chunk, nchunks, nchunks1, nblocks, bpx, lpitch;
-    size_t lds_bytes;
-    double score;
-    bool ok;
-};
-
-struct KernelCfg { int NT, R, KH; };
-
-}  // namespace
-
-struct hj_ctx {
-    int ndim, dtype, device;
-    int64_t N[HJ_MAX_DIM];
-    double xmin[HJ_MAX_DIM], dx[HJ_MAX_DIM];
-    int bc[HJ_MAX_DIM], tz[HJ_MAX_DIM];
-    int halo_lo, halo_hi;
-    hipStream_t stream;
-    size_t esz;
-    int64_t total;
-    void* coord[HJ_MAX_DIM];           // device, dtype
-    std::vector<double> coord_host[HJ_MAX_DIM];
-    void* aux[4];
-    int64_t aux_n[4];
-    unsigned long long* ring;          // RING_SLOTS * HJ_MAX_DIM keys
-    int ring_pos;
-    int slot_ring[HJ_BOUND_SLOTS];     // user slot -> ring index (-1 = none)
-    unsigned long long* keys;          // scratch keys: [0,32) weno eps (8 groups x 4 dims), [32,36) upwind min/max
-    void* weno_vals;                   // HJ_MAX_DIM values of dtype
-    const void* weno_src;              // caller-provided eps source or null
-    int* flag;                         // nan flag
-    double* partials;                  // per-workgroup partial maxima of max_d1sq_kernel
-    int partials_cap;
-    // static step bound cache
-    int sb_ham;
-    double sb_par[4], sb_val, sb_local, sb_alpha[HJ_MAX_DIM];
-    int diss_local;                    // hj_ctx_set_dissipation: step bound of the local LF variants
-    int post_step_op;                  // hj_ctx_set_post_step: fused into the last stage of hj_rk_step
-    const void* post_arr[2];           // hj_ctx_set_post_arrays
-    int post_arr_op[2];
-    bool sb_valid;
-    int internal_slot;
-    // slab communication (hj_comm_*)
-    ncclComm_t comm;
-    int comm_rank, comm_size, lo_rank, hi_rank;
-    hipStream_t comm_stream, edge_stream;
-    hipEvent_t ev_start, ev_edge, ev_edge2, ev_comm;
-    hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
-    int slab_pending;
-    int external_exchange;             // hj_comm_init_external: the caller fills the pad planes itself
-    hipEvent_t launch_stop;            // if set, the next tiled launch signals this event on completion
-    int ext_events;                    // HJ_EXT_EVENTS (default 1): use that instead of hipEventRecord
-    // axis-0 tables extended by pad0 planes either side (deep-halo stepper computes on pad planes)
-    int pad0;
-    void* coord0_ext;
-    void* aux_ext[2];
-    // tuning
-    KernelCfg cfg;
-    int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
-    int target_blocks, min_chunk, warmup_cost;
-    size_t lds_limit;
-    // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
-    std::map<std::pair<const void*, size_t>, int> occ_cache;
-};
-
-namespace {
-
-using namespace hj;
 
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
@@ -226,14 +130,28 @@ void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int block
     t.bpx = (t.nblocks + 7) / 8;
 }
 
-template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
-    for (int d = 0; d < HJ_MAX_DIM; ++d) H.coord[d] = (const T*)c->coord[d];
-    for (int s = 0; s < 4; ++s) H.aux[s] = (const T*)c->aux[s];
-    if (c->coord0_ext) H.coord[0] = (const T*)c->coord0_ext + c->pad0;
-    for (int s = 0; s < 2; ++s)
-        if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
-    for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
+int cfg_kh(int nd, int nt, int r) {
+#define X(NT_, R_, KH_, OCC_, PD_) if (nt == NT_ && r == R_) return KH_;
+    if (nd == 4) { HJ_CONFIGS_4D(X) }
+    else { HJ_CONFIGS(X) }
+#undef X
+    return -1;
 }
+
+// one object file per (dtype, Hamiltonian): hj_inst.hip
+extern template int launch_scheme<double, HamDubinsRel<double>>(hj_ctx*, const SubstepCall&);
+extern template int launch_scheme<double, HamDoubleIntegrator<double>>(hj_ctx*, const SubstepCall&);
+extern template int launch_scheme<double, HamDoublePendulum<double>>(hj_ctx*, const SubstepCall&);
+extern template int launch_scheme<float, HamDubinsRel<float>>(hj_ctx*, const SubstepCall&);
+extern template int launch_scheme<float, HamDoubleIntegrator<float>>(hj_ctx*, const SubstepCall&);
+extern template int launch_scheme<float, HamDoublePendulum<float>>(hj_ctx*, const SubstepCall&);
+
+}  // namespace hjh
+
+using namespace hj;
+using namespace hjh;
+
+namespace {
 
 int ham_ndim(int ham) {
     switch (ham) {
@@ -250,266 +168,6 @@ int ham_npar(int ham) {
         case HJ_HAM_DOUBLE_PENDULUM: return 1;
     }
     return 0;
-}
-
-template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G) {
-    long long s = 1;
-    for (int d = ND - 1; d >= 0; --d) {
-        G.n[d] = (int)c->N[d];
-        G.bc[d] = c->bc[d];
-        G.km[d] = c->tz[d] ? T(-1) : T(1);
-        G.inv_dx[d] = (T)(1.0 / c->dx[d]);
-        fill_stencil_constants<T>(c->dx[d], G.K[d]);
-        G.stride[d] = s;
-        s *= c->N[d];
-    }
-    G.halo_lo = c->halo_lo;
-    G.halo_hi = c->halo_hi;
-    G.total = c->total;
-}
-
-// costate scale the scheme's stencil leaves out (hj_device.h, scaling note)
-template <typename T> T scheme_scale(int scheme, double dx) {
-    if (scheme == HJ_WENO5_ASSHIPPED) return (T)((1.0 / dx) * (1.0 / 60.0));
-    if (scheme == HJ_WENO5) return (T)((1.0 / dx) * (1.0 / 12.0));
-    return (T)((1.0 / dx) * 0.5);     // ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
-}
-
-struct SubstepCall {
-    int scheme, ham, stage, restrict_sign;
-    const double* par;
-    double dt;
-    const void *y, *y0;
-    void* out;
-    unsigned long long* bound;
-    int64_t p0, p1;
-    int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
-    int post_op = 0;          // fused post-step min/max with the state the step started from
-    bool on_aux = false;      // launch on the ctx's auxiliary (edge) stream instead of the ctx stream
-};
-
-inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s.on_aux ? c->edge_stream : c->stream; }
-
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
-int launch_tiled(hj_ctx* c, const SubstepCall& s, Tiling t) {
-    constexpr int ND = HAM::ND;
-    {
-        auto kern0 = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD>;
-        const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
-        auto it = c->occ_cache.find(key);
-        if (it == c->occ_cache.end()) {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
-            it = c->occ_cache.emplace(key, nb).first;
-        }
-        const int occ_blocks = it->second;
-        choose_chunks(c, t, s.p0, s.p1, occ_blocks);
-        if (!t.ok) return fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
-        t.nchunks1 = t.nchunks;
-        if (s.q1 > s.q0) {     // second range: same chunk length
-            t.nchunks += (int)((s.q1 - s.q0 + t.chunk - 1) / t.chunk);
-            t.nblocks = t.nchunks * t.ntiles;
-            t.bpx = (t.nblocks + 7) / 8;
-        }
-        if (c->debug) {
-            fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
-                    NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.lpitch, t.ntiles, t.chunk,
-                    t.nchunks, t.nblocks, occ_blocks, t.lds_bytes, t.score);
-            c->debug = 0;
-        }
-    }
-    FusedArgs<T, ND> A;
-    memset(&A, 0, sizeof(A));
-    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
-    A.bound = s.bound;
-    long long st = 1;
-    for (int d = ND - 1; d >= 0; --d) {
-        A.n[d] = (int)c->N[d];
-        A.bc[d] = c->bc[d];
-        A.km[d] = c->tz[d] ? T(-1) : T(1);
-        fill_stencil_constants<T>(c->dx[d], A.K[d]);
-        A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
-        A.pstride[d] = (d >= 1) ? (int)st : 0;
-        if (d == 0) A.stride0 = st;
-        st *= c->N[d];
-        A.E[d] = t.E[d];
-        A.ntile[d] = t.ntile[d];
-    }
-    A.halo_lo = c->halo_lo;
-    A.halo_hi = c->halo_hi;
-    A.ntiles = t.ntiles;
-    A.lpitch = t.lpitch;
-    A.chunk = t.chunk;
-    A.nchunks = t.nchunks;
-    A.plane_begin = (int)s.p0;
-    A.plane_end = (int)s.p1;
-    A.plane_begin2 = (int)s.q0;
-    A.plane_end2 = (int)s.q1;
-    A.nchunks1 = t.nchunks1;
-    A.nblocks = t.nblocks;
-    A.blocks_per_xcd = t.bpx;
-    A.ydot_only = (s.stage == HJ_STAGE_YDOT);
-    A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
-    switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
-        case HJ_STAGE_RK3_HALF: A.ca = T(0.75); A.cb = T(0.25); break;           // ode_cfl_3.py:184,193
-        case HJ_STAGE_RK3_FULL: A.ca = T(1.0 / 3.0); A.cb = T(2.0 / 3.0); break; // :226,241
-        case HJ_STAGE_RK2_FULL: A.ca = T(0.5); A.cb = T(0.5); break;             // ode_cfl_2.py:184,201
-        default: A.ca = T(0); A.cb = T(1); break;
-    }
-    A.dt = (T)s.dt;
-    A.post_op = s.post_op;
-    A.do_clamp = s.restrict_sign != 0;
-    A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
-    A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
-    fill_ham<T>(c, s.par, A.ham);
-    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD>;
-    if (t.lds_bytes > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    }
-    const char* dump = getenv("HJ_TIMING_DUMP");    // debug: per-workgroup start/end clocks of every launch
-    unsigned long long* tbuf = nullptr;
-    if (dump && *dump) {
-        HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), call_stream(c, s)));
-        A.timing = tbuf;
-    }
-    if (c->launch_stop) {
-        // completion signal attached to the dispatch packet itself: a separate hipEventRecord costs a
-        // marker packet and ~6 us of bubble before the next kernel of the stream (slab timeline)
-        hipExtLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
-                              (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
-        c->launch_stop = nullptr;
-    } else {
-        hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0,
-                           (T*)s.out, A);
-    }
-    HIP_TRY(hipGetLastError());
-    if (tbuf) {
-        std::vector<unsigned long long> h((size_t)t.nblocks * 4);
-        HIP_TRY(hipStreamSynchronize(call_stream(c, s)));
-        HIP_TRY(hipMemcpy(h.data(), tbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipFree(tbuf));
-        if (FILE* f = fopen(dump, "a")) {
-            fprintf(f, "# launch nblocks=%d ntiles=%d chunk=%d stage=%d\n", t.nblocks, t.ntiles, t.chunk, s.stage);
-            for (int i = 0; i < t.nblocks; ++i)
-                fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
-            fclose(f);
-        }
-    }
-    return HJ_OK;
-}
-
-template <typename T, typename HAM, int SCHEME>
-int launch_direct(hj_ctx* c, const SubstepCall& s) {
-    constexpr int ND = HAM::ND;
-    DirectArgs<T, ND> A;
-    memset(&A, 0, sizeof(A));
-    A.y = (const T*)s.y;
-    A.y0 = (const T*)s.y0;
-    A.out = (T*)s.out;
-    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
-    A.bound = s.bound;
-    fill_grid<T, ND>(c, A.G);
-    for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
-    if (s.p0 < 0 || s.p1 > c->N[0] || (s.q1 > s.q0 && (s.q0 < 0 || s.q1 > c->N[0])))
-        return fail(HJ_EUNSUPPORTED, "pad planes need the tiled kernel");
-    const long long plane = c->total / c->N[0];
-    A.cell_begin = s.p0 * plane;
-    A.cell_end = s.p1 * plane;
-    A.stage = s.stage;
-    A.post_op = s.post_op;
-    A.restrict_sign = s.restrict_sign;
-    A.dt = (T)s.dt;
-    fill_ham<T>(c, s.par, A.ham);
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-            if (s.q1 <= s.q0) break;
-            A.cell_begin = s.q0 * plane;
-            A.cell_end = s.q1 * plane;
-        }
-        const long long cells = A.cell_end - A.cell_begin;
-        if (cells <= 0) continue;
-        int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, call_stream(c, s), A);
-        HIP_TRY(hipGetLastError());
-    }
-    return HJ_OK;
-}
-
-// (threads per workgroup, cells per thread, halo slots per thread) instantiated for the tiled kernel
-#ifndef HJ_CONFIGS
-#ifdef HJ_ALL_CONFIGS   // the full sweep table (tools/cfgsweep.sh); ~2.5 min to compile
-#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(1024, 2, 1, 4, 2) X(512, 2, 1, 4, 2) X(256, 4, 3, 2, 2) X(256, 2, 2, 4, 2) \
-                      X(512, 1, 1, 4, 2) X(256, 1, 2, 6, 2) X(1024, 1, 1, 4, 2) \
-                      X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
-                      X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
-#else                   // the defaults per scheme plus the runners-up of the round-1 sweeps
-#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(256, 4, 3, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
-#endif
-#endif
-
-// 4-D grids tile three plane axes: the halo cross is ~2x the tile, so more halo slots per thread
-#ifndef HJ_CONFIGS_4D
-#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2) X(1024, 1, 2, 2, 2)
-#endif
-
-int cfg_kh(int nd, int nt, int r) {
-#define X(NT_, R_, KH_, OCC_, PD_) if (nt == NT_ && r == R_) return KH_;
-    if (nd == 4) { HJ_CONFIGS_4D(X) }
-    else { HJ_CONFIGS(X) }
-#undef X
-    return -1;
-}
-
-template <typename T, typename HAM, int SCHEME>
-int launch_cfg(hj_ctx* c, const SubstepCall& s) {
-#ifdef HJ_TUNE_BUILD
-    // quick-iteration build: only fp64 Dubins with the two WENO5 arithmetics is compiled tiled
-    constexpr bool tiled_ok = std::is_same<T, double>::value && HAM::ID == HJ_HAM_DUBINS_REL &&
-                              (SCHEME == HJ_WENO5 || SCHEME == HJ_WENO5_ASSHIPPED);
-#else
-    constexpr bool tiled_ok = true;
-#endif
-    if constexpr (tiled_ok) {
-        if (!c->force_direct) {
-            KernelCfg k = c->cfg;
-            int pd = c->pd, occ = c->occ_hint;
-            if (!c->cfg_from_env) {
-                // round-1 sweeps (profiles/): the heavier the per-cell arithmetic, the fewer cells per
-                // thread fit in the 256-VGPR budget without scratch
-                if (HAM::ND == 4) { k.NT = sizeof(T) == 4 ? 1024 : 512; k.R = sizeof(T) == 4 ? 1 : 2; pd = 2; occ = 2; }
-                // the light stencils keep 4 cells per thread in registers on large grids; below ~12 M cells
-                // (201^3 = 8.1 M: 32 k cells per CU) three small independent workgroups per CU with longer
-                // chunks win (sweeps at 101^3 ... 401^3 after the deferred-ghost fix)
-                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total >= 12000000) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
-                // tiny grids (<= ~135^3) run one wave per SIMD and a launch is a chain of ~10 plane
-                // iterations: one cell per thread shortens every iteration (7-10 % at 51^3 ... 129^3)
-                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total < 2500000) { k.NT = 512; k.R = 1; pd = 2; occ = 4; }
-                else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
-                k.KH = cfg_kh(HAM::ND, k.NT, k.R);
-            }
-            Tiling t = make_tiling(c, k, s.p0, s.p1);
-            if (t.ok) {
-#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
-                if constexpr (HAM::ND == 4) { HJ_CONFIGS_4D(X) }
-                else { HJ_CONFIGS(X) }
-#undef X
-            }
-        }
-    }
-    return launch_direct<T, HAM, SCHEME>(c, s);
-}
-
-template <typename T, typename HAM>
-int launch_scheme(hj_ctx* c, const SubstepCall& s) {
-    switch (s.scheme) {
-        case HJ_ENO2: return launch_cfg<T, HAM, HJ_ENO2>(c, s);
-        case HJ_ENO3: return launch_cfg<T, HAM, HJ_ENO3>(c, s);
-        case HJ_WENO5: return launch_cfg<T, HAM, HJ_WENO5>(c, s);
-        case HJ_WENO5_ASSHIPPED: return launch_cfg<T, HAM, HJ_WENO5_ASSHIPPED>(c, s);
-    }
-    return fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
 }
 
 template <typename T>
@@ -985,7 +643,7 @@ int slab_join(hj_ctx* c) {
 // =========================================================================================== ABI
 extern "C" {
 
-const char* hj_last_error(void) { return g_err; }
+const char* hj_last_error(void) { return hjh::g_err; }
 const char* hj_version(void) { return "hj_mi355x 0.1 (gfx950)"; }
 
 int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,
@@ -1042,6 +700,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // planes of loads a chunk pays before its first result: 2*HJ_STENCIL = 6 (HJ_WARMUP_COST: sweep knob)
     c->warmup_cost = std::max(0, env_int("HJ_WARMUP_COST", 2 * HJ_STENCIL));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
+    c->no_plain = env_int("HJ_NO_PLAIN", 0);     // test / A-B knob: always run the runtime-flag kernel (MODE 0)
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);

@@ -119,12 +119,18 @@ __device__ __forceinline__ PlaneSrc<T> plane_src(const FusedArgs<T, ND>& A, int 
     return s;
 }
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
+// MODE: 0 = every combination (ydot only, termRestrictUpdate clamp, fused post-step operator) decided by
+// runtime flags; 1 / 2 = the plain RK stages that make up almost every launch -- Euler (no y0 operand) /
+// convex combination with y0 -- with those flags compiled out (the clamp alone is ~12 VALU operations per
+// cell and the flags cost ~5 scalar branches per cell).  Same expressions, so the results are bitwise equal.
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE = 0>
 __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restrict__ y,
                                                            const T* __restrict__ y0,
                                                            T* __restrict__ out,
                                                            const FusedArgs<T, HAM::ND> A) {
     constexpr int ND = HAM::ND;
+    constexpr bool GEN = (MODE == 0);
+    const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
     extern __shared__ __align__(16) unsigned char hj_smem[];
     // dynamic LDS only (keeps the carve base 16-byte aligned): [0,512) reduction scratch, then planes
     double (*red)[ND] = reinterpret_cast<double (*)[ND]>(hj_smem);
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const int p_lo = p_begin - HJ_STENCIL;                       // lowest plane the chunk touches
     const unsigned span = (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;   // host keeps this < 4 GiB
     const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
-    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, A.use_y0 ? span : 0u);
+    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
     const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
     auto load_own = [&](int p, T* dst) {
         const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
     };
     auto load_y0 = [&](int p, T* dst) {
-        if (A.use_y0) {
+        if (use_y0) {
             const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
             for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_Y0>(ry0, own_g[r], so, T());
@@ -462,16 +468,16 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             }
             T ydot = -(H - diss);
             // termRestrictUpdate clamp; written so that a NaN stays a NaN
-            if (A.do_clamp) {
+            if (GEN && A.do_clamp) {
                 ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
                 ydot = (ydot > A.clamp_hi) ? A.clamp_hi : ydot;
             }
             T o;
-            if (A.ydot_only) o = ydot;
+            if (GEN && A.ydot_only) o = ydot;
             else {
                 o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
                 // the step started from y0 (stages that read it) or from y itself (Euler step)
-                if (A.post_op) o = post_step(A.post_op, o, A.use_y0 ? y0_c[r] : q[r][3]);
+                if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0_c[r] : q[r][3]);
             }
 #if defined(HJ_ABLATE) && (HJ_ABLATE & 4)
             asm volatile("" ::"v"(o));

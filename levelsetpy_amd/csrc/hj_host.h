@@ -1,0 +1,183 @@
+// Host-side declarations shared by the translation units of libhj_mi355x.so: the ctx, the tiling of
+// the fused kernel, and the per-(dtype, Hamiltonian) launch entry that hj_inst.hip instantiates.
+// The library is built from hj_api.hip (C ABI, split-path kernels) plus one object per (dtype, Hamiltonian)
+// of hj_inst.hip (the fused / direct substep kernels), so that the expensive kernel instantiations compile
+// in parallel (make -j).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <rccl/rccl.h>   // types only: the library is dlopen'ed (hj_comm_*), so libhj loads without RCCL
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/hj_mi355x.h"
+#include "hj_device.h"
+#include "hj_split.h"
+
+namespace hjh {
+
+int fail(int code, const char* fmt, ...);     // records the message for hj_last_error(), returns code
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return hjh::fail(HJ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys)
+
+struct Tiling {
+    int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
+    int ntiles, chunk, nchunks, nchunks1, nblocks, bpx, lpitch;
+    size_t lds_bytes;
+    double score;
+    bool ok;
+};
+
+struct KernelCfg { int NT, R, KH; };
+
+}  // namespace hjh
+
+struct hj_ctx {
+    int ndim, dtype, device;
+    int64_t N[HJ_MAX_DIM];
+    double xmin[HJ_MAX_DIM], dx[HJ_MAX_DIM];
+    int bc[HJ_MAX_DIM], tz[HJ_MAX_DIM];
+    int halo_lo, halo_hi;
+    hipStream_t stream;
+    size_t esz;
+    int64_t total;
+    void* coord[HJ_MAX_DIM];           // device, dtype
+    std::vector<double> coord_host[HJ_MAX_DIM];
+    void* aux[4];
+    int64_t aux_n[4];
+    unsigned long long* ring;          // RING_SLOTS * HJ_MAX_DIM keys
+    int ring_pos;
+    int slot_ring[HJ_BOUND_SLOTS];     // user slot -> ring index (-1 = none)
+    unsigned long long* keys;          // scratch keys: [0,32) weno eps (8 groups x 4 dims), [32,36) upwind min/max
+    void* weno_vals;                   // HJ_MAX_DIM values of dtype
+    const void* weno_src;              // caller-provided eps source or null
+    int* flag;                         // nan flag
+    double* partials;                  // per-workgroup partial maxima of max_d1sq_kernel
+    int partials_cap;
+    // static step bound cache
+    int sb_ham;
+    double sb_par[4], sb_val, sb_local, sb_alpha[HJ_MAX_DIM];
+    int diss_local;                    // hj_ctx_set_dissipation: step bound of the local LF variants
+    int post_step_op;                  // hj_ctx_set_post_step: fused into the last stage of hj_rk_step
+    const void* post_arr[2];           // hj_ctx_set_post_arrays
+    int post_arr_op[2];
+    bool sb_valid;
+    int internal_slot;
+    // slab communication (hj_comm_*)
+    ncclComm_t comm;
+    int comm_rank, comm_size, lo_rank, hi_rank;
+    hipStream_t comm_stream, edge_stream;
+    hipEvent_t ev_start, ev_edge, ev_edge2, ev_comm;
+    hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
+    int slab_pending;
+    int external_exchange;             // hj_comm_init_external: the caller fills the pad planes itself
+    hipEvent_t launch_stop;            // if set, the next tiled launch signals this event on completion
+    int ext_events;                    // HJ_EXT_EVENTS (default 1): use that instead of hipEventRecord
+    // axis-0 tables extended by pad0 planes either side (deep-halo stepper computes on pad planes)
+    int pad0;
+    void* coord0_ext;
+    void* aux_ext[2];
+    // tuning
+    hjh::KernelCfg cfg;
+    int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
+    int target_blocks, min_chunk, warmup_cost, no_plain;
+    size_t lds_limit;
+    // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
+    std::map<std::pair<const void*, size_t>, int> occ_cache;
+};
+
+namespace hjh {
+
+using namespace hj;
+
+int env_int(const char* name, int dflt);
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1);
+void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu);
+int cfg_kh(int nd, int nt, int r);
+
+template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
+    for (int d = 0; d < HJ_MAX_DIM; ++d) H.coord[d] = (const T*)c->coord[d];
+    for (int s = 0; s < 4; ++s) H.aux[s] = (const T*)c->aux[s];
+    if (c->coord0_ext) H.coord[0] = (const T*)c->coord0_ext + c->pad0;
+    for (int s = 0; s < 2; ++s)
+        if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
+    for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
+}
+
+template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G) {
+    long long s = 1;
+    for (int d = ND - 1; d >= 0; --d) {
+        G.n[d] = (int)c->N[d];
+        G.bc[d] = c->bc[d];
+        G.km[d] = c->tz[d] ? T(-1) : T(1);
+        G.inv_dx[d] = (T)(1.0 / c->dx[d]);
+        fill_stencil_constants<T>(c->dx[d], G.K[d]);
+        G.stride[d] = s;
+        s *= c->N[d];
+    }
+    G.halo_lo = c->halo_lo;
+    G.halo_hi = c->halo_hi;
+    G.total = c->total;
+}
+
+// costate scale the scheme's stencil leaves out (hj_device.h, scaling note)
+template <typename T> T scheme_scale(int scheme, double dx) {
+    if (scheme == HJ_WENO5_ASSHIPPED) return (T)((1.0 / dx) * (1.0 / 60.0));
+    if (scheme == HJ_WENO5) return (T)((1.0 / dx) * (1.0 / 12.0));
+    return (T)((1.0 / dx) * 0.5);     // ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
+}
+
+struct SubstepCall {
+    int scheme, ham, stage, restrict_sign;
+    const double* par;
+    double dt;
+    const void *y, *y0;
+    void* out;
+    unsigned long long* bound;
+    int64_t p0, p1;
+    int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
+    int post_op = 0;          // fused post-step min/max with the state the step started from
+    bool on_aux = false;      // launch on the ctx's auxiliary (edge) stream instead of the ctx stream
+};
+
+inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s.on_aux ? c->edge_stream : c->stream; }
+
+// (threads per workgroup, cells per thread, halo slots per thread) instantiated for the tiled kernel
+#ifndef HJ_CONFIGS
+#ifdef HJ_ALL_CONFIGS   // the full sweep table (tools/cfgsweep.sh); ~2.5 min to compile
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(1024, 2, 1, 4, 2) X(512, 2, 1, 4, 2) X(256, 4, 3, 2, 2) X(256, 2, 2, 4, 2) \
+                      X(512, 1, 1, 4, 2) X(256, 1, 2, 6, 2) X(1024, 1, 1, 4, 2) \
+                      X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
+                      X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
+#else                   // the defaults per scheme plus the runners-up of the round-1 sweeps
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(256, 4, 3, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
+#endif
+#endif
+
+// 4-D grids tile three plane axes: the halo cross is ~2x the tile, so more halo slots per thread
+#ifndef HJ_CONFIGS_4D
+#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2) X(1024, 1, 2, 2, 2)
+#endif
+
+// the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
+// instantiated in hj_inst.hip
+template <typename T, typename HAM> int launch_scheme(hj_ctx* c, const SubstepCall& s);
+
+}  // namespace hjh

@@ -1,0 +1,217 @@
+// The fused / direct RK-substep kernels of ONE (dtype, Hamiltonian) pair and their launch code.
+// Compiled once per pair with -DHJ_INST_T=<double|float> -DHJ_INST_HAM=<HamDubinsRel|...> (Makefile), so
+// the kernel instantiations build in parallel.  gfx950 only.
+#include "hj_host.h"
+#include "hj_fused.h"
+
+namespace hjh {
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE>
+int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
+    constexpr int ND = HAM::ND;
+    {
+        auto kern0 = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE>;
+        const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
+        auto it = c->occ_cache.find(key);
+        if (it == c->occ_cache.end()) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+            it = c->occ_cache.emplace(key, nb).first;
+        }
+        const int occ_blocks = it->second;
+        choose_chunks(c, t, s.p0, s.p1, occ_blocks);
+        if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
+        t.nchunks1 = t.nchunks;
+        if (s.q1 > s.q0) {     // second range: same chunk length
+            t.nchunks += (int)((s.q1 - s.q0 + t.chunk - 1) / t.chunk);
+            t.nblocks = t.nchunks * t.ntiles;
+            t.bpx = (t.nblocks + 7) / 8;
+        }
+        if (c->debug) {
+            fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
+                    NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.lpitch, t.ntiles, t.chunk,
+                    t.nchunks, t.nblocks, occ_blocks, t.lds_bytes, t.score);
+            c->debug = 0;
+        }
+    }
+    FusedArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    A.bound = s.bound;
+    long long st = 1;
+    for (int d = ND - 1; d >= 0; --d) {
+        A.n[d] = (int)c->N[d];
+        A.bc[d] = c->bc[d];
+        A.km[d] = c->tz[d] ? T(-1) : T(1);
+        fill_stencil_constants<T>(c->dx[d], A.K[d]);
+        A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
+        A.pstride[d] = (d >= 1) ? (int)st : 0;
+        if (d == 0) A.stride0 = st;
+        st *= c->N[d];
+        A.E[d] = t.E[d];
+        A.ntile[d] = t.ntile[d];
+    }
+    A.halo_lo = c->halo_lo;
+    A.halo_hi = c->halo_hi;
+    A.ntiles = t.ntiles;
+    A.lpitch = t.lpitch;
+    A.chunk = t.chunk;
+    A.nchunks = t.nchunks;
+    A.plane_begin = (int)s.p0;
+    A.plane_end = (int)s.p1;
+    A.plane_begin2 = (int)s.q0;
+    A.plane_end2 = (int)s.q1;
+    A.nchunks1 = t.nchunks1;
+    A.nblocks = t.nblocks;
+    A.blocks_per_xcd = t.bpx;
+    A.ydot_only = (s.stage == HJ_STAGE_YDOT);
+    A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
+    switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
+        case HJ_STAGE_RK3_HALF: A.ca = T(0.75); A.cb = T(0.25); break;           // ode_cfl_3.py:184,193
+        case HJ_STAGE_RK3_FULL: A.ca = T(1.0 / 3.0); A.cb = T(2.0 / 3.0); break; // :226,241
+        case HJ_STAGE_RK2_FULL: A.ca = T(0.5); A.cb = T(0.5); break;             // ode_cfl_2.py:184,201
+        default: A.ca = T(0); A.cb = T(1); break;
+    }
+    A.dt = (T)s.dt;
+    A.post_op = s.post_op;
+    A.do_clamp = s.restrict_sign != 0;
+    A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
+    A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
+    fill_ham<T>(c, s.par, A.ham);
+    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE>;
+    if (t.lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    }
+    const char* dump = getenv("HJ_TIMING_DUMP");    // debug: per-workgroup start/end clocks of every launch
+    unsigned long long* tbuf = nullptr;
+    if (dump && *dump) {
+        HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), call_stream(c, s)));
+        A.timing = tbuf;
+    }
+    if (c->launch_stop) {
+        // completion signal attached to the dispatch packet itself: a separate hipEventRecord costs a
+        // marker packet and ~6 us of bubble before the next kernel of the stream (slab timeline)
+        hipExtLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
+                              (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
+        c->launch_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0,
+                           (T*)s.out, A);
+    }
+    HIP_TRY(hipGetLastError());
+    if (tbuf) {
+        std::vector<unsigned long long> h((size_t)t.nblocks * 4);
+        HIP_TRY(hipStreamSynchronize(call_stream(c, s)));
+        HIP_TRY(hipMemcpy(h.data(), tbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(tbuf));
+        if (FILE* f = fopen(dump, "a")) {
+            fprintf(f, "# launch nblocks=%d ntiles=%d chunk=%d stage=%d\n", t.nblocks, t.ntiles, t.chunk, s.stage);
+            for (int i = 0; i < t.nblocks; ++i)
+                fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+            fclose(f);
+        }
+    }
+    return HJ_OK;
+}
+
+// plain RK stages (no clamp, no post-step operator, not ydot-only) run the flag-free instantiations
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
+int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
+    const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0 && !c->no_plain;
+    if (plain && s.stage == HJ_STAGE_EULER) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 1>(c, s, t);
+    if (plain) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 2>(c, s, t);
+    return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 0>(c, s, t);
+}
+
+template <typename T, typename HAM, int SCHEME>
+int launch_direct(hj_ctx* c, const SubstepCall& s) {
+    constexpr int ND = HAM::ND;
+    DirectArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.y = (const T*)s.y;
+    A.y0 = (const T*)s.y0;
+    A.out = (T*)s.out;
+    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    A.bound = s.bound;
+    fill_grid<T, ND>(c, A.G);
+    for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
+    if (s.p0 < 0 || s.p1 > c->N[0] || (s.q1 > s.q0 && (s.q0 < 0 || s.q1 > c->N[0])))
+        return hjh::fail(HJ_EUNSUPPORTED, "pad planes need the tiled kernel");
+    const long long plane = c->total / c->N[0];
+    A.cell_begin = s.p0 * plane;
+    A.cell_end = s.p1 * plane;
+    A.stage = s.stage;
+    A.post_op = s.post_op;
+    A.restrict_sign = s.restrict_sign;
+    A.dt = (T)s.dt;
+    fill_ham<T>(c, s.par, A.ham);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (s.q1 <= s.q0) break;
+            A.cell_begin = s.q0 * plane;
+            A.cell_end = s.q1 * plane;
+        }
+        const long long cells = A.cell_end - A.cell_begin;
+        if (cells <= 0) continue;
+        int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, call_stream(c, s), A);
+        HIP_TRY(hipGetLastError());
+    }
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME>
+int launch_cfg(hj_ctx* c, const SubstepCall& s) {
+#ifdef HJ_TUNE_BUILD
+    // quick-iteration build: only fp64 Dubins with the two WENO5 arithmetics is compiled tiled
+    constexpr bool tiled_ok = std::is_same<T, double>::value && HAM::ID == HJ_HAM_DUBINS_REL &&
+                              (SCHEME == HJ_WENO5 || SCHEME == HJ_WENO5_ASSHIPPED);
+#else
+    constexpr bool tiled_ok = true;
+#endif
+    if constexpr (tiled_ok) {
+        if (!c->force_direct) {
+            KernelCfg k = c->cfg;
+            int pd = c->pd, occ = c->occ_hint;
+            if (!c->cfg_from_env) {
+                // round-1 sweeps (profiles/): the heavier the per-cell arithmetic, the fewer cells per
+                // thread fit in the 256-VGPR budget without scratch
+                if (HAM::ND == 4) { k.NT = sizeof(T) == 4 ? 1024 : 512; k.R = sizeof(T) == 4 ? 1 : 2; pd = 2; occ = 2; }
+                // the light stencils keep 4 cells per thread in registers on large grids; below ~12 M cells
+                // (201^3 = 8.1 M: 32 k cells per CU) three small independent workgroups per CU with longer
+                // chunks win (sweeps at 101^3 ... 401^3 after the deferred-ghost fix)
+                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total >= 12000000) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
+                // tiny grids (<= ~135^3) run one wave per SIMD and a launch is a chain of ~10 plane
+                // iterations: one cell per thread shortens every iteration (7-10 % at 51^3 ... 129^3)
+                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total < 2500000) { k.NT = 512; k.R = 1; pd = 2; occ = 4; }
+                else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
+                k.KH = cfg_kh(HAM::ND, k.NT, k.R);
+            }
+            Tiling t = make_tiling(c, k, s.p0, s.p1);
+            if (t.ok) {
+#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
+                if constexpr (HAM::ND == 4) { HJ_CONFIGS_4D(X) }
+                else { HJ_CONFIGS(X) }
+#undef X
+            }
+        }
+    }
+    return launch_direct<T, HAM, SCHEME>(c, s);
+}
+
+template <typename T, typename HAM>
+int launch_scheme(hj_ctx* c, const SubstepCall& s) {
+    switch (s.scheme) {
+        case HJ_ENO2: return launch_cfg<T, HAM, HJ_ENO2>(c, s);
+        case HJ_ENO3: return launch_cfg<T, HAM, HJ_ENO3>(c, s);
+        case HJ_WENO5: return launch_cfg<T, HAM, HJ_WENO5>(c, s);
+        case HJ_WENO5_ASSHIPPED: return launch_cfg<T, HAM, HJ_WENO5_ASSHIPPED>(c, s);
+    }
+    return hjh::fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
+}
+
+template int launch_scheme<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const SubstepCall&);
+
+}  // namespace hjh

@@ -279,3 +279,43 @@ def test_fp32_4d_rk3_steps_vs_fp64_oracle(scheme):
         assert rel.max() <= 1e-4, rel.max()
     else:
         assert np.mean(rel > 1e-4) <= 5e-3 and rel.max() <= 0.05, (float(np.mean(rel > 1e-4)), rel.max())
+
+
+# ------------------------------------------------------------------------------ kernel variants
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((33, 21, 19), 2), ((20, 45), None), ((9, 8, 10, 7), (0, 1, 2, 3))])
+def test_plain_stage_kernels_bitwise_equal_generic(scheme, n, pd, monkeypatch):
+    """The flag-free instantiations (MODE 1/2: plain Euler / convex-combination stages) against the
+    runtime-flag kernel (HJ_NO_PLAIN=1) on one RK3 and one RK2 step: bitwise."""
+    nd = len(n)
+    if nd == 3:
+        g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+        ham, par = _ffi.HAM_DUBINS_REL, PAR_DUBINS
+        data = O.shape_cylinder(og, 2, None, .5)
+    elif nd == 2:
+        g, og = mk([-1, -1], [1, 1], n, pd)
+        ham, par = _ffi.HAM_DOUBLE_INTEGRATOR, [1.5, 0, 0, 0]
+        data = O.shape_sphere(og, None, .25)
+    else:
+        g, og = pendulum_grid(n, pd)
+        ham, par = _ffi.HAM_DOUBLE_PENDULUM, [1.0, 0, 0, 0]
+        data = O.shape_sphere(og, None, 1.5)
+    data = data + 0.02 * np.random.default_rng(8).standard_normal(n)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HJ_NO_PLAIN", flag)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        y = dg.to_device(data)
+        outs = []
+        for order in (3, 2):
+            nxt, w0, w1 = dg.empty(), dg.empty(), dg.empty()
+            tout, dtout = C.c_double(), C.c_double()
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), 0., 1e9, 0.8, 1e300, 0,
+                                         dg.ptr(y), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+            dg.sync()
+            outs.append(nxt)
+        res[flag] = outs
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    assert float((res["0"][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 0
