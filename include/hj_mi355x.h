@@ -136,6 +136,19 @@ int hj_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham
                double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
                void* y_out, void* work0, void* work1, double* t_out, double* dt_out);
 
+/* Two RK stages in ONE launch (hj_fused12.h; no reference counterpart -- the reference evaluates every stage
+ * as its own chain of array expressions, ode_cfl_3.py:129-193):
+ *     y1 = y + dt*L(y);   out = ca*y + cb*(y1 + dt*L(y1))        (ca, cb) = (3/4, 1/4) RK3, (1/2, 1/2) RK2
+ * y1 is kept on chip (1R + 1W words per cell instead of 5).  Bitwise equal to hj_rk_substep(EULER) followed by
+ * hj_rk_substep(RK3_HALF | RK2_FULL).  2-D / 3-D grids, every scheme but HJ_WENO5 (its epsilon is a global
+ * reduction over y1), single domain (no slab halos), arrays below 4 GiB; HJ_EUNSUPPORTED otherwise.
+ * hj_rk_step uses it by itself where it pays (large grids; HJ_FUSE12=0/1 overrides):
+ * hj_rk_plan reports the number of kernel launches one hj_rk_step makes and whether stages 1+2 are fused. */
+int hj_rk_stage12(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, double dt, double ca, double cb,
+                  const void* y, void* out, int bound_slot);
+int hj_rk_plan(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, int restrict_sign,
+               int* launches_host, int* stage_fused_host);
+
 /* The whole odeCFLn loop of a time span in one call (ode_cfl_3.py:125-251 with singleStep off and no
  * postTimeStep / terminalEvent callbacks): steps from t0 until tf - t < 100*eps*|tf| (or max_steps > 0
  * steps; stop_tol >= 0 replaces the stopping test by HJIPDE_solve's `t < tf - stop_tol`,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "hj_rk_substep": (_i, [_vp, _i, _i, _pd, _d, _i, _d, _i, _vp, _vp, _vp, _i, _i64, _i64]),
     "hj_read_step_bound": (_i, [_vp, _i, _pd, _pd]),
     "hj_rk_step": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _pd, _pd]),
+    "hj_rk_stage12": (_i, [_vp, _i, _i, _pd, _d, _d, _d, _vp, _vp, _i]),
+    "hj_rk_plan": (_i, [_vp, _i, _i, _i, _pd, _i, _pi, _pi]),
     "hj_rk_integrate": (_i, [_vp, _i, _i, _i, _pd, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _i64, _d, _pd, _pi64, _pi]),
     "hj_ctx_set_post_step": (_i, [_vp, _i]),
     "hj_ctx_set_post_arrays": (_i, [_vp, _i, _vp, _i, _vp]),

@@ -145,6 +145,12 @@ extern template int launch_scheme<double, HamDoublePendulum<double>>(hj_ctx*, co
 extern template int launch_scheme<float, HamDubinsRel<float>>(hj_ctx*, const SubstepCall&);
 extern template int launch_scheme<float, HamDoubleIntegrator<float>>(hj_ctx*, const SubstepCall&);
 extern template int launch_scheme<float, HamDoublePendulum<float>>(hj_ctx*, const SubstepCall&);
+extern template int launch_stage12<double, HamDubinsRel<double>>(hj_ctx*, const Stage12Call&);
+extern template int launch_stage12<double, HamDoubleIntegrator<double>>(hj_ctx*, const Stage12Call&);
+extern template int launch_stage12<double, HamDoublePendulum<double>>(hj_ctx*, const Stage12Call&);
+extern template int launch_stage12<float, HamDubinsRel<float>>(hj_ctx*, const Stage12Call&);
+extern template int launch_stage12<float, HamDoubleIntegrator<float>>(hj_ctx*, const Stage12Call&);
+extern template int launch_stage12<float, HamDoublePendulum<float>>(hj_ctx*, const Stage12Call&);
 
 }  // namespace hjh
 
@@ -320,6 +326,55 @@ int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
     s.bound = next_ring(c, user_slot, &rc);
     if (rc) return rc;
     return c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
+}
+
+template <typename T> int stage12_ham(hj_ctx* c, const Stage12Call& s) {
+    switch (s.ham) {
+        case HJ_HAM_DUBINS_REL: return launch_stage12<T, HamDubinsRel<T>>(c, s);
+        case HJ_HAM_DOUBLE_INTEGRATOR: return launch_stage12<T, HamDoubleIntegrator<T>>(c, s);
+        case HJ_HAM_DOUBLE_PENDULUM: return launch_stage12<T, HamDoublePendulum<T>>(c, s);
+    }
+    return fail(HJ_EINVAL, "unknown Hamiltonian id %d", s.ham);
+}
+
+// Two RK stages in one launch (hj_fused12.h).  probe: only report whether the kernel can take this grid.
+int do_stage12(hj_ctx* c, Stage12Call& s, int user_slot) {
+    int rc = check_ham(c, s.ham, s.par);
+    if (rc) return rc;
+    if (c->ndim > 3 || s.scheme == HJ_WENO5 || s.scheme < 0 || s.scheme > 3)
+        return fail(HJ_EUNSUPPORTED, "no stage-fused kernel for this scheme / dimension");
+    if (c->halo_lo || c->halo_hi) return fail(HJ_EUNSUPPORTED, "the stage-fused kernel does not take slab halos");
+    if ((double)c->total * (double)c->esz >= 4294967295.0) return fail(HJ_EUNSUPPORTED, "array of 4 GiB or more");
+    if (c->N[0] < 8) return fail(HJ_EUNSUPPORTED, "fewer than 8 planes");
+    for (int d = 1; d < c->ndim; ++d)
+        if (c->N[d] < 4) return fail(HJ_EUNSUPPORTED, "fewer than 4 nodes along dim %d", d);
+    if (!s.probe) {
+        if (!s.y || !s.out) return fail(HJ_EINVAL, "null array argument");
+        if (s.y == s.out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
+        s.bound = next_ring(c, user_slot, &rc);
+        if (rc) return rc;
+    }
+    return c->dtype == HJ_F64 ? stage12_ham<double>(c, s) : stage12_ham<float>(c, s);
+}
+
+// does hj_rk_step fuse the first two stages on this ctx?  (cached per scheme / Hamiltonian)
+bool use_stage12(hj_ctx* c, int order, int scheme, int ham, const double* par, int restrict_sign) {
+    if (order < 2 || c->fuse12 == 0 || restrict_sign != 0) return false;
+    if (order == 2 && c->post_step_op != 0) return false;     // the fused post-step operator rides on the LAST stage
+    if (c->fuse12 < 0) {
+        // auto: the fusion trades HBM traffic for redundant ring / warm-up work; it pays once the arrays are
+        // far beyond the 256 MB Infinity Cache (3-D) or whenever the ring is a sliver of the tile (2-D)
+        const double bytes = (double)c->total * (double)c->esz;
+        if (c->ndim == 3 && bytes < 300e6) return false;
+        if (c->ndim == 2 && bytes < 32e6) return false;
+    }
+    const int key = scheme * 8 + ham;
+    auto it = c->f12_ok.find(key);
+    if (it == c->f12_ok.end()) {
+        Stage12Call s{scheme, ham, par, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr, true};
+        it = c->f12_ok.emplace(key, do_stage12(c, s, -1) == HJ_OK).first;
+    }
+    return it->second;
 }
 
 int read_ring(hj_ctx* c, int pos, double* sb, double* amax) {
@@ -700,7 +755,13 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // planes of loads a chunk pays before its first result: 2*HJ_STENCIL = 6 (HJ_WARMUP_COST: sweep knob)
     c->warmup_cost = std::max(0, env_int("HJ_WARMUP_COST", 2 * HJ_STENCIL));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
-    c->no_plain = env_int("HJ_NO_PLAIN", 0);     // test / A-B knob: always run the runtime-flag kernel (MODE 0)
+    c->no_plain = env_int("HJ_NO_PLAIN", 0);
+    c->fuse12 = env_int("HJ_FUSE12", -1);         // 0 never, 1 whenever a tiling exists, -1 by grid size
+    c->f12_nt = env_int("HJ_F12_NT", 0);
+    c->f12_r = env_int("HJ_F12_R", 0);
+    c->f12_kh = env_int("HJ_F12_KH", 0);
+    c->f12_warm = env_int("HJ_F12_WARM", 9);
+    c->f12_e2 = env_int("HJ_F12_E2", 0);     // test / A-B knob: always run the runtime-flag kernel (MODE 0)
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);
@@ -951,11 +1012,29 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     const int64_t n0 = c->N[0];
     auto slot = [&]() { int s = c->internal_slot; c->internal_slot = (s + 1) % (HJ_BOUND_SLOTS - 1); return s; };
     double t = t0;
+    const bool fuse = use_stage12(c, order, scheme, ham, par, restrict_sign);
     if (order == 1) {
         SubstepCall s{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, y_out, nullptr, 0, n0};
         s.post_op = c->post_step_op;
         if ((rc = do_substep(c, s, slot()))) return rc;
         t = t0 + dt;
+    } else if (order == 2 && fuse) {
+        // both stages in one launch: y_out = (y + (y1 + dt L(y1)))/2 with y1 = y + dt L(y)  (ode_cfl_2.py:151-201)
+        Stage12Call a{scheme, ham, par, dt, 0.5, 0.5, y_in, y_out, nullptr};
+        if ((rc = do_stage12(c, a, slot()))) return rc;
+        const double t1 = t0 + dt, t2 = t1 + dt;
+        t = 0.5 * (t0 + t2);
+    } else if (order == 3 && fuse) {
+        // stages 1+2 in one launch (y1 never reaches HBM), then the third stage  (ode_cfl_3.py:151-241)
+        Stage12Call a{scheme, ham, par, dt, 0.75, 0.25, y_in, work1, nullptr};
+        if ((rc = do_stage12(c, a, slot()))) return rc;
+        SubstepCall d{scheme, ham, HJ_STAGE_RK3_FULL, restrict_sign, par, dt, work1, y_in, y_out, nullptr, 0, n0};
+        d.post_op = c->post_step_op;
+        if ((rc = do_substep(c, d, slot()))) return rc;
+        const double t1 = t0 + dt, t2 = t1 + dt;
+        const double tHalf = 0.25 * (3 * t0 + t2);
+        const double tThreeHalf = tHalf + dt;
+        t = (1.0 / 3.0) * (t0 + 2 * tThreeHalf);
     } else if (order == 2) {
         SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, work0, nullptr, 0, n0};
         if ((rc = do_substep(c, a, slot()))) return rc;
@@ -987,6 +1066,26 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     }
     if (t_out) *t_out = t;
     if (dt_out) *dt_out = dt;
+    return HJ_OK;
+}
+
+int hj_rk_stage12(hj_ctx* c, int scheme, int ham, const double* par, double dt, double ca, double cb,
+                  const void* y, void* out, int bound_slot) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (bound_slot < 0 || bound_slot >= HJ_BOUND_SLOTS) return fail(HJ_EINVAL, "bound_slot out of range");
+    Stage12Call s{scheme, ham, par, dt, ca, cb, y, out, nullptr};
+    return do_stage12(c, s, bound_slot);
+}
+
+int hj_rk_plan(hj_ctx* c, int order, int scheme, int ham, const double* par, int restrict_sign, int* launches,
+               int* stage_fused) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    if (order < 1 || order > 3) return fail(HJ_EINVAL, "order must be 1, 2 or 3");
+    int rc = check_ham(c, ham, par);
+    if (rc) return rc;
+    const bool f = use_stage12(c, order, scheme, ham, par, restrict_sign);
+    if (launches) *launches = (f ? order - 1 : order) * (scheme == HJ_WENO5 ? 3 : 1);
+    if (stage_fused) *stage_fused = f ? 1 : 0;
     return HJ_OK;
 }
 

@@ -44,16 +44,20 @@ namespace hj {
 #endif
 
 // LDS stencil read.  ds_read2_b64 moves 16 B/lane in 8 LDS cycles, two ds_read_b64 in 4
-// (MI355X_MICROARCH.md, LDS table): a volatile access keeps the compiler from pairing the reads.
+// (MI355X_MICROARCH.md, LDS table), and the LDS pipe is the busiest unit of this kernel (PMC: 65 % at 513^3,
+// half of it counted as bank-conflict cycles).  The back end pairs any two LDS reads that share a base
+// register and differ by a constant offset, i.e. the six neighbours along the contiguous axis; passing each
+// address through an empty asm makes the bases opaque, so they stay single ds_read_b64 (one extra 32-bit
+// add per read).  Measured (round 2): the opaque offsets cost 12-18 VGPRs -- one wave per SIMD less at 201^3
+// (172 -> 184 VGPRs), scratch at 401^3+ -- and gain nothing; default 0 = let the compiler pair.
 #ifndef HJ_LDS_NO_READ2
-#define HJ_LDS_NO_READ2 0   // measured: volatile LDS reads are far slower (profiles/r01 notes); kept as a switch
+#define HJ_LDS_NO_READ2 0
 #endif
-template <typename T> __device__ __forceinline__ T lds_read(const T* p) {
+template <typename T> __device__ __forceinline__ T lds_read(const T* buf, int o) {
 #if HJ_LDS_NO_READ2
-    return *reinterpret_cast<const volatile T*>(p);
-#else
-    return *p;
+    if constexpr (sizeof(T) == 8) asm("" : "+v"(o));     // the 32-bit element offset, so that `buf` keeps its LDS address space
 #endif
+    return buf[o];
 }
 
 template <typename T, int ND> struct FusedArgs {
@@ -448,7 +452,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
                 for (int j = 0; j < 7; ++j) v[j] = q[r][j];
 #else
 #pragma unroll
-                for (int j = 0; j < 7; ++j) v[j] = (j == 3) ? q[r][3] : lds_read(c + (j - 3) * ls[d]);
+                for (int j = 0; j < 7; ++j) {
+                    const int o = own_lds[r] + (j - 3) * ls[d];
+                    // only the contiguous axis yields constant offsets from one base (what the back end pairs)
+                    v[j] = (j == 3) ? q[r][3] : (d == ND - 1 ? lds_read(buf, o) : buf[o]);
+                }
 #endif
 #if defined(HJ_ABLATE) && (HJ_ABLATE & 1)
                 pc[d] = v[0]; hd[d] = v[6];

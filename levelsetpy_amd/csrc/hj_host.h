@@ -98,9 +98,11 @@ struct hj_ctx {
     hjh::KernelCfg cfg;
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
     int target_blocks, min_chunk, warmup_cost, no_plain;
+    int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;    // stage-fused kernel: 0 off, 1 on, -1 auto (by grid size); config override
     size_t lds_limit;
     // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
     std::map<std::pair<const void*, size_t>, int> occ_cache;
+    std::map<int, bool> f12_ok;        // (scheme, Hamiltonian) -> the stage-fused kernel has a tiling for this grid
 };
 
 namespace hjh {
@@ -179,5 +181,17 @@ inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s
 // the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
 // instantiated in hj_inst.hip
 template <typename T, typename HAM> int launch_scheme(hj_ctx* c, const SubstepCall& s);
+
+// two RK stages in one launch (hj_fused12.h): out = ca*y + cb*(y1 + dt*L(y1)), y1 = y + dt*L(y)
+struct Stage12Call {
+    int scheme, ham;
+    const double* par;
+    double dt, ca, cb;
+    const void* y;
+    void* out;
+    unsigned long long* bound;
+    bool probe = false;       // only answer whether a tiling exists (HJ_OK) or not (HJ_EUNSUPPORTED)
+};
+template <typename T, typename HAM> int launch_stage12(hj_ctx* c, const Stage12Call& s);
 
 }  // namespace hjh

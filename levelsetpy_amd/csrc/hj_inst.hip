@@ -3,6 +3,7 @@
 // the kernel instantiations build in parallel.  gfx950 only.
 #include "hj_host.h"
 #include "hj_fused.h"
+#include "hj_fused12.h"
 
 namespace hjh {
 
@@ -212,6 +213,189 @@ int launch_scheme(hj_ctx* c, const SubstepCall& s) {
     return hjh::fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
 }
 
+// ------------------------------------------------------------------------------------ stage-fused launch
+// (threads, A slots per thread, H slots per thread, waves/SIMD hint)
+#ifndef HJ_CONFIGS12
+#define HJ_CONFIGS12(X) X(512, 4, 2, 2) X(512, 3, 2, 2) X(512, 2, 2, 2) X(768, 2, 2, 3) X(1024, 2, 1, 4)
+#endif
+
+struct Tiling12 {
+    int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
+    int ntiles, chunk, nchunks, nblocks, bpx, nA, nH;
+    size_t lds_bytes;
+    double score;
+    bool ok;
+};
+
+inline Tiling12 make_tiling12(const hj_ctx* c, int NT, int R, int KH, size_t lds_limit) {
+    const int nd = c->ndim, W = HJ_STENCIL;
+    Tiling12 best;
+    best.ok = false;
+    best.score = 1e300;
+    int n[HJ_MAX_DIM];
+    for (int d = 0; d < nd; ++d) n[d] = (int)c->N[d];
+    std::vector<int> cand2;                 // extents of the last axis
+    for (int parts = 1; parts <= 128; ++parts) {
+        int e = (n[nd - 1] + parts - 1) / parts;
+        if (cand2.empty() || cand2.back() != e) cand2.push_back(e);
+        if (e <= 2) break;
+    }
+    if (c->f12_e2 > 0) cand2.assign(1, std::min(c->f12_e2, n[nd - 1]));      // tuning knob: force the row extent
+    for (int e2 : cand2) {
+        if (e2 < 2) continue;
+        const int e1max = nd == 3 ? n[1] : 1;
+        for (int e1 = (nd == 3 ? 2 : 1); e1 <= e1max; ++e1) {
+            long long T0, nA, nH, ybox, wbox, cells;
+            if (nd == 3) {
+                cells = (long long)e1 * e2;
+                nA = cells + 2 * W * (e1 + e2);
+                nH = 4 * W * (e1 + e2) + 4 * W * W;
+                T0 = cells + 4 * W * (e1 + e2) + 4 * W * W;
+                ybox = (long long)(e1 + 4 * W) * (e2 + 4 * W);
+                wbox = (long long)(e1 + 2 * W) * (e2 + 2 * W);
+            } else {
+                cells = e2;
+                nA = cells + 2 * W;
+                nH = 4 * W;
+                T0 = cells + 4 * W;
+                ybox = e2 + 4 * W;
+                wbox = e2 + 2 * W;
+            }
+            if (nA > (long long)NT * R || nH > (long long)NT * KH) continue;
+            const size_t lds = 512 + (size_t)(2 * ybox + 7 * wbox) * c->esz;
+            if (lds > lds_limit) continue;
+            const int E[3] = {1, nd == 3 ? e1 : e2, e2};
+            double waste = 1.0;
+            for (int d = 1; d < nd; ++d) {
+                const int ed = (nd == 3) ? E[d] : e2;
+                const int nt = (n[d] + ed - 1) / ed;
+                waste *= (double)nt * ed / (double)n[d];
+            }
+            const double row_cost = 1.0 + (48.0 / (double)c->esz) / (double)e2;
+            const double util = (double)nA / (double)(((nA + NT - 1) / NT) * NT);
+            // loads per output cell + evaluations per output cell (stage 1 on T1, stage 2 on T)
+            const double score = ((double)T0 / cells * row_cost + 0.6 * (double)(nA + cells) / cells / util) * waste;
+            if (score < best.score) {
+                best.ok = true;
+                best.score = score;
+                best.lds_bytes = lds;
+                best.nA = (int)nA;
+                best.nH = (int)nH;
+                best.ntiles = 1;
+                best.E[0] = 1; best.ntile[0] = 1;
+                for (int d = 1; d < nd; ++d) {
+                    best.E[d] = (nd == 3) ? E[d] : e2;
+                    best.ntile[d] = (n[d] + best.E[d] - 1) / best.E[d];
+                    best.ntiles *= best.ntile[d];
+                }
+            }
+        }
+    }
+    return best;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
+int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
+    constexpr int ND = HAM::ND;
+    auto kern = fused12_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
+    if (t.lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    const auto key = std::make_pair(reinterpret_cast<const void*>(kern), t.lds_bytes);
+    auto it = c->occ_cache.find(key);
+    if (it == c->occ_cache.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+        it = c->occ_cache.emplace(key, nb).first;
+    }
+    {   // axis-0 chunking: whole rounds of resident workgroups; a chunk pays 12 planes of loads and 6 of stage 1
+        const int64_t planes = c->N[0];
+        const int64_t capacity = (int64_t)c->num_cus * it->second;
+        int64_t best_nch = 1;
+        double best_cost = 1e300;
+        for (int64_t nch = 1; nch <= std::max<int64_t>(1, planes / 8); ++nch) {
+            const int64_t chunk = (planes + nch - 1) / nch;
+            const int64_t blocks = ((planes + chunk - 1) / chunk) * t.ntiles;
+            const int64_t rounds = (blocks + capacity - 1) / capacity;
+            const double cost = (double)rounds * ((double)chunk + (double)c->f12_warm);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best_nch = nch; }
+        }
+        if (c->target_blocks > 0) best_nch = std::max<int64_t>(1, std::min<int64_t>(planes / 8, c->target_blocks / t.ntiles));
+        t.chunk = (int)((planes + best_nch - 1) / best_nch);
+        t.nchunks = (int)((planes + t.chunk - 1) / t.chunk);
+        t.nblocks = t.nchunks * t.ntiles;
+        t.bpx = (t.nblocks + 7) / 8;
+    }
+    if (c->debug) {
+        fprintf(stderr, "[hj] fused12 NT=%d R=%d KH=%d OCC=%d E=(%d,%d) nA=%d nH=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
+                NT, R, KH, OCC, t.E[1], ND > 2 ? t.E[2] : 0, t.nA, t.nH, t.ntiles, t.chunk, t.nchunks, t.nblocks, it->second, t.lds_bytes, t.score);
+        c->debug = 0;
+    }
+    Fused12Args<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.bound = s.bound;
+    long long st = 1;
+    for (int d = ND - 1; d >= 0; --d) {
+        A.n[d] = (int)c->N[d];
+        A.bc[d] = c->bc[d];
+        A.km[d] = c->tz[d] ? T(-1) : T(1);
+        fill_stencil_constants<T>(c->dx[d], A.K[d]);
+        A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
+        A.pstride[d] = (d >= 1) ? (int)st : 0;
+        if (d == 0) A.stride0 = st;
+        st *= c->N[d];
+        A.E[d] = t.E[d];
+        A.ntile[d] = t.ntile[d];
+    }
+    A.total_bytes = (unsigned)((size_t)c->total * c->esz);
+    A.ntiles = t.ntiles;
+    A.chunk = t.chunk;
+    A.nchunks = t.nchunks;
+    A.plane_begin = 0;
+    A.plane_end = (int)c->N[0];
+    A.nblocks = t.nblocks;
+    A.blocks_per_xcd = t.bpx;
+    A.nA = t.nA;
+    A.nH = t.nH;
+    A.ca = (T)s.ca;
+    A.cb = (T)s.cb;
+    A.dt = (T)s.dt;
+    fill_ham<T>(c, s.par, A.ham);
+    hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (T*)s.out, A);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME>
+int launch_stage12_cfg(hj_ctx* c, const Stage12Call& s) {
+    if constexpr (HAM::ND == 4 || SCHEME == HJ_WENO5) {
+        return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused kernel for this scheme / dimension");
+    } else {
+        // heavier per-cell arithmetic -> fewer A slots per thread fit in 256 VGPRs
+        int NT = 512, R = (SCHEME == HJ_ENO3) ? 2 : (SCHEME == HJ_ENO2 ? 4 : 3), KH = 2;
+        if (c->f12_nt > 0) NT = c->f12_nt;
+        if (c->f12_r > 0) R = c->f12_r;
+        if (c->f12_kh > 0) KH = c->f12_kh;
+        const Tiling12 t = make_tiling12(c, NT, R, KH, (size_t)160 * 1024 - 256);
+        if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused tiling for this grid");
+        if (s.probe) return HJ_OK;
+#define X(NT_, R_, KH_, OCC_) if (NT == NT_ && R == R_ && KH == KH_) return launch_fused12<T, HAM, SCHEME, NT_, R_, KH_, OCC_>(c, s, t);
+        HJ_CONFIGS12(X)
+#undef X
+        return hjh::fail(HJ_EUNSUPPORTED, "stage-fused configuration (%d,%d,%d) is not built", NT, R, KH);
+    }
+}
+
+template <typename T, typename HAM>
+int launch_stage12(hj_ctx* c, const Stage12Call& s) {
+    switch (s.scheme) {
+        case HJ_ENO2: return launch_stage12_cfg<T, HAM, HJ_ENO2>(c, s);
+        case HJ_ENO3: return launch_stage12_cfg<T, HAM, HJ_ENO3>(c, s);
+        case HJ_WENO5_ASSHIPPED: return launch_stage12_cfg<T, HAM, HJ_WENO5_ASSHIPPED>(c, s);
+    }
+    return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused kernel for scheme %d", s.scheme);
+}
+
 template int launch_scheme<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const SubstepCall&);
+template int launch_stage12<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const Stage12Call&);
 
 }  // namespace hjh

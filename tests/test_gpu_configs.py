@@ -319,3 +319,86 @@ def test_plain_stage_kernels_bitwise_equal_generic(scheme, n, pd, monkeypatch):
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b), float((a - b).abs().max())
     assert float((res["0"][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------ stage-fused kernel (RK stages 1+2)
+def _stage12_case(n, pd, tz=None):
+    nd = len(n)
+    if nd == 3:
+        g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+        ham, par = _ffi.HAM_DUBINS_REL, PAR_DUBINS
+        data = O.shape_cylinder(og, 2, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[1])
+    else:
+        g, og = mk([-1, -1], [1, 1], n, pd)
+        ham, par = _ffi.HAM_DOUBLE_INTEGRATOR, [1.5, 0, 0, 0]
+        data = O.shape_sphere(og, None, .25) + 0.05 * np.sin(5 * og.xs[0] + 3 * og.xs[1])
+    if tz:
+        g.bdryData = [L.Bundle(dict(towardZero=True)) if d in tz else None for d in range(nd)]
+    data = data + 0.02 * np.random.default_rng(4).standard_normal(n)
+    return g, ham, par, data
+
+
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO3", "ENO2"])
+@pytest.mark.parametrize("n,pd,tz", [
+    ((40, 37, 29), 2, None),            # Dubins: axis 2 periodic, axes 0/1 extrapolated; several tiles per axis
+    ((23, 90, 70), (0, 2), None),       # periodic march axis
+    ((31, 45, 33), None, (1,)),         # all extrapolated, towardZero ghost data on axis 1
+    ((9, 8, 200), (1,), None),          # thin grid, long rows, periodic axis 1 narrower than a ring wrap
+    ((64, 700), None, None),            # 2-D: one tile per row
+    ((30, 5000), (1,), None),           # 2-D: several tiles, periodic along the row
+    ((50, 41), (0,), None),             # 2-D: periodic march axis
+])
+def test_stage_fused_kernel_bitwise_equals_two_substeps(scheme, n, pd, tz, monkeypatch):
+    """hj_rk_stage12 (RK stages 1+2 in one launch, y1 kept on chip) against hj_rk_substep(EULER) followed by
+    hj_rk_substep(RK3_HALF / RK2_FULL): BITWISE, for both coefficient pairs; tilings forced small so that
+    interior tiles, edge tiles, shifted last tiles and several chunks all occur."""
+    g, ham, par, data = _stage12_case(n, pd, tz)
+    for knobs in ({}, {"HJ_F12_R": "2", "HJ_TARGET_BLOCKS": "40"}):
+        for k in ("HJ_F12_R", "HJ_TARGET_BLOCKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        y = dg.to_device(data)
+        for (ca, cb, st2) in ((0.75, 0.25, _ffi.STAGE_RK3_HALF), (0.5, 0.5, _ffi.STAGE_RK2_FULL)):
+            y1, ref, got = dg.empty(), dg.empty(), torch.full(dg.shape, float("nan"), dtype=torch.float64, device="cuda")
+            dt = 1.5e-3
+            _substep(dg, scheme, ham, par, _ffi.STAGE_EULER, dt, y, None, y1)
+            _substep(dg, scheme, ham, par, st2, dt, y1, y, ref, slot=4)
+            _ffi.check(dg.lib.hj_rk_stage12(dg.ctx, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), dt, ca, cb,
+                                            dg.ptr(y), dg.ptr(got), 5))
+            dg.sync()
+            assert bool(torch.isfinite(got).all()), "cells left unwritten: %d" % int((~torch.isfinite(got)).sum())
+            assert torch.equal(got, ref), "%s max diff %g at %s" % (knobs, float((got - ref).abs().max()),
+                                                                  np.unravel_index(int((got - ref).abs().argmax()), n))
+            sb1, sb2 = C.c_double(), C.c_double()
+            _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 4, C.byref(sb1), None))
+            _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 5, C.byref(sb2), None))
+            assert sb1.value == sb2.value
+
+
+@pytest.mark.parametrize("order", [2, 3])
+def test_rk_step_with_stage_fusion_equals_unfused(order, monkeypatch):
+    """hj_rk_step with HJ_FUSE12=1 against HJ_FUSE12=0 (three / two launches): bitwise, same t and dt; and
+    hj_rk_plan reports the launch counts."""
+    g, ham, par, data = _stage12_case((36, 50, 44), 2)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HJ_FUSE12", flag)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        cur, nxt, w0, w1 = dg.to_device(data), dg.empty(), dg.empty(), dg.empty()
+        tout, dtout = C.c_double(), C.c_double()
+        nl, fused = C.c_int(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_plan(dg.ctx, order, _ffi.WENO5_ASSHIPPED, ham, _ffi.darr(par), 0, C.byref(nl), C.byref(fused)))
+        assert (nl.value, fused.value) == ((order - 1, 1) if flag == "1" else (order, 0))
+        t = 0.
+        for _ in range(3):
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, _ffi.WENO5_ASSHIPPED, ham, _ffi.darr(par), t, 1e9, 0.8, 1e300, 0,
+                                         dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+            cur, nxt, t = nxt, cur, float(tout.value)
+        dg.sync()
+        res[flag] = (cur.clone(), t, dtout.value)
+    assert res["0"][1:] == res["1"][1:]
+    assert torch.equal(res["0"][0], res["1"][0]), float((res["0"][0] - res["1"][0]).abs().max())

@@ -10,7 +10,7 @@ for f in files:
         k = k.split("(")[0][:70]
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, c in agg.items():
-    if "fused" not in k and "direct" not in k and "max_d1" not in k:
+    if "fused" not in k and "direct" not in k and "max_d1" not in k and "seam" not in k:
         continue
     print(k)
     for name, vals in sorted(c.items()):
