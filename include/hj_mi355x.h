@@ -107,6 +107,27 @@ int hj_ghost(hj_ctx* ctx, int dim, int width, const void* in, void* out);
 int hj_upwind(hj_ctx* ctx, int scheme, int dim, const void* phi, void* derivL, void* derivR,
               double* minmax4_host);
 
+/* ---- termLaxFriedrichs with FOREIGN hamFunc / partialFunc callbacks (the reference's general case:
+ * term_lax_friedrich.py:106-128 around artificial_diss_glf.py:75-109) in two device calls around the callbacks:
+ *   hj_lf_split_begin   derivL[d], derivR[d] = CoStateCalc(grid, data, d) for every d (ndim launches back to
+ *                       back) and the 4*ndim reductions {min L, max L, min R, max R} per dim with ONE host
+ *                       synchronisation (minmax4n_host nullable: no synchronisation).
+ *   ... the caller's hamFunc / partialFunc run on the device arrays ...
+ *   hj_lf_split_end     diss = sum_d (0.5*(derivR_d - derivL_d))*alpha_d, out = -(ham - diss)  (ham == NULL: out =
+ *                       diss, i.e. artificialDissipationGLF's own return value); alpha_d is the device array
+ *                       alpha_arr[d] or, where that is NULL, the scalar alpha_scalar[d];
+ *                       stepBound = 1/sum_d max(alpha_d)/dx_d with the max taken for the array-valued alphas only
+ *                       (artificial_diss_glf.py:101-109).  Bit-identical to the reference's NumPy expressions.
+ *   hj_rk_combine       the array expression of one odeCFLn stage for an arbitrary schemeFunc: mode 1
+ *                       y + dt*z (ode_cfl_3.py:151), 2 0.25*(3*x0 + (y + dt*z)) (:184-193), 3
+ *                       (1/3)*(x0 + 2*(y + dt*z)) (:226-241), 4 0.5*(x0 + (y + dt*z)) (ode_cfl_2.py:184-201). */
+int hj_lf_split_begin(hj_ctx* ctx, int scheme, const void* y, void* const* derivL, void* const* derivR,
+                      double* minmax4n_host);
+int hj_lf_split_end(hj_ctx* ctx, const void* const* derivL, const void* const* derivR, const void* const* alpha_arr,
+                    const double* alpha_scalar, const void* ham, void* out, double* step_bound_host,
+                    double* alpha_max_host);
+int hj_rk_combine(hj_ctx* ctx, int mode, double dt, const void* x0, const void* y, const void* z, void* out, int64_t n);
+
 /* ---- ydot, stepBound = termLaxFriedrichs(t, y, schemeData) with a native hamFunc/partialFunc and
  * artificialDissipationGLF (term_lax_friedrich.py:8, artificial_diss_glf.py:7), one fused kernel.
  * restrict_sign: 0 none; +1 ydot=max(ydot,0); -1 ydot=min(ydot,0) (termRestrictUpdate,

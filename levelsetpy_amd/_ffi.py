@@ -36,6 +36,9 @@ SIGNATURES = {
     "hj_ctx_set_slab": (_i, [_vp, _i, _i]),
     "hj_ghost": (_i, [_vp, _i, _i, _vp, _vp]),
     "hj_upwind": (_i, [_vp, _i, _i, _vp, _vp, _vp, _pd]),
+    "hj_lf_split_begin": (_i, [_vp, _i, _vp, C.POINTER(_vp), C.POINTER(_vp), _pd]),
+    "hj_lf_split_end": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pd, _vp, _vp, _pd, _pd]),
+    "hj_rk_combine": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i64]),
     "hj_lf_term": (_i, [_vp, _i, _i, _pd, _d, _i, _vp, _vp, _pd]),
     "hj_rk_substep": (_i, [_vp, _i, _i, _pd, _d, _i, _d, _i, _vp, _vp, _vp, _i, _i64, _i64]),
     "hj_read_step_bound": (_i, [_vp, _i, _pd, _pd]),

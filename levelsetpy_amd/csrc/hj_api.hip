@@ -265,6 +265,9 @@ int weno_eps_to(hj_ctx* c, const void* y, void* out) {
     const int64_t S = c->total / c->N[0];
     const int bx = (int)((S + 255) / 256);
     // enough workgroups to fill the GPU a few times over, chunks of at least 8 planes
+    // (round 2: folding the partials in the last workgroup to arrive -- one launch instead of two -- was
+    // measured and is no faster: 2000 ticket atomics on one word cost 23 us, and with 320 workgroups the
+    // serial tail of the finisher eats the launch it saves: 29.4 us against 22 + 5.7)
     int by = (int)std::max<int64_t>(1, std::min<int64_t>((c->N[0] + 7) / 8, (256 * 8 + bx - 1) / bx));
     const int chunk = (int)((c->N[0] + by - 1) / by);
     by = (int)((c->N[0] + chunk - 1) / chunk);
@@ -695,6 +698,29 @@ int slab_join(hj_ctx* c) {
     return HJ_OK;
 }
 
+template <typename T>
+static int split_end_launch(hj_ctx* c, const void* const* dL, const void* const* dR, const void* const* alpha,
+                            const double* alpha_s, const void* ham, void* out, unsigned long long* keys) {
+    SplitEndArgs<T> A;
+    memset(&A, 0, sizeof(A));
+    for (int d = 0; d < c->ndim; ++d) {
+        A.dL[d] = (const T*)dL[d];
+        A.dR[d] = (const T*)dR[d];
+        A.alpha[d] = alpha ? (const T*)alpha[d] : nullptr;
+        A.alpha_s[d] = alpha_s ? (T)alpha_s[d] : T(0);
+    }
+    A.ham = (const T*)ham;
+    A.out = (T*)out;
+    A.keys = keys;
+    A.n = c->total;
+    A.nd = c->ndim;
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL((lf_split_end_kernel<T>), dim3(blocks), dim3(256), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+
 // =========================================================================================== ABI
 extern "C" {
 
@@ -756,7 +782,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->warmup_cost = std::max(0, env_int("HJ_WARMUP_COST", 2 * HJ_STENCIL));
     c->lds_limit = (size_t)env_int("HJ_LDS_LIMIT", 64 * 1024);
     c->no_plain = env_int("HJ_NO_PLAIN", 0);
-    c->fuse12 = env_int("HJ_FUSE12", -1);         // 0 never, 1 whenever a tiling exists, -1 by grid size
+    c->fuse12 = env_int("HJ_FUSE12", 0);          // 0 never (default: measured slower), 1 whenever a tiling exists, -1 by grid size
     c->f12_nt = env_int("HJ_F12_NT", 0);
     c->f12_r = env_int("HJ_F12_R", 0);
     c->f12_kh = env_int("HJ_F12_KH", 0);
@@ -884,6 +910,94 @@ int hj_upwind(hj_ctx* c, int scheme, int dim, const void* phi, void* dL, void* d
         mm[0] = -key_to_double(k[0]); mm[1] = key_to_double(k[1]);
         mm[2] = -key_to_double(k[2]); mm[3] = key_to_double(k[3]);
     }
+    return HJ_OK;
+}
+
+int hj_lf_split_begin(hj_ctx* c, int scheme, const void* y, void* const* dL, void* const* dR, double* mm) {
+    if (!c || !y || !dL || !dR) return fail(HJ_EINVAL, "null argument");
+    if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    for (int d = 0; d < c->ndim; ++d) {
+        if (!dL[d] || !dR[d]) return fail(HJ_EINVAL, "null derivative array for dim %d", d);
+        if (c->N[d] < HJ_STENCIL) return fail(HJ_EINVAL, "grid too small along dim %d (N=%lld)", d, (long long)c->N[d]);
+    }
+    int rc;
+    const void* epsv = c->weno_src ? c->weno_src : c->weno_vals;
+    if (scheme == HJ_WENO5 && !c->weno_src) {
+        if ((rc = weno_eps_pass(c, y))) return rc;
+        if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+    }
+    // all dimensions are launched back to back; ONE host synchronisation fetches the 4*ndim reductions
+    unsigned long long* keys = c->keys + 8;        // [8, 8 + 4*HJ_MAX_DIM)
+    if (mm) HIP_TRY(hipMemsetAsync(keys, 0, 4 * HJ_MAX_DIM * sizeof(unsigned long long), c->stream));
+    for (int d = 0; d < c->ndim; ++d) {
+        unsigned long long* k = mm ? keys + 4 * d : nullptr;
+        rc = c->dtype == HJ_F64 ? upwind_launch<double>(c, scheme, d, y, dL[d], dR[d], k, (const double*)epsv)
+                                : upwind_launch<float>(c, scheme, d, y, dL[d], dR[d], k, (const float*)epsv);
+        if (rc) return rc;
+    }
+    if (mm) {
+        unsigned long long k[4 * HJ_MAX_DIM];
+        HIP_TRY(hipMemcpyAsync(k, keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int d = 0; d < c->ndim; ++d) {
+            mm[4 * d + 0] = -key_to_double(k[4 * d + 0]); mm[4 * d + 1] = key_to_double(k[4 * d + 1]);
+            mm[4 * d + 2] = -key_to_double(k[4 * d + 2]); mm[4 * d + 3] = key_to_double(k[4 * d + 3]);
+        }
+    }
+    return HJ_OK;
+}
+
+int hj_lf_split_end(hj_ctx* c, const void* const* dL, const void* const* dR, const void* const* alpha,
+                    const double* alpha_s, const void* ham, void* out, double* sb, double* amax) {
+    if (!c || !dL || !dR || !out) return fail(HJ_EINVAL, "null argument");
+    bool any_arr = false;
+    for (int d = 0; d < c->ndim; ++d) {
+        if (!dL[d] || !dR[d]) return fail(HJ_EINVAL, "null derivative array for dim %d", d);
+        if (!(alpha && alpha[d]) && !alpha_s) return fail(HJ_EINVAL, "alpha of dim %d is neither an array nor a scalar", d);
+        any_arr = any_arr || (alpha && alpha[d]);
+    }
+    unsigned long long* keys = c->keys + 24;       // [24, 28)
+    if (any_arr) HIP_TRY(hipMemsetAsync(keys, 0, HJ_MAX_DIM * sizeof(unsigned long long), c->stream));
+    int rc = c->dtype == HJ_F64 ? split_end_launch<double>(c, dL, dR, alpha, alpha_s, ham, out, keys)
+                                : split_end_launch<float>(c, dL, dR, alpha, alpha_s, ham, out, keys);
+    if (rc) return rc;
+    if (sb || amax) {
+        unsigned long long k[HJ_MAX_DIM] = {0, 0, 0, 0};
+        if (any_arr) {
+            HIP_TRY(hipMemcpyAsync(k, keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        // stepBound = 1 / sum_d max(alpha_d)/dx_d   (artificial_diss_glf.py:107-109)
+        double inv = 0.0;
+        for (int d = 0; d < c->ndim; ++d) {
+            double a;
+            if (alpha && alpha[d]) {
+                if (k[d] == 0) return fail(HJ_ESTATE, "no reduction for the alpha array of dim %d", d);
+                a = key_to_double(k[d]);
+            } else {
+                a = alpha_s[d];
+            }
+            if (amax) amax[d] = a;
+            inv += a / c->dx[d];
+        }
+        if (sb) *sb = 1.0 / inv;
+    }
+    return HJ_OK;
+}
+
+int hj_rk_combine(hj_ctx* c, int mode, double dt, const void* x0, const void* y, const void* z, void* out, int64_t n) {
+    if (!c || !y || !z || !out) return fail(HJ_EINVAL, "null argument");
+    if (mode < 1 || mode > 4) return fail(HJ_EINVAL, "unknown combine mode %d", mode);
+    if (mode >= 2 && !x0) return fail(HJ_EINVAL, "mode %d needs x0", mode);
+    if (n <= 0) return HJ_OK;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    if (c->dtype == HJ_F64)
+        hipLaunchKernelGGL((rk_combine_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, mode, dt, (const double*)x0,
+                           (const double*)y, (const double*)z, (double*)out, (long long)n);
+    else
+        hipLaunchKernelGGL((rk_combine_kernel<float>), dim3(blocks), dim3(256), 0, c->stream, mode, (float)dt, (const float*)x0,
+                           (const float*)y, (const float*)z, (float*)out, (long long)n);
+    HIP_TRY(hipGetLastError());
     return HJ_OK;
 }
 

@@ -379,6 +379,78 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
     }
 }
 
+
+// ---- split-path epilogue: what termLaxFriedrichs / artificialDissipationGLF do AFTER the user's hamFunc /
+// partialFunc callbacks have run (term_lax_friedrich.py:122-128, artificial_diss_glf.py:91-104), as one pass:
+//     diss = sum_d (0.5*(derivR_d - derivL_d))*alpha_d          (in dimension order, like the reference's loop)
+//     out  = -(ham - diss)   if ham is given (the term's ydot), else diss (the dissipation function's result)
+// alpha_d is an array (alpha[d] != null) or the scalar alpha_s[d]; keys[d] collects max alpha_d of the
+// array-valued ones (the reference reduces only those: artificial_diss_glf.py:101-104).
+// Contraction is off: the result is bit-identical to the reference's NumPy expressions.
+template <typename T> struct SplitEndArgs {
+    const T* dL[HJ_MAX_DIM];
+    const T* dR[HJ_MAX_DIM];
+    const T* alpha[HJ_MAX_DIM];
+    T alpha_s[HJ_MAX_DIM];
+    const T* ham;
+    T* out;
+    unsigned long long* keys;
+    long long n;
+    int nd;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void lf_split_end_kernel(const SplitEndArgs<T> A) {
+#pragma clang fp contract(off)
+    double m[HJ_MAX_DIM] = {-1e300, -1e300, -1e300, -1e300};
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < A.n;
+         t += (long long)gridDim.x * blockDim.x) {
+        T diss = T(0);
+#pragma unroll
+        for (int d = 0; d < HJ_MAX_DIM; ++d) {
+            if (d >= A.nd) break;
+            T a = A.alpha_s[d];
+            if (A.alpha[d]) { a = A.alpha[d][t]; m[d] = fmax(m[d], (double)a); }
+            const T half = T(0.5) * (A.dR[d][t] - A.dL[d][t]);
+            diss = diss + half * a;
+        }
+        A.out[t] = A.ham ? -(A.ham[t] - diss) : diss;
+    }
+    __shared__ double red[4][HJ_MAX_DIM];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < HJ_MAX_DIM; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A.nd && A.alpha[threadIdx.x]) {
+        const int d = threadIdx.x;
+        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
+        if (w > -1e299) atomicMax(A.keys + d, max_key(w));
+    }
+}
+
+// ---- the array expressions of one odeCFLn stage for an arbitrary schemeFunc (ode_cfl_3.py:151,184-193,
+// 226-241; ode_cfl_2.py:151,184-201), one pass instead of 3-5 elementwise launches; contraction off, so
+// the values are those of the reference's NumPy expressions:
+//   1: y + dt*z      2: 0.25*(3*x0 + (y + dt*z))      3: (1/3)*(x0 + 2*(y + dt*z))      4: 0.5*(x0 + (y + dt*z))
+template <typename T>
+__global__ __launch_bounds__(256) void rk_combine_kernel(int mode, T dt, const T* __restrict__ x0,
+                                                         const T* __restrict__ y, const T* __restrict__ z,
+                                                         T* __restrict__ out, long long n) {
+#pragma clang fp contract(off)
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const T step = dt * z[t];
+        const T e = y[t] + step;
+        T o = e;
+        if (mode == 2) { const T a = T(3) * x0[t]; o = T(0.25) * (a + e); }
+        else if (mode == 3) { const T a = T(2) * e; o = (T(1) / T(3)) * (x0[t] + a); }
+        else if (mode == 4) { o = T(0.5) * (x0[t] + e); }
+        out[t] = o;
+    }
+}
+
 // ---- HJIPDE_solve post-step operators and NaN guard
 template <typename T>
 __global__ void minmax_kernel(T* __restrict__ y, const T* __restrict__ o, long long n, int op) {

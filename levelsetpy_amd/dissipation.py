@@ -8,7 +8,12 @@ import numpy as np
 from .context import is_tensor
 from .utilities import isfield, cell
 
-__all__ = ["artificialDissipationGLF", "artificialDissipationLLF", "artificialDissipationLLLF"]
+__all__ = ["artificialDissipationGLF", "artificialDissipationLLF", "artificialDissipationLLLF", "glf_device"]
+
+
+# HJ_SPLIT_KERNELS=0: A/B knob -- the split path's epilogues as stock torch elementwise launches (round-1 behaviour)
+import os
+SPLIT_KERNELS = os.environ.get("HJ_SPLIT_KERNELS", "1") != "0"
 
 
 def _amin(a):
@@ -19,6 +24,53 @@ def _amax(a):
     return float(a.max())
 
 
+def glf_device(t, data, derivL, derivR, schemeData, ham=None):
+    """artificialDissipationGLF on device tensors in ONE kernel after the partialFunc callbacks
+    (hj_lf_split_end): returns (diss, stepBound), or (ydot, stepBound) with ydot = -(ham - diss) when the
+    term hands its Hamiltonian array in (term_lax_friedrich.py:122-128).  None if the arrays are not
+    device tensors of the grid's ctx."""
+    import ctypes as C
+    from . import _ffi
+    from .context import device_grid, array_dtype_name
+    from .spatial import cached_minmax
+    grid = schemeData.grid
+    dim = grid.dim
+    if not all(is_tensor(a) and a.is_cuda for a in list(derivL) + list(derivR)) or (ham is not None and not is_tensor(ham)):
+        return None
+    dg = device_grid(grid, array_dtype_name(derivL[0]))
+    if any(tuple(a.shape) != dg.shape or a.dtype != dg.tdtype for a in list(derivL) + list(derivR)):
+        return None
+    derivMin, derivMax = cell(dim), cell(dim)
+    for i in range(dim):
+        mm = cached_minmax(derivL[i], derivR[i])
+        if mm is None:
+            mm = (min(_amin(derivL[i]), _amin(derivR[i])), max(_amax(derivL[i]), _amax(derivR[i])))
+        derivMin[i], derivMax[i] = mm                             # artificial_diss_glf.py:80-88
+    arrs, scal, keep = [None] * dim, [0.0] * dim, []
+    for i in range(dim):
+        alpha = schemeData.partialFunc(t, data, derivMin, derivMax, schemeData, i)   # :98
+        if is_tensor(alpha) and alpha.dim() > 0:
+            a = dg.to_device(alpha.expand(dg.shape) if tuple(alpha.shape) != dg.shape else alpha)
+            keep.append(a)
+            arrs[i] = a.data_ptr()
+        elif isinstance(alpha, np.ndarray) and alpha.ndim > 0:
+            a = dg.to_device(np.broadcast_to(alpha, dg.shape))
+            keep.append(a)
+            arrs[i] = a.data_ptr()
+        else:
+            scal[i] = float(alpha)
+    dg.bind_stream()
+    cL = [dg.to_device(a) for a in derivL]
+    cR = [dg.to_device(a) for a in derivR]
+    out = dg.empty()
+    vp = C.c_void_p * dim
+    sb = C.c_double()
+    hamc = dg.to_device(ham.reshape(dg.shape)) if ham is not None else None
+    _ffi.check(dg.lib.hj_lf_split_end(dg.ctx, vp(*[a.data_ptr() for a in cL]), vp(*[a.data_ptr() for a in cR]),
+                                      vp(*arrs), _ffi.darr(scal), dg.ptr(hamc), dg.ptr(out), C.byref(sb), None))
+    return out, float(sb.value)
+
+
 def artificialDissipationGLF(t, data, derivL, derivR, schemeData):
     if not isfield(schemeData, 'grid'):
         raise ValueError('grid is not a structure')               # :65-66
@@ -26,6 +78,10 @@ def artificialDissipationGLF(t, data, derivL, derivR, schemeData):
         raise ValueError('partialFunc is not a structure')        # :67-68
     grid = schemeData.grid
     dim = grid.dim
+    if is_tensor(derivL[0]) and derivL[0].is_cuda and SPLIT_KERNELS:
+        res = glf_device(t, data, derivL, derivR, schemeData)
+        if res is not None:
+            return res
     derivMin, derivMax, derivDiff = cell(dim), cell(dim), cell(dim)
     from .spatial import cached_minmax
     for i in range(dim):

@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _ffi
 from .context import device_grid, array_dtype_name, is_tensor
+from . import dissipation as _diss
 from .term import termLaxFriedrichs, termRestrictUpdate, native_plan
 from .utilities import (Bundle, isbundle, isfield, iscell, strcmp, warn, info, cputime, eps,
                         realmax, error)
@@ -287,6 +288,22 @@ def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, 
     return float(tout.value), out.reshape(y.shape)
 
 
+def _any_device_grid(schemeData, like):
+    """The DeviceGrid of the grid a (possibly wrapped) schemeData carries, for the dtype of `like`; None if
+    there is none (the elementwise stage kernels only need a ctx of the right dtype and device)."""
+    sd = schemeData[0] if iscell(schemeData) else schemeData
+    for _ in range(4):
+        if sd is None:
+            return None
+        if isfield(sd, 'grid'):
+            try:
+                return device_grid(sd.grid, array_dtype_name(like))
+            except (ValueError, RuntimeError):
+                return None
+        sd = getattr(sd, 'innerData', None)
+    return None
+
+
 def _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small, safetyFactorCFL):
     t = tspan[0]
     tf = tspan[1]
@@ -295,6 +312,29 @@ def _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small,
     y = copy.copy(y0)
     post = _post_hook(options)
     eventValueOld = None
+
+    def combine(mode, deltaT, x0, ycur, ydot):
+        """One odeCFLn stage expression (ode_cfl_3.py:151,184-193,226-241; ode_cfl_2.py:184-201): a single
+        hj_rk_combine launch for device tensors of one of our grids, the reference's array expression otherwise."""
+        e = None
+        if _diss.SPLIT_KERNELS and is_tensor(ycur) and is_tensor(ydot) and ycur.is_cuda and ydot.is_cuda and ycur.dtype == ydot.dtype \
+                and ycur.is_contiguous() and ydot.is_contiguous() and tuple(ycur.shape) == tuple(ydot.shape) \
+                and (x0 is None or (is_tensor(x0) and x0.is_cuda and x0.is_contiguous() and x0.dtype == ycur.dtype)):
+            dg = _any_device_grid(schemeData, ycur)
+            if dg is not None:
+                out = ycur.new_empty(ycur.shape)
+                dg.bind_stream()
+                _ffi.check(dg.lib.hj_rk_combine(dg.ctx, mode, float(deltaT), dg.ptr(x0), dg.ptr(ycur), dg.ptr(ydot),
+                                                dg.ptr(out), ycur.numel()))
+                return out
+        e = ycur + deltaT * ydot
+        if mode == 1:
+            return e
+        if mode == 2:
+            return 0.25 * (3 * x0 + e)
+        if mode == 3:
+            return (1 / 3) * (x0 + 2 * e)
+        return 0.5 * (x0 + e)
 
     def bound_check(deltaT, stepBound, which):
         if deltaT > safetyFactorCFL * stepBound:          # ode_cfl_3.py:173-175,215-217
@@ -308,7 +348,7 @@ def _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small,
                              % (tuple(ydot.shape), tuple(y.shape)))
         deltaT = min(options.factorCFL * stepBound, tf - t, options.maxStep)    # :142
         t1 = t + deltaT
-        y1 = y + deltaT * ydot
+        y1 = combine(1, deltaT, None, y, ydot)            # y + deltaT*ydot
         yOld, tOld = y, t
         if order == 1:
             y, t = y1, t1
@@ -316,19 +356,17 @@ def _integrate_generic(order, schemeFunc, tspan, y0, options, schemeData, small,
             ydot, stepBound, schemeData = schemeFunc(t1, y1, schemeData)
             bound_check(deltaT, stepBound, 'Second')
             t2 = t1 + deltaT
-            y2 = y1 + deltaT * ydot
             if order == 2:
                 t = 0.5 * (t + t2)                        # ode_cfl_2.py:200-201
-                y = 0.5 * (y + y2)
+                y = combine(4, deltaT, y, y1, ydot)       # 0.5*(y + (y1 + deltaT*ydot))
             else:
                 tHalf = 0.25 * (3 * t + t2)               # ode_cfl_3.py:188-193
-                yHalf = 0.25 * (3 * y + y2)
+                yHalf = combine(2, deltaT, y, y1, ydot)   # 0.25*(3*y + (y1 + deltaT*ydot))
                 ydot, stepBound, schemeData = schemeFunc(tHalf, yHalf, schemeData)
                 bound_check(deltaT, stepBound, 'Third')
                 tThreeHalf = tHalf + deltaT
-                yThreeHalf = yHalf + deltaT * ydot
                 t = (1 / 3) * (t + 2 * tThreeHalf)        # :236-241
-                y = (1 / 3) * (y + 2 * yThreeHalf)
+                y = combine(3, deltaT, y, yHalf, ydot)    # (1/3)*(y + 2*(yHalf + deltaT*ydot))
         steps += 1
         if post:
             y, schemeData = odeCFLcallPostTimestep(t, y, schemeData, options)

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _ffi
 from .context import device_grid, array_dtype_name, is_tensor
-from .utilities import error
+from .utilities import Bundle, error
 
 __all__ = ["upwindFirstENO2", "upwindFirstENO3", "upwindFirstENO3a", "upwindFirstWENO5",
            "upwindFirstWENO5a", "upwindFirstWENO5Intended", "upwindFirstENO3aHelper",
@@ -65,6 +65,29 @@ def _upwind(scheme_name, grid, data, dim):
     return dg.like(dL, data), dg.like(dR, data)
 
 
+def upwind_all_dims(fn, grid, data):
+    """derivL[d], derivR[d] for every d with ONE native call and one host synchronisation (hj_lf_split_begin)
+    when `fn` is one of this module's derivative functions and `data` is a device tensor; else None."""
+    sid = scheme_id_of(fn)
+    if sid is None or not is_tensor(data):
+        return None
+    dg = device_grid(grid, array_dtype_name(data))
+    if tuple(data.shape) != dg.shape:
+        error('data parameter does not agree in array size with grid')
+    dg.bind_stream()
+    phi = dg.to_device(data)
+    dL = [dg.empty() for _ in range(dg.dim)]
+    dR = [dg.empty() for _ in range(dg.dim)]
+    vp = C.c_void_p * dg.dim
+    mm = (C.c_double * (4 * dg.dim))()
+    _ffi.check(dg.lib.hj_lf_split_begin(dg.ctx, sid, dg.ptr(phi), vp(*[t.data_ptr() for t in dL]),
+                                        vp(*[t.data_ptr() for t in dR]), mm))
+    for d in range(dg.dim):
+        dL[d]._hj_minmax = (weakref.ref(dR[d]), dL[d]._version, dR[d]._version,
+                            min(mm[4 * d], mm[4 * d + 2]), max(mm[4 * d + 1], mm[4 * d + 3]))
+    return dL, dR
+
+
 def cached_minmax(dL, dR):
     """(min, max) over derivL and derivR if this exact, unmodified pair came out of hj_upwind, else None."""
     tag = getattr(dL, "_hj_minmax", None) if is_tensor(dL) else None
@@ -73,9 +96,11 @@ def cached_minmax(dL, dR):
     return tag[3], tag[4]
 
 
-def _candidates(grid, data, dim, order):
+def _candidates(grid, data, dim, order, approx4=False, want_dd=False):
     """generateAll=True: the ENO candidates (upwind_first_eno3a.py:62-80, eno2.py:119-126), from
-    the padded array's divided differences (compatibility path: array ops on the device)."""
+    the padded array's divided differences (compatibility path: array ops on the device).  With want_dd the
+    divided-difference tables come back too, stripped as the reference returns them (ENO3aHelper.py:99-112:
+    D1 with N+1 entries along dim, D2 with N+2, D3 with N+3)."""
     dg = device_grid(grid, "float64")
     g = grid.bdry[dim](dg.to_device(data), dim, order, grid.bdryData[dim])
     dx = dg.dx[dim]
@@ -89,6 +114,7 @@ def _candidates(grid, data, dim, order):
 
     D1 = (1 / dx) * diff(g)
     D2 = (0.5 / dx) * diff(D1)
+    dd = None
     if order == 2:
         D1s = take(D1, 1, N + 2)
         dL = [take(D1s, 0, N) + dx * take(D2, 0, N), take(D1s, 0, N) + dx * take(D2, 1, N + 1)]
@@ -103,7 +129,16 @@ def _candidates(grid, data, dim, order):
         dR = [r - dx * take(D2s, 1, N + 1) - dx * dx * take(D3, 1, N + 1),
               r - dx * take(D2s, 1, N + 1) - dx * dx * take(D3, 2, N + 2),
               r - dx * take(D2s, 2, N + 2) + 2 * dx * dx * take(D3, 3, N + 3)]
-    return [dg.like(a.contiguous(), data) for a in dL], [dg.like(a.contiguous(), data) for a in dR]
+        if approx4:
+            # the middle approximation reached right-then-left through the difference tree
+            # (ENO3aHelper.py:139-141,148-149,168-170,178-179): equals element [1] up to rounding
+            dL.append(l + dx * take(D2s, 1, N + 1) - dx * dx * take(D3, 1, N + 1))
+            dR.append(r - dx * take(D2s, 2, N + 2) + 2 * dx * dx * take(D3, 2, N + 2))
+        if want_dd:
+            dd = Bundle(dict(D1=dg.like(D1s.contiguous(), data), D2=dg.like(D2s.contiguous(), data),
+                             D3=dg.like(D3.contiguous(), data)))
+    out = [dg.like(a.contiguous(), data) for a in dL], [dg.like(a.contiguous(), data) for a in dR]
+    return out + (dd,) if want_dd else out
 
 
 def upwindFirstENO2(grid, data, dim, generateAll=False):
@@ -124,10 +159,11 @@ upwindFirstENO3a = upwindFirstENO3
 
 
 def upwindFirstENO3aHelper(grid, data, dim, approx4=False, stripDD=False):
-    """ENO3aHelper.py:11: the three candidates per side (the divided-difference Bundle is not
-    reproduced: nothing on the path outside the derivative functions reads it)."""
-    dL, dR = _candidates(grid, data, dim, 3)
-    return dL, dR, None
+    """ENO3aHelper.py:11: the three (approx4: four) candidates per side and the divided-difference Bundle
+    DD with fields D1, D2, D3.  The reference returns the STRIPPED tables whatever stripDD says (the
+    unstripped Bundle built at :93 is overwritten at :112); so does this."""
+    dL, dR, DD = _candidates(grid, data, dim, 3, approx4=bool(approx4), want_dd=True)
+    return dL, dR, DD
 
 
 def upwindFirstWENO5(grid, data, dim, generateAll=False):

@@ -14,9 +14,10 @@ import numpy as np
 
 from . import _ffi
 from .context import device_grid, array_dtype_name, is_tensor
-from .dissipation import artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF
+from . import dissipation as _diss
+from .dissipation import artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF, glf_device
 from .dynamics import native_of
-from .spatial import scheme_id_of
+from .spatial import scheme_id_of, upwind_all_dims
 from .utilities import isfield, iscell
 
 __all__ = ["termLaxFriedrichs", "termRestrictUpdate"]
@@ -110,8 +111,9 @@ def termLaxFriedrichs(t, y, schemeData):
     data = y0.reshape(grid.shape)
     calc = _deriv_func(thisSchemeData)
     derivL, derivR, derivC = [None] * grid.dim, [None] * grid.dim, [None] * grid.dim
+    both = upwind_all_dims(calc, grid, data) if _diss.SPLIT_KERNELS else None   # device tensors + one of our schemes: one call, one sync
     for i in range(grid.dim):
-        derivL[i], derivR[i] = calc(grid, data, i)
+        derivL[i], derivR[i] = (both[0][i], both[1][i]) if both is not None else calc(grid, data, i)
         derivC[i] = 0.5 * (derivL[i] + derivR[i])
     result = thisSchemeData.hamFunc(t, data, derivC, thisSchemeData)
     if isinstance(result, tuple):
@@ -122,6 +124,11 @@ def termLaxFriedrichs(t, y, schemeData):
             schemeData = copy.copy(thisSchemeData)
     else:
         ham = result
+    if thisSchemeData.dissFunc is artificialDissipationGLF and is_tensor(ham) and _diss.SPLIT_KERNELS:
+        # dissipation, -(ham - diss) and the per-dimension max(alpha) in ONE kernel after the partialFunc callbacks
+        res = glf_device(t, data, derivL, derivR, thisSchemeData, ham=ham)
+        if res is not None:
+            return res[0].reshape(-1, 1), res[1], schemeData
     diss, stepBound = thisSchemeData.dissFunc(t, data, derivL, derivR, thisSchemeData)
     delta = ham - diss
     ydot = (-delta).reshape(-1, 1)

@@ -402,3 +402,133 @@ def test_rk_step_with_stage_fusion_equals_unfused(order, monkeypatch):
         res[flag] = (cur.clone(), t, dtout.value)
     assert res["0"][1:] == res["1"][1:]
     assert torch.equal(res["0"][0], res["1"][0]), float((res["0"][0] - res["1"][0]).abs().max())
+
+
+# ------------------------------------------------------------------------------ split path on device kernels
+class _ForeignDubins(object):
+    """A user-side system the package knows nothing about (plain callables, torch arithmetic on whatever
+    arrays it is handed): what every non-native system of the reference looks like to termLaxFriedrichs
+    (DynamicalSystems/bird.py:277,346, flock.py:190,237)."""
+
+    def __init__(self, g, v=1.0, w=1.0):
+        self.g, self.v, self.w = g, v, w
+        self.calls = 0
+        # trigonometry once, in NumPy, so that the NumPy and the tensor runs see the same bits
+        self.tab = {"x1": np.asarray(g.xs[0]), "x2": np.asarray(g.xs[1]),
+                    "c3": np.cos(np.asarray(g.xs[2])), "s3": np.sin(np.asarray(g.xs[2]))}
+        self.tab = {k: np.ascontiguousarray(np.broadcast_to(a, g.shape)) for k, a in self.tab.items()}
+        self.ttab = {}
+
+    def _t(self, name, like):
+        if not torch.is_tensor(like):
+            return self.tab[name]
+        key = (name, like.device)
+        if key not in self.ttab:
+            self.ttab[key] = torch.as_tensor(self.tab[name], device=like.device)
+        return self.ttab[key]
+
+    def ham(self, t, data, p, sd):
+        self.calls += 1
+        x1, x2, c3, s3 = (self._t(k, p[0]) for k in ("x1", "x2", "c3", "s3"))
+        return (p[0] * (self.v - self.v * c3) - p[1] * (self.v * s3)
+                - self.w * abs(p[0] * x2 - p[1] * x1 - p[2]) + self.w * abs(p[2]))
+
+    def part(self, t, data, dmin, dmax, sd, dim):
+        x1, x2, c3, s3 = (self._t(k, data) for k in ("x1", "x2", "c3", "s3"))
+        if dim == 0:
+            return abs(self.v - self.v * c3) + abs(self.w * x2)
+        if dim == 1:
+            return abs(self.v * s3) + abs(self.w * x1)
+        return 2 * self.w                      # a scalar alpha: used as is (artificial_diss_glf.py:101-104)
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED", "WENO5"])
+def test_split_path_device_kernels_vs_reference_arithmetic(scheme):
+    """Foreign hamFunc / partialFunc on device tensors: hj_lf_split_begin (all dims, one sync) -> callbacks ->
+    hj_lf_split_end (diss, -(ham - diss), max alpha in one kernel).  Against (1) the same pipeline on NumPy
+    arrays (per-dimension hj_upwind + the reference's array expressions): bit-identical ydot and stepBound;
+    (2) the oracle; (3) the fused native path."""
+    g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / 17)], (19, 18, 17), 2)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.02 * np.random.default_rng(3).standard_normal(og.shape)
+    fs = _ForeignDubins(g)
+    sd = L.Bundle(dict(grid=g, hamFunc=fs.ham, partialFunc=fs.part, dissFunc=L.artificialDissipationGLF,
+                       CoStateCalc=DERIV[scheme]))
+    y = data.reshape(-1, 1)
+    yd_np, sb_np, _ = L.termLaxFriedrichs(0., y, sd)
+    yt = torch.as_tensor(y, device="cuda")
+    yd_t, sb_t, _ = L.termLaxFriedrichs(0., yt, sd)
+    assert torch.is_tensor(yd_t) and yd_t.shape == yt.shape
+    assert sb_t == sb_np
+    assert np.array_equal(yd_t.cpu().numpy(), yd_np)
+    yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 1), scheme, 0., y)
+    assert abs(sb_t - sbo) <= 1e-13 * sbo
+    assert np.max(np.abs(yd_np - yo)) <= 1e-11 * max(1.0, np.max(np.abs(yo)))
+    fused, sbf, _ = L.termLaxFriedrichs(0., yt, sdata(g, L.DubinsVehicleRel(g, 1, 1), DERIV[scheme]))
+    assert abs(sbf - sb_t) <= 1e-13 * sbf
+    assert float((fused - yd_t).abs().max()) <= 1e-11 * max(1.0, float(fused.abs().max()))
+    # the dissipation function on its own (ham = None): diss and stepBound, tensors in -> tensor out
+    dL, dR = zip(*[DERIV[scheme](g, torch.as_tensor(data, device="cuda"), i) for i in range(3)])
+    diss_t, sb2 = L.artificialDissipationGLF(0., torch.as_tensor(data, device="cuda"), list(dL), list(dR), sd)
+    dLn, dRn = [a.cpu().numpy() for a in dL], [a.cpu().numpy() for a in dR]
+    diss_n, sb3 = L.artificialDissipationGLF(0., data, dLn, dRn, sd)
+    assert sb2 == sb3 == sb_t
+    assert np.array_equal(diss_t.cpu().numpy(), np.asarray(diss_n))
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_generic_integrator_stage_kernels_bitwise(order):
+    """odeCFLn with a foreign schemeFunc (the generic loop): on device tensors every stage expression is one
+    hj_rk_combine launch; the result must equal the NumPy-array run of the same loop bit for bit, and the
+    native device integrator to rounding."""
+    g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / 15)], (17, 16, 15), 2)
+    data = O.shape_cylinder(og, 2, None, .5) + 0.02 * np.random.default_rng(5).standard_normal(og.shape)
+    fs = _ForeignDubins(g)
+    sd = L.Bundle(dict(grid=g, hamFunc=fs.ham, partialFunc=fs.part, dissFunc=L.artificialDissipationGLF,
+                       CoStateCalc=L.upwindFirstWENO5))
+    ode = {1: L.odeCFL1, 2: L.odeCFL2, 3: L.odeCFL3}[order]
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='off')))
+    y0 = data.reshape(-1, 1)
+    t_np, y_np, _ = ode(L.termLaxFriedrichs, [0., 0.02], y0, op, sd)
+    t_t, y_t, _ = ode(L.termLaxFriedrichs, [0., 0.02], torch.as_tensor(y0, device="cuda"), op, sd)
+    assert t_np == t_t and torch.is_tensor(y_t)
+    assert np.array_equal(y_t.cpu().numpy(), y_np)
+    sdn = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+    t_n, y_n, _ = ode(L.termLaxFriedrichs, [0., 0.02], y0, op, sdn)
+    assert abs(t_n - t_np) <= 1e-14
+    assert np.max(np.abs(y_n - y_np)) <= 1e-11
+    # the kernel against the reference's expressions, every mode, odd length
+    dg = DeviceGrid(g, "float64")
+    rng = np.random.default_rng(9)
+    x0, yy, zz = (rng.standard_normal(4097) for _ in range(3))
+    dt = 0.0123
+    want = {1: yy + dt * zz, 2: 0.25 * (3 * x0 + (yy + dt * zz)), 3: (1 / 3) * (x0 + 2 * (yy + dt * zz)),
+            4: 0.5 * (x0 + (yy + dt * zz))}
+    tx, ty, tz = (torch.as_tensor(a, device="cuda") for a in (x0, yy, zz))
+    for mode, ref in want.items():
+        out = torch.empty_like(tx)
+        _ffi.check(dg.lib.hj_rk_combine(dg.ctx, mode, dt, dg.ptr(tx), dg.ptr(ty), dg.ptr(tz), dg.ptr(out), out.numel()))
+        assert np.array_equal(out.cpu().numpy(), ref), mode
+
+
+def test_eno3a_helper_returns_reference_dd_bundle(golden):
+    """upwindFirstENO3aHelper: candidates AND the divided-difference Bundle (stripped tables D1 N+1, D2 N+2,
+    D3 N+3 entries along dim: ENO3aHelper.py:99-112,190) against the reference's goldens; approx4's fourth
+    element equals the second up to rounding (ENO3aHelper.py:28-32)."""
+    G = golden("deriv.npz")
+    for tag, nd in (("g2", 2), ("g3", 3)):
+        pd = 1 if tag == "g2" else 2
+        n = G[tag + "_data"].shape
+        g, og = mk(G[tag + "_min"], G[tag + "_max"], n, pd)
+        data = G[tag + "_data"]
+        for dim in range(nd):
+            dL, dR, DD = L.upwindFirstENO3aHelper(g, data, dim, True, False)
+            assert len(dL) == 4 and len(dR) == 4
+            for k in range(3):
+                assert np.max(np.abs(dL[k] - G["%s_helper_dL%d_d%d" % (tag, k, dim)])) <= 1e-11
+                assert np.max(np.abs(dR[k] - G["%s_helper_dR%d_d%d" % (tag, k, dim)])) <= 1e-11
+            assert np.max(np.abs(dL[3] - dL[1])) <= 1e-10 and np.max(np.abs(dR[3] - dR[1])) <= 1e-10
+            for name in ("D1", "D2", "D3"):
+                ref = G["%s_helper_%s_d%d" % (tag, name, dim)]
+                got = getattr(DD, name)
+                assert got.shape == ref.shape
+                assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref)))
