@@ -29,5 +29,7 @@ from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      
 from .hji_solver import HJIPDE_solve                                            # noqa: F401
 from .gradients import computeGradients                                         # noqa: F401
 from .convection import termConvection                                          # noqa: F401
+from .normal_reinit import termNormal, termReinit                               # noqa: F401
+from .opt_traj import computeOptTraj, find_earliest_BRS_ind                     # noqa: F401
 
 __version__ = "0.1.0"

@@ -299,6 +299,46 @@ def gen_known():
     print("wrote known_answers.json")
 
 
+# ------------------------------------------------------------------ (9) round 2: what else the shipped code can run
+def gen_extra():
+    """(a) upwindFirstENO3aHelper with approx4 (fourth candidate); (b) artificialDissipationLLF for the one case
+    the shipped function runs: a partialFunc that returns a 0-d array for EVERY dimension, so that
+    `(1 / stepBoundInv).get().item()` (diss_local_laxfried.py:121) is applied to a scalar.  The alpha of
+    dimension i is built from the GLOBAL costate range of another dimension (derivMin/derivMax are scalars
+    there, :84-99) and from the per-node range of dimension i reduced to its extrema (:108-109), so the
+    fixture pins what ranges the function hands to partialFunc."""
+    import cupy as cp
+    from LevelSetPy.ExplicitIntegration.Dissipation.diss_local_laxfried import artificialDissipationLLF
+    rng = np.random.default_rng(7)
+    out = {}
+    g3, gmin, gmax, n = dubins_grid([9, 10, 11])
+    d3 = shapeCylinder(g3, 2, np.zeros((3, 1)), .5) + 0.05 * rng.standard_normal(g3.shape)
+    out["g3_min"], out["g3_max"], out["g3_data"] = gmin.ravel(), gmax.ravel(), d3
+    for dim in range(3):
+        dL, dR, DD = upwindFirstENO3aHelper(g3, d3, dim, True, False)
+        assert len(dL) == 4
+        out["g3_helper4_dL3_d%d" % dim] = A(dL[3])
+        out["g3_helper4_dR3_d%d" % dim] = A(dR[3])
+    dL = [rng.standard_normal(g3.shape) for _ in range(3)]
+    dR = [rng.standard_normal(g3.shape) for _ in range(3)]
+    seen = []
+
+    def partial(t, data, derivMin, derivMax, schemeData, dim):
+        j = (dim + 1) % 3
+        glob = max(abs(float(A(derivMin[j]))), abs(float(A(derivMax[j]))))       # scalars: the global range of dim j
+        loc = max(abs(float(A(derivMin[dim]).min())), abs(float(A(derivMax[dim]).max())))   # arrays: per-node range of dim
+        seen.append((dim, tuple(np.ndim(A(derivMin[k])) for k in range(3))))
+        return cp.asarray(0.25 * (dim + 1) + 0.5 * glob + 0.125 * loc)
+
+    sd = Bundle(dict(grid=g3, partialFunc=partial))
+    diss, sb = artificialDissipationLLF(0., d3, dL, dR, sd)
+    for i in range(3):
+        out["llf_dL%d" % i], out["llf_dR%d" % i] = dL[i], dR[i]
+    out["llf_diss"], out["llf_sb"] = A(diss), A(sb)
+    out["llf_range_ndims"] = A([list(s[1]) for s in seen])
+    save("extra.npz", **out)
+
+
 if __name__ == "__main__":
     gen_ghost()
     gen_deriv()
@@ -306,3 +346,4 @@ if __name__ == "__main__":
     gen_ode()
     gen_hjipde()
     gen_known()
+    gen_extra()

@@ -532,3 +532,137 @@ def test_eno3a_helper_returns_reference_dd_bundle(golden):
                 got = getattr(DD, name)
                 assert got.shape == ref.shape
                 assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref)))
+
+
+# ------------------------------------------------------------------------------ more terms
+def _noisy_circle(n=(41, 37)):
+    g, og = mk([-1, -1.1], [1, 1.1], n, None)
+    rng = np.random.default_rng(11)
+    phi = O.shape_sphere(og, None, .5) * (1.0 + 0.4 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[1])) + 0.01 * rng.standard_normal(n)
+    return g, og, phi
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_term_normal_vs_oracle_and_unit_speed_growth(scheme):
+    """termNormal on NumPy arrays and on device tensors against oracle.term_normal (speed as scalar, array and
+    callable), and its behaviour: a circle moving along its normal at unit speed stays a signed distance, phi(t) =
+    phi(0) - t, away from the centre kink and the domain edge."""
+    g, og, phi = _noisy_circle()
+    speed = 0.5 + 0.3 * np.cos(og.xs[0])
+    for sp in (1.5, speed, lambda t, data, sd: speed):
+        sd = L.Bundle(dict(grid=g, derivFunc=DERIV[scheme], speed=sp))
+        yo, sbo = O.term_normal(og, sp if not callable(sp) else speed, scheme, 0., phi.reshape(-1, 1))
+        for y in (phi.reshape(-1, 1), torch.as_tensor(phi.reshape(-1, 1), device="cuda")):
+            yd, sb, _ = L.termNormal(0., y, sd)
+            ydn = yd.cpu().numpy() if torch.is_tensor(yd) else yd
+            assert ydn.shape == yo.shape
+            assert np.max(np.abs(ydn - yo)) <= 1e-11 * max(1.0, np.max(np.abs(yo)))
+            assert abs(sb - sbo) <= 1e-12 * sbo
+    g2, og2 = mk([-1, -1], [1, 1], (81, 81), None)
+    sdf = O.shape_sphere(og2, None, .3)
+    sd = L.Bundle(dict(grid=g2, derivFunc=DERIV[scheme], speed=1.0))
+    t, y, _ = L.odeCFL3(L.termNormal, [0., 0.2], torch.as_tensor(sdf.reshape(-1, 1), device="cuda"),
+                        L.odeCFLset(factorCFL=.5), sd)
+    got = y.cpu().numpy().reshape(81, 81)
+    r = np.sqrt(og2.xs[0] ** 2 + og2.xs[1] ** 2)
+    band = (r > 0.35) & (r < 0.85)
+    assert abs(t - 0.2) <= 1e-12
+    assert np.max(np.abs(got[band] - (sdf[band] - 0.2))) <= 2e-3
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "WENO5_ASSHIPPED"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_term_reinit_vs_oracle_and_signed_distance(scheme, order):
+    """termReinit (with and without the subcell fix) on NumPy arrays and device tensors against
+    oracle.term_reinit, and its purpose: a distorted implicit function relaxes to a signed distance function
+    (|grad phi| -> 1 near the interface) while the zero level set stays where it was."""
+    g, og, phi = _noisy_circle()
+    sd = L.Bundle(dict(grid=g, derivFunc=DERIV[scheme], initial=phi, subcell_fix_order=order))
+    yo, sbo = O.term_reinit(og, phi, scheme, 0., phi.reshape(-1, 1), order)
+    for y in (phi.reshape(-1, 1), torch.as_tensor(phi.reshape(-1, 1), device="cuda")):
+        yd, sb, _ = L.termReinit(0., y, sd)
+        ydn = yd.cpu().numpy() if torch.is_tensor(yd) else yd
+        assert np.max(np.abs(ydn - yo)) <= 1e-10 * max(1.0, np.max(np.abs(yo)))
+        assert abs(sb - sbo) <= 1e-12 * sbo
+    g2, og2 = mk([-1, -1], [1, 1], (101, 101), None)
+    true = O.shape_sphere(og2, None, .5)
+    bad = true * (1.5 + np.sin(4 * og2.xs[0]) * np.cos(3 * og2.xs[1]))        # same zero level set, wrong slopes
+    sd = L.Bundle(dict(grid=g2, derivFunc=DERIV[scheme], initial=torch.as_tensor(bad, device="cuda"), subcell_fix_order=order))
+    t, y, _ = L.odeCFL3(L.termReinit, [0., 0.6], torch.as_tensor(bad.reshape(-1, 1), device="cuda"),
+                        L.odeCFLset(factorCFL=.5), sd)
+    got = y.cpu().numpy().reshape(101, 101)
+    band = np.abs(true) < 0.2
+    assert np.max(np.abs(got[band] - true[band])) <= (0.03 if order == 0 else 0.015), np.max(np.abs(got[band] - true[band]))
+
+
+class _DoubleIntegratorPlant(object):
+    """dynSys protocol of computeOptTraj (compute_opt_traj.py:124-131) for xddot = u, |u| <= 1."""
+
+    def __init__(self, x):
+        self.x = np.asarray(x, dtype=np.float64)
+
+    def get_opt_u(self, t, deriv, uMode, x):
+        s = np.sign(deriv[1]) if deriv[1] != 0 else 1.0
+        return -s if uMode == 'min' else s
+
+    def update_state(self, u, dt, x, d=None):
+        k = lambda z: np.array([z[1], u])                                   # noqa: E731  RK4 of (x1' = x2, x2' = u)
+        k1 = k(x); k2 = k(x + .5 * dt * k1); k3 = k(x + .5 * dt * k2); k4 = k(x + dt * k3)
+        self.x = x + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        return self.x
+
+
+def test_compute_opt_traj_reaches_the_target_in_minimum_time():
+    """HJIPDE_solve (native double integrator, minVOverTime, all times stored, flipped) -> computeOptTraj: the
+    bang-bang trajectory from (0.5, 0) enters the target disc, and it does so no later than the closed-form
+    minimum time to the origin, 2*sqrt(0.5) (double_integrator.py:91-119), plus one sampling interval."""
+    n = 101
+    g, og = mk([-1, -1], [1, 1], (n, n), None)
+    data0 = L.shapeSphere(g, np.zeros((2, 1)), .1)
+    sys_ = L.DoubleIntegrator(g, 1)
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=L.artificialDissipationGLF,
+                       derivFunc=L.upwindFirstENO3))
+    tau = np.linspace(0, 1.6, 33)
+    data, tau2, _ = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, flipOutput=True)))
+    assert data.shape == (33, n, n)
+    plant = _DoubleIntegratorPlant([0.5, 0.0])
+    traj, ttau = L.computeOptTraj(g, data, tau, plant, L.Bundle(dict(uMode='min', subSamples=8)))
+    assert traj.shape[0] == 2 and traj.shape[1] == ttau.shape[0] and traj.shape[1] >= 10
+    end = traj[:, -1]
+    assert np.hypot(end[0], end[1]) <= 0.1 + 2 * float(np.asarray(g.dx).max()), end
+    assert ttau[-1] <= 2 * np.sqrt(0.5) + 0.05 + 1e-9, ttau[-1]
+    assert np.all(np.isfinite(traj))
+    # the switching structure: decelerate first (x2 goes negative), then brake
+    assert traj[1].min() < -0.4
+
+
+def test_llf_scalar_alpha_and_fourth_candidate_vs_reference_golden(golden):
+    """The product's artificialDissipationLLF against the reference's own output for the case the shipped
+    function runs (a 0-d alpha for every dimension: tests/golden/make_golden.py:gen_extra), on NumPy arrays and
+    on device tensors; and upwindFirstENO3aHelper's approx4 candidate against the reference."""
+    G = golden("extra.npz")
+    n = G["g3_data"].shape
+    g, og = mk(G["g3_min"], G["g3_max"], n, 2)
+    seen = []
+
+    def partial(t, data, derivMin, derivMax, schemeData, dim):
+        j = (dim + 1) % 3
+        glob = max(abs(float(derivMin[j])), abs(float(derivMax[j])))
+        loc = max(abs(float(derivMin[dim].min())), abs(float(derivMax[dim].max())))
+        seen.append([int(np.ndim(derivMin[k]) if not torch.is_tensor(derivMin[k]) else derivMin[k].dim()) for k in range(3)])
+        return 0.25 * (dim + 1) + 0.5 * glob + 0.125 * loc
+
+    sd = L.Bundle(dict(grid=g, partialFunc=partial))
+    for conv in (np.asarray, lambda a: torch.as_tensor(np.asarray(a), device="cuda")):
+        dL = [conv(G["llf_dL%d" % i]) for i in range(3)]
+        dR = [conv(G["llf_dR%d" % i]) for i in range(3)]
+        del seen[:]
+        diss, sb = L.artificialDissipationLLF(0., conv(G["g3_data"]), dL, dR, sd)
+        diss = diss.cpu().numpy() if torch.is_tensor(diss) else np.asarray(diss)
+        assert np.max(np.abs(diss - G["llf_diss"])) <= 1e-12 * max(1.0, np.max(np.abs(G["llf_diss"])))
+        assert abs(sb - float(G["llf_sb"])) <= 1e-14 * sb
+        assert seen == G["llf_range_ndims"].tolist()
+    for dim in range(3):
+        dL, dR, DD = L.upwindFirstENO3aHelper(g, G["g3_data"], dim, True)
+        assert np.max(np.abs(dL[3] - G["g3_helper4_dL3_d%d" % dim])) <= 1e-11
+        assert np.max(np.abs(dR[3] - G["g3_helper4_dR3_d%d" % dim])) <= 1e-11

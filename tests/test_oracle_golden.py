@@ -239,3 +239,38 @@ def test_known_answers_51cubed():
         assert abs(y.sum() - ka["sum5"]) <= 1e-11 * abs(ka["sum5"])
         assert abs(np.linalg.norm(y) - ka["l2_5"]) <= 1e-12 * ka["l2_5"]
         assert abs(y.min() - ka["min5"]) <= 1e-12 and abs(y.max() - ka["max5"]) <= 1e-12
+
+
+class _RangeProbe(object):
+    """The partialFunc of tests/golden/make_golden.py:gen_extra: a scalar alpha built from the global range of
+    the next dimension and the extrema of this dimension's per-node range."""
+
+    @staticmethod
+    def dissipation(t, data, derivMin, derivMax, sd, dim):
+        j = (dim + 1) % 3
+        glob = max(abs(float(np.asarray(derivMin[j]))), abs(float(np.asarray(derivMax[j]))))
+        loc = max(abs(float(np.asarray(derivMin[dim]).min())), abs(float(np.asarray(derivMax[dim]).max())))
+        return 0.25 * (dim + 1) + 0.5 * glob + 0.125 * loc
+
+
+def test_llf_scalar_alpha_vs_reference(golden):
+    """artificialDissipationLLF pinned for the one case the shipped function runs (0-d alpha for every
+    dimension, diss_local_laxfried.py:116-121): diss, stepBound, and WHICH ranges partialFunc receives
+    (per-node arrays in its own dimension, global scalars in the others)."""
+    G = golden("extra.npz")
+    g = mkgrid(G["g3_min"], G["g3_max"], G["g3_data"].shape, [0, 0, 1])
+    dL = [G["llf_dL%d" % i] for i in range(3)]
+    dR = [G["llf_dR%d" % i] for i in range(3)]
+    diss, sb = O.artificial_dissipation_local(g, _RangeProbe, 0., G["g3_data"], dL, dR, False)
+    close(diss, G["llf_diss"])
+    assert abs(sb - float(G["llf_sb"])) <= 1e-14 * sb
+    assert G["llf_range_ndims"].tolist() == [[3, 0, 0], [0, 3, 0], [0, 0, 3]]
+
+
+def test_eno3_helper_fourth_candidate_vs_reference(golden):
+    G = golden("extra.npz")
+    g = mkgrid(G["g3_min"], G["g3_max"], G["g3_data"].shape, [0, 0, 1])
+    for dim in range(3):
+        dL, dR, _ = O.eno3_helper(g, G["g3_data"], dim, approx4=True)
+        close(dL[3], G["g3_helper4_dL3_d%d" % dim])
+        close(dR[3], G["g3_helper4_dR3_d%d" % dim])
