@@ -186,6 +186,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     int own_lds[R];
     unsigned own_g[R];
     typename HAM::Cell hcell[R];
+    int own_idx[R][ND];
     // only the last round of the deal can run past the tile: shadows compute but do not write
     const bool last_real = (tid + (R - 1) * NT) < tile_cells;
 #pragma unroll
@@ -206,8 +207,92 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);   // byte offset within a plane
-        hcell[r] = HAM::cell(A.ham, idx, A.sc);   // per-column Hamiltonian constants
+#pragma unroll
+        for (int d = 0; d < ND; ++d) own_idx[r][d] = idx[d];
     }
+
+    // ---- The loads every workgroup needs before its first plane (7 planes of its own cells, the first
+    // prefetch sets, the RK operand) are issued HERE, ahead of the halo-slot index arithmetic and the table
+    // loads below: all workgroups of a launch start together, so this burst is not hidden by anybody else's
+    // arithmetic -- the setup that follows is what it overlaps with.
+    // ---- loaders.  p is wave-uniform and clamped by the callers to planes that exist.  One buffer
+    // descriptor per array for the whole chunk (base = 3 planes below the chunk; SGPRs), the plane
+    // goes into the scalar offset and the cell into the per-lane 32-bit byte offset; the hardware
+    // range check covers the chunk's planes.  Ghost / wrapped planes of axis 0 (first and last chunk
+    // only) build their own descriptor.
+    const unsigned plane_bytes = (unsigned)(A.stride0 * (long long)sizeof(T));
+    const int p_lo = p_begin - HJ_STENCIL;                       // lowest plane the chunk touches
+    const unsigned span = (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;   // host keeps this < 4 GiB
+    const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
+    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
+    auto load_own = [&](int p, T* dst) {
+        const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
+        if (direct) {
+            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_OWN>(ry, own_g[r], so, T());
+        } else {
+            const PlaneSrc<T> s = plane_src<T, ND>(A, p);
+            const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
+            if (!s.ghost) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], 0u, T());
+            } else {
+                const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    dst[r] = ghost_value(buf_load(rb, own_g[r], 0u, T()), buf_load(ri, own_g[r], 0u, T()), s.km);
+            }
+        }
+    };
+    auto load_y0 = [&](int p, T* dst) {
+        if (use_y0) {
+            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_Y0>(ry0, own_g[r], so, T());
+        }
+    };
+    const int p_last = p_end - 1;
+
+    // ---- prologue: axis-0 queue q[r][j] <-> plane p-3+j, j = 0..6
+    T q[R][7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        T tmp[R];
+        load_own(p_begin - 3 + j, tmp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r][j] = tmp[r];
+    }
+    // register sets of the pipeline.  PD < 10: one depth for everything; else PD = 100*y0 + 10*halo + own
+    // (e.g. 241: own cells 1 plane ahead, halo ring 4, y0 2 -- the halo ring of plane P is then
+    // requested in the same iteration in which the neighbouring tiles request P as their own cells,
+    // so the second requester finds the lines in L2).  Set (p - p_begin) % depth serves plane p.
+    constexpr int PDO = PD < 10 ? PD : PD % 10;
+    constexpr int PDH = PD < 10 ? PD : (PD / 10) % 10;
+    constexpr int PDY = PD < 10 ? PD : PD / 100;
+    T own[PDO][R], y0s[PDY][R];
+    typename HAM::Plane pls[PDY];
+#pragma unroll
+    for (int s = 0; s < PDO; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) own[s][r] = T(0);
+        // own[s] holds plane p+4 for the iteration of plane p = p_begin+s; the last set is filled
+        // by the first iteration
+        if (s < PDO - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < PDY; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) y0s[s][r] = T(0);
+        const int ps = min(p_begin + s, p_last);
+        load_y0(ps, y0s[s]);
+        pls[s] = HAM::plane(A.ham, ps, A.sc);
+    }
+    const typename HAM::Plane& plX = pls[0];
+    // per-column Hamiltonian constants (table loads: issued behind the queue loads, consumed in the loop)
+#pragma unroll
+    for (int r = 0; r < R; ++r) hcell[r] = HAM::cell(A.ham, own_idx[r], A.sc);
 
     // ---- halo slots: for each plane axis d, 3 cells below and 3 above the tile, over the
     // tile's extent on the other axes (a "cross": no corners).  Surplus slots shadow slot 0.
@@ -289,37 +374,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
     }
 
-    // ---- loaders.  p is wave-uniform and clamped by the callers to planes that exist.  One buffer
-    // descriptor per array for the whole chunk (base = 3 planes below the chunk; SGPRs), the plane
-    // goes into the scalar offset and the cell into the per-lane 32-bit byte offset; the hardware
-    // range check covers the chunk's planes.  Ghost / wrapped planes of axis 0 (first and last chunk
-    // only) build their own descriptor.
-    const unsigned plane_bytes = (unsigned)(A.stride0 * (long long)sizeof(T));
-    const int p_lo = p_begin - HJ_STENCIL;                       // lowest plane the chunk touches
-    const unsigned span = (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;   // host keeps this < 4 GiB
-    const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
-    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
-    const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
-    auto load_own = [&](int p, T* dst) {
-        const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
-        if (direct) {
-            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
-#pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_OWN>(ry, own_g[r], so, T());
-        } else {
-            const PlaneSrc<T> s = plane_src<T, ND>(A, p);
-            const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
-            if (!s.ghost) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) dst[r] = buf_load(rb, own_g[r], 0u, T());
-            } else {
-                const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    dst[r] = ghost_value(buf_load(rb, own_g[r], 0u, T()), buf_load(ri, own_g[r], 0u, T()), s.km);
-            }
-        }
-    };
     // the halo ring of a tile that touches an extrapolated edge needs two loads per slot (edge and
     // inner cell).  Both are only ISSUED here; the ghost arithmetic is done when the slot is
     // consumed, PD planes later -- forming the ghost value at load time would make the wave wait
@@ -339,56 +393,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             }
         }
     };
-    auto load_y0 = [&](int p, T* dst) {
-        if (use_y0) {
-            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
-#pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load<HJ_AUX_Y0>(ry0, own_g[r], so, T());
-        }
-    };
-    const int p_last = p_end - 1;
 
-    // ---- prologue: axis-0 queue q[r][j] <-> plane p-3+j, j = 0..6
-    T q[R][7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        T tmp[R];
-        load_own(p_begin - 3 + j, tmp);
-#pragma unroll
-        for (int r = 0; r < R; ++r) q[r][j] = tmp[r];
-    }
-    // register sets of the pipeline.  PD < 10: one depth for everything; else PD = 100*y0 + 10*halo + own
-    // (e.g. 241: own cells 1 plane ahead, halo ring 4, y0 2 -- the halo ring of plane P is then
-    // requested in the same iteration in which the neighbouring tiles request P as their own cells,
-    // so the second requester finds the lines in L2).  Set (p - p_begin) % depth serves plane p.
-    constexpr int PDO = PD < 10 ? PD : PD % 10;
-    constexpr int PDH = PD < 10 ? PD : (PD / 10) % 10;
-    constexpr int PDY = PD < 10 ? PD : PD / 100;
-    T own[PDO][R], hal[PDH][KH], hin[PDH][KH], y0s[PDY][R];
-    typename HAM::Plane pls[PDY];
-#pragma unroll
-    for (int s = 0; s < PDO; ++s) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) own[s][r] = T(0);
-        // own[s] holds plane p+4 for the iteration of plane p = p_begin+s; the last set is filled
-        // by the first iteration
-        if (s < PDO - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
-    }
+    T hal[PDH][KH], hin[PDH][KH];
 #pragma unroll
     for (int s = 0; s < PDH; ++s) {
 #pragma unroll
         for (int k = 0; k < KH; ++k) { hal[s][k] = T(0); hin[s][k] = T(0); }
         load_halo(min(p_begin + s, p_last), hal[s], hin[s]);
     }
-#pragma unroll
-    for (int s = 0; s < PDY; ++s) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) y0s[s][r] = T(0);
-        const int ps = min(p_begin + s, p_last);
-        load_y0(ps, y0s[s]);
-        pls[s] = HAM::plane(A.ham, ps, A.sc);
-    }
-    const typename HAM::Plane& plX = pls[0];
 
     double amax[ND];
 #pragma unroll
@@ -409,7 +421,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // one plane.  own_c holds plane p+4 (joins the queue at the end); own_n is refilled with plane
     // p+3+PD; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
     // are refilled for plane p+PD once consumed.
+#ifdef HJ_STAMP
+    // diagnostic build: shader-clock time of the phases of a plane iteration, summed per wave
+    unsigned long long st_acc[4] = {0, 0, 0, 0};
+#define HJ_ST(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define HJ_ST(var)
+#endif
     auto body = [&](int p, T* own_c, T* own_n, T* hal_c, T* hin_c, T* y0_c, typename HAM::Plane& pl_c) {
+        HJ_ST(st0);
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
         load_own(min(p + 3 + PDO, p_end + 2), own_n);
         // stage the centre plane
@@ -426,7 +446,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             for (int k = 0; k < KH; ++k)
                 if (h_real[k]) buf[h_lds[k]] = hal_c[k];
         }
+        HJ_ST(st1);
         __syncthreads();
+        HJ_ST(st2);
         const int p2 = min(p + PDY, p_last);
         load_halo(min(p + PDH, p_last), hal_c, hin_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
@@ -493,6 +515,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             if (r < R - 1 || last_real) buf_store<HJ_AUX_ST>(o, rout, own_g[r], so_out);
 #endif
         }
+        HJ_ST(st3);
         load_y0(p2, y0_c);
         // rotate the queue: own_c was loaded two iterations ago
 #pragma unroll
@@ -501,6 +524,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             for (int j = 0; j < 6; ++j) q[r][j] = q[r][j + 1];
             q[r][6] = own_c[r];
         }
+#ifdef HJ_STAMP
+        {
+            const unsigned long long st4 = __builtin_readcyclecounter();
+            st_acc[0] += st1 - st0; st_acc[1] += st2 - st1; st_acc[2] += st3 - st2; st_acc[3] += st4 - st3;
+        }
+#endif
     };
 
     constexpr int L1 = PDO * PDH / (PDO % PDH == 0 ? PDH : (PDH % PDO == 0 ? PDO : 1));   // lcm for 1..4
@@ -531,6 +560,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
     }
     if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
+#ifdef HJ_STAMP
+    // phases of wave 0 and of the last wave, after the 4*nblocks words of the start/end records
+    if (A.timing && (tid == 0 || tid == NT - 64)) {
+        unsigned long long* dst = A.timing + 4 * (size_t)A.nblocks + 8 * (size_t)L + (tid == 0 ? 0 : 4);
+        for (int k = 0; k < 4; ++k) dst[k] = st_acc[k];
+    }
+#endif
 }
 
 }  // namespace hj

@@ -169,7 +169,7 @@ inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s
                       X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
                       X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
 #else                   // the defaults per scheme plus the runners-up of the round-1 sweeps
-#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(256, 4, 3, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 3, 2) X(256, 2, 2, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
 #endif
 #endif
 

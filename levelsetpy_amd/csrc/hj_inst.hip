@@ -87,8 +87,8 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     const char* dump = getenv("HJ_TIMING_DUMP");    // debug: per-workgroup start/end clocks of every launch
     unsigned long long* tbuf = nullptr;
     if (dump && *dump) {
-        HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 4 * sizeof(unsigned long long), call_stream(c, s)));
+        HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 12 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(tbuf, 0, (size_t)t.nblocks * 12 * sizeof(unsigned long long), call_stream(c, s)));
         A.timing = tbuf;
     }
     if (c->launch_stop) {
@@ -103,14 +103,18 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     }
     HIP_TRY(hipGetLastError());
     if (tbuf) {
-        std::vector<unsigned long long> h((size_t)t.nblocks * 4);
+        std::vector<unsigned long long> h((size_t)t.nblocks * 12);
         HIP_TRY(hipStreamSynchronize(call_stream(c, s)));
         HIP_TRY(hipMemcpy(h.data(), tbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipFree(tbuf));
         if (FILE* f = fopen(dump, "a")) {
             fprintf(f, "# launch nblocks=%d ntiles=%d chunk=%d stage=%d\n", t.nblocks, t.ntiles, t.chunk, s.stage);
-            for (int i = 0; i < t.nblocks; ++i)
-                fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+            for (int i = 0; i < t.nblocks; ++i) {
+                fprintf(f, "%d %llu %llu %llu %llu", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+                // HJ_STAMP builds: shader-clock sums of the four phases of wave 0 and of the last wave (else zeros)
+                const unsigned long long* ph = h.data() + 4 * (size_t)t.nblocks + 8 * (size_t)i;
+                fprintf(f, " %llu %llu %llu %llu %llu %llu %llu %llu\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+            }
             fclose(f);
         }
     }
@@ -187,6 +191,9 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // tiny grids (<= ~135^3) run one wave per SIMD and a launch is a chain of ~10 plane
                 // iterations: one cell per thread shortens every iteration (7-10 % at 51^3 ... 129^3)
                 else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total < 2500000) { k.NT = 512; k.R = 1; pd = 2; occ = 4; }
+                // (the flag-free stage-2/3 instantiation of the as-shipped WENO5 lands on 170 VGPRs: two workgroups
+                // per CU with 34-plane chunks instead of three with 23.  Forcing 168 through the launch bound --
+                // config (256,2,2,3,2) -- was measured at 151^3 ... 251^3: within +-2 % of this, not kept)
                 else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
                 k.KH = cfg_kh(HAM::ND, k.NT, k.R);
             }
