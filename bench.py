@@ -257,9 +257,12 @@ def summarize(r, steps):
 
 
 def source_hash():
+    """Hash of every kernel / host source of the library (csrc/*.h, *.hip)."""
+    import glob
     h = hashlib.sha256()
-    for f in ("hj_api.hip", "hj_device.h", "hj_fused.h", "hj_split.h"):
-        with open(os.path.join(ROOT, "levelsetpy_amd", "csrc", f), "rb") as fh:
+    csrc = os.path.join(ROOT, "levelsetpy_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 

@@ -129,16 +129,25 @@ class DeviceGrid(object):
             if t.device != self.device or t.dtype != self.tdtype:
                 t = t.to(device=self.device, dtype=self.tdtype)
             return t.contiguous()
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(
-            device=self.device, dtype=self.tdtype)
+        h = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        # a page-locked source (e.g. an array this package returned) goes over at the DMA rate
+        return h.to(device=self.device, dtype=self.tdtype, non_blocking=False)
 
     def like(self, t, proto, shape=None):
-        """Return `t` in the array type of `proto` (NumPy in -> NumPy out, tensor in -> tensor out)."""
+        """Return `t` in the array type of `proto` (NumPy in -> NumPy out, tensor in -> tensor out).
+        The NumPy result lives in page-locked host memory from torch's caching host allocator (the D2H copy
+        runs at the DMA rate instead of through a pageable bounce buffer, and an array handed back to the next
+        call is recognised as pinned by to_device)."""
         if shape is not None:
             t = t.reshape(shape)
         if is_tensor(proto):
             return t
-        return t.detach().cpu().numpy()
+        t = t.detach()
+        if t.is_cuda and t.numel() * t.element_size() >= (1 << 20):
+            host = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t)
+            return host.numpy()
+        return t.cpu().numpy()
 
     def empty(self, shape=None):
         return self.torch.empty(self.shape if shape is None else shape, dtype=self.tdtype,

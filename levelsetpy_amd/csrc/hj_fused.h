@@ -541,10 +541,16 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             body(p + (u), own[(u) % PDO], own[((u) + PDO - 1) % PDO], hal[(u) % PDH], hin[(u) % PDH],  \
                  y0s[(u) % PDY], pls[(u) % PDY]);                                                                    \
     }
+#ifdef HJ_STAMP
+    const unsigned long long st_loop0 = wall_clock64(), st_cyc0 = __builtin_readcyclecounter();
+#endif
     for (int p = p_begin; p < p_end; p += UNR) {
         HJ_BODY(0) HJ_BODY(1) HJ_BODY(2) HJ_BODY(3) HJ_BODY(4) HJ_BODY(5)
     }
 #undef HJ_BODY
+#ifdef HJ_STAMP
+    const unsigned long long st_loop1 = wall_clock64(), st_cyc1 = __builtin_readcyclecounter();
+#endif
 
     // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim
     const int lane = tid & 63, wv = tid >> 6;
@@ -565,6 +571,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     if (A.timing && (tid == 0 || tid == NT - 64)) {
         unsigned long long* dst = A.timing + 4 * (size_t)A.nblocks + 8 * (size_t)L + (tid == 0 ? 0 : 4);
         for (int k = 0; k < 4; ++k) dst[k] = st_acc[k];
+        // the last wave's record carries the loop's wall-clock window and its shader-cycle length instead of
+        // phases C, D: (loop start, loop end) on the 100 MHz clock, cycles
+        if (tid != 0) { dst[1] = st_loop0; dst[2] = st_loop1; dst[3] = st_cyc1 - st_cyc0; }
     }
 #endif
 }

@@ -1,23 +1,29 @@
 #!/bin/bash
 # usage: tools/profile_round.sh <round-tag>      (on the GPU box; writes under gpurun_out/<tag>/)
-# 1. rocprofv3 --kernel-trace --stats of the default bench command
-# 2. separate --pmc passes: FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ issue/wait counters
-tag=${1:-r01}
+# 1. rocprofv3 --kernel-trace --stats of the default bench command (the driver's: --steps 20 --warmup 5)
+# 2. separate --pmc passes at 201^3 and 513^3: FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ issue/wait and LDS counters
+# 3. profiles/traffic.json rows (with the hash of the kernel sources they were measured on) printed at the end
+tag=${1:-r02}
 root=$PWD
 export TMPDIR=/tmp
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
-for n in 201 401; do
-  for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
+for n in 201 513; do
+  for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
     name=$(echo $ctr | cut -d' ' -f1)
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${n}_$name -- python3 $root/bench.py --no-cpu-baseline --steps 4 --warmup 1 --extra-schemes "" --n $n > /dev/null 2> $out/pmc_${n}_$name.err
+    HJ_BENCH_SPINUP=20 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${n}_$name -- python3 $root/bench.py --no-cpu-baseline --no-also --steps 4 --warmup 1 --repeats 1 --n $n > /dev/null 2> $out/pmc_${n}_$name.err
     echo "== n=$n $ctr" >> $out/pmc_summary.txt
     python3 $root/tools/pmc_summary.py $out/pmc_${n}_$name >> $out/pmc_summary.txt 2>&1
   done
 done
 cd $root
 find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
-cat $out/kernel_stats.csv | cut -c1-220 | head -8
+python3 - "$out" <<'PY'
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1] + "/kernel_stats.csv")))[:12]:
+    print("%-110s calls %5s avg_ns %10.0f  %5.1f %%" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]), float(r["Percentage"])))
+PY
 cat $out/pmc_summary.txt
+python3 tools/make_traffic.py $out

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the phase stamps of an HJ_STAMP build's HJ_TIMING_DUMP file (last launches): per workgroup the
-shader-clock time wave 0 and the last wave spent in the four phases of a plane iteration:
+"""Summarise the stamps of an HJ_STAMP build's HJ_TIMING_DUMP file (last launches).  Per workgroup: wall-clock
+(100 MHz) start / loop start / loop end / end, the loop's shader-cycle count (-> effective shader clock), and the
+share of wave 0's loop time in the phases of a plane iteration:
   A issue loads + LDS staging writes   B waiting at the barrier   C halo issue + LDS stencil reads + arithmetic + store
   D y0 issue + queue rotation."""
 import sys
@@ -16,11 +17,16 @@ for line in open(sys.argv[1]):
 if cur:
     launches.append((hdr, np.array(cur, dtype=np.float64)))
 for hdr, a in launches[-3:]:
-    dur = (a[:, 2] - a[:, 1]) / 100.0
-    print(hdr, " wg duration us: p50 %.1f max %.1f" % (np.median(dur), dur.max()))
-    for name, off in (("wave 0   ", 5), ("last wave", 9)):
-        ph = a[:, off:off + 4]
-        tot = ph.sum(axis=1)
-        frac = ph / tot[:, None]
-        print("   %s cycles/launch p50 %.0f   A %.2f  B(barrier) %.2f  C(compute) %.2f  D %.2f" %
-              (name, np.median(tot), *[np.median(frac[:, k]) for k in range(4)]))
+    t0 = a[:, 1].min()
+    st, en = (a[:, 1] - t0) / 100.0, (a[:, 2] - t0) / 100.0
+    l0, l1 = (a[:, 10] - t0) / 100.0, (a[:, 11] - t0) / 100.0
+    cyc = a[:, 12]
+    print(hdr)
+    print("   launch: first start 0, last end %.1f us;  per workgroup (p50): prologue %.1f us, loop %.1f us, epilogue %.1f us"
+          % (en.max(), np.median(l0 - st), np.median(l1 - l0), np.median(en - l1)))
+    print("   shader clock inside the loop: %.2f GHz (p50)" % np.median(cyc / ((l1 - l0) * 1e3)))
+    ph = a[:, 5:9]
+    frac = ph / ph.sum(axis=1)[:, None]
+    print("   wave 0 loop phases: A %.2f  B(barrier) %.2f  C(compute) %.2f  D %.2f" % tuple(np.median(frac[:, k]) for k in range(4)))
+    print("   start p10/p50/p90: %.1f %.1f %.1f   end p10/p50/p90: %.1f %.1f %.1f" %
+          (*np.percentile(st, [10, 50, 90]), *np.percentile(en, [10, 50, 90])))
