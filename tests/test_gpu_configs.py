@@ -666,3 +666,33 @@ def test_llf_scalar_alpha_and_fourth_candidate_vs_reference_golden(golden):
         dL, dR, DD = L.upwindFirstENO3aHelper(g, G["g3_data"], dim, True)
         assert np.max(np.abs(dL[3] - G["g3_helper4_dL3_d%d" % dim])) <= 1e-11
         assert np.max(np.abs(dR[3] - G["g3_helper4_dR3_d%d" % dim])) <= 1e-11
+
+
+def test_eno3_non_finite_selection_semantics():
+    """Documented divergence: the reference forms all three ENO3 candidates and multiplies
+    them by boolean masks (upwind_first_eno3a.py:133-141), so an Inf anywhere in a cell's 7-point footprint turns
+    the cell into NaN even if the candidate holding it is not selected; the kernels select first and only then
+    form the chosen candidate.  Away from the non-finite value both agree; inside its footprint the oracle
+    (reference semantics) is non-finite everywhere, the kernel only where the selected stencil touches it."""
+    g, og = mk([-1, -1], [1, 1], (24, 40), None)
+    rng = np.random.default_rng(2)
+    data = O.shape_sphere(og, None, .4) + 0.05 * rng.standard_normal((24, 40))
+    data[12, 20] = np.inf
+    for dim in (0, 1):
+        Lo, Ro = O.upwind_first_eno3(og, data, dim)
+        Lk, Rk = L.upwindFirstENO3(g, data, dim)
+        idx = np.arange(data.shape[dim])
+        far = np.abs(idx - (12 if dim == 0 else 20)) > 3
+        sl = [slice(None)] * 2
+        sl[dim] = far
+        for a, b in ((Lk, Lo), (Rk, Ro)):
+            assert np.all(np.isfinite(b[tuple(sl)])) and np.max(np.abs(a[tuple(sl)] - b[tuple(sl)])) <= 1e-11
+        line_o = (Lo[:, 20], Ro[:, 20]) if dim == 0 else (Lo[12, :], Ro[12, :])
+        line_k = (Lk[:, 20], Rk[:, 20]) if dim == 0 else (Lk[12, :], Rk[12, :])
+        c = 12 if dim == 0 else 20
+        near = slice(c - 2, c + 3)
+        assert not np.any(np.isfinite(line_o[0][near])) and not np.any(np.isfinite(line_o[1][near]))
+        bad_k = (~np.isfinite(line_k[0])).sum() + (~np.isfinite(line_k[1])).sum()
+        bad_o = (~np.isfinite(line_o[0])).sum() + (~np.isfinite(line_o[1])).sum()
+        assert 0 < bad_k <= bad_o
+        assert not np.isfinite(line_k[0][c]) or not np.isfinite(line_k[1][c])
