@@ -23,9 +23,11 @@ int env_int(const char* name, int dflt) {
 // ------------------------------------------------------------------------------------ tiling
 // Pick tile extents E[1..nd-1] (cells <= NT*R, halo slots <= KH*NT, LDS <= limit) minimising
 // (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
-Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) {
+// vec = 2: the pair kernel (hj_fusedv.h) -- k.R counts PAIRS per thread, the extent of the last axis is even, its LDS
+// rows are E + 8 cells apart (left pad 4)
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec) {
     const int nd = c->ndim;
-    const int cap = k.NT * k.R;
+    const int cap = k.NT * k.R * vec;
     Tiling best;
     best.ok = false;
     best.score = 1e300;
@@ -40,6 +42,15 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
             if (e == 1) break;
         }
     }
+    if (vec == 2) {            // even extents only (a tile never exceeds the axis: the last one is shifted back)
+        std::vector<int> ev;
+        for (int e : cand[nd - 1]) {
+            int e2 = std::min((e + 1) & ~1, n[nd - 1] & ~1);
+            if (e2 >= 2 && (ev.empty() || ev.back() != e2)) ev.push_back(e2);
+        }
+        cand[nd - 1] = ev;
+        if (ev.empty()) return best;
+    }
     if (c->full_rows == 1) {   // tuning knob: the last axis is never split (contiguous tile planes)
         cand[nd - 1].assign(1, n[nd - 1]);
     } else if (c->full_rows > 1) {   // tuning knob: force the last-axis extent
@@ -53,17 +64,20 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1) 
         for (int d = 2; d < nd; ++d) { E[d] = cand[d][it[d]]; cells *= E[d]; }
         if (cells <= cap) {
             E[1] = (int)std::min<long long>(n[1], std::max<long long>(1, cap / cells));
+            if (vec == 2 && nd == 2) E[1] &= ~1;
+            if (E[1] < 1) E[1] = 1;
+            const bool odd_row = vec == 2 && (E[nd - 1] & 1);      // the pair kernel needs an even row extent
             // E[1] must also be one of "n/parts" only for balance; any value works for correctness
             cells *= E[1];
             long long halo = 0, box = 1;
             for (int d = 1; d < nd; ++d) { halo += 6 * (cells / E[d]); box *= (E[d] + 6); }
             // bank-friendly row pitch (E + 32) when it fits, else the minimal E + 6
             const long long rows = box / (E[nd - 1] + 6);
-            int pitch = E[nd - 1] + 6;
-            if (c->lds_pad && nd >= 3 && 512 + 2 * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= c->lds_limit) pitch = E[nd - 1] + 32;
+            int pitch = E[nd - 1] + (vec == 2 ? 8 : 6);
+            if (vec == 1 && c->lds_pad && nd >= 3 && 512 + 2 * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= c->lds_limit) pitch = E[nd - 1] + 32;
             box = rows * pitch;
             size_t lds = 512 + 2 * (size_t)box * c->esz;
-            if (halo <= (long long)k.KH * k.NT && lds <= c->lds_limit) {
+            if (!odd_row && halo <= (long long)k.KH * k.NT && lds <= c->lds_limit) {
                 double util = (double)cells / (double)(((cells + k.NT - 1) / k.NT) * k.NT);
                 // cells recomputed by the shifted last tile on each axis
                 double waste = 1.0;
@@ -790,7 +804,12 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_r = env_int("HJ_F12_R", 0);
     c->f12_kh = env_int("HJ_F12_KH", 0);
     c->f12_warm = env_int("HJ_F12_WARM", 9);
-    c->f12_e2 = env_int("HJ_F12_E2", 0);     // test / A-B knob: always run the runtime-flag kernel (MODE 0)
+    c->f12_e2 = env_int("HJ_F12_E2", 0);
+    c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on 2-D / 3-D grids of >= 2.5 M cells (0: scalar kernel everywhere, 2: pair kernel whatever the size)
+    c->pair_nt = env_int("HJ_PAIR_NT", 0);
+    c->pair_r = env_int("HJ_PAIR_R", 0);
+    c->pair_kh = env_int("HJ_PAIR_KH", 0);
+    c->pair_occ = env_int("HJ_PAIR_OCC", 0);     // test / A-B knob: always run the runtime-flag kernel (MODE 0)
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);

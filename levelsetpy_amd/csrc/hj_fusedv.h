@@ -1,0 +1,433 @@
+// fused_substep_kernel with TWO ADJACENT CELLS PER LANE along the contiguous (last) grid axis (gfx950).
+//
+// Same algorithm, same per-cell arithmetic (so the results are bitwise those of fused_substep_kernel), other
+// thread <-> cell map: a "slot" is a pair of cells (j, j+1) of one tile row with j even in tile coordinates, and
+// a thread owns R slots dealt round-robin like the single cells of the scalar kernel.  What it buys (round-2
+// counters, DESIGN.md 4.2: both kernels are bound by memory / LDS instruction issue per cell, not by bytes):
+//   * HBM: one 16-byte buffer_load / buffer_store per pair instead of two 8-byte ones (own cells, y0, output);
+//   * LDS staging: one ds_write_b128 per pair;
+//   * LDS stencil reads of a pair: the row-direction neighbours j-3 .. j+4 are one ds_read_b64 + two ds_read_b128
+//     + one ds_read_b64 (8 distinct values; the scalar kernel reads 12, as 6 ds_read2_b64 at half rate), the
+//     other plane axis is 6 ds_read_b128 (aligned: the LDS row starts on an even cell, left pad 4 instead of 3, and
+//     the row pitch is even): 36 LDS cycles per pair instead of 72, 10 LDS instructions instead of 18-24;
+//   * half the address arithmetic.
+// Halo slots stay single cells (the halo columns are 3 cells wide).  The tile extent along the last axis must
+// be even; the last tile of an axis is shifted back inside the domain as before, so a global pair may start on
+// an odd cell (8-byte aligned 16-byte buffer access: legal, one more cache line per wave instruction).
+#pragma once
+#include "hj_fused.h"
+
+namespace hj {
+
+template <typename T> struct Pair;
+template <> struct Pair<double> { typedef double V __attribute__((ext_vector_type(2))); };
+template <> struct Pair<float> { typedef float V __attribute__((ext_vector_type(2))); };
+
+__device__ __forceinline__ Pair<double>::V buf_load2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, double) {
+    return __builtin_bit_cast(Pair<double>::V, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
+}
+__device__ __forceinline__ Pair<float>::V buf_load2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, float) {
+    return __builtin_bit_cast(Pair<float>::V, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+}
+// HAZARD (found in round 2, gfx950 / ROCm 7.2): a buffer store with MORE than 8 bytes of data reads its data
+// VGPRs late; a VALU instruction that overwrites them within two wait states corrupts the store.  hipcc's
+// hazard recogniser inserts the wait states only when the store has NO SGPR in its soffset field (it assumes the
+// SGPR form is safe); here the plane offset IS in soffset, and the next slot's arithmetic did clobber the data
+// registers in the very next instruction: racy, wrong values (an intermediate of the next cell's stencil) in a
+// few lanes of a plane.  A separate `asm volatile("s_nop")` after the builtin is not enough either - the
+// scheduler moves VALU work between the two - so the store and its wait states are ONE asm statement.  (The
+// compiler does not count this store in vmcnt; with in-order load returns that only makes its waits stricter.
+// Nor does its hazard recogniser look inside an asm statement: the SRD or soffset may have just been restored from
+// a spill lane by v_readlane (VALU-written SGPR read by VMEM needs 5 wait states), hence the leading s_nop 4.)
+__device__ __forceinline__ void buf_store2(Pair<double>::V v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 2"
+                 :: "v"(v), "v"(off), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    using W = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(W, v), r, off, soff, 0);
+}
+
+constexpr int HJ_VPAD = 4;      // left pad of an LDS row (cells): even, so that tile cell 0 of a row is 16-byte aligned
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int MODE = 0>
+__global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict__ y, const T* __restrict__ y0,
+                                                             T* __restrict__ out, const FusedArgs<T, HAM::ND> A) {
+    constexpr int ND = HAM::ND;
+    constexpr int LA = ND - 1;                  // the contiguous axis
+    constexpr int PD = 2;
+    constexpr bool GEN = (MODE == 0);
+    using V = typename Pair<T>::V;
+    const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
+    extern __shared__ __align__(16) unsigned char hj_smem[];
+    double (*red)[ND] = reinterpret_cast<double (*)[ND]>(hj_smem);
+    T* lds = reinterpret_cast<T*>(hj_smem + 512);
+    static_assert((NT / 64) * ND * 8 <= 512, "reduction scratch");
+
+    const int b = blockIdx.x;
+    const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
+    if (L >= A.nblocks) return;
+    const int chunk_id = L / A.ntiles;
+    int rem = L - chunk_id * A.ntiles;
+    int org[ND];
+#pragma unroll
+    for (int d = ND - 1; d >= 1; --d) {
+        const int qd = rem / A.ntile[d];
+        org[d] = min((rem - qd * A.ntile[d]) * A.E[d], A.n[d] - A.E[d]);
+        rem = qd;
+    }
+    const bool second = chunk_id >= A.nchunks1;
+    const int p_begin = second ? A.plane_begin2 + (chunk_id - A.nchunks1) * A.chunk : A.plane_begin + chunk_id * A.chunk;
+    const int p_end = min(p_begin + A.chunk, second ? A.plane_end2 : A.plane_end);
+
+    // ---- LDS geometry: rows of the last axis are A.lpitch (even) apart, cell j of a row sits at j + HJ_VPAD;
+    // the other plane axes keep the 3-cell pad
+    int ls[ND];
+    ls[LA] = 1;
+#pragma unroll
+    for (int d = ND - 2; d >= 1; --d) ls[d] = (d == ND - 2) ? A.lpitch : ls[d + 1] * (A.E[d + 1] + 2 * HJ_STENCIL);
+    const int lds_plane = (ND >= 3) ? ls[1] * (A.E[1] + 2 * HJ_STENCIL) : A.lpitch;
+    auto pad_of = [](int d) { return d == LA ? HJ_VPAD : HJ_STENCIL; };
+    int tile_cells = 1;
+#pragma unroll
+    for (int d = 1; d < ND; ++d) tile_cells *= A.E[d];
+    const int tile_slots = tile_cells >> 1;
+
+    const int tid = threadIdx.x;
+
+    // ---- own slots (pairs); surplus threads shadow the last slot
+    int own_lds[R];
+    unsigned own_g[R];
+    typename HAM::Cell hcell[R][2];
+    int own_idx[R][ND];
+    const bool last_real = (tid + (R - 1) * NT) < tile_slots;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int c = 2 * min(tid + r * NT, tile_slots - 1);
+        int lo = 0, g = 0;
+        int idx[ND];
+        idx[0] = 0;
+#pragma unroll
+        for (int d = ND - 1; d >= 1; --d) {
+            const int qd = c / A.E[d];
+            const int j = c - qd * A.E[d];
+            c = qd;
+            const int gi = org[d] + j;
+            idx[d] = gi;
+            lo += (j + pad_of(d)) * ls[d];
+            g += gi * A.pstride[d];
+        }
+        own_lds[r] = lo;
+        own_g[r] = (unsigned)g * (unsigned)sizeof(T);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) own_idx[r][d] = idx[d];
+    }
+
+    // ---- loaders of the own pairs, issued ahead of the rest of the setup (as in the scalar kernel)
+    const unsigned plane_bytes = (unsigned)(A.stride0 * (long long)sizeof(T));
+    const int p_lo = p_begin - HJ_STENCIL;
+    const unsigned span = (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;
+    const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
+    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
+    auto load_own = [&](int p, V* dst) {
+        const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
+        if (direct) {
+            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = buf_load2(ry, own_g[r], so, T());
+        } else {
+            const PlaneSrc<T> s = plane_src<T, ND>(A, p);
+            const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
+            if (!s.ghost) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) dst[r] = buf_load2(rb, own_g[r], 0u, T());
+            } else {
+                const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const V e = buf_load2(rb, own_g[r], 0u, T()), in = buf_load2(ri, own_g[r], 0u, T());
+                    V gv;
+                    gv.x = ghost_value<T>(e.x, in.x, s.km);
+                    gv.y = ghost_value<T>(e.y, in.y, s.km);
+                    dst[r] = gv;
+                }
+            }
+        }
+    };
+    auto load_y0 = [&](int p, V* dst) {
+        if (use_y0) {
+            const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = buf_load2(ry0, own_g[r], so, T());
+        }
+    };
+    const int p_last = p_end - 1;
+
+    // axis-0 queue q[r][c][j] <-> plane p-3+j of cell c of slot r
+    T q[R][2][7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        V tmp[R];
+        load_own(p_begin - 3 + j, tmp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { q[r][0][j] = tmp[r].x; q[r][1][j] = tmp[r].y; }
+    }
+    V own[PD][R], y0s[PD][R];
+    typename HAM::Plane pls[PD];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { own[s][r].x = T(0); own[s][r].y = T(0); }
+        if (s < PD - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { y0s[s][r].x = T(0); y0s[s][r].y = T(0); }
+        const int ps = min(p_begin + s, p_last);
+        load_y0(ps, y0s[s]);
+        pls[s] = HAM::plane(A.ham, ps, A.sc);
+    }
+    const typename HAM::Plane& plX = pls[0];
+
+    // per-column Hamiltonian constants of both cells of every slot
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int idx[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) idx[d] = own_idx[r][d];
+        hcell[r][0] = HAM::cell(A.ham, idx, A.sc);
+        idx[LA] += 1;
+        hcell[r][1] = HAM::cell(A.ham, idx, A.sc);
+    }
+
+    // ---- halo slots (single cells): the cross around the tile, as in the scalar kernel
+    int h_lds[KH], h_dlt[KH];
+    unsigned h_src[KH];
+    T h_km[KH];
+    bool h_real[KH];
+    {
+        int area[ND], base[ND + 1];
+        base[1] = 0;
+#pragma unroll
+        for (int d = 1; d < ND; ++d) {
+            area[d] = tile_cells / A.E[d];
+            base[d + 1] = base[d] + 2 * HJ_STENCIL * area[d];
+        }
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            int h = tid + k * NT;
+            h_real[k] = h < base[ND];
+            if (!h_real[k]) h = 0;
+            h_lds[k] = 0; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
+#pragma unroll
+            for (int d = 1; d < ND; ++d) {
+                if (h < base[d] || h >= base[d + 1]) continue;
+                const int hh = h - base[d];
+                const int lay = hh / area[d];
+                int c = hh - lay * area[d];
+                const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
+                int lo = 0, g = 0;
+#pragma unroll
+                for (int e = ND - 1; e >= 1; --e) {
+                    if (e == d) continue;
+                    const int qe = c / A.E[e];
+                    const int j = c - qe * A.E[e];
+                    c = qe;
+                    lo += (j + pad_of(e)) * ls[e];
+                    g += (org[e] + j) * A.pstride[e];
+                }
+                lo += (jd + pad_of(d)) * ls[d];
+                int gi = org[d] + jd;
+                const int nd = A.n[d];
+                int dlt = 0;
+                T km = T(0);
+                if (gi < 0) {
+                    if (A.bc[d] == HJ_BC_PERIODIC) gi += nd;
+                    else { km = T(-gi) * A.km[d]; dlt = A.pstride[d]; gi = 0; }
+                } else if (gi >= nd) {
+                    if (A.bc[d] == HJ_BC_PERIODIC) gi -= nd;
+                    else { km = T(gi - nd + 1) * A.km[d]; dlt = -A.pstride[d]; gi = nd - 1; }
+                }
+                h_lds[k] = lo;
+                h_src[k] = (unsigned)(g + gi * A.pstride[d]) * (unsigned)sizeof(T);
+                h_dlt[k] = dlt * (int)sizeof(T);
+                h_km[k] = km;
+            }
+        }
+    }
+    bool any_ghost = false;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) any_ghost = any_ghost || (h_dlt[k] != 0);
+    const bool tile_ghost = __syncthreads_or(any_ghost ? 1 : 0) != 0;
+
+    T eps[ND];
+    WenoK<T> wk[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { eps[d] = T(0); wk[d].c13 = T(0); wk[d].c4 = T(0); }
+    if constexpr (SCHEME == HJ_WENO5) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            wk[d] = weno_consts<T>(eps[d], A.K[d]);
+        }
+    }
+
+    auto load_halo = [&](int p, T* dst, T* dst_in) {
+        const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
+        if (tile_ghost) {
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                dst_in[k] = T(0);
+                if (h_dlt[k] != 0) dst_in[k] = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
+            }
+        }
+    };
+    T hal[PD][KH], hin[PD][KH];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+        for (int k = 0; k < KH; ++k) { hal[s][k] = T(0); hin[s][k] = T(0); }
+        load_halo(min(p_begin + s, p_last), hal[s], hin[s]);
+    }
+
+    double amax[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
+    {
+        T pz[ND], Hz, az[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) pz[d] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                HAM::eval(A.ham, hcell[r][c], plX, A.sc, pz, Hz, az);
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
+            }
+    }
+
+    auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* y0_c, typename HAM::Plane& pl_c) {
+        T* buf = lds + ((p - p_begin) & 1) * lds_plane;
+        load_own(min(p + 3 + PD, p_end + 2), own_n);
+        // stage the centre plane: one 16-byte LDS store per pair
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < R - 1 || last_real) {
+                V c2;
+                c2.x = q[r][0][3];
+                c2.y = q[r][1][3];
+                *reinterpret_cast<V*>(buf + own_lds[r]) = c2;
+            }
+        if (tile_ghost) {
+#pragma unroll
+            for (int k = 0; k < KH; ++k)
+                if (h_real[k]) buf[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KH; ++k)
+                if (h_real[k]) buf[h_lds[k]] = hal_c[k];
+        }
+        __syncthreads();
+        const int p2 = min(p + PD, p_last);
+        load_halo(min(p + PD, p_last), hal_c, hin_c);
+        const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
+        const typename HAM::Plane pl_use = pl_c;
+        pl_c = HAM::plane(A.ham, p2, A.sc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            T pc[2][ND], hd[2][ND];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) upwind_cd<SCHEME, T>(q[r][c], A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+            const T* base = buf + own_lds[r];
+            // plane axes other than the contiguous one: the pair's neighbours are pairs (16-byte LDS reads)
+#pragma unroll
+            for (int d = 1; d < LA; ++d) {
+                T va[7], vb[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    if (j == 3) { va[j] = q[r][0][3]; vb[j] = q[r][1][3]; continue; }
+                    const V n2 = *reinterpret_cast<const V*>(base + (j - 3) * ls[d]);
+                    va[j] = n2.x;
+                    vb[j] = n2.y;
+                }
+                upwind_cd<SCHEME, T>(va, A.K[d], eps[d], wk[d], pc[0][d], hd[0][d]);
+                upwind_cd<SCHEME, T>(vb, A.K[d], eps[d], wk[d], pc[1][d], hd[1][d]);
+            }
+            {   // the contiguous axis: cells j-3 .. j+4 = [b64][b128][own pair][b128][b64]
+                T w[8];
+                w[0] = base[-3];
+                const V l2 = *reinterpret_cast<const V*>(base - 2);
+                w[1] = l2.x; w[2] = l2.y;
+                w[3] = q[r][0][3]; w[4] = q[r][1][3];
+                const V r2 = *reinterpret_cast<const V*>(base + 2);
+                w[5] = r2.x; w[6] = r2.y;
+                w[7] = base[4];
+                upwind_cd<SCHEME, T>(w, A.K[LA], eps[LA], wk[LA], pc[0][LA], hd[0][LA]);
+                upwind_cd<SCHEME, T>(w + 1, A.K[LA], eps[LA], wk[LA], pc[1][LA], hd[1][LA]);
+            }
+            V o2;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                T H, alpha[ND];
+                HAM::eval(A.ham, hcell[r][c], pl_use, A.sc, pc[c], H, alpha);
+                T diss = T(0);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    diss += hd[c][d] * alpha[d];
+                    if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = fmax(amax[d], (double)alpha[d]);
+                }
+                T ydot = -(H - diss);
+                if (GEN && A.do_clamp) {
+                    ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
+                    ydot = (ydot > A.clamp_hi) ? A.clamp_hi : ydot;
+                }
+                const T y0v = c == 0 ? y0_c[r].x : y0_c[r].y;
+                T o;
+                if (GEN && A.ydot_only) o = ydot;
+                else {
+                    o = A.ca * y0v + A.cb * (q[r][c][3] + A.dt * ydot);
+                    if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0v : q[r][c][3]);
+                }
+                if (c == 0) o2.x = o; else o2.y = o;
+            }
+            if (r < R - 1 || last_real) buf_store2(o2, rout, own_g[r], so_out);
+        }
+        load_y0(p2, y0_c);
+#ifdef HJ_PAIR_SYNC2
+        __syncthreads();
+#endif
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { q[r][0][j] = q[r][0][j + 1]; q[r][1][j] = q[r][1][j + 1]; }
+            q[r][0][6] = own_c[r].x;
+            q[r][1][6] = own_c[r].y;
+        }
+    };
+
+    for (int p = p_begin; p < p_end; p += PD) {
+        body(p, own[0], own[1], hal[0], hin[0], y0s[0], pls[0]);
+        if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], hin[1], y0s[1], pls[1]);
+    }
+
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double m = wave_max(amax[d]) / (double)A.sc[d];
+        if (lane == 0) red[wv][d] = m;
+    }
+    __syncthreads();
+    if (tid < ND) {
+        double m = red[0][tid];
+        for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
+        if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+    }
+}
+
+}  // namespace hj

@@ -98,7 +98,8 @@ struct hj_ctx {
     hjh::KernelCfg cfg;
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
     int target_blocks, min_chunk, warmup_cost, no_plain;
-    int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;    // stage-fused kernel: 0 off, 1 on, -1 auto (by grid size); config override
+    int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;
+    int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on; config overrides    // stage-fused kernel: 0 off, 1 on, -1 auto (by grid size); config override
     size_t lds_limit;
     // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
     std::map<std::pair<const void*, size_t>, int> occ_cache;
@@ -110,7 +111,7 @@ namespace hjh {
 using namespace hj;
 
 int env_int(const char* name, int dflt);
-Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1);
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1);
 void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu);
 int cfg_kh(int nd, int nt, int r);
 

@@ -4,14 +4,22 @@
 #include "hj_host.h"
 #include "hj_fused.h"
 #include "hj_fused12.h"
+#include "hj_fusedv.h"
 
 namespace hjh {
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE>
+// PAIR: the two-cells-per-lane kernel (hj_fusedv.h; R = pairs per thread) instead of fused_substep_kernel
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE, bool PAIR>
+auto tiled_kernel() {
+    if constexpr (PAIR) return fused_pair_kernel<T, HAM, SCHEME, NT, R, KH, OCC, MODE>;
+    else return fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE>;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE, bool PAIR = false>
 int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     constexpr int ND = HAM::ND;
     {
-        auto kern0 = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE>;
+        auto kern0 = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
         const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
         auto it = c->occ_cache.find(key);
         if (it == c->occ_cache.end()) {
@@ -29,8 +37,8 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
             t.bpx = (t.nblocks + 7) / 8;
         }
         if (c->debug) {
-            fprintf(stderr, "[hj] tiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
-                    NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.lpitch, t.ntiles, t.chunk,
+            fprintf(stderr, "[hj] %stiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
+                    PAIR ? "pair " : "", NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.lpitch, t.ntiles, t.chunk,
                     t.nchunks, t.nblocks, occ_blocks, t.lds_bytes, t.score);
             c->debug = 0;
         }
@@ -79,7 +87,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
     A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
     fill_ham<T>(c, s.par, A.ham);
-    auto kern = fused_substep_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE>;
+    auto kern = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
     if (t.lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
@@ -122,13 +130,18 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
 }
 
 // plain RK stages (no clamp, no post-step operator, not ydot-only) run the flag-free instantiations
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD>
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, bool PAIR = false>
 int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
     const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0 && !c->no_plain;
-    if (plain && s.stage == HJ_STAGE_EULER) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 1>(c, s, t);
-    if (plain) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 2>(c, s, t);
-    return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 0>(c, s, t);
+    if (plain && s.stage == HJ_STAGE_EULER) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 1, PAIR>(c, s, t);
+    if (plain) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 2, PAIR>(c, s, t);
+    return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 0, PAIR>(c, s, t);
 }
+
+// (threads, PAIRS per thread, halo slots per thread, waves/SIMD hint) of the pair kernel
+#ifndef HJ_CONFIGS_PAIR
+#define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(256, 1, 2, 3) X(512, 2, 2, 2) X(512, 1, 1, 2)
+#endif
 
 template <typename T, typename HAM, int SCHEME>
 int launch_direct(hj_ctx* c, const SubstepCall& s) {
@@ -196,6 +209,24 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // config (256,2,2,3,2) -- was measured at 151^3 ... 251^3: within +-2 % of this, not kept)
                 else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
                 k.KH = cfg_kh(HAM::ND, k.NT, k.R);
+            }
+            if (c->pair != 0 && HAM::ND <= 3 && (c->total >= 2500000 || c->pair_nt > 0 || c->pair == 2)) {
+                // two cells per lane (hj_fusedv.h), round-2 A/B at 151^3 ... 513^3: the light stencils
+                // run 2 pairs per thread in 512-thread workgroups (220-232 VGPRs against 246-256 for four single
+                // cells), the heavy ones 1 pair in 256-thread workgroups
+                KernelCfg kp{512, 2, 2};
+                int occp = 2;
+                if (!(SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
+                if (c->pair_nt > 0) kp.NT = c->pair_nt;
+                if (c->pair_r > 0) kp.R = c->pair_r;
+                if (c->pair_kh > 0) kp.KH = c->pair_kh;
+                if (c->pair_occ > 0) occp = c->pair_occ;
+                const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2);
+                if (tp.ok) {
+#define X(NT_, R_, KH_, OCC_) if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp);
+                    HJ_CONFIGS_PAIR(X)
+#undef X
+                }
             }
             Tiling t = make_tiling(c, k, s.p0, s.p1);
             if (t.ok) {

@@ -696,3 +696,44 @@ def test_eno3_non_finite_selection_semantics():
         bad_o = (~np.isfinite(line_o[0])).sum() + (~np.isfinite(line_o[1])).sum()
         assert 0 < bad_k <= bad_o
         assert not np.isfinite(line_k[0][c]) or not np.isfinite(line_k[1][c])
+
+
+# ------------------------------------------------------------------------------ two cells per lane (hj_fusedv.h)
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd,tz", [
+    ((40, 37, 29), 2, None),            # odd row length: the last tile of the row is shifted back onto an odd cell
+    ((23, 30, 70), (0, 2), None),       # periodic march axis
+    ((31, 45, 34), None, (1, 2)),       # all extrapolated, towardZero on two axes
+    ((9, 8, 200), (1,), None),          # long rows, several tiles per row
+    ((64, 701), None, None),            # 2-D, odd row
+    ((30, 5000), (1,), None),           # 2-D, several tiles, periodic along the row
+])
+def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch):
+    """fused_pair_kernel (two adjacent cells per lane: 16-byte HBM / LDS accesses) against fused_substep_kernel on
+    an RK3 step, a clamped ydot-only term evaluation and a post-step-fused RK2 step: BITWISE."""
+    g, ham, par, data = _stage12_case(n, pd, tz)
+    res = {}
+    for flag in ("0", "2"):                        # 2: the pair kernel whatever the grid size
+        monkeypatch.setenv("HJ_PAIR", flag)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        y = dg.to_device(data)
+        outs = []
+        for order, post in ((3, 0), (2, 1)):
+            _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, post))
+            nxt, w0, w1 = dg.empty(), dg.empty(), dg.empty()
+            tout, dtout = C.c_double(), C.c_double()
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), 0., 1e9, 0.8, 1e300, 0,
+                                         dg.ptr(y), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+            outs.append(nxt)
+        _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, 0))
+        yd, sb = dg.empty(), C.c_double()
+        _ffi.check(dg.lib.hj_lf_term(dg.ctx, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), 0., -1, dg.ptr(y), dg.ptr(yd), C.byref(sb)))
+        dg.sync()
+        outs.append(yd)
+        res[flag] = (outs, sb.value)
+    assert res["0"][1] == res["2"][1]
+    for a, b in zip(res["0"][0], res["2"][0]):
+        assert torch.equal(a, b), "max diff %g at %s" % (float((a - b).abs().max()),
+                                                         np.unravel_index(int((a - b).abs().argmax()), n))
+    assert float((res["0"][0][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 0
