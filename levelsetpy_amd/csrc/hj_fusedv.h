@@ -30,18 +30,37 @@ __device__ __forceinline__ Pair<float>::V buf_load2(__amdgpu_buffer_rsrc_t r, un
     return __builtin_bit_cast(Pair<float>::V, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
 }
 // HAZARD (found in round 2, gfx950 / ROCm 7.2): a buffer store with MORE than 8 bytes of data reads its data
-// VGPRs late; a VALU instruction that overwrites them within two wait states corrupts the store.  hipcc's
-// hazard recogniser inserts the wait states only when the store has NO SGPR in its soffset field (it assumes the
-// SGPR form is safe); here the plane offset IS in soffset, and the next slot's arithmetic did clobber the data
-// registers in the very next instruction: racy, wrong values (an intermediate of the next cell's stencil) in a
-// few lanes of a plane.  A separate `asm volatile("s_nop")` after the builtin is not enough either - the
-// scheduler moves VALU work between the two - so the store and its wait states are ONE asm statement.  (The
-// compiler does not count this store in vmcnt; with in-order load returns that only makes its waits stricter.
-// Nor does its hazard recogniser look inside an asm statement: the SRD or soffset may have just been restored from
-// a spill lane by v_readlane (VALU-written SGPR read by VMEM needs 5 wait states), hence the leading s_nop 4.)
+// VGPRs late; a VALU instruction that overwrites them within two wait states corrupts the store (one wait state
+// was seen to corrupt as well).  hipcc's hazard recogniser inserts wait states only when the store has NO SGPR in
+// its soffset field (it assumes the SGPR form is safe); here the plane offset IS in soffset, and the next slot's
+// arithmetic did overwrite the data registers in the very next instruction: racy, wrong values (an intermediate
+// of the next cell's stencil) in a few lanes of a plane.  A bare `asm volatile("s_nop")` after the builtin is not
+// enough - the scheduler moves VALU work between the two.  Default form: the compiler's store (so it stays in the
+// vmcnt accounting), followed by a nop statement that takes the data as an INPUT and clobbers memory: the clobber
+// keeps it after the store, the input keeps the data registers live (unwritable) up to the nop.
+// tools/check_store_hazard.py disassembles the built library and verifies the rule for every wide store
+// (tests/test_cabi.py runs it).  -DHJ_ST_ASM: store + wait states as ONE asm statement (2-3 % slower: the
+// compiler no longer counts the store in vmcnt; it also needs the leading s_nop 4, because the hazard recogniser
+// does not look inside asm and the SRD / soffset may just have been restored from a spill lane by v_readlane).
+#ifndef HJ_ST_PRE
+#define HJ_ST_PRE 4
+#endif
+#ifndef HJ_ST_POST
+#define HJ_ST_POST 2
+#endif
+#define HJ_STR2(x) #x
+#define HJ_STR(x) HJ_STR2(x)
 __device__ __forceinline__ void buf_store2(Pair<double>::V v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
-    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 2"
+#if defined(HJ_ST_ASM)
+    asm volatile("s_nop " HJ_STR(HJ_ST_PRE) "\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop " HJ_STR(HJ_ST_POST)
                  :: "v"(v), "v"(off), "s"(r), "s"(soff) : "memory");
+#else
+    using W = decltype(__builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(W, v), r, off, soff, 0);
+#if !defined(HJ_ST_UNSAFE)      // HJ_ST_UNSAFE: tuning only (what the wait states cost); results can be wrong
+    asm volatile("s_nop " HJ_STR(HJ_ST_POST) :: "v"(v) : "memory");
+#endif
+#endif
 }
 __device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
     using W = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));

@@ -99,3 +99,17 @@ def test_no_gpu_fails_loudly():
         L.upwindFirstENO3(g, np.zeros((8, 8)), 0)
     with pytest.raises(RuntimeError):
         L.addGhostPeriodic(np.zeros((4, 4)), 0, 1)
+
+
+def test_wide_store_hazard_rule_holds_in_built_library():
+    """Disassembles the gfx950 code objects of the built library: no VGPR holding the data of a >8-byte store may be
+    written within two wait states of the store (hj_fusedv.h).  Static check, no GPU needed."""
+    import importlib.util, os
+    from levelsetpy_amd import _ffi
+    if not os.path.exists(_ffi.LIB_PATH) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("library or llvm-objdump not present")
+    spec = importlib.util.spec_from_file_location(
+        "check_store_hazard", os.path.join(os.path.dirname(__file__), "..", "tools", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    total, bad = mod.main(_ffi.LIB_PATH)
+    assert total > 0 and not bad, bad[:5]

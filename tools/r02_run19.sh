@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B on one box: one-cell-per-lane kernel vs pair kernel (asm 16-byte store) across sizes and schemes
+out=gpurun_out/r02s; mkdir -p $out; rm -f $out/*
+run() { echo "== $* $EXTRA" >> $out/ab.txt; env "$@" timeout -k 10 200 python bench.py --no-cpu-baseline --no-also --steps 30 --repeats 5 $EXTRA >> $out/ab.txt 2>> $out/ab.err; }
+for n in 201 251 301 401 513; do
+  EXTRA="--n $n" run HJ_PAIR=0
+  EXTRA="--n $n" run HJ_PAIR=1
+  EXTRA="--n $n" run HJ_PAIR=2 HJ_PAIR_NT=256 HJ_PAIR_R=1 HJ_PAIR_KH=2
+done
+for p in 0 1; do
+echo "== also HJ_PAIR=$p" >> $out/ab.txt
+HJ_PAIR=$p python bench.py --no-cpu-baseline --steps 20 --also WENO5,ENO3,ENO2,C3 >> $out/ab.txt 2>> $out/ab.err
+done
+python - <<'PY'
+import json
+for ln in open("gpurun_out/r02s/ab.txt"):
+    if ln.startswith("=="): print(ln.strip()); continue
+    d = json.loads(ln)
+    print("   %.4e  frac %.3f  ms/step %.4f spread %.3f" % (d["value"], d["roofline"]["frac"], d["ms_per_step"], d["repeats"]["spread"]))
+    for k, v in d.get("also", {}).items():
+        print("      also %-26s %.4e frac %.3f" % (k, v.get("value", 0), v.get("roofline_frac", 0)))
+PY
