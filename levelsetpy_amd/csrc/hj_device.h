@@ -24,6 +24,19 @@ template <> struct Lim<float>  { static constexpr float  tiny = 1e-30f; };
 template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
 template <> __device__ __forceinline__ double t_abs<double>(double x) { return __builtin_fabs(x); }
 template <> __device__ __forceinline__ float  t_abs<float>(float x)   { return __builtin_fabsf(x); }
+
+// Index division by a runtime divisor through one float reciprocal: ~9 instructions instead of the ~35 of the
+// exact 32-bit sequence.  Valid for 0 <= a < 2^22, 0 < d (every index of a launch: hj_inst.hip checks nblocks):
+// the float quotient is within 1 of the true one, and one correction in each direction settles it.  The kernels'
+// setup code is instruction-bound (two waves per SIMD), its dozen index divisions were a quarter of it.
+struct FDiv { int d; float r; };
+__device__ __forceinline__ FDiv fdiv_make(int d) { return FDiv{d, __builtin_amdgcn_rcpf((float)d)}; }
+__device__ __forceinline__ void fdivmod(int a, const FDiv& f, int& q, int& rem) {
+    q = (int)((float)a * f.r);
+    rem = a - q * f.d;
+    if (rem < 0) { --q; rem += f.d; }
+    if (rem >= f.d) { ++q; rem -= f.d; }
+}
 template <typename T> __device__ __forceinline__ T t_max(T a, T b) { return a > b ? a : b; }
 template <typename T> __device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
 
@@ -316,16 +329,24 @@ template <typename T> struct HamDubinsRel {
     // with p_d = sc_d q_d:  a' = sc0 a, b' = sc1 b, x1' = sc0 x1, x0' = sc1 x0
     struct Cell { T a, b, x1, alpha0; };      // a', b', x1', sc0*alpha0
     struct Plane { T x0, awx0; };             // x0', sc1*|w x0|
-    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
+    // cell_raw issues the table loads, cell_fin does the arithmetic: the fused kernels put their own loads between
+    struct Raw { T c, s, x1; };
+    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {
+        return Raw{P.aux[0][idx[2]], P.aux[1][idx[2]], P.coord[1][idx[1]]};
+    }
+    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>& P, const Raw& r, const T* sc) {
         Cell c;
-        const T a = P.par[0] - P.par[1] * P.aux[0][idx[2]];
-        const T b = P.par[1] * P.aux[1][idx[2]];
-        const T x1 = P.coord[1][idx[1]];
+        const T a = P.par[0] - P.par[1] * r.c;
+        const T b = P.par[1] * r.s;
+        const T x1 = r.x1;
         c.alpha0 = sc[0] * (t_abs(a) + t_abs(P.par[2] * x1));
         c.a = sc[0] * a;
         c.b = sc[1] * b;
         c.x1 = sc[0] * x1;
         return c;
+    }
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
+        return cell_fin(P, cell_raw(P, idx), sc);
     }
     __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T* sc) {
         Plane u;
@@ -352,12 +373,16 @@ template <typename T> struct HamDoubleIntegrator {
     static constexpr unsigned PLANE_DEP = 0x0;
     struct Cell { T x1, alpha0; };            // sc0*x2, sc0*|x2|
     struct Plane { int unused; };
-    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
+    struct Raw { T x1; };
+    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) { return Raw{P.coord[1][idx[1]]}; }
+    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>&, const Raw& r, const T* sc) {
         Cell c;
-        const T x1 = P.coord[1][idx[1]];
-        c.x1 = sc[0] * x1;
-        c.alpha0 = sc[0] * t_abs(x1);
+        c.x1 = sc[0] * r.x1;
+        c.alpha0 = sc[0] * t_abs(r.x1);
         return c;
+    }
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
+        return cell_fin(P, cell_raw(P, idx), sc);
     }
     __device__ static __forceinline__ Plane plane(const HamTables<T>&, int, const T*) { return Plane{0}; }
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane&,
@@ -378,13 +403,18 @@ template <typename T> struct HamDoublePendulum {
     static constexpr unsigned PLANE_DEP = 0xA;
     struct Cell { T w1, w2, s2, c2; };
     struct Plane { T s1, c1; };
-    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T*) {
+    using Raw = Cell;
+    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {
         Cell c;
         c.w1 = P.coord[1][idx[1]];
         c.w2 = P.coord[3][idx[3]];
         c.s2 = P.aux[2][idx[2]];
         c.c2 = P.aux[3][idx[2]];
         return c;
+    }
+    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>&, const Raw& r, const T*) { return r; }
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
+        return cell_fin(P, cell_raw(P, idx), sc);
     }
     __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T*) {
         Plane u;

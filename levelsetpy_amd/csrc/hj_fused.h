@@ -146,21 +146,24 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const int b = blockIdx.x;
     const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
     if (L >= A.nblocks) return;
-    const int chunk_id = L / A.ntiles;
-    int rem = L - chunk_id * A.ntiles;
+    int chunk_id, rem;
+    fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);     // index divisions through a float reciprocal (hj_device.h)
     if (A.timing && threadIdx.x == 0) {
         A.timing[4 * L + 0] = wall_clock64();
         A.timing[4 * L + 2] = (unsigned long long)(b & 7);
         A.timing[4 * L + 3] = (unsigned long long)chunk_id;
     }
     int org[ND];
+    FDiv fE[ND];
 #pragma unroll
     for (int d = ND - 1; d >= 1; --d) {
-        const int q = rem / A.ntile[d];
+        int q, rd;
+        fdivmod(rem, fdiv_make(A.ntile[d]), q, rd);
         // the last tile on an axis is shifted back so that no tile straddles the domain edge
         // (it recomputes a few cells of its neighbour: identical values, benign duplicate stores)
-        org[d] = min((rem - q * A.ntile[d]) * A.E[d], A.n[d] - A.E[d]);
+        org[d] = min(rd * A.E[d], A.n[d] - A.E[d]);
         rem = q;
+        fE[d] = fdiv_make(A.E[d]);
     }
     // two plane ranges may share a launch (the low and high edge planes of a slab)
     const bool second = chunk_id >= A.nchunks1;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     int own_lds[R];
     unsigned own_g[R];
     typename HAM::Cell hcell[R];
-    int own_idx[R][ND];
+    typename HAM::Raw hraw[R];
     // only the last round of the deal can run past the tile: shadows compute but do not write
     const bool last_real = (tid + (R - 1) * NT) < tile_cells;
 #pragma unroll
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         idx[0] = 0;
 #pragma unroll
         for (int d = ND - 1; d >= 1; --d) {
-            const int q = c / A.E[d];
-            const int j = c - q * A.E[d];
+            int q, j;
+            fdivmod(c, fE[d], q, j);
             c = q;
             const int gi = org[d] + j;
             idx[d] = gi;
@@ -207,8 +210,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);   // byte offset within a plane
-#pragma unroll
-        for (int d = 0; d < ND; ++d) own_idx[r][d] = idx[d];
+        // table loads of the per-column Hamiltonian constants go out FIRST (loads return in order: whatever waits
+        // for them later waits for nothing else); the arithmetic on them follows the halo setup
+        hraw[r] = HAM::cell_raw(A.ham, idx);
     }
 
     // ---- The loads every workgroup needs before its first plane (7 planes of its own cells, the first
@@ -289,10 +293,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         load_y0(ps, y0s[s]);
         pls[s] = HAM::plane(A.ham, ps, A.sc);
     }
-    const typename HAM::Plane& plX = pls[0];
-    // per-column Hamiltonian constants (table loads: issued behind the queue loads, consumed in the loop)
-#pragma unroll
-    for (int r = 0; r < R; ++r) hcell[r] = HAM::cell(A.ham, own_idx[r], A.sc);
 
     // ---- halo slots: for each plane axis d, 3 cells below and 3 above the tile, over the
     // tile's extent on the other axes (a "cross": no corners).  Surplus slots shadow slot 0.
@@ -303,10 +303,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     {
         int area[ND], base[ND + 1];
         base[1] = 0;
+        FDiv fA[ND];
 #pragma unroll
         for (int d = 1; d < ND; ++d) {
-            area[d] = tile_cells / A.E[d];
+            area[d] = 1;
+#pragma unroll
+            for (int e = 1; e < ND; ++e) if (e != d) area[d] *= A.E[e];
             base[d + 1] = base[d] + 2 * HJ_STENCIL * area[d];
+            fA[d] = fdiv_make(area[d]);
         }
 #pragma unroll
         for (int k = 0; k < KH; ++k) {
@@ -320,15 +324,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             for (int d = 1; d < ND; ++d) {
                 if (h < base[d] || h >= base[d + 1]) continue;
                 const int hh = h - base[d];
-                const int lay = hh / area[d];          // 0..5: which halo layer
-                int c = hh - lay * area[d];            // index over the other axes (last fastest)
+                int lay, c;                            // lay 0..5: which halo layer; c: index over the other axes
+                fdivmod(hh, fA[d], lay, c);
                 const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
                 int lo = 0, g = 0;
 #pragma unroll
                 for (int e = ND - 1; e >= 1; --e) {
                     if (e == d) continue;
-                    const int q = c / A.E[e];
-                    const int j = c - q * A.E[e];
+                    int q, j;
+                    fdivmod(c, fE[e], q, j);
                     c = q;
                     lo += (j + HJ_STENCIL) * ls[e];
                     g += (org[e] + j) * A.pstride[e];
@@ -355,10 +359,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 
     // does any halo slot of this tile lie outside the domain on an extrapolated axis?  (block-uniform:
     // interior tiles skip the ghost arithmetic and its second load altogether)
-    bool any_ghost = false;
+    // (wave-uniform, from the tile's position: the halo layers reach HJ_STENCIL cells past both ends of the tile.
+    // Until round 2 this was a __syncthreads_or over the slots -- a barrier that also waited for every load above)
+    bool tile_ghost = false;
 #pragma unroll
-    for (int k = 0; k < KH; ++k) any_ghost = any_ghost || (h_dlt[k] != 0);
-    const bool tile_ghost = __syncthreads_or(any_ghost ? 1 : 0) != 0;
+    for (int d = 1; d < ND; ++d)
+        tile_ghost = tile_ghost || (A.bc[d] != HJ_BC_PERIODIC && (org[d] < HJ_STENCIL || org[d] + A.E[d] + HJ_STENCIL > A.n[d]));
 
     T eps[ND];
 #pragma unroll
@@ -402,21 +408,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         load_halo(min(p_begin + s, p_last), hal[s], hin[s]);
     }
 
+    // the arithmetic on the Hamiltonian tables, now that every load of the setup is in flight
+#pragma unroll
+    for (int r = 0; r < R; ++r) hcell[r] = HAM::cell_fin(A.ham, hraw[r], A.sc);
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
-    {   // alphas that are constant along the march: one max per column
-        T pz[ND], Hz, az[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) pz[d] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            HAM::eval(A.ham, hcell[r], plX, A.sc, pz, Hz, az);
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-                if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
-        }
-    }
 
     // one plane.  own_c holds plane p+4 (joins the queue at the end); own_n is refilled with plane
     // p+3+PD; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
@@ -551,6 +548,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #ifdef HJ_STAMP
     const unsigned long long st_loop1 = wall_clock64(), st_cyc1 = __builtin_readcyclecounter();
 #endif
+
+    {   // alphas that are constant along the march: one max per column, taken once (any plane does)
+        T pz[ND], Hz, az[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) pz[d] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            HAM::eval(A.ham, hcell[r], pls[0], A.sc, pz, Hz, az);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
+        }
+    }
 
     // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim
     const int lane = tid & 63, wv = tid >> 6;

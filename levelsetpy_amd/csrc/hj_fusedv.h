@@ -86,14 +86,23 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     const int b = blockIdx.x;
     const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
     if (L >= A.nblocks) return;
-    const int chunk_id = L / A.ntiles;
-    int rem = L - chunk_id * A.ntiles;
+    int chunk_id, rem;
+    fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);
+    if (A.timing && threadIdx.x == 0) {         // HJ_TIMING_DUMP: start clock, XCC the hardware put us on, chunk, HW_ID
+        A.timing[4 * L + 0] = wall_clock64();
+        A.timing[4 * L + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);
+        A.timing[4 * L + 3] = (unsigned long long)chunk_id;
+        A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
     int org[ND];
+    FDiv fE[ND];
 #pragma unroll
     for (int d = ND - 1; d >= 1; --d) {
-        const int qd = rem / A.ntile[d];
-        org[d] = min((rem - qd * A.ntile[d]) * A.E[d], A.n[d] - A.E[d]);
+        int qd, rd;
+        fdivmod(rem, fdiv_make(A.ntile[d]), qd, rd);
+        org[d] = min(rd * A.E[d], A.n[d] - A.E[d]);
         rem = qd;
+        fE[d] = fdiv_make(A.E[d]);
     }
     const bool second = chunk_id >= A.nchunks1;
     const int p_begin = second ? A.plane_begin2 + (chunk_id - A.nchunks1) * A.chunk : A.plane_begin + chunk_id * A.chunk;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     int own_lds[R];
     unsigned own_g[R];
     typename HAM::Cell hcell[R][2];
-    int own_idx[R][ND];
+    typename HAM::Raw hraw[R][2];
     const bool last_real = (tid + (R - 1) * NT) < tile_slots;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -128,8 +137,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         idx[0] = 0;
 #pragma unroll
         for (int d = ND - 1; d >= 1; --d) {
-            const int qd = c / A.E[d];
-            const int j = c - qd * A.E[d];
+            int qd, j;
+            fdivmod(c, fE[d], qd, j);
             c = qd;
             const int gi = org[d] + j;
             idx[d] = gi;
@@ -138,8 +147,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) own_idx[r][d] = idx[d];
+        // table loads of the per-column Hamiltonian constants go out FIRST (loads return in order: whatever waits
+        // for them later waits for nothing else); the arithmetic on them follows the halo setup
+        hraw[r][0] = HAM::cell_raw(A.ham, idx);
+        idx[LA] += 1;
+        hraw[r][1] = HAM::cell_raw(A.ham, idx);
     }
 
     // ---- loaders of the own pairs, issued ahead of the rest of the setup (as in the scalar kernel)
@@ -192,6 +204,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) { q[r][0][j] = tmp[r].x; q[r][1][j] = tmp[r].y; }
     }
+    if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 0] = wall_clock64();
     V own[PD][R], y0s[PD][R];
     typename HAM::Plane pls[PD];
 #pragma unroll
@@ -208,19 +221,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         load_y0(ps, y0s[s]);
         pls[s] = HAM::plane(A.ham, ps, A.sc);
     }
-    const typename HAM::Plane& plX = pls[0];
 
-    // per-column Hamiltonian constants of both cells of every slot
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int idx[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) idx[d] = own_idx[r][d];
-        hcell[r][0] = HAM::cell(A.ham, idx, A.sc);
-        idx[LA] += 1;
-        hcell[r][1] = HAM::cell(A.ham, idx, A.sc);
-    }
-
+    if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 1] = wall_clock64();
     // ---- halo slots (single cells): the cross around the tile, as in the scalar kernel
     int h_lds[KH], h_dlt[KH];
     unsigned h_src[KH];
@@ -229,10 +231,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     {
         int area[ND], base[ND + 1];
         base[1] = 0;
+        FDiv fA[ND];
 #pragma unroll
         for (int d = 1; d < ND; ++d) {
-            area[d] = tile_cells / A.E[d];
+            area[d] = 1;
+#pragma unroll
+            for (int e = 1; e < ND; ++e) if (e != d) area[d] *= A.E[e];
             base[d + 1] = base[d] + 2 * HJ_STENCIL * area[d];
+            fA[d] = fdiv_make(area[d]);
         }
 #pragma unroll
         for (int k = 0; k < KH; ++k) {
@@ -244,15 +250,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             for (int d = 1; d < ND; ++d) {
                 if (h < base[d] || h >= base[d + 1]) continue;
                 const int hh = h - base[d];
-                const int lay = hh / area[d];
-                int c = hh - lay * area[d];
+                int lay, c;
+                fdivmod(hh, fA[d], lay, c);
                 const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
                 int lo = 0, g = 0;
 #pragma unroll
                 for (int e = ND - 1; e >= 1; --e) {
                     if (e == d) continue;
-                    const int qe = c / A.E[e];
-                    const int j = c - qe * A.E[e];
+                    int qe, j;
+                    fdivmod(c, fE[e], qe, j);
                     c = qe;
                     lo += (j + pad_of(e)) * ls[e];
                     g += (org[e] + j) * A.pstride[e];
@@ -276,10 +282,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             }
         }
     }
-    bool any_ghost = false;
+    // does any halo slot of this tile lie outside a non-periodic plane axis?  (wave-uniform; the halo layers reach
+    // HJ_STENCIL cells past both ends of the tile)
+    bool tile_ghost = false;
 #pragma unroll
-    for (int k = 0; k < KH; ++k) any_ghost = any_ghost || (h_dlt[k] != 0);
-    const bool tile_ghost = __syncthreads_or(any_ghost ? 1 : 0) != 0;
+    for (int d = 1; d < ND; ++d)
+        tile_ghost = tile_ghost || (A.bc[d] != HJ_BC_PERIODIC && (org[d] < HJ_STENCIL || org[d] + A.E[d] + HJ_STENCIL > A.n[d]));
+    if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 2] = wall_clock64();
 
     T eps[ND];
     WenoK<T> wk[ND];
@@ -313,23 +322,16 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         load_halo(min(p_begin + s, p_last), hal[s], hin[s]);
     }
 
+    if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 3] = wall_clock64();
+    // the arithmetic on the Hamiltonian tables, now that every load of the setup is in flight
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        hcell[r][0] = HAM::cell_fin(A.ham, hraw[r][0], A.sc);
+        hcell[r][1] = HAM::cell_fin(A.ham, hraw[r][1], A.sc);
+    }
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
-    {
-        T pz[ND], Hz, az[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) pz[d] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                HAM::eval(A.ham, hcell[r][c], plX, A.sc, pz, Hz, az);
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
-            }
-    }
 
     auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* y0_c, typename HAM::Plane& pl_c) {
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
@@ -430,9 +432,27 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         }
     };
 
+    if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 5] = wall_clock64();   // loop start
     for (int p = p_begin; p < p_end; p += PD) {
         body(p, own[0], own[1], hal[0], hin[0], y0s[0], pls[0]);
         if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], hin[1], y0s[1], pls[1]);
+        if (A.timing && tid == 0 && p == p_begin) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 7] = wall_clock64();
+    }
+    if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
+
+    {   // alpha of the dimensions that do not vary along the march: column constants, taken once (any plane does)
+        T pz[ND], Hz, az[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) pz[d] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                HAM::eval(A.ham, hcell[r][c], pls[0], A.sc, pz, Hz, az);
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
+            }
     }
 
     const int lane = tid & 63, wv = tid >> 6;
@@ -447,6 +467,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
         if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
     }
+    if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
 }
 
 }  // namespace hj

@@ -72,6 +72,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.plane_end2 = (int)s.q1;
     A.nchunks1 = t.nchunks1;
     A.nblocks = t.nblocks;
+    if (t.nblocks >= (1 << 22)) return hjh::fail(HJ_EUNSUPPORTED, "more than 4 M workgroups in one launch (index arithmetic of the kernels)");
     A.blocks_per_xcd = t.bpx;
     A.ydot_only = (s.stage == HJ_STAGE_YDOT);
     A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
