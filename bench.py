@@ -238,8 +238,9 @@ def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
         devs.append(e0.elapsed_time(e1))
     assert bool(torch.isfinite(state["cur"]).all()), "non-finite state after the timed steps (%s)" % desc
     launches = lib.hj_launches_per_step(dg.ctx, 3, sid) if hasattr(lib, "hj_launches_per_step") else 3
+    kern = lib.hj_last_kernel(dg.ctx)
     return {"desc": desc, "cells": dg.numel, "dtype": dtype, "scheme": scheme, "walls": walls, "devs": devs,
-            "launches_per_step": int(launches)}
+            "launches_per_step": int(launches), "kernel": kern.decode() if kern else "?"}
 
 
 def summarize(r, steps):
@@ -388,8 +389,11 @@ def run(a, rank, world, local, slab_leg, cpu):
         # the step's launches as one unit: algorithmic bytes of an RK3 step (8 words per cell) over the HIP-event
         # time of a step's launches, back to back on the ctx stream (median repeat)
         "roofline": {"bound": "hbm", "achieved": s["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s["frac"],
-                     "traffic": tr["bytes_per_step"] if tr else None,
-                     "kernel": "fused_substep_kernel x %d launches = one RK3 step" % r["launches_per_step"],
+                     # measured HBM bytes per launch (mean of the step's launches; null unless the PMC passes in
+                     # profiles/traffic.json were taken on exactly these kernel sources)
+                     "traffic": tr["bytes_per_launch"] if tr else None,
+                     "traffic_per_step": tr["bytes_per_step"] if tr else None,
+                     "kernel": "%s x %d launches = one RK3 step" % (r["kernel"], r["launches_per_step"]),
                      "kernel_ms": s["dev_step_ms"] / r["launches_per_step"], "step_ms": s["dev_step_ms"],
                      "algorithmic_bytes_per_launch": cells * 3 * bps / r["launches_per_step"],
                      "algorithmic_bytes_per_step": cells * 3 * bps},

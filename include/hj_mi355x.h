@@ -271,6 +271,10 @@ int hj_slab_rk_step_deep(hj_ctx* ctx, int order, int scheme, int ham_id, const d
 
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);
+/* Name of the substep kernel the last hj_rk_substep / hj_rk_step / hj_lf_term on this ctx launched:
+ * "fused_pair_kernel", "fused_substep_kernel", "fused12_kernel" or "direct_substep_kernel" (bench.py names the
+ * kernel its roofline is about; no reference counterpart). */
+const char* hj_last_kernel(hj_ctx* ctx);
 const char* hj_version(void);
 
 #ifdef __cplusplus

@@ -67,6 +67,7 @@ SIGNATURES = {
     "hj_slab_rk_step_deep": (_i, [_vp, _i, _i, _i, _pd, _d, _i, _vp, _vp, _vp, _vp]),
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
+    "hj_last_kernel": (C.c_char_p, [C.c_void_p]),
     "hj_version": (C.c_char_p, []),
 }
 

@@ -739,6 +739,7 @@ static int split_end_launch(hj_ctx* c, const void* const* dL, const void* const*
 extern "C" {
 
 const char* hj_last_error(void) { return hjh::g_err; }
+const char* hj_last_kernel(hj_ctx* c) { return c ? c->last_kernel : ""; }
 const char* hj_version(void) { return "hj_mi355x 0.1 (gfx950)"; }
 
 int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,

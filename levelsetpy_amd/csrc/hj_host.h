@@ -99,7 +99,8 @@ struct hj_ctx {
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
     int target_blocks, min_chunk, warmup_cost, no_plain;
     int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;
-    int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on; config overrides    // stage-fused kernel: 0 off, 1 on, -1 auto (by grid size); config override
+    int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
+    const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)
     size_t lds_limit;
     // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
     std::map<std::pair<const void*, size_t>, int> occ_cache;

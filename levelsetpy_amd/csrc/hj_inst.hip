@@ -89,6 +89,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
     fill_ham<T>(c, s.par, A.ham);
     auto kern = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
+    c->last_kernel = PAIR ? "fused_pair_kernel" : "fused_substep_kernel";
     if (t.lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
@@ -175,6 +176,7 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
         const long long cells = A.cell_end - A.cell_begin;
         if (cells <= 0) continue;
         int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
+        c->last_kernel = "direct_substep_kernel";
         hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, call_stream(c, s), A);
         HIP_TRY(hipGetLastError());
     }
@@ -337,6 +339,7 @@ template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
 int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     constexpr int ND = HAM::ND;
     auto kern = fused12_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
+    c->last_kernel = "fused12_kernel";
     if (t.lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     const auto key = std::make_pair(reinterpret_cast<const void*>(kern), t.lds_bytes);

@@ -24,7 +24,7 @@ def mean_counter(d, name):
     vals = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == name and "fused_substep_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == name and ("fused_substep_kernel" in r["Kernel_Name"] or "fused_pair_kernel" in r["Kernel_Name"]):
                 vals.append(float(r["Counter_Value"]))
     return sum(vals) / len(vals) if vals else None
 

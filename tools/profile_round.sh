@@ -10,6 +10,11 @@ out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
+# 1b. the headline workload alone (201^3, the default K/W): this stats file's average for the dominant kernel is the
+#     number bench.py's roofline.kernel_ms has to agree with (the default command above mixes 201^3 and 513^3 launches
+#     of the same instantiation in one row)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats201 -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also > $out/stats201_bench.json 2> $out/stats201.err
+find $out/stats201 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_201.csv
 for n in 201 513; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
     name=$(echo $ctr | cut -d' ' -f1)
