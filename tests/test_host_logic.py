@@ -54,3 +54,21 @@ def test_trim_keeps_nodes_strictly_inside_four_cells():
     dx = np.asarray(g2.dx).ravel()
     keep = [np.nonzero((vs[d] > vs[d][0] + 4 * dx[d]) & (vs[d] < vs[d][-1] - 4 * dx[d]))[0] for d in range(3)]
     assert np.array_equal(t, b[np.ix_(*keep)])
+
+
+def test_float_reciprocal_index_division_is_exact_below_2_pow_22():
+    """hj_device.h fdivmod: q = (int)((float)a * rcp(d)) followed by one correction in each direction.  NumPy float32
+    replica over every dividend below 2^22 for divisors of the sizes the kernels use (tile extents, tile counts, halo
+    areas), with the hardware reciprocal's 1-ulp error taken in both directions."""
+    a = np.arange(0, 1 << 22, dtype=np.int64)
+    af = a.astype(np.float32)
+    for d in (1, 3, 7, 15, 27, 30, 68, 84, 133, 513, 4096, 65521):
+        r0 = np.float32(1.0) / np.float32(d)
+        for r in (r0, np.nextafter(r0, np.float32(0)), np.nextafter(r0, np.float32(2))):
+            q = (af * r).astype(np.int64)             # float32 product, truncated like v_cvt_i32_f32
+            rem = a - q * d
+            lo = rem < 0
+            q = q - lo; rem = rem + lo * d
+            hi = rem >= d
+            q = q + hi; rem = rem - hi * d
+            assert np.array_equal(q, a // d) and np.array_equal(rem, a % d), (d, float(r))
