@@ -23,11 +23,20 @@ template <typename T> struct Pair;
 template <> struct Pair<double> { typedef double V __attribute__((ext_vector_type(2))); };
 template <> struct Pair<float> { typedef float V __attribute__((ext_vector_type(2))); };
 
+// cache-policy experiments (gfx940+ aux encoding: 1 = sc0, 2 = nt, 16 = sc1): -DHJ_PAIR_AUX_Y0=2 / -DHJ_PAIR_AUX_OUT=2
+#ifndef HJ_PAIR_AUX_Y0
+#define HJ_PAIR_AUX_Y0 0
+#endif
+#ifndef HJ_PAIR_AUX_OUT
+#define HJ_PAIR_AUX_OUT 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ Pair<double>::V buf_load2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, double) {
-    return __builtin_bit_cast(Pair<double>::V, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
+    return __builtin_bit_cast(Pair<double>::V, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ Pair<float>::V buf_load2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff, float) {
-    return __builtin_bit_cast(Pair<float>::V, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+    return __builtin_bit_cast(Pair<float>::V, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, AUX));
 }
 // HAZARD (found in round 2, gfx950 / ROCm 7.2): a buffer store with MORE than 8 bytes of data reads its data
 // VGPRs late; a VALU instruction that overwrites them within two wait states corrupts the store (one wait state
@@ -56,7 +65,7 @@ __device__ __forceinline__ void buf_store2(Pair<double>::V v, __amdgpu_buffer_rs
                  :: "v"(v), "v"(off), "s"(r), "s"(soff) : "memory");
 #else
     using W = decltype(__builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(W, v), r, off, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(W, v), r, off, soff, HJ_PAIR_AUX_OUT);
 #if !defined(HJ_ST_UNSAFE)      // HJ_ST_UNSAFE: tuning only (what the wait states cost); results can be wrong
     asm volatile("s_nop " HJ_STR(HJ_ST_POST) :: "v"(v) : "memory");
 #endif
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (use_y0) {
             const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load2(ry0, own_g[r], so, T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load2<HJ_PAIR_AUX_Y0>(ry0, own_g[r], so, T());
         }
     };
     const int p_last = p_end - 1;
