@@ -144,6 +144,10 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
 #ifndef HJ_CONFIGS_PAIR
 #define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(256, 1, 2, 3) X(512, 2, 2, 2) X(512, 1, 1, 2)
 #endif
+// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile): only on request (HJ_PAIR_NT/R/KH/OCC)
+#ifndef HJ_CONFIGS_PAIR_4D
+#define HJ_CONFIGS_PAIR_4D(X) X(512, 1, 5, 2) X(512, 2, 7, 2) X(256, 2, 5, 2)
+#endif
 
 template <typename T, typename HAM, int SCHEME>
 int launch_direct(hj_ctx* c, const SubstepCall& s) {
@@ -213,7 +217,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
                 k.KH = cfg_kh(HAM::ND, k.NT, k.R);
             }
-            if (c->pair != 0 && HAM::ND <= 3 && (c->total >= 2500000 || c->pair_nt > 0 || c->pair == 2)) {
+            if (c->pair != 0 && (HAM::ND <= 3 ? (c->total >= 2500000 || c->pair_nt > 0 || c->pair == 2) : (c->pair_nt > 0))) {
                 // two cells per lane (hj_fusedv.h), round-2 A/B at 151^3 ... 513^3: the light stencils
                 // run 2 pairs per thread in 512-thread workgroups (220-232 VGPRs against 246-256 for four single
                 // cells), the heavy ones 1 pair in 256-thread workgroups
@@ -227,7 +231,8 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2);
                 if (tp.ok) {
 #define X(NT_, R_, KH_, OCC_) if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp);
-                    HJ_CONFIGS_PAIR(X)
+                    if constexpr (HAM::ND == 4) { HJ_CONFIGS_PAIR_4D(X) }
+                    else { HJ_CONFIGS_PAIR(X) }
 #undef X
                 }
             }
