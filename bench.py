@@ -22,7 +22,8 @@ grid).  Before it is timed, a decomposition has to reproduce the single-domain r
 it runs on ("slab_check_max_abs_diff").
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (algorithmic bytes / measured kernel time vs
-the 8 TB/s HBM peak) and "cpu_baseline" (the NumPy oracle timed on this host's cores on a bounded sample
+the 8 TB/s HBM peak; "traffic" = fabric bytes per launch from two rocprofv3 --pmc child passes of this very
+run, taken before the timed legs) and "cpu_baseline" (the NumPy oracle timed on this host's cores on a bounded sample
 of the same workload; N = 1 only).
 """
 import argparse
@@ -66,6 +67,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported under 'also'")
     ap.add_argument("--also", default="WENO5,513,C3,C5", help="comma list of the extra workloads to time")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -268,6 +271,47 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def live_traffic(a):
+    """roofline.traffic measured IN THIS RUN: two child passes of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE need separate passes, MI355X_MICROARCH.md), 4 steps of the headline workload each, started BEFORE this
+    process touches the GPU (a process that holds the GPU must not fork/exec on this pool) and finished before the
+    timed legs begin.  bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB averaged over the launches of the substep
+    kernel (FETCH_SIZE doubled: the guide's gfx950 correction for wide coalesced reads).  Returns None when rocprofv3
+    is missing or a pass fails; the caller then falls back to profiles/traffic.json (same-source rows only)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    vals, t0 = {}, time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP="20")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also", "--no-live-traffic", "--steps", "4",
+               "--warmup", "1", "--repeats", "1", "--n", str(a.n), "--scheme", a.scheme, "--dtype", a.dtype]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            v = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        k = r["Kernel_Name"]
+                        if r["Counter_Name"] == ctr and ("fused_pair_kernel" in k or "fused_substep_kernel" in k):
+                            v.append(float(r["Counter_Value"]))
+            if not v:
+                return None
+            vals[ctr] = (sum(v) / len(v), len(v))
+        except Exception:  # noqa: BLE001
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    per_launch = (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024
+    return {"bytes_per_launch": per_launch, "bytes_per_step": 3 * per_launch, "fetch_kib": vals["FETCH_SIZE"][0],
+            "write_kib": vals["WRITE_SIZE"][0], "launches_sampled": vals["FETCH_SIZE"][1],
+            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (4 RK3 steps each, %.0f s)"
+                      % (time.perf_counter() - t0)}
+
+
 def measured_traffic(n, scheme, dtype):
     """HBM bytes per RK3 step from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs by tools/profile_round.sh, FETCH_SIZE doubled per
@@ -297,6 +341,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not slab_leg and not a.no_cpu_baseline:
         cpu = CpuBaseline(a.scheme)          # before the GPU is touched; idle until the GPU legs are done
+    a.live = None
+    # (quick runs -- --no-also -- and runs that are themselves being profiled skip the passes)
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rank == 0 and world == 1 and not slab_leg and not a.no_live_traffic and not a.no_also and not profiled:
+        a.live = live_traffic(a)             # two rocprofv3 child passes, also before this process touches the GPU
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version header at
     # communicator creation, for one) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -377,7 +426,11 @@ def run(a, rank, world, local, slab_leg, cpu):
     r = time_single(torch, _ffi, DeviceGrid, wl, a.steps, a.warmup, a.repeats, SPINUP_STEPS)
     s = summarize(r, a.steps)
     cells = r["cells"]
-    tr = measured_traffic(a.n, a.scheme, a.dtype)
+    tr = getattr(a, "live", None)
+    if tr is None:
+        tr = measured_traffic(a.n, a.scheme, a.dtype)
+        if tr is not None:
+            tr = dict(tr, source="profiles/traffic.json (PMC passes of tools/profile_round.sh on these kernel sources)")
     out = {
         "metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI %d^3 %s" % (a.n, "fp64" if a.dtype == "float64" else "fp32"),
         "value": s["value"], "unit": "cell-substeps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
@@ -393,6 +446,7 @@ def run(a, rank, world, local, slab_leg, cpu):
                      # profiles/traffic.json were taken on exactly these kernel sources)
                      "traffic": tr["bytes_per_launch"] if tr else None,
                      "traffic_per_step": tr["bytes_per_step"] if tr else None,
+                     "traffic_source": tr["source"] if tr else None,
                      "kernel": "%s x %d launches = one RK3 step" % (r["kernel"], r["launches_per_step"]),
                      "kernel_ms": s["dev_step_ms"] / r["launches_per_step"], "step_ms": s["dev_step_ms"],
                      "algorithmic_bytes_per_launch": cells * 3 * bps / r["launches_per_step"],

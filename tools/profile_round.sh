@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $out/stats_bench.json 2> $out/stats.err
 # 1b. the headline workload alone (201^3, the default K/W): this stats file's average for the dominant kernel is the
 #     number bench.py's roofline.kernel_ms has to agree with (the default command above mixes 201^3 and 513^3 launches
 #     of the same instantiation in one row)
