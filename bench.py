@@ -271,7 +271,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def live_traffic(a):
+def live_traffic(a, n=None):
     """roofline.traffic measured IN THIS RUN: two child passes of this script under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE need separate passes, MI355X_MICROARCH.md), 4 steps of the headline workload each, started BEFORE this
     process touches the GPU (a process that holds the GPU must not fork/exec on this pool) and finished before the
@@ -288,7 +288,7 @@ def live_traffic(a):
         env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP="20")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also", "--no-live-traffic", "--steps", "4",
-               "--warmup", "1", "--repeats", "1", "--n", str(a.n), "--scheme", a.scheme, "--dtype", a.dtype]
+               "--warmup", "1", "--repeats", "1", "--n", str(n or a.n), "--scheme", a.scheme, "--dtype", a.dtype]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
             v = []
@@ -341,11 +341,13 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not slab_leg and not a.no_cpu_baseline:
         cpu = CpuBaseline(a.scheme)          # before the GPU is touched; idle until the GPU legs are done
-    a.live = None
+    a.live, a.live_also = None, {}
     # (quick runs -- --no-also -- and runs that are themselves being profiled skip the passes)
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if rank == 0 and world == 1 and not slab_leg and not a.no_live_traffic and not a.no_also and not profiled:
         a.live = live_traffic(a)             # two rocprofv3 child passes, also before this process touches the GPU
+        # the same for the digit entries of --also (513^3: the point where the arrays do not fit the Infinity Cache)
+        a.live_also = {x: live_traffic(a, int(x)) for x in a.also.split(",") if x.isdigit()} if a.live else {}
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version header at
     # communicator creation, for one) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -469,7 +471,11 @@ def run(a, rank, world, local, slab_leg, cpu):
                 s2 = summarize(r2, st)
                 also[key] = {"workload": r2["desc"], "dtype": "f64" if r2["dtype"] == "float64" else "f32", "steps": st,
                              "value": s2["value"], "ms_per_step": s2["ms_per_step"], "roofline_frac": s2["frac"],
-                             "achieved_GBps": s2["achieved"], "repeats": s2["repeats"]}
+                             "achieved_GBps": s2["achieved"], "repeats": s2["repeats"], "kernel": r2["kernel"]}
+                lt = getattr(a, "live_also", {}).get(name)
+                if lt:
+                    also[key].update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"],
+                                      "algorithmic_bytes_per_launch": r2["cells"] * 3 * BYTES_PER_SUBSTEP[r2["dtype"]] / r2["launches_per_step"]})
                 del r2, wl2
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001 -- an extra workload must not take the headline down
