@@ -25,7 +25,7 @@ int env_int(const char* name, int dflt) {
 // (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
 // vec = 2: the pair kernel (hj_fusedv.h) -- k.R counts PAIRS per thread, the extent of the last axis is even, its LDS
 // rows are E + 8 cells apart (left pad 4)
-Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec) {
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf) {
     const int nd = c->ndim;
     const int cap = k.NT * k.R * vec;
     Tiling best;
@@ -76,8 +76,9 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
             int pitch = E[nd - 1] + (vec == 2 ? 8 : 6);
             if (vec == 1 && c->lds_pad && nd >= 3 && 512 + 2 * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= c->lds_limit) pitch = E[nd - 1] + 32;
             box = rows * pitch;
-            size_t lds = 512 + 2 * (size_t)box * c->esz;
-            if (!odd_row && halo <= (long long)k.KH * k.NT && lds <= c->lds_limit) {
+            size_t lds = 512 + (size_t)nbuf * (size_t)box * c->esz;
+            const size_t lds_cap = nbuf > 2 ? (size_t)160 * 1024 - 1024 : c->lds_limit;   // the ring variant may take the whole CU
+            if (!odd_row && halo <= (long long)k.KH * k.NT && lds <= lds_cap) {
                 double util = (double)cells / (double)(((cells + k.NT - 1) / k.NT) * k.NT);
                 // cells recomputed by the shifted last tile on each axis
                 double waste = 1.0;
@@ -810,7 +811,8 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->pair_nt = env_int("HJ_PAIR_NT", 0);
     c->pair_r = env_int("HJ_PAIR_R", 0);
     c->pair_kh = env_int("HJ_PAIR_KH", 0);
-    c->pair_occ = env_int("HJ_PAIR_OCC", 0);     // test / A-B knob: always run the runtime-flag kernel (MODE 0)
+    c->pair_occ = env_int("HJ_PAIR_OCC", 0);
+    c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) (512,2) configuration on >= 8 M cells
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);

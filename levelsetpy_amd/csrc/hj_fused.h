@@ -79,6 +79,9 @@ template <typename T, int ND> struct FusedArgs {
     int plane_begin, plane_end;
     int plane_begin2, plane_end2, nchunks1;   // optional second plane range (slab edges): chunks >= nchunks1
     int nblocks, blocks_per_xcd;
+    // pair kernel only: LDS plane buffers (2 = double buffer) and how many planes ahead of its use the halo ring
+    // of a plane is parked in LDS (0 = written in the iteration that consumes it)
+    int lds_nbuf, halo_ahead;
     // out = ydot                                   (ydot_only)
     //     = ca*y0 + cb*(y + dt*ydot)               otherwise; y0 is read iff use_y0
     int ydot_only, use_y0;

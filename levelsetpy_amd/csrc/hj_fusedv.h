@@ -323,13 +323,33 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             }
         }
     };
+    // Halo ring schedule.  AH = 0: the ring of plane P is requested PD planes ahead and written to LDS in iteration P.
+    // AH = 3 (large grids, HJ_PAIR_RING): it is requested PD + 3 = 5 planes ahead -- in the very iteration in which
+    // the neighbouring workgroup requests the same cells as ITS OWN cells of plane P, so that the second of the two
+    // requests finds the lines in L2 (three iterations later they are gone: an XCD's 32 workgroups stream ~1.7 MB per
+    // iteration through a 4 MB L2) -- and parked in the LDS buffer of plane P, a ring of NB = 5 plane buffers, from
+    // iteration P - 3 on.  Same values either way.
+    const int NB = A.lds_nbuf, AH = A.halo_ahead;
     T hal[PD][KH], hin[PD][KH];
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
+    for (int s = 0; s < PD; ++s)
 #pragma unroll
         for (int k = 0; k < KH; ++k) { hal[s][k] = T(0); hin[s][k] = T(0); }
-        load_halo(min(p_begin + s, p_last), hal[s], hin[s]);
+    if (AH > 0) {
+        // the rings of the first AH planes go straight to their LDS buffers (the first barrier of the loop orders them)
+        for (int a = 0; a < AH; ++a) {
+            T th[KH], ti[KH];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) { th[k] = T(0); ti[k] = T(0); }
+            load_halo(min(p_begin + a, p_last), th, ti);
+            T* bufa = lds + a * lds_plane;
+#pragma unroll
+            for (int k = 0; k < KH; ++k)
+                if (h_real[k]) bufa[h_lds[k]] = tile_ghost ? ghost_value(th[k], ti[k], h_km[k]) : th[k];
+        }
     }
+#pragma unroll
+    for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s]);
 
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 3] = wall_clock64();
     // the arithmetic on the Hamiltonian tables, now that every load of the setup is in flight
@@ -342,8 +362,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
 
+    int ring_c = 0;                                            // LDS buffer of the plane the next iteration computes
     auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* y0_c, typename HAM::Plane& pl_c) {
-        T* buf = lds + ((p - p_begin) & 1) * lds_plane;
+        T* buf = lds + ring_c * lds_plane;                      // plane p
+        int ring_h = ring_c + AH;
+        if (ring_h >= NB) ring_h -= NB;
+        T* bufh = lds + ring_h * lds_plane;                     // plane p + AH: where hal_c goes
+        ring_c = (ring_c + 1 == NB) ? 0 : ring_c + 1;
         load_own(min(p + 3 + PD, p_end + 2), own_n);
         // stage the centre plane: one 16-byte LDS store per pair
 #pragma unroll
@@ -357,15 +382,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (tile_ghost) {
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) buf[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
+                if (h_real[k]) bufh[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) buf[h_lds[k]] = hal_c[k];
+                if (h_real[k]) bufh[h_lds[k]] = hal_c[k];
         }
         __syncthreads();
         const int p2 = min(p + PD, p_last);
-        load_halo(min(p + PD, p_last), hal_c, hin_c);
+        load_halo(min(p + PD + AH, p_last), hal_c, hin_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
         pl_c = HAM::plane(A.ham, p2, A.sc);

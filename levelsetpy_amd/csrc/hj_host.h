@@ -100,6 +100,8 @@ struct hj_ctx {
     int target_blocks, min_chunk, warmup_cost, no_plain;
     int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
+    int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
+    int last_nbuf = 2;
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)
     size_t lds_limit;
     // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
@@ -112,7 +114,7 @@ namespace hjh {
 using namespace hj;
 
 int env_int(const char* name, int dflt);
-Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1);
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1, int nbuf = 2);
 void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu);
 int cfg_kh(int nd, int nt, int r);
 

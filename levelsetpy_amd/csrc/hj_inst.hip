@@ -74,6 +74,8 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.nblocks = t.nblocks;
     if (t.nblocks >= (1 << 22)) return hjh::fail(HJ_EUNSUPPORTED, "more than 4 M workgroups in one launch (index arithmetic of the kernels)");
     A.blocks_per_xcd = t.bpx;
+    A.lds_nbuf = PAIR ? c->last_nbuf : 2;
+    A.halo_ahead = (PAIR && c->last_nbuf > 2) ? 3 : 0;
     A.ydot_only = (s.stage == HJ_STAGE_YDOT);
     A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
     switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
@@ -228,7 +230,12 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 if (c->pair_r > 0) kp.R = c->pair_r;
                 if (c->pair_kh > 0) kp.KH = c->pair_kh;
                 if (c->pair_occ > 0) occp = c->pair_occ;
-                const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2);
+                // halo ring parked in LDS (5 plane buffers, hj_fusedv.h): pays for the two-pairs-per-thread configuration
+                // from 201^3 up (A/B tools/experiments/r02_run32.sh, r02_run33.sh: +1 % at 201^3, +3.6 % at 513^3 with
+                // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
+                const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
+                c->last_nbuf = ring ? 5 : 2;
+                const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2, c->last_nbuf);
                 if (tp.ok) {
 #define X(NT_, R_, KH_, OCC_) if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp);
                     if constexpr (HAM::ND == 4) { HJ_CONFIGS_PAIR_4D(X) }
