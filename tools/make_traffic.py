@@ -22,7 +22,9 @@ def source_hash():
 
 def mean_counter(d, name):
     vals = []
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # only the newest pass (gpurun merges every call's output into the local copy of the directory)
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name and ("fused_substep_kernel" in r["Kernel_Name"] or "fused_pair_kernel" in r["Kernel_Name"]):
                 vals.append(float(r["Counter_Value"]))
