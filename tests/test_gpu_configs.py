@@ -709,12 +709,14 @@ def test_eno3_non_finite_selection_semantics():
     ((30, 5000), (1,), None),           # 2-D, several tiles, periodic along the row
 ])
 def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch):
-    """fused_pair_kernel (two adjacent cells per lane: 16-byte HBM / LDS accesses) against fused_substep_kernel on
-    an RK3 step, a clamped ydot-only term evaluation and a post-step-fused RK2 step: BITWISE."""
+    """fused_pair_kernel (two adjacent cells per lane: 16-byte HBM / LDS accesses), with the double-buffered and with
+    the 5-plane-ring LDS schedule, against fused_substep_kernel on an RK3 step, a clamped ydot-only term evaluation and
+    a post-step-fused RK2 step: BITWISE."""
     g, ham, par, data = _stage12_case(n, pd, tz)
     res = {}
-    for flag in ("0", "2"):                        # 2: the pair kernel whatever the grid size
-        monkeypatch.setenv("HJ_PAIR", flag)
+    for flag in ("0", "2", "2r"):                  # 2: the pair kernel whatever the grid size; r: with the LDS halo ring
+        monkeypatch.setenv("HJ_PAIR", flag[0])
+        monkeypatch.setenv("HJ_PAIR_RING", "1" if flag.endswith("r") else "0")
         dg = DeviceGrid(g, "float64")
         dg.bind_stream()
         y = dg.to_device(data)
@@ -732,8 +734,9 @@ def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch
         dg.sync()
         outs.append(yd)
         res[flag] = (outs, sb.value)
-    assert res["0"][1] == res["2"][1]
-    for a, b in zip(res["0"][0], res["2"][0]):
-        assert torch.equal(a, b), "max diff %g at %s" % (float((a - b).abs().max()),
-                                                         np.unravel_index(int((a - b).abs().argmax()), n))
+    for other in ("2", "2r"):
+        assert res["0"][1] == res[other][1]
+        for a, b in zip(res["0"][0], res[other][0]):
+            assert torch.equal(a, b), "%s: max diff %g at %s" % (other, float((a - b).abs().max()),
+                                                                 np.unravel_index(int((a - b).abs().argmax()), n))
     assert float((res["0"][0][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 0
