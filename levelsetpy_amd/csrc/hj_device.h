@@ -29,6 +29,14 @@ template <> __device__ __forceinline__ float  t_abs<float>(float x)   { return _
 // exact 32-bit sequence.  Valid for 0 <= a < 2^22, 0 < d (every index of a launch: hj_inst.hip checks nblocks):
 // the float quotient is within 1 of the true one, and one correction in each direction settles it.  The kernels'
 // setup code is instruction-bound (two waves per SIMD), its dozen index divisions were a quarter of it.
+// max for the per-thread alpha accumulation of the plane loop: ONE v_max_f64.  fmax() costs three there (the
+// compiler canonicalises both operands first -- the running maximum is a loop-carried value it cannot prove quiet);
+// same result for every input that is not a signalling NaN (a NaN operand is ignored, as fmax does).
+__device__ __forceinline__ double max_acc(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 struct FDiv { int d; float r; };
 __device__ __forceinline__ FDiv fdiv_make(int d) { return FDiv{d, __builtin_amdgcn_rcpf((float)d)}; }
 __device__ __forceinline__ void fdivmod(int a, const FDiv& f, int& q, int& rem) {

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 diss += hd[d] * alpha[d];
-                if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = fmax(amax[d], (double)alpha[d]);
+                if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
             }
             T ydot = -(H - diss);
             // termRestrictUpdate clamp; written so that a NaN stays a NaN

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     diss += hd[c][d] * alpha[d];
-                    if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = fmax(amax[d], (double)alpha[d]);
+                    if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
                 }
                 T ydot = -(H - diss);
                 if (GEN && A.do_clamp) {
