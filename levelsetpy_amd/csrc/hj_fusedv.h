@@ -454,9 +454,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             if (r < R - 1 || last_real) buf_store2(o2, rout, own_g[r], so_out);
         }
         load_y0(p2, y0_c);
-#ifdef HJ_PAIR_SYNC2
-        __syncthreads();
-#endif
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
