@@ -362,8 +362,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
 
+#ifdef HJ_STAMP
+    unsigned long long st_acc[4] = {0, 0, 0, 0};
+#endif
     int ring_c = 0;                                            // LDS buffer of the plane the next iteration computes
     auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* y0_c, typename HAM::Plane& pl_c) {
+#ifdef HJ_STAMP
+        const unsigned long long st0 = __builtin_readcyclecounter();
+#endif
         T* buf = lds + ring_c * lds_plane;                      // plane p
         int ring_h = ring_c + AH;
         if (ring_h >= NB) ring_h -= NB;
@@ -388,7 +394,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             for (int k = 0; k < KH; ++k)
                 if (h_real[k]) bufh[h_lds[k]] = hal_c[k];
         }
+#ifdef HJ_STAMP
+        const unsigned long long st1 = __builtin_readcyclecounter();
+#endif
         __syncthreads();
+#ifdef HJ_STAMP
+        const unsigned long long st2 = __builtin_readcyclecounter();
+#endif
         const int p2 = min(p + PD, p_last);
         load_halo(min(p + PD + AH, p_last), hal_c, hin_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
@@ -453,6 +465,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             }
             if (r < R - 1 || last_real) buf_store2(o2, rout, own_g[r], so_out);
         }
+#ifdef HJ_STAMP
+        const unsigned long long st3 = __builtin_readcyclecounter();
+#endif
         load_y0(p2, y0_c);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -461,6 +476,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             q[r][0][6] = own_c[r].x;
             q[r][1][6] = own_c[r].y;
         }
+#ifdef HJ_STAMP
+        {   // diagnostic build: shader-clock time of the phases of a plane iteration, summed per wave
+            const unsigned long long st4 = __builtin_readcyclecounter();
+            st_acc[0] += st1 - st0; st_acc[1] += st2 - st1; st_acc[2] += st3 - st2; st_acc[3] += st4 - st3;
+        }
+#endif
     };
 
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 5] = wall_clock64();   // loop start
@@ -499,6 +520,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
     }
     if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
+#ifdef HJ_STAMP
+    if (A.timing && tid == 0)
+        for (int k = 0; k < 4; ++k) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + k] = st_acc[k];
+#endif
 }
 
 }  // namespace hj
