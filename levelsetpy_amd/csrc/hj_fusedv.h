@@ -397,7 +397,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #ifdef HJ_STAMP
         const unsigned long long st1 = __builtin_readcyclecounter();
 #endif
+#ifndef HJ_ABLATE_NOSYNC        // timing experiment only (results are wrong without the barrier)
         __syncthreads();
+#endif
 #ifdef HJ_STAMP
         const unsigned long long st2 = __builtin_readcyclecounter();
 #endif
