@@ -1,6 +1,7 @@
 // The fused / direct RK-substep kernels of ONE (dtype, Hamiltonian) pair and their launch code.
 // Compiled once per pair with -DHJ_INST_T=<double|float> -DHJ_INST_HAM=<HamDubinsRel|...> (Makefile), so
 // the kernel instantiations build in parallel.  gfx950 only.
+#include <mutex>
 #include "hj_host.h"
 #include "hj_fused.h"
 #include "hj_fused12.h"
@@ -93,8 +94,16 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     auto kern = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
     c->last_kernel = PAIR ? "fused_pair_kernel" : "fused_substep_kernel";
     if (t.lds_bytes > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+        // once per (device, kernel), raised but never lowered: the attribute belongs to the function, not to a context
+        static std::mutex mu;
+        static std::map<std::pair<int, const void*>, size_t> granted_by_kernel;
+        std::lock_guard<std::mutex> lock(mu);
+        size_t& granted = granted_by_kernel[std::make_pair(c->device, reinterpret_cast<const void*>(kern))];
+        if (granted < t.lds_bytes) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+            granted = t.lds_bytes;
+        }
     }
     const char* dump = getenv("HJ_TIMING_DUMP");    // debug: per-workgroup start/end clocks of every launch
     unsigned long long* tbuf = nullptr;
