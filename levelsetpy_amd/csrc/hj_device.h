@@ -488,15 +488,30 @@ __device__ __forceinline__ unsigned long long max_key(double v) {
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+// Wavefront max / min of a double, every lane receives the result.  DPP data moves (row_shr 1,2,4,8 inside the four
+// 16-lane rows, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 ends up with the
+// reduction of all 64 lanes) instead of six ds_bpermute round trips through the LDS crossbar: the reductions sit in
+// every workgroup's epilogue, which nothing overlaps.  Lanes without a source keep the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v, double ident) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
+template <bool MAX>
+__device__ __forceinline__ double wave_reduce(double v) {
+    const double ident = MAX ? -__builtin_huge_val() : __builtin_huge_val();
+    auto op = [](double a, double b) { return MAX ? fmax(a, b) : fmin(a, b); };
+    v = op(v, dpp_move<0x111, 0xF>(v, ident));      // row_shr:1
+    v = op(v, dpp_move<0x112, 0xF>(v, ident));      // row_shr:2
+    v = op(v, dpp_move<0x114, 0xF>(v, ident));      // row_shr:4
+    v = op(v, dpp_move<0x118, 0xF>(v, ident));      // row_shr:8   -> lane 15 of each row holds the row's result
+    v = op(v, dpp_move<0x142, 0xA>(v, ident));      // row_bcast:15 into rows 1, 3
+    v = op(v, dpp_move<0x143, 0xC>(v, ident));      // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's result
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<true>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<false>(v); }
 
 }  // namespace hj
