@@ -812,6 +812,9 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->pair_r = env_int("HJ_PAIR_R", 0);
     c->pair_kh = env_int("HJ_PAIR_KH", 0);
     c->pair_occ = env_int("HJ_PAIR_OCC", 0);
+    // planes the ring is parked ahead: 3 aligns it exactly with the neighbours' own loads (best from 251^3 up); on the
+    // 201^3-class grids 2 is 0.7 % faster (one plane less to fetch synchronously in the setup; same-box A/B r02_run43.sh)
+    c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
     c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) (512,2) configuration on >= 8 M cells
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);

@@ -76,7 +76,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     if (t.nblocks >= (1 << 22)) return hjh::fail(HJ_EUNSUPPORTED, "more than 4 M workgroups in one launch (index arithmetic of the kernels)");
     A.blocks_per_xcd = t.bpx;
     A.lds_nbuf = PAIR ? c->last_nbuf : 2;
-    A.halo_ahead = (PAIR && c->last_nbuf > 2) ? 3 : 0;
+    A.halo_ahead = (PAIR && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
     A.ydot_only = (s.stage == HJ_STAGE_YDOT);
     A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
     switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
@@ -243,7 +243,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // from 201^3 up (A/B tools/experiments/r02_run32.sh, r02_run33.sh: +1 % at 201^3, +3.6 % at 513^3 with
                 // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
                 const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
-                c->last_nbuf = ring ? 5 : 2;
+                c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
                 const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2, c->last_nbuf);
                 if (tp.ok) {
 #define X(NT_, R_, KH_, OCC_) if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp);
