@@ -714,9 +714,11 @@ def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch
     a post-step-fused RK2 step: BITWISE."""
     g, ham, par, data = _stage12_case(n, pd, tz)
     res = {}
-    for flag in ("0", "2", "2r"):                  # 2: the pair kernel whatever the grid size; r: with the LDS halo ring
+    flags = ("0", "2", "2r1", "2r2", "2r3")        # 2: the pair kernel whatever the grid size; rK: LDS halo ring K planes ahead
+    for flag in flags:
         monkeypatch.setenv("HJ_PAIR", flag[0])
-        monkeypatch.setenv("HJ_PAIR_RING", "1" if flag.endswith("r") else "0")
+        monkeypatch.setenv("HJ_PAIR_RING", "1" if "r" in flag else "0")
+        monkeypatch.setenv("HJ_PAIR_AH", flag[-1] if "r" in flag else "3")
         dg = DeviceGrid(g, "float64")
         dg.bind_stream()
         y = dg.to_device(data)
@@ -734,7 +736,7 @@ def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch
         dg.sync()
         outs.append(yd)
         res[flag] = (outs, sb.value)
-    for other in ("2", "2r"):
+    for other in flags[1:]:
         assert res["0"][1] == res[other][1]
         for a, b in zip(res["0"][0], res[other][0]):
             assert torch.equal(a, b), "%s: max diff %g at %s" % (other, float((a - b).abs().max()),

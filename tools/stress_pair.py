@@ -23,9 +23,11 @@ for it in range(cases):
     data = L.shapeSphere(g, np.zeros((nd, 1)), .4) + 0.05 * rng.standard_normal(n)
     order = int(rng.integers(1, 4))
     res = {}
+    ah = str(int(rng.integers(1, 4)))
     for flag in ("0", "2", "2r"):
         os.environ["HJ_PAIR"] = flag[0]
         os.environ["HJ_PAIR_RING"] = "1" if flag.endswith("r") else "0"
+        os.environ["HJ_PAIR_AH"] = ah
         dg = DeviceGrid(g, "float64"); dg.bind_stream()
         y = dg.to_device(data)
         nxt, w0, w1 = dg.empty(), dg.empty(), dg.empty()
