@@ -88,6 +88,11 @@ template <typename T> struct DD {
 //   K[0] = 1/dx        K[1] = 1/(2dx)     K[2] = 1/(3dx)     K[3] = dx    K[4] = dx^2   K[5] = 2dx^2
 //   as-shipped WENO5 (c = 1/(60dx)):  K[6] = 45c  K[7] = -9c  K[8] = c  K[9] = 15c  K[10] = -6c  K[11] = -20c
 constexpr int HJ_NK = 12;
+// 1 (default): ENO2 / ENO3 select their stencils on the reference's divided-difference tables, bit for bit (upwind_cd);
+// 0: the lean arithmetic of rounds 1-2 on undivided differences (same result except at exact |D2| / |D3| ties)
+#ifndef HJ_ENO_EXACT
+#define HJ_ENO_EXACT 1
+#endif
 template <typename T> inline void fill_stencil_constants(double dx, T* K) {
     const double inv = 1.0 / dx;
     K[0] = (T)inv;
@@ -267,7 +272,52 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
             pc = Lq + Rq;
             hd = Rq - Lq;
         }
+    } else if constexpr ((SCHEME == HJ_ENO3 || SCHEME == HJ_ENO2) && HJ_ENO_EXACT) {
+        // Bit-faithful ENO (round 3; the drop-in default).  The reference chooses its stencil by comparing
+        // |D2| / |D3| of the DIVIDED-difference tables D1 = dxInv*(g[j+1]-g[j]), D2 = (0.5*dxInv)*(dD1),
+        // D3 = ((1/3)*dxInv)*(dD2) (ENO3aHelper.py:78-88, upwind_first_eno3a.py:105-128, upwind_first_eno2.py:80-84,
+        // 136-141).  On exactly symmetric data those moduli tie, and which side wins a tie depends on how the
+        // operands were ROUNDED: comparing the undivided differences (the lean branch below) is the same test in
+        // exact arithmetic but resolves ties differently.  Here the tables are formed in the reference's operation
+        // order with contraction off, so every comparison sees NumPy's operands bit for bit; the selected candidate
+        // is then formed in the reference's order as well (ENO3aHelper.py:140-187: D1 + coeff*D2, then += coeff*D3),
+        // also uncontracted: derivL / derivR equal the reference's bitwise on finite data.  Selection comes first
+        // (an unselected candidate is never formed): see DESIGN.md section 2 for non-finite data.
+        // Returns the true centred costate and half jump (sc[d] = 1).
+#pragma clang fp contract(off)
+        DD<T> t;
+        dd_tables(v, K, t);
+        const T dx = K[3], dx2 = K[4], tdx2 = K[5];
+        const bool sL0 = t_abs(t.D2[1]) < t_abs(t.D2[2]), sL1 = t_abs(t.D2[2]) < t_abs(t.D2[3]);   // strict '<': ties go right
+        T L, R;
+        if constexpr (SCHEME == HJ_ENO2) {
+            const T eL = dx * (sL0 ? t.D2[1] : t.D2[2]);
+            const T eR = dx * (sL1 ? t.D2[2] : t.D2[3]);
+            L = t.D1[2] + eL;
+            R = t.D1[3] - eR;
+        } else {
+            const bool sT0 = t_abs(t.D3[0]) < t_abs(t.D3[1]), sT1 = t_abs(t.D3[1]) < t_abs(t.D3[2]);
+            const bool sT2 = t_abs(t.D3[2]) < t_abs(t.D3[3]);
+            // left:  LL = sT0 & sL0 -> D2[1], +2dx^2 D3[0];  M = (sT1 & !sL0) | (!sT0 & sL0): written as the reference
+            // forms it, going left on D2 then right on D3 -> D2[1], +2dx^2 D3[1];  RR = !sT1 & !sL0 -> D2[2], -dx^2 D3[2]
+            const bool lRR = !sL0 && !sT1;
+            const T l2 = dx * (lRR ? t.D2[2] : t.D2[1]);
+            const T l3a = tdx2 * ((sL0 && sT0) ? t.D3[0] : t.D3[1]);
+            const T l3b = dx2 * t.D3[2];
+            const T lb = t.D1[2] + l2;
+            L = lRR ? (lb - l3b) : (lb + l3a);
+            // right: LL -> D2[2], -dx^2 D3[1];  M -> D2[2], -dx^2 D3[2];  RR -> D2[3], +2dx^2 D3[3]
+            const bool rRR = !sL1 && !sT2;
+            const T r2 = dx * (rRR ? t.D2[3] : t.D2[2]);
+            const T r3a = dx2 * ((sL1 && sT1) ? t.D3[1] : t.D3[2]);
+            const T r3b = tdx2 * t.D3[3];
+            const T rb = t.D1[3] - r2;
+            R = rRR ? (rb + r3b) : (rb - r3a);
+        }
+        pc = T(0.5) * (L + R);
+        hd = T(0.5) * (R - L);
     } else if constexpr (SCHEME == HJ_ENO3) {
+        // lean ENO3 (-DHJ_ENO_EXACT=0; rounds 1-2): selectors on the undivided differences
         // ENO3 (upwind_first_eno3a.py:105-141, ENO3aHelper.py:116-189) on UNDIVIDED differences
         // u_j = v[j+1]-v[j], s_j = u_{j+1}-u_j, t_j = s_{j+1}-s_j  (D1 = u/dx, D2 = s/(2dx^2), D3 = t/(6dx^3);
         // the |D2| / |D3| comparisons are comparisons of |s| / |t|), select FIRST, then form the one

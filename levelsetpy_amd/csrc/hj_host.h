@@ -99,6 +99,8 @@ struct hj_ctx {
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
     int target_blocks, min_chunk, warmup_cost, no_plain;
     int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;
+    int f12_e1 = 0;                                 // tuning / tests: force the tile's row count (pair variant)
+    int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
     int last_nbuf = 2;
@@ -148,7 +150,11 @@ template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G
 template <typename T> T scheme_scale(int scheme, double dx) {
     if (scheme == HJ_WENO5_ASSHIPPED) return (T)((1.0 / dx) * (1.0 / 60.0));
     if (scheme == HJ_WENO5) return (T)((1.0 / dx) * (1.0 / 12.0));
-    return (T)((1.0 / dx) * 0.5);     // ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
+#if HJ_ENO_EXACT
+    return T(1);                      // ENO2 / ENO3 on the reference's divided-difference tables: true costates
+#else
+    return (T)((1.0 / dx) * 0.5);     // lean ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
+#endif
 }
 
 struct SubstepCall {

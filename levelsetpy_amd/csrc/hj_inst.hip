@@ -6,6 +6,7 @@
 #include "hj_fused.h"
 #include "hj_fused12.h"
 #include "hj_fusedv.h"
+#include "hj_fused12v.h"
 
 namespace hjh {
 
@@ -356,11 +357,17 @@ inline Tiling12 make_tiling12(const hj_ctx* c, int NT, int R, int KH, size_t lds
     return best;
 }
 
-template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, bool PAIR>
+auto stage12_kernel() {
+    if constexpr (PAIR) return fused12_pair_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
+    else return fused12_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, bool PAIR = false>
 int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     constexpr int ND = HAM::ND;
-    auto kern = fused12_kernel<T, HAM, SCHEME, NT, R, KH, OCC>;
-    c->last_kernel = "fused12_kernel";
+    auto kern = stage12_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PAIR>();
+    c->last_kernel = PAIR ? "fused12_pair_kernel" : "fused12_kernel";
     if (t.lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     const auto key = std::make_pair(reinterpret_cast<const void*>(kern), t.lds_bytes);
@@ -389,8 +396,8 @@ int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
         t.bpx = (t.nblocks + 7) / 8;
     }
     if (c->debug) {
-        fprintf(stderr, "[hj] fused12 NT=%d R=%d KH=%d OCC=%d E=(%d,%d) nA=%d nH=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
-                NT, R, KH, OCC, t.E[1], ND > 2 ? t.E[2] : 0, t.nA, t.nH, t.ntiles, t.chunk, t.nchunks, t.nblocks, it->second, t.lds_bytes, t.score);
+        fprintf(stderr, "[hj] fused12%s NT=%d R=%d KH=%d OCC=%d E=(%d,%d) nA=%d nH=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
+                PAIR ? " pair" : "", NT, R, KH, OCC, t.E[1], ND > 2 ? t.E[2] : 0, t.nA, t.nH, t.ntiles, t.chunk, t.nchunks, t.nblocks, it->second, t.lds_bytes, t.score);
         c->debug = 0;
     }
     Fused12Args<T, ND> A;
@@ -428,16 +435,118 @@ int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     return HJ_OK;
 }
 
+// ---- the two-cells-per-lane stage-fused kernel (hj_fused12v.h): (threads, A PAIR slots per thread, H slots per
+// thread, waves/SIMD hint)
+#ifndef HJ_CONFIGS12V
+#define HJ_CONFIGS12V(X) X(512, 2, 2, 2) X(512, 3, 2, 2) X(256, 4, 4, 1)
+#endif
+
+// Tiles of the pair variant: even extent on the contiguous axis, no pair of T1 may straddle a domain edge
+// (pairs start on even tile columns -4, -2, .., E2+2: the unshifted remainder of the last tile must not be 1 or
+// 3 columns), LDS = 2 y boxes (E1+12) x (E2+16) + 7 y1 boxes (E1+6) x (E2+8).
+inline Tiling12 make_tiling12v(const hj_ctx* c, int NT, int R, int KH, size_t lds_limit) {
+    const int nd = c->ndim, W = HJ_STENCIL;
+    Tiling12 best;
+    best.ok = false;
+    best.score = 1e300;
+    int n[HJ_MAX_DIM];
+    for (int d = 0; d < nd; ++d) n[d] = (int)c->N[d];
+    const int nl = n[nd - 1];
+    for (int e2 = 4; e2 <= std::min(nl, 1024); e2 += 2) {
+        if (c->f12_e2 > 0 && e2 != std::min(c->f12_e2 & ~1, nl & ~1)) continue;
+        const int nt2 = (nl + e2 - 1) / e2;
+        const int rem2 = nl - (nt2 - 1) * e2;
+        if (nt2 > 1 && (rem2 == 1 || rem2 == 3)) continue;
+        if (nt2 == 1 && e2 != nl) continue;                   // a single tile must span the (even) axis exactly
+        const int e1max = nd == 3 ? n[1] : 1;
+        for (int e1 = (nd == 3 ? 2 : 1); e1 <= e1max; ++e1) {
+            if (nd == 3 && c->f12_e1 > 0 && e1 != std::min(c->f12_e1, e1max)) continue;
+            long long nA, nH, T0, ybox, wbox, cells;
+            cells = (long long)e1 * e2;
+            if (nd == 3) {
+                nA = cells / 2 + 2 * W * (e2 / 2) + 4 * e1;
+                nH = 4 * W * (e1 + e2) + 4 * W * W;
+                T0 = cells + 4 * W * (e1 + e2) + 4 * W * W + 2 * e1;
+                ybox = (long long)(e1 + 4 * W) * (e2 + 16);
+                wbox = (long long)(e1 + 2 * W) * (e2 + 8);
+            } else {
+                nA = cells / 2 + 4;
+                nH = 4 * W;
+                T0 = cells + 4 * W + 2;
+                ybox = e2 + 16;
+                wbox = e2 + 8;
+            }
+            if (nA > (long long)NT * R || nH > (long long)NT * KH) continue;
+            const size_t lds = 512 + (size_t)(2 * ybox + 7 * wbox) * c->esz;
+            if (lds > lds_limit) continue;
+            double waste = 1.0;
+            {
+                const int nt = (nl + e2 - 1) / e2;
+                waste *= (double)nt * e2 / (double)nl;
+                if (nd == 3) {
+                    const int nt1 = (n[1] + e1 - 1) / e1;
+                    waste *= (double)nt1 * e1 / (double)n[1];
+                }
+            }
+            const double row_cost = 1.0 + (48.0 / (double)c->esz) / (double)e2;
+            // slot evaluations per output pair: every A slot runs stage 1, the slots that hold interior pairs
+            // (whole waves) run stage 2
+            const long long s1 = ((nA + 63) / 64) * 64, s2 = ((cells / 2 + 63) / 64) * 64;
+            const double evals = (double)(s1 + s2) / (double)(cells / 2);
+            const double score = ((double)T0 / cells * row_cost + 0.6 * evals) * waste;
+            if (score < best.score) {
+                best.ok = true;
+                best.score = score;
+                best.lds_bytes = lds;
+                best.nA = (int)nA;
+                best.nH = (int)nH;
+                best.ntiles = 1;
+                best.E[0] = 1; best.ntile[0] = 1;
+                for (int d = 1; d < nd; ++d) {
+                    best.E[d] = (nd == 3 && d == 1) ? e1 : e2;
+                    best.ntile[d] = (n[d] + best.E[d] - 1) / best.E[d];
+                    best.ntiles *= best.ntile[d];
+                }
+            }
+        }
+    }
+    return best;
+}
+
 template <typename T, typename HAM, int SCHEME>
 int launch_stage12_cfg(hj_ctx* c, const Stage12Call& s) {
-    if constexpr (HAM::ND == 4 || SCHEME == HJ_WENO5) {
+#ifdef HJ_TUNE_BUILD
+    constexpr bool built = std::is_same<T, double>::value && HAM::ID == HJ_HAM_DUBINS_REL && SCHEME == HJ_WENO5_ASSHIPPED;
+#else
+    constexpr bool built = true;
+#endif
+    if constexpr (HAM::ND == 4 || SCHEME == HJ_WENO5 || !built) {
         return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused kernel for this scheme / dimension");
     } else {
+        if (c->f12_pair) {
+            // two cells per lane (round 3): 2 pair slots per thread in 512-thread workgroups
+            int NT = 512, R = 2, KH = 2;
+            if (c->f12_nt > 0) NT = c->f12_nt;
+            if (c->f12_r > 0) R = c->f12_r;
+            if (c->f12_kh > 0) KH = c->f12_kh;
+            const Tiling12 t = make_tiling12v(c, NT, R, KH, (size_t)160 * 1024 - 256);
+            if (t.ok) {
+                if (s.probe) return HJ_OK;
+#define X(NT_, R_, KH_, OCC_) if (NT == NT_ && R == R_ && KH == KH_) return launch_fused12<T, HAM, SCHEME, NT_, R_, KH_, OCC_, true>(c, s, t);
+                HJ_CONFIGS12V(X)
+#undef X
+                return hjh::fail(HJ_EUNSUPPORTED, "stage-fused pair configuration (%d,%d,%d) is not built", NT, R, KH);
+            }
+            if (c->f12_pair > 1) return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused pair tiling for this grid");
+        }
         // heavier per-cell arithmetic -> fewer A slots per thread fit in 256 VGPRs
         int NT = 512, R = (SCHEME == HJ_ENO3) ? 2 : (SCHEME == HJ_ENO2 ? 4 : 3), KH = 2;
+        if (c->f12_pair) { NT = 512; KH = 2; }                // the env overrides describe the pair configuration
+        else {
         if (c->f12_nt > 0) NT = c->f12_nt;
         if (c->f12_r > 0) R = c->f12_r;
         if (c->f12_kh > 0) KH = c->f12_kh;
+        }
         const Tiling12 t = make_tiling12(c, NT, R, KH, (size_t)160 * 1024 - 256);
         if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused tiling for this grid");
         if (s.probe) return HJ_OK;

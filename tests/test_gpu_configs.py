@@ -348,13 +348,19 @@ def _stage12_case(n, pd, tz=None):
     ((30, 5000), (1,), None),           # 2-D: several tiles, periodic along the row
     ((50, 41), (0,), None),             # 2-D: periodic march axis
 ])
-def test_stage_fused_kernel_bitwise_equals_two_substeps(scheme, n, pd, tz, monkeypatch):
+@pytest.mark.parametrize("pair", ["0", "2"])
+def test_stage_fused_kernel_bitwise_equals_two_substeps(scheme, n, pd, tz, pair, monkeypatch):
     """hj_rk_stage12 (RK stages 1+2 in one launch, y1 kept on chip) against hj_rk_substep(EULER) followed by
     hj_rk_substep(RK3_HALF / RK2_FULL): BITWISE, for both coefficient pairs; tilings forced small so that
-    interior tiles, edge tiles, shifted last tiles and several chunks all occur."""
+    interior tiles, edge tiles, shifted last tiles and several chunks all occur.  pair = "2": the two-cells-per-lane
+    kernel of round 3 (hj_fused12v.h; HJ_F12_PAIR=2 fails instead of falling back), "0": the one-cell-per-lane one."""
     g, ham, par, data = _stage12_case(n, pd, tz)
-    for knobs in ({}, {"HJ_F12_R": "2", "HJ_TARGET_BLOCKS": "40"}):
-        for k in ("HJ_F12_R", "HJ_TARGET_BLOCKS"):
+    monkeypatch.setenv("HJ_F12_PAIR", pair)
+    small = {"HJ_F12_R": "2", "HJ_TARGET_BLOCKS": "40"}
+    if pair == "2":        # several tiles on both plane axes, shifted last tiles, an odd tile origin
+        small = {"HJ_F12_E2": "12", "HJ_F12_E1": "10", "HJ_TARGET_BLOCKS": "40"}
+    for knobs in ({}, small):
+        for k in ("HJ_F12_R", "HJ_TARGET_BLOCKS", "HJ_F12_E2", "HJ_F12_E1"):
             monkeypatch.delenv(k, raising=False)
         for k, v in knobs.items():
             monkeypatch.setenv(k, v)
@@ -369,6 +375,7 @@ def test_stage_fused_kernel_bitwise_equals_two_substeps(scheme, n, pd, tz, monke
             _ffi.check(dg.lib.hj_rk_stage12(dg.ctx, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), dt, ca, cb,
                                             dg.ptr(y), dg.ptr(got), 5))
             dg.sync()
+            assert dg.lib.hj_last_kernel(dg.ctx) == (b"fused12_pair_kernel" if pair == "2" else b"fused12_kernel")
             assert bool(torch.isfinite(got).all()), "cells left unwritten: %d" % int((~torch.isfinite(got)).sum())
             assert torch.equal(got, ref), "%s max diff %g at %s" % (knobs, float((got - ref).abs().max()),
                                                                   np.unravel_index(int((got - ref).abs().argmax()), n))
