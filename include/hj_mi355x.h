@@ -269,6 +269,24 @@ int hj_halo_exchange_depth(hj_ctx* ctx, void* buf, int depth);
 int hj_slab_rk_step_deep(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double dt,
                          int restrict_sign, const void* cur, void* y_out, void* work0, void* work1);
 
+/* ---- the other schemeFuncs of the reference that share the upwind derivatives, ONE launch each
+ * (hj_terms.h): derivatives of every dimension, Godunov's upwind choice, |grad phi|, ydot and the CFL maxima.
+ * The shipped reference functions raise: the formulas are their docstrings' and the oracle's.
+ *   hj_term_normal      termNormal      ExplicitIntegration/Term/term_normal.py:7 (:143-181)
+ *                       ydot = -a |grad phi|; speed = array of the grid (or null: speed_scalar)
+ *   hj_term_reinit      termReinit      ExplicitIntegration/Term/term_reinit.py:7 (:181-312)
+ *                       ydot = -S(initial)(|grad phi| - 1), sub-cell fix of order 0 (smeared sign) or 1
+ *   hj_term_convection  termConvection  ExplicitIntegration/Term/term_convection.py:7 (:154-180)
+ *                       ydot = -V . grad phi; velocity[d] = array of the grid or null (velocity_scalar[d])
+ * y, ydot (must differ) and the arrays are device pointers of the ctx dtype; *step_bound as the reference returns it
+ * (inf when nothing moves).  One host synchronisation per call (the step bound). */
+int hj_term_normal(hj_ctx* ctx, int scheme, const void* y, const void* speed, double speed_scalar, void* ydot,
+                   double* step_bound);
+int hj_term_reinit(hj_ctx* ctx, int scheme, const void* y, const void* initial, int subcell_order, void* ydot,
+                   double* step_bound);
+int hj_term_convection(hj_ctx* ctx, int scheme, const void* y, const void* const* velocity, const double* velocity_scalar,
+                       void* ydot, double* step_bound);
+
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);
 /* Name of the substep kernel the last hj_rk_substep / hj_rk_step / hj_lf_term on this ctx launched:

@@ -65,6 +65,9 @@ SIGNATURES = {
     "hj_comm_init_external": (_i, [_vp, _i, _i, _i, _i]),
     "hj_halo_exchange_depth": (_i, [_vp, _vp, _i]),
     "hj_slab_rk_step_deep": (_i, [_vp, _i, _i, _i, _pd, _d, _i, _vp, _vp, _vp, _vp]),
+    "hj_term_normal": (_i, [_vp, _i, _vp, _vp, _d, _vp, _pd]),
+    "hj_term_reinit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _pd]),
+    "hj_term_convection": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _pd]),
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
     "hj_last_kernel": (C.c_char_p, [C.c_void_p]),

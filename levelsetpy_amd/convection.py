@@ -10,15 +10,19 @@ The one-sided derivatives come from the HIP upwind kernels (hj_upwind); the rema
 run on the device arrays those return.
 
 Deviations from the shipped reference, which does not run: its accumulator is an integer array
-(`zeros(size(data))`, :151), so `delta += deriv * v` (:170) raises a casting error under NumPy and CuPy
-alike, and the upwinding block sits OUTSIDE the loop over dimensions (:154-172), so only the last
+(`zeros(size(data))`, :154), so `delta += deriv * v` (:170) raises a casting error under NumPy and CuPy
+alike, and the upwinding block sits OUTSIDE the loop over dimensions (:157-172), so only the last
 dimension's term would ever be added.  Here every dimension contributes, as the docstring
 (`-V . grad phi`) and the toolbox it ports say.  Parity is therefore UNPINNED for this function: it is
 checked against oracle.term_convection (same formulas on the oracle's reference-pinned derivatives).
 """
+import ctypes as C
+
 import numpy as np
 
-from .context import is_tensor
+from . import _ffi
+from .context import is_tensor, device_grid, array_dtype_name
+from .spatial import scheme_id_of
 from .utilities import isfield, iscell, error
 
 __all__ = ["termConvection"]
@@ -36,17 +40,42 @@ def termConvection(t, y, schemeData):
     data = y0.reshape(grid.shape)
     velocity = thisSchemeData.velocity
     if callable(velocity):
-        velocity = velocity(t, data, thisSchemeData)                       # :127-147
+        velocity = velocity(t, data, thisSchemeData)                       # :124-147
     if not isinstance(velocity, (list, tuple)) or len(velocity) != grid.dim:
         error('schemeData.velocity must be a cell vector or a function handle')   # :149-150
+    sid = scheme_id_of(derivFunc)
+    if sid is not None:
+        # one of this package's derivative functions: the whole term is ONE kernel launch (hj_term_convection,
+        # csrc/hj_terms.h; round 3)
+        dg = device_grid(grid, array_dtype_name(data))
+        if tuple(data.shape) != dg.shape:
+            error('data parameter does not agree in array size with grid')
+        dg.bind_stream()
+        phi = dg.to_device(data)
+        arrs, scal = [], []
+        for v in velocity:
+            if np.isscalar(v) or (isinstance(v, np.ndarray) and v.ndim == 0):
+                arrs.append(None)
+                scal.append(float(v))
+            else:
+                if is_tensor(v):
+                    a = v.reshape(grid.shape)
+                else:
+                    a = np.broadcast_to(np.asarray(v, dtype=np.float64), grid.shape)
+                arrs.append(dg.to_device(a))
+                scal.append(0.0)
+        out, sb = dg.empty(), C.c_double()
+        vp = (C.c_void_p * dg.dim)(*[(a.data_ptr() if a is not None else None) for a in arrs])
+        _ffi.check(dg.lib.hj_term_convection(dg.ctx, sid, dg.ptr(phi), vp, _ffi.darr(scal), dg.ptr(out), C.byref(sb)))
+        return dg.like(out, y0, (-1, 1)), float(sb.value), schemeData
     delta = 0
     stepBoundInv = 0.0
     for i in range(grid.dim):
-        derivL, derivR = derivFunc(grid, data, i)                          # :157
+        derivL, derivR = derivFunc(grid, data, i)                          # :158
         v = velocity[i]
         if np.isscalar(v):
             v = float(v)
-            deriv = derivL if v > 0 else (derivR if v < 0 else 0 * derivL)  # :160-167
+            deriv = derivL if v > 0 else (derivR if v < 0 else 0 * derivL)  # :161-167
             vmax = abs(v)
         else:
             if is_tensor(derivL) and not is_tensor(v):

@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 
 #include "hj_host.h"
+#include "hj_terms.h"
 
 namespace hjh {
 
@@ -1012,6 +1013,118 @@ int hj_lf_split_end(hj_ctx* c, const void* const* dL, const void* const* dR, con
         }
         if (sb) *sb = 1.0 / inv;
     }
+    return HJ_OK;
+}
+
+// ---- termNormal / termReinit / termConvection: one launch each (hj_terms.h)
+extern "C++" {
+namespace {
+template <typename T, int ND>
+int term_launch_nd(hj_ctx* c, int kind, int scheme, const void* y, const void* const* arr, const double* scal, int order,
+                   void* out, unsigned long long* keys) {
+    TermArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.y = (const T*)y;
+    A.out = (T*)out;
+    hjh::fill_grid<T, ND>(c, A.G);
+    A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    double mdx = 0.0;
+    for (int d = 0; d < ND; ++d) {
+        A.arr[d] = arr ? (const T*)arr[d] : nullptr;
+        A.scal[d] = scal ? (T)scal[d] : T(0);
+        A.dx_inv[d] = (T)(1.0 / c->dx[d]);
+        A.dx[d] = (T)c->dx[d];
+        mdx = std::max(mdx, c->dx[d]);
+    }
+    A.max_dx = (T)mdx;
+    A.subcell_order = order;
+    const double e = (double)std::numeric_limits<double>::epsilon();
+    A.small2 = (T)((1e6 * e) * (1e6 * e));     // robust_small_epsilon^2, term_reinit.py:128,274
+    A.tiny = (T)e;                             // term_reinit.py:206
+    A.keys = keys;
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 16);
+#define HJ_TK(S, K) hipLaunchKernelGGL((term_kernel<T, ND, S, K>), dim3(blocks), dim3(256), 0, c->stream, A)
+#define HJ_TS(K)                                                                       \
+    switch (scheme) {                                                                  \
+        case HJ_ENO2: HJ_TK(HJ_ENO2, K); break;                                        \
+        case HJ_ENO3: HJ_TK(HJ_ENO3, K); break;                                        \
+        case HJ_WENO5: HJ_TK(HJ_WENO5, K); break;                                      \
+        default: HJ_TK(HJ_WENO5_ASSHIPPED, K); break;                                  \
+    }
+    if (kind == HJ_TERM_NORMAL) { HJ_TS(HJ_TERM_NORMAL) }
+    else if (kind == HJ_TERM_REINIT) { HJ_TS(HJ_TERM_REINIT) }
+    else { HJ_TS(HJ_TERM_CONVECTION) }
+#undef HJ_TS
+#undef HJ_TK
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+// launches the term and fetches its ND + 1 maxima (one host synchronisation): k[d] < 0 = no cell contributed
+int term_run(hj_ctx* c, int kind, int scheme, const void* y, const void* const* arr, const double* scal, int order,
+             void* out, double* k) {
+    if (!c || !y || !out) return fail(HJ_EINVAL, "null argument");
+    if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    if (y == out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
+    for (int d = 0; d < c->ndim; ++d)
+        if (c->N[d] < HJ_STENCIL) return fail(HJ_EINVAL, "grid too small along dim %d (N=%lld)", d, (long long)c->N[d]);
+    int rc;
+    if (scheme == HJ_WENO5 && !c->weno_src) {
+        if ((rc = weno_eps_pass(c, y))) return rc;
+        if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+    }
+    unsigned long long* keys = c->keys + 8;        // scratch keys of the split path: [8, 8 + HJ_MAX_DIM + 1)
+    HIP_TRY(hipMemsetAsync(keys, 0, (HJ_MAX_DIM + 1) * sizeof(unsigned long long), c->stream));
+#define HJ_TN(T_, ND_) rc = term_launch_nd<T_, ND_>(c, kind, scheme, y, arr, scal, order, out, keys)
+    if (c->dtype == HJ_F64) { if (c->ndim == 2) HJ_TN(double, 2); else if (c->ndim == 3) HJ_TN(double, 3); else HJ_TN(double, 4); }
+    else { if (c->ndim == 2) HJ_TN(float, 2); else if (c->ndim == 3) HJ_TN(float, 3); else HJ_TN(float, 4); }
+#undef HJ_TN
+    if (rc) return rc;
+    unsigned long long h[HJ_MAX_DIM + 1];
+    HIP_TRY(hipMemcpyAsync(h, keys, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int d = 0; d <= c->ndim; ++d) k[d] = h[d] ? key_to_double(h[d]) : -1.0;
+    return HJ_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int hj_term_normal(hj_ctx* c, int scheme, const void* y, const void* speed, double speed_scalar, void* ydot, double* step_bound) {
+    const void* arr[HJ_MAX_DIM] = {speed, nullptr, nullptr, nullptr};
+    const double scal[HJ_MAX_DIM] = {speed_scalar, 0, 0, 0};
+    double k[HJ_MAX_DIM + 1];
+    int rc = term_run(c, HJ_TERM_NORMAL, scheme, y, arr, scal, 0, ydot, k);
+    if (rc) return rc;
+    // stepBound = 1 / max over nodes with |grad phi| > 0 of (sum_i |a| |p_i| / dx_i) / |grad phi|   (term_normal.py:162-164)
+    if (step_bound) *step_bound = k[c->ndim] > 0.0 ? 1.0 / k[c->ndim] : std::numeric_limits<double>::infinity();
+    return HJ_OK;
+}
+
+int hj_term_reinit(hj_ctx* c, int scheme, const void* y, const void* initial, int subcell_order, void* ydot, double* step_bound) {
+    if (!initial) return fail(HJ_EINVAL, "null initial array");
+    if (subcell_order != 0 && subcell_order != 1) return fail(HJ_EINVAL, "Reinit subcell fix order of accuracy %d not supported", subcell_order);
+    const void* arr[HJ_MAX_DIM] = {initial, nullptr, nullptr, nullptr};
+    double k[HJ_MAX_DIM + 1];
+    int rc = term_run(c, HJ_TERM_REINIT, scheme, y, arr, nullptr, subcell_order, ydot, k);
+    if (rc) return rc;
+    double inv = 0.0;                               // sum_i max|S p_i / |p|| / dx_i   (term_reinit.py:217,305)
+    for (int d = 0; d < c->ndim; ++d) inv += (k[d] > 0.0 ? k[d] : 0.0) / c->dx[d];
+    if (step_bound) *step_bound = inv > 0.0 ? 1.0 / inv : std::numeric_limits<double>::infinity();
+    return HJ_OK;
+}
+
+int hj_term_convection(hj_ctx* c, int scheme, const void* y, const void* const* velocity, const double* velocity_scalar,
+                       void* ydot, double* step_bound) {
+    if (!velocity && !velocity_scalar) return fail(HJ_EINVAL, "velocity is neither arrays nor scalars");
+    if (c)
+        for (int d = 0; d < c->ndim; ++d)
+            if (!(velocity && velocity[d]) && !velocity_scalar) return fail(HJ_EINVAL, "velocity of dim %d is neither an array nor a scalar", d);
+    double k[HJ_MAX_DIM + 1];
+    int rc = term_run(c, HJ_TERM_CONVECTION, scheme, y, velocity, velocity_scalar, 0, ydot, k);
+    if (rc) return rc;
+    double inv = 0.0;                               // sum_i max|v_i| / dx_i   (term_convection.py:175-177)
+    for (int d = 0; d < c->ndim; ++d) inv += (k[d] > 0.0 ? k[d] : 0.0) / c->dx[d];
+    if (step_bound) *step_bound = inv > 0.0 ? 1.0 / inv : std::numeric_limits<double>::infinity();
     return HJ_OK;
 }
 

@@ -22,6 +22,17 @@
 
 namespace hj {
 
+#ifndef HJ_F12_STAGGER
+#define HJ_F12_STAGGER 0
+#endif
+// HJ_F12_ABLATE (tuning builds only, WRONG results): 1 no barrier, 2 no LDS stencil reads, 4 no global loads in the loop
+#ifndef HJ_F12_ABLATE
+#define HJ_F12_ABLATE 0
+#endif
+#if HJ_F12_ABLATE && !defined(HJ_TUNE_BUILD)
+#error "HJ_F12_ABLATE gives wrong results: tuning builds only"
+#endif
+
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>
 __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restrict__ y, T* __restrict__ out,
                                                                const Fused12Args<T, HAM::ND> A) {
@@ -377,6 +388,9 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 if (j == 3) { va[j] = v0[0][3]; vb[j] = v0[1][3]; continue; }
+#if HJ_F12_ABLATE & 2      // timing experiment: no LDS stencil reads (results are wrong)
+                va[j] = v0[0][j]; vb[j] = v0[1][j]; continue;
+#endif
                 const V n2 = *reinterpret_cast<const V*>(base + (j - 3) * ls1);
                 va[j] = n2.x;
                 vb[j] = n2.y;
@@ -386,6 +400,9 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
         }
         {   // the contiguous axis: cells j-3 .. j+4 = [b64][b128][own pair][b128][b64]
             T w[8];
+#if HJ_F12_ABLATE & 2
+            w[0] = v0[0][0]; w[1] = v0[0][1]; w[2] = v0[0][2]; w[3] = v0[0][3]; w[4] = v0[1][3]; w[5] = v0[1][4]; w[6] = v0[1][5]; w[7] = v0[1][6];
+#else
             w[0] = base[-3];
             const V l2 = *reinterpret_cast<const V*>(base - 2);
             w[1] = l2.x; w[2] = l2.y;
@@ -393,6 +410,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
             const V r2 = *reinterpret_cast<const V*>(base + 2);
             w[5] = r2.x; w[6] = r2.y;
             w[7] = base[4];
+#endif
             upwind_cd<SCHEME, T>(w, A.K[LA], eps[LA], wk[LA], pc[0][LA], hd[0][LA]);
             upwind_cd<SCHEME, T>(w + 1, A.K[LA], eps[LA], wk[LA], pc[1][LA], hd[1][LA]);
         }
@@ -415,7 +433,9 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
         const bool s1 = s1_plane(q);
         T* bufY = ldsY + (q & 1) * ybox;
         T* bufWq = ldsW + sW[6];
+#if !(HJ_F12_ABLATE & 4)
         if (q + W + 1 < q1 + W) load_own(q + W + 1, pw_load, own_c);
+#endif
         pw_load = inc0(pw_load);
         if (s1) {
 #pragma unroll
@@ -436,8 +456,17 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                     if (h_act[k]) bufY[h_oy[k]] = hal_c[k];
             }
         }
+#if !(HJ_F12_ABLATE & 1)    // timing experiment: no barrier (results are wrong)
         __syncthreads();
+#endif
+#if HJ_F12_STAGGER > 0
+        // the waves of a SIMD leave the barrier together and would run their LDS-read bursts and their arithmetic in
+        // lock-step; the second half of the workgroup starts late, so that one wave computes while its partner reads
+        if (tid >= NT / 2) __builtin_amdgcn_s_sleep(HJ_F12_STAGGER);
+#endif
+#if !(HJ_F12_ABLATE & 4)
         if (s1_plane(q + 1) && q + 1 < q1) load_halo(pw_h, hal_c, hin_c);
+#endif
         pw_h = inc0(pw_h);
         // ---- y1 ghost cells of plane q-1 on extrapolated in-plane boundaries (boundary rule applied to y1)
         if (tile_fix && q - 1 >= q0 && s1_plane(q - 1)) {
@@ -508,6 +537,9 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                 T v0[2][7];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
+#if HJ_F12_ABLATE & 2
+                    v0[0][j] = yq[r][0][j]; v0[1][j] = yq[r][1][j]; continue;
+#endif
                     const V n2 = *reinterpret_cast<const V*>(ldsW + sW[j] + a_ow[r]);
                     v0[0][j] = n2.x;
                     v0[1][j] = n2.y;

@@ -19,6 +19,12 @@
 
 namespace hj {
 
+// HJ_ST_UNSAFE (no wait states after the 16-byte store), HJ_ABLATE / HJ_ABLATE_NOSYNC (parts of the kernel removed) exist
+// to price those parts; the results are WRONG with them, so only a tuning build may define them
+#if (defined(HJ_ST_UNSAFE) || defined(HJ_ABLATE_NOSYNC) || defined(HJ_ABLATE)) && !defined(HJ_TUNE_BUILD)
+#error "HJ_ST_UNSAFE / HJ_ABLATE* give wrong results: tuning builds (-DHJ_TUNE_BUILD) only"
+#endif
+
 template <typename T> struct Pair;
 template <> struct Pair<double> { typedef double V __attribute__((ext_vector_type(2))); };
 template <> struct Pair<float> { typedef float V __attribute__((ext_vector_type(2))); };

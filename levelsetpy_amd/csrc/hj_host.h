@@ -172,22 +172,39 @@ struct SubstepCall {
 
 inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s.on_aux ? c->edge_stream : c->stream; }
 
-// (threads per workgroup, cells per thread, halo slots per thread) instantiated for the tiled kernel
+// (threads per workgroup, cells per thread, halo slots per thread, waves/SIMD hint, prefetch depth) instantiated for
+// the tiled kernel.  Only what launch_cfg's default chooser can pick is built (round 3: the round-2 tables also
+// carried runners-up that spill and that nobody selected); cfg_built() narrows the table per scheme, so that the
+// heavy stencils (ENO3, intended WENO5) are not compiled in the 4-cells-per-thread shapes they would spill in.
+// A configuration requested through HJ_NT / HJ_PAIR_NT ... that is not built is an ERROR, not a silent fallback.
 #ifndef HJ_CONFIGS
 #ifdef HJ_ALL_CONFIGS   // the full sweep table (tools/cfgsweep.sh); ~2.5 min to compile
 #define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(1024, 2, 1, 4, 2) X(512, 2, 1, 4, 2) X(256, 4, 3, 2, 2) X(256, 2, 2, 4, 2) \
                       X(512, 1, 1, 4, 2) X(256, 1, 2, 6, 2) X(1024, 1, 1, 4, 2) \
                       X(512, 4, 2, 2, 3) X(256, 4, 3, 2, 3) X(512, 1, 1, 4, 3) X(512, 2, 1, 3, 3) X(512, 2, 1, 3, 2) \
                       X(512, 2, 1, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 2, 2) X(256, 4, 3, 1, 2) X(256, 2, 2, 3, 2)
-#else                   // the defaults per scheme plus the runners-up of the round-1 sweeps
-#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 3, 2) X(256, 2, 2, 2, 2) X(512, 2, 1, 2, 2) X(512, 1, 1, 4, 2)
+#else
+#define HJ_CONFIGS(X) X(512, 4, 2, 2, 2) X(256, 2, 2, 2, 2) X(512, 1, 1, 4, 2)
 #endif
 #endif
 
 // 4-D grids tile three plane axes: the halo cross is ~2x the tile, so more halo slots per thread
 #ifndef HJ_CONFIGS_4D
-#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2) X(1024, 1, 2, 2, 2)
+#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2)
 #endif
+
+// light stencils: few enough live values that 4 cells (2 pairs) per thread fit in 256 VGPRs without scratch
+constexpr bool light_scheme(int scheme) { return scheme == HJ_WENO5_ASSHIPPED || scheme == HJ_ENO2; }
+// is configuration (NT, R) of the one-cell-per-lane / pair kernel compiled for this scheme?
+constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair) {
+#ifdef HJ_ALL_CONFIGS
+    return true;
+#else
+    if (nd == 4) return true;
+    if (pair) return light_scheme(scheme) ? (nt == 512 && r == 2) || (nt == 256 && r == 1) : (nt == 256 && r == 1);
+    return light_scheme(scheme) ? true : (nt == 256 && r == 2);
+#endif
+}
 
 // the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
 // instantiated in hj_inst.hip

@@ -154,11 +154,12 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
 
 // (threads, PAIRS per thread, halo slots per thread, waves/SIMD hint) of the pair kernel
 #ifndef HJ_CONFIGS_PAIR
-#define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(256, 1, 2, 3) X(512, 2, 2, 2) X(512, 1, 1, 2)
+#define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(512, 2, 2, 2)
 #endif
-// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile): only on request (HJ_PAIR_NT/R/KH/OCC)
+// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile): the pair kernel was measured 5-15 % slower
+// there in round 2 and every fp64 shape of it spills; built only where a tuning build defines the table
 #ifndef HJ_CONFIGS_PAIR_4D
-#define HJ_CONFIGS_PAIR_4D(X) X(512, 1, 5, 2) X(512, 2, 7, 2) X(256, 2, 5, 2)
+#define HJ_CONFIGS_PAIR_4D(X)
 #endif
 
 template <typename T, typename HAM, int SCHEME>
@@ -247,18 +248,24 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
                 const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2, c->last_nbuf);
                 if (tp.ok) {
-#define X(NT_, R_, KH_, OCC_) if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp);
+#define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true)) { if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
                     if constexpr (HAM::ND == 4) { HJ_CONFIGS_PAIR_4D(X) }
                     else { HJ_CONFIGS_PAIR(X) }
 #undef X
+                    if (c->pair_nt > 0 || c->pair_r > 0 || c->pair_kh > 0 || c->pair_occ > 0)
+                        return hjh::fail(HJ_EUNSUPPORTED, "pair-kernel configuration (%d,%d,%d,%d) requested through HJ_PAIR_* is not built for scheme %d",
+                                         kp.NT, kp.R, kp.KH, occp, SCHEME);
                 }
             }
             Tiling t = make_tiling(c, k, s.p0, s.p1);
             if (t.ok) {
-#define X(NT_, R_, KH_, OCC_, PD_) if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t);
+#define X(NT_, R_, KH_, OCC_, PD_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, false)) { if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t); }
                 if constexpr (HAM::ND == 4) { HJ_CONFIGS_4D(X) }
                 else { HJ_CONFIGS(X) }
 #undef X
+                if (c->cfg_from_env)
+                    return hjh::fail(HJ_EUNSUPPORTED, "kernel configuration (%d,%d,%d,%d,%d) requested through HJ_NT/HJ_R/HJ_KH/HJ_OCC/HJ_PD is not built for scheme %d",
+                                     k.NT, k.R, k.KH, occ, pd, SCHEME);
             }
         }
     }
@@ -279,7 +286,7 @@ int launch_scheme(hj_ctx* c, const SubstepCall& s) {
 // ------------------------------------------------------------------------------------ stage-fused launch
 // (threads, A slots per thread, H slots per thread, waves/SIMD hint)
 #ifndef HJ_CONFIGS12
-#define HJ_CONFIGS12(X) X(512, 4, 2, 2) X(512, 3, 2, 2) X(512, 2, 2, 2) X(768, 2, 2, 3) X(1024, 2, 1, 4)
+#define HJ_CONFIGS12(X) X(512, 4, 2, 2) X(512, 3, 2, 2) X(512, 2, 2, 2)
 #endif
 
 struct Tiling12 {
@@ -550,7 +557,8 @@ int launch_stage12_cfg(hj_ctx* c, const Stage12Call& s) {
         const Tiling12 t = make_tiling12(c, NT, R, KH, (size_t)160 * 1024 - 256);
         if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused tiling for this grid");
         if (s.probe) return HJ_OK;
-#define X(NT_, R_, KH_, OCC_) if (NT == NT_ && R == R_ && KH == KH_) return launch_fused12<T, HAM, SCHEME, NT_, R_, KH_, OCC_>(c, s, t);
+        // at most the scheme's default number of A slots per thread is built: 4 (ENO2), 3 (as-shipped WENO5), 2 (ENO3)
+#define X(NT_, R_, KH_, OCC_) if constexpr (R_ <= ((SCHEME == HJ_ENO3) ? 2 : (SCHEME == HJ_ENO2 ? 4 : 3)) || NT_ != 512) { if (NT == NT_ && R == R_ && KH == KH_) return launch_fused12<T, HAM, SCHEME, NT_, R_, KH_, OCC_>(c, s, t); }
         HJ_CONFIGS12(X)
 #undef X
         return hjh::fail(HJ_EUNSUPPORTED, "stage-fused configuration (%d,%d,%d) is not built", NT, R, KH);

@@ -101,9 +101,7 @@ def test_no_gpu_fails_loudly():
         L.addGhostPeriodic(np.zeros((4, 4)), 0, 1)
 
 
-def test_wide_store_hazard_rule_holds_in_built_library():
-    """Disassembles the gfx950 code objects of the built library: no VGPR holding the data of a >8-byte store may be
-    written within two wait states of the store (hj_fusedv.h).  Static check, no GPU needed."""
+def _check_wide_store_hazard():
     import importlib.util, os
     from levelsetpy_amd import _ffi
     if not os.path.exists(_ffi.LIB_PATH) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
@@ -113,3 +111,15 @@ def test_wide_store_hazard_rule_holds_in_built_library():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     total, bad = mod.main(_ffi.LIB_PATH)
     assert total > 0 and not bad, bad[:5]
+
+
+def test_wide_store_hazard_rule_holds_in_built_library():
+    """Disassembles the gfx950 code objects of the built library: no VGPR holding the data of a >8-byte store may be
+    written within two wait states of the store (hj_fusedv.h).  Static check, no GPU needed; the
+    Makefile runs the same check after every link, and so does the GPU suite on the library it actually loads."""
+    _check_wide_store_hazard()
+
+
+@pytest.mark.gpu
+def test_wide_store_hazard_rule_holds_in_loaded_library():
+    _check_wide_store_hazard()

@@ -22,7 +22,7 @@ from levelsetpy_amd import _ffi  # noqa: E402
 from levelsetpy_amd.context import DeviceGrid  # noqa: E402
 from oracle import hj_oracle as O  # noqa: E402
 
-from test_gpu_parity import mk, sdata, DERIV, SCHEMES, _substep  # noqa: E402
+from test_gpu_parity import mk, sdata, DERIV, SCHEMES, _substep, dubins  # noqa: E402
 
 PAR_DUBINS = [1., 1., 1., 2.]
 
@@ -602,6 +602,44 @@ def test_term_reinit_vs_oracle_and_signed_distance(scheme, order):
     assert np.max(np.abs(got[band] - true[band])) <= (0.03 if order == 0 else 0.015), np.max(np.abs(got[band] - true[band]))
 
 
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5", "WENO5_ASSHIPPED"])
+def test_fused_term_kernels_equal_the_array_path(scheme):
+    """Round 3: termNormal / termReinit / termConvection with one of this package's derivative functions are ONE
+    kernel launch each (hj_term_*, csrc/hj_terms.h).  The same terms with a FOREIGN derivFunc (a wrapper the package
+    cannot recognise) take the derivatives from hj_upwind and run the array expressions of normal_reinit.py /
+    convection.py.  Both evaluate the same expressions in the same order (contraction off in the kernel): equal to
+    the last bit (termReinit: to 1 ulp) on a 3-D grid with periodic and extrapolated axes; step bounds equal to rounding."""
+    g, og = dubins((19, 16, 14))
+    rng = np.random.default_rng(5)
+    phi = O.shape_cylinder(og, 2, None, .5) * (1.0 + 0.3 * np.sin(2 * og.xs[0])) + 0.02 * rng.standard_normal(g.shape)
+    native = DERIV[scheme]
+    foreign = lambda grid, data, dim: native(grid, data, dim)     # noqa: E731  (no _hj_scheme tag: array path)
+    y = torch.as_tensor(phi.reshape(-1, 1), device="cuda")
+    speed = torch.as_tensor(0.5 + 0.3 * np.cos(og.xs[0]) * np.ones(g.shape), device="cuda")
+    vel = [0.7, torch.as_tensor(-0.4 + 0.5 * np.sin(3 * og.xs[1]) * np.ones(g.shape), device="cuda"), -0.2]
+    cases = [
+        (L.termNormal, dict(speed=speed)),
+        (L.termNormal, dict(speed=-1.25)),
+        (L.termReinit, dict(initial=torch.as_tensor(phi, device="cuda"), subcell_fix_order=0)),
+        (L.termReinit, dict(initial=torch.as_tensor(phi, device="cuda"), subcell_fix_order=1)),
+        (L.termConvection, dict(velocity=vel)),
+    ]
+    for fn, extra in cases:
+        a, sba, _ = fn(0., y, L.Bundle(dict(grid=g, derivFunc=native, **extra)))
+        b, sbb, _ = fn(0., y, L.Bundle(dict(grid=g, derivFunc=foreign, **extra)))
+        assert torch.is_tensor(a) and a.is_cuda and a.shape == b.shape == y.shape
+        # termNormal and termConvection: to the last bit; termReinit's quotient chain S*p/|p| is rounded differently by
+        # torch's elementwise kernels in places (measured: 1 ulp, 2.8e-17 absolute)
+        if fn is L.termReinit:
+            assert float((a - b).abs().max()) <= 4e-16 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+        else:
+            assert torch.equal(a, b), "%s %s: max diff %g" % (fn.__name__, sorted(extra), float((a - b).abs().max()))
+        assert abs(sba - sbb) <= 4e-16 * abs(sbb), (fn.__name__, sba, sbb)
+        # NumPy in -> NumPy out through the same kernel
+        c, sbc, _ = fn(0., phi.reshape(-1, 1), L.Bundle(dict(grid=g, derivFunc=native, **extra)))
+        assert isinstance(c, np.ndarray) and np.array_equal(c, a.cpu().numpy()) and sbc == sba
+
+
 class _DoubleIntegratorPlant(object):
     """dynSys protocol of computeOptTraj (compute_opt_traj.py:124-131) for xddot = u, |u| <= 1."""
 
@@ -641,6 +679,66 @@ def test_compute_opt_traj_reaches_the_target_in_minimum_time():
     assert np.all(np.isfinite(traj))
     # the switching structure: decelerate first (x2 goes negative), then brake
     assert traj[1].min() < -0.4
+
+
+class _DubinsPursuerPlant(object):
+    """A 3-D plant on the Dubins-relative grid (periodic heading): x' = (-v + v cos x3 + u x2, v sin x3 - u x1, -u),
+    |u| <= 1, the control chosen from the costate as the reference's systems do (dubins_relative.py:83-88)."""
+
+    def __init__(self, x):
+        self.x = np.asarray(x, dtype=np.float64)
+
+    def get_opt_u(self, t, deriv, uMode, x):
+        det = deriv[0] * x[1] - deriv[1] * x[0] - deriv[2]
+        s = 1.0 if det >= 0 else -1.0
+        return -s if uMode == 'min' else s
+
+    def get_opt_v(self, t, deriv, dMode, x):
+        return 0.0
+
+    def update_state(self, u, dt, x, d=None):
+        f = lambda z: np.array([-1.0 + np.cos(z[2]) + u * z[1], np.sin(z[2]) - u * z[0], -u])    # noqa: E731
+        k1 = f(x); k2 = f(x + .5 * dt * k1); k3 = f(x + .5 * dt * k2); k4 = f(x + dt * k3)
+        self.x = x + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        return self.x
+
+
+@pytest.mark.parametrize("case", ["double_integrator", "dubins"])
+def test_compute_opt_traj_equals_oracle_point_by_point(case):
+    """computeOptTraj (costates from the HIP upwind kernels, 2^dim corner values read per evaluation) against
+    oracle.compute_opt_traj (NumPy restatement: pinned derivatives, eval_u as the reference's RegularGridInterpolator
+    on the periodically augmented table) on the SAME stored value function: every trajectory point within 1e-9, the
+    same time stamps.  The shipped reference raises: parity unpinned, this pins the product to
+    the oracle."""
+    if case == "double_integrator":
+        n = 61
+        g, og = mk([-1, -1], [1, 1], (n, n), None)
+        data0 = L.shapeSphere(g, np.zeros((2, 1)), .1)
+        sys_ = L.DoubleIntegrator(g, 1)
+        tau = np.linspace(0, 1.2, 25)
+        mk_plant = lambda: _DoubleIntegratorPlant([0.45, 0.05])        # noqa: E731
+        deriv = L.upwindFirstENO3
+    else:
+        g, og = dubins((31, 31, 24))
+        data0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+        sys_ = L.DubinsVehicleRel(g, 1, 1)
+        tau = np.linspace(0, 0.6, 13)
+        mk_plant = lambda: _DubinsPursuerPlant([1.1, 0.3, 2.9])        # noqa: E731   (heading near the periodic seam)
+        deriv = L.upwindFirstWENO5
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=L.artificialDissipationGLF,
+                       derivFunc=deriv))
+    data, _, _ = L.HJIPDE_solve(data0, tau, sd, 'minVOverTime', L.Bundle(dict(quiet=True, flipOutput=True)))
+    data = np.asarray(data)
+    pa, pb = mk_plant(), mk_plant()
+    traj, ttau = L.computeOptTraj(g, data, tau, pa, L.Bundle(dict(uMode='min', subSamples=4)))
+    otraj, otau = O.compute_opt_traj(og, data, tau, pb, 'min', None, 4)
+    assert traj.shape == otraj.shape and traj.shape[1] >= 5, (traj.shape, otraj.shape)
+    assert np.array_equal(ttau, otau)
+    assert np.max(np.abs(traj - otraj)) <= 1e-9, np.max(np.abs(traj - otraj))
+    # and on a device-resident table
+    pc = mk_plant()
+    traj2, _ = L.computeOptTraj(g, torch.as_tensor(data, device="cuda"), tau, pc, L.Bundle(dict(uMode='min', subSamples=4)))
+    assert np.max(np.abs(traj2 - otraj)) <= 1e-9
 
 
 def test_llf_scalar_alpha_and_fourth_candidate_vs_reference_golden(golden):

@@ -274,3 +274,27 @@ def test_eno3_helper_fourth_candidate_vs_reference(golden):
         dL, dR, _ = O.eno3_helper(g, G["g3_data"], dim, approx4=True)
         close(dL[3], G["g3_helper4_dL3_d%d" % dim])
         close(dR[3], G["g3_helper4_dR3_d%d" % dim])
+
+
+def test_oracle_eval_u_is_the_reference_interpolant():
+    """oracle.eval_u restates ValueFuncs/evaluate_u.py:64-120: scipy's RegularGridInterpolator ('linear') on the node
+    vectors, periodic axes augmented by one wrapped node and the state shifted by whole periods.  Checked against
+    scipy itself (the reference's own call, :104-113) on random states, inside and across the periodic seam."""
+    from scipy.interpolate import RegularGridInterpolator
+    og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / 12)], [9, 11, 12], [2])
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal(og.shape)
+    vs = [v.ravel() for v in og.vs]
+    vs[2] = np.concatenate([vs[2], [vs[2][-1] + og.dx[2, 0]]])
+    aug = np.concatenate([data, data[:, :, :1]], axis=2)
+    ref = RegularGridInterpolator(vs, aug)
+    for _ in range(50):
+        x = np.array([rng.uniform(-.75, 3.25), rng.uniform(-1.25, 1.25), rng.uniform(-3 * np.pi, 3 * np.pi)])
+        xw = x.copy()
+        period = vs[2][-1] - vs[2][0]
+        while xw[2] > vs[2][-1]:
+            xw[2] -= period
+        while xw[2] < vs[2][0]:
+            xw[2] += period
+        assert abs(O.eval_u(og, data, x) - float(ref(xw)[0])) <= 1e-13
+    assert np.isnan(O.eval_u(og, data, [4.0, 0.0, 0.0]))

@@ -49,15 +49,23 @@ def regs(tok):
 
 
 def dest_regs(ins, ops):
-    """VGPRs an instruction writes (first operand for VALU / loads; nothing for stores, SALU, waits)."""
-    if ins.startswith(("buffer_store", "global_store", "flat_store", "ds_write", "s_", "buffer_wbl2", "buffer_inv")):
+    """VGPRs an instruction writes.  VALU / DPP / SDWA / MFMA / loads write their first operand (a scalar or condition
+    destination there yields no VGPR); the swap family writes BOTH of its operands; loads into LDS (`... lds`),
+    stores, SALU, waits and compares write none."""
+    if ins.startswith(("buffer_store", "global_store", "flat_store", "scratch_store", "ds_write", "ds_store", "s_",
+                       "buffer_wbl2", "buffer_inv", "buffer_atomic", "global_atomic", "flat_atomic")) and "_rtn" not in ins:
+        if not (ins.startswith(("buffer_atomic", "global_atomic", "flat_atomic")) and " sc0" in (" " + ops)):
+            return set()
+    if ins.startswith("v_cmp"):                         # v_cmp / v_cmpx write VCC / EXEC / an SGPR pair
         return set()
-    if ins.startswith("v_cmp") and not ins.startswith("v_cmpx"):
+    if ops.rstrip().endswith(" lds") or " lds " in ops:  # LDS-DMA: no register destination
         return set()
-    first = ops.split(",")[0] if ops else ""
-    d = regs(first)
-    if ins.startswith("v_mad_u64_u32") or ins.startswith("v_mad_i64_i32"):
-        d |= set()
+    toks = [t.strip() for t in ops.split(",")] if ops else []
+    if not toks:
+        return set()
+    d = regs(toks[0].split()[0]) if toks[0] else set()
+    if ins.startswith(("v_swap_b", "v_permlane16_swap", "v_permlane32_swap")) and len(toks) > 1:
+        d |= regs(toks[1].split()[0])
     return d
 
 
