@@ -5,6 +5,7 @@ torch is plumbing here: device memory, the current HIP stream, (in dist.py)
 torch.distributed.  All arithmetic on the path runs in libhj_mi355x.so.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -143,10 +144,16 @@ class DeviceGrid(object):
         if is_tensor(proto):
             return t
         t = t.detach()
-        if t.is_cuda and t.numel() * t.element_size() >= (1 << 20):
-            host = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            host.copy_(t)
-            return host.numpy()
+        nbytes = t.numel() * t.element_size()
+        # HJ_PIN_RESULTS=0 turns the page-locked results off; HJ_PIN_MAX_MB caps a single pinned result (default 2048:
+        # arrays held by the caller keep their pages locked for their lifetime, and torch's host cache keeps the blocks)
+        if t.is_cuda and nbytes >= (1 << 20) and _PIN_RESULTS and nbytes <= _PIN_MAX_BYTES:
+            try:
+                host = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                host.copy_(t)
+                return host.numpy()
+            except RuntimeError:        # no page-locked memory to be had (ulimit -l, host pressure): pageable copy
+                pass
         return t.cpu().numpy()
 
     def empty(self, shape=None):
@@ -165,6 +172,10 @@ class DeviceGrid(object):
 
     def sync(self):
         _ffi.check(self.lib.hj_sync(self.ctx))
+
+
+_PIN_RESULTS = os.environ.get("HJ_PIN_RESULTS", "1") != "0"
+_PIN_MAX_BYTES = int(float(os.environ.get("HJ_PIN_MAX_MB", "2048")) * (1 << 20))
 
 
 def device_grid(grid, dtype="float64"):

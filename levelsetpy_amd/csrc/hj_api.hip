@@ -363,6 +363,8 @@ int do_stage12(hj_ctx* c, Stage12Call& s, int user_slot) {
     if (c->ndim > 3 || s.scheme == HJ_WENO5 || s.scheme < 0 || s.scheme > 3)
         return fail(HJ_EUNSUPPORTED, "no stage-fused kernel for this scheme / dimension");
     if (c->halo_lo || c->halo_hi) return fail(HJ_EUNSUPPORTED, "the stage-fused kernel does not take slab halos");
+    if (np_order(s.scheme) && !s.probe && !((s.ca == 0.75 && s.cb == 0.25) || (s.ca == 0.5 && s.cb == 0.5)))
+        return fail(HJ_EUNSUPPORTED, "ENO schemes evaluate the reference's own stage expressions: (ca, cb) must be (3/4, 1/4) or (1/2, 1/2)");
     if ((double)c->total * (double)c->esz >= 4294967295.0) return fail(HJ_EUNSUPPORTED, "array of 4 GiB or more");
     if (c->N[0] < 8) return fail(HJ_EUNSUPPORTED, "fewer than 8 planes");
     for (int d = 1; d < c->ndim; ++d)

@@ -93,6 +93,16 @@ constexpr int HJ_NK = 12;
 #ifndef HJ_ENO_EXACT
 #define HJ_ENO_EXACT 1
 #endif
+// NumPy operation order ("NP") for a scheme: with HJ_ENO_EXACT the ENO2 / ENO3 substep is evaluated operation by
+// operation as the reference's array expressions evaluate it, contraction off from the derivatives to the RK update:
+// the one-sided derivatives (upwind_cd), the Hamiltonian (HAM::eval<true>), the dissipation sum and -(H - diss)
+// (lf_ydot), and the stage expression (rk_stage_out).  Why the WHOLE substep: the selectors alone are not enough --
+// after one substep the state differs from the reference's in the last bit wherever an FMA was formed, and a near-tie
+// |D2_a| ~ |D2_b| then flips on that noise (measured in round 3: with bit-faithful selectors only, 1.9 % of the cells of
+// the symmetric 5-step golden still differed).  With every operation rounded as NumPy rounds it the states are the
+// reference's bit for bit and so is every later choice.  The WENO5 arithmetics keep their contracted forms (linear /
+// smooth in the data: no discrete choices to flip).
+constexpr bool np_order(int scheme) { return HJ_ENO_EXACT && (scheme == HJ_ENO2 || scheme == HJ_ENO3); }
 template <typename T> inline void fill_stencil_constants(double dx, T* K) {
     const double inv = 1.0 / dx;
     K[0] = (T)inv;
@@ -393,6 +403,9 @@ template <typename T> struct HamDubinsRel {
         return Raw{P.aux[0][idx[2]], P.aux[1][idx[2]], P.coord[1][idx[1]]};
     }
     __device__ static __forceinline__ Cell cell_fin(const HamTables<T>& P, const Raw& r, const T* sc) {
+        // contraction off (once per thread, in the setup): v_e - v_p cos x3 rounded as NumPy rounds it
+        // (dubins_relative.py:84,108), so that alpha -- and with it stepBound and deltaT -- is the reference's bit for bit
+#pragma clang fp contract(off)
         Cell c;
         const T a = P.par[0] - P.par[1] * r.c;
         const T b = P.par[1] * r.s;
@@ -413,11 +426,18 @@ template <typename T> struct HamDubinsRel {
         u.awx0 = sc[1] * t_abs(P.par[2] * x0);
         return u;
     }
+    // NP: the reference's expression (dubins_relative.py:87-88) operation by operation, no FMA (sc = 1 there)
+    template <bool NP = false>
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& u,
                                                 const T* sc, const T* q, T& H, T* alpha) {
         const T w = P.par[2];
         const T p2 = sc[2] * q[2];
-        H = q[0] * c.a - q[1] * c.b - w * t_abs(q[0] * c.x1 - q[1] * u.x0 - p2) + w * t_abs(p2);
+        if constexpr (NP) {
+#pragma clang fp contract(off)
+            H = q[0] * c.a - q[1] * c.b - w * t_abs(q[0] * c.x1 - q[1] * u.x0 - p2) + w * t_abs(p2);
+        } else {
+            H = q[0] * c.a - q[1] * c.b - w * t_abs(q[0] * c.x1 - q[1] * u.x0 - p2) + w * t_abs(p2);
+        }
         alpha[0] = c.alpha0;
         alpha[1] = t_abs(c.b) + u.awx0;
         alpha[2] = sc[2] * P.par[3];
@@ -443,10 +463,17 @@ template <typename T> struct HamDoubleIntegrator {
         return cell_fin(P, cell_raw(P, idx), sc);
     }
     __device__ static __forceinline__ Plane plane(const HamTables<T>&, int, const T*) { return Plane{0}; }
+    // NP: -(p1*x2 - |p2|*u) operation by operation (double_integrator.py:73-74)
+    template <bool NP = false>
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane&,
                                                 const T* sc, const T* q, T& H, T* alpha) {
         const T us = sc[1] * P.par[0];
-        H = -(q[0] * c.x1 - t_abs(q[1]) * us);
+        if constexpr (NP) {
+#pragma clang fp contract(off)
+            H = -(q[0] * c.x1 - t_abs(q[1]) * us);
+        } else {
+            H = -(q[0] * c.x1 - t_abs(q[1]) * us);
+        }
         alpha[0] = c.alpha0;
         alpha[1] = t_abs(us);
     }
@@ -480,6 +507,7 @@ template <typename T> struct HamDoublePendulum {
         u.c1 = P.aux[1][i0];
         return u;
     }
+    template <bool NP = false>      // (build-defined system: there is no reference expression order to follow)
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& pl,
                                                 const T* sc, const T* q, T& H, T* alpha) {
         // the generic (unfolded) form: scale the costates first
@@ -504,6 +532,45 @@ template <typename T> struct HamDoublePendulum {
         alpha[3] = sc[3] * (t_abs(f3) + u);
     }
 };
+
+// ---- the tail of one cell's substep, shared by every kernel (fused, pair, stage-fused, direct)
+// ydot = -(H - sum_d hd_d alpha_d): termLaxFriedrichs / artificialDissipationGLF (term_lax_friedrich.py:111-128,
+// artificial_diss_glf.py:94-100: `diss += 0.5*derivDiff[i]*alpha`, hd = 0.5*(derivR - derivL)); alpha[] comes back
+template <bool NP, typename HAM, typename T>
+__device__ __forceinline__ T lf_ydot(const HamTables<T>& P, const typename HAM::Cell& c, const typename HAM::Plane& u,
+                                     const T* sc, const T* pc, const T* hd, T* alpha) {
+    T H;
+    HAM::template eval<NP>(P, c, u, sc, pc, H, alpha);
+    if constexpr (NP) {
+#pragma clang fp contract(off)
+        T diss = T(0);
+#pragma unroll
+        for (int d = 0; d < HAM::ND; ++d) diss = diss + hd[d] * alpha[d];
+        return -(H - diss);
+    } else {
+        T diss = T(0);
+#pragma unroll
+        for (int d = 0; d < HAM::ND; ++d) diss += hd[d] * alpha[d];
+        return -(H - diss);
+    }
+}
+// the stage expression of odeCFLn.  Contracted form (default): ca*y0 + cb*(y + dt*ydot) with (ca, cb) = (0,1), (3/4,1/4),
+// (1/3,2/3), (1/2,1/2).  NP: the reference's own expressions, operation by operation -- y + dt*ydot (ode_cfl_3.py:151,184,
+// 226), 0.25*(3*y0 + y2) (:193), (1/3)*(y0 + 2*y32) (:241), 0.5*(y0 + y2) (ode_cfl_2.py:201)
+template <bool NP, typename T>
+__device__ __forceinline__ T rk_stage_out(int stage, T ca, T cb, T dt, T y0, T y, T ydot) {
+    if constexpr (NP) {
+#pragma clang fp contract(off)
+        const T step = dt * ydot;
+        const T e = y + step;
+        if (stage == HJ_STAGE_RK3_HALF) { const T a = T(3) * y0; return T(0.25) * (a + e); }
+        if (stage == HJ_STAGE_RK3_FULL) { const T a = T(2) * e; return (T(1) / T(3)) * (y0 + a); }
+        if (stage == HJ_STAGE_RK2_FULL) return T(0.5) * (y0 + e);
+        return e;
+    } else {
+        return ca * y0 + cb * (y + dt * ydot);
+    }
+}
 
 // ---- buffer (SRD) addressing: wave-uniform 128-bit descriptor in SGPRs + per-lane 32-bit byte
 // offset, hardware range check (out-of-range loads return 0, stores are dropped)

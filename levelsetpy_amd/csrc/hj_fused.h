@@ -85,6 +85,7 @@ template <typename T, int ND> struct FusedArgs {
     // out = ydot                                   (ydot_only)
     //     = ca*y0 + cb*(y + dt*ydot)               otherwise; y0 is read iff use_y0
     int ydot_only, use_y0;
+    int stage;                    // HJ_STAGE_*: which stage expression (the NumPy-order ENO path evaluates the reference's own form)
     T ca, cb, dt;
     int post_op;                  // 0 none, 1/2: out = min/max(out, state at the start of the step)
     int do_clamp;                 // termRestrictUpdate: ydot clamped to [lo, hi]
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
                                                            const FusedArgs<T, HAM::ND> A) {
     constexpr int ND = HAM::ND;
     constexpr bool GEN = (MODE == 0);
+    constexpr bool NP = np_order(SCHEME);       // ENO2 / ENO3: every operation rounded as NumPy rounds it (hj_device.h)
     const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
     extern __shared__ __align__(16) unsigned char hj_smem[];
     // dynamic LDS only (keeps the carve base 16-byte aligned): [0,512) reduction scratch, then planes
@@ -328,7 +330,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
                 if (h < base[d] || h >= base[d + 1]) continue;
                 const int hh = h - base[d];
                 int lay, c;                            // lay 0..5: which halo layer; c: index over the other axes
-                fdivmod(hh, fA[d], lay, c);
+                if (d == ND - 1) {
+                    // contiguous axis: the LAYER runs fastest, so that consecutive lanes fetch the 3 + 3 cells either side
+                    // of one tile row (two cache lines) instead of one cell from each of 64 rows (64 lines per wave
+                    // instruction: round 3 found the halo columns issuing more line requests than the whole tile)
+                    c = hh / (2 * HJ_STENCIL);
+                    lay = hh - c * (2 * HJ_STENCIL);
+                } else {
+                    fdivmod(hh, fA[d], lay, c);
+                }
                 const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
                 int lo = 0, g = 0;
 #pragma unroll
@@ -488,15 +498,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
                 upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pc[d], hd[d]);
 #endif
             }
-            T H, alpha[ND];
-            HAM::eval(A.ham, hcell[r], pl_use, A.sc, pc, H, alpha);
-            T diss = T(0);
+            T alpha[ND];
+            T ydot = lf_ydot<NP, HAM>(A.ham, hcell[r], pl_use, A.sc, pc, hd, alpha);
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                diss += hd[d] * alpha[d];
+            for (int d = 0; d < ND; ++d)
                 if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
-            }
-            T ydot = -(H - diss);
             // termRestrictUpdate clamp; written so that a NaN stays a NaN
             if (GEN && A.do_clamp) {
                 ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             T o;
             if (GEN && A.ydot_only) o = ydot;
             else {
-                o = A.ca * y0_c[r] + A.cb * (q[r][3] + A.dt * ydot);
+                o = rk_stage_out<NP>(A.stage, A.ca, A.cb, A.dt, y0_c[r], q[r][3], ydot);
                 // the step started from y0 (stages that read it) or from y itself (Euler step)
                 if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0_c[r] : q[r][3]);
             }

@@ -42,6 +42,7 @@ template <typename T, int ND> struct Fused12Args {
     int plane_begin, plane_end;
     int nblocks, blocks_per_xcd;
     int nA, nH;                   // A / H index-space sizes (host-computed, = the formulas in the kernel)
+    int stage2;                   // HJ_STAGE_RK3_HALF or HJ_STAGE_RK2_FULL: the second stage's expression
     T ca, cb, dt;
     HamTables<T> ham;
 };
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_kernel(const T* __restrict__ 
                                                           const Fused12Args<T, HAM::ND> A) {
     constexpr int ND = HAM::ND;
     constexpr int W = HJ_STENCIL;
+    constexpr bool NP = np_order(SCHEME);
     static_assert(ND == 2 || ND == 3, "fused12: 2-D and 3-D grids");
     static_assert(SCHEME != HJ_WENO5, "fused12: the intended WENO5 needs a global reduction between the stages");
     extern __shared__ __align__(16) unsigned char hj_smem[];
@@ -386,12 +388,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_kernel(const T* __restrict__ 
             for (int j = 0; j < 7; ++j) v[j] = (j == 3) ? v0[3] : c[(j - 3) * ls[d]];
             upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pc[d], hd[d]);
         }
-        T H;
-        HAM::eval(A.ham, hc, pl, A.sc, pc, H, alpha);
-        T diss = T(0);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) diss += hd[d] * alpha[d];
-        return -(H - diss);
+        return lf_ydot<NP, HAM>(A.ham, hc, pl, A.sc, pc, hd, alpha);
     };
 
     // one iteration: stage 1 on plane q, stage 2 on plane q - W.  own_c holds plane q+4 (joins the queue at the
@@ -439,7 +436,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_kernel(const T* __restrict__ 
                 T alpha[ND];
                 const T ydot = lf_rhs(yq[r], bufY, a_oy[r], lsY, hcell[r], pl1, alpha);
                 // the Euler stage as fused_substep_kernel forms it (ca = 0, cb = 1, no y0 operand)
-                y1n[r] = T(0) * T(0) + T(1) * (yq[r][3] + A.dt * ydot);
+                y1n[r] = rk_stage_out<NP>(HJ_STAGE_EULER, T(0), T(1), A.dt, T(0), yq[r][3], ydot);
                 if (a_act[r]) bufWq[a_ow[r]] = y1n[r];
             }
         } else if (q >= n0) {
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_kernel(const T* __restrict__ 
                 for (int d = 0; d < ND; ++d)
                     if (((HAM::PLANE_DEP >> d) & 1u) && a_int[r]) amax[d] = fmax(amax[d], (double)alpha[d]);
                 // yq[r][0] is y on plane p: the y0 operand of the second stage
-                const T o = A.ca * yq[r][0] + A.cb * (v0[3] + A.dt * ydot);
+                const T o = rk_stage_out<NP>(A.stage2, A.ca, A.cb, A.dt, yq[r][0], v0[3], ydot);
                 if (a_int[r]) buf_store(o, rout, a_g[r], so_out);
             }
         }

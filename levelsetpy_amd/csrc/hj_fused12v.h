@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
     constexpr int LA = ND - 1;
     constexpr int W = HJ_STENCIL;
     constexpr int PYL = 8, PWL = 4;             // left pads (cells) of a row of the y / y1 box: even
+    constexpr bool NP = np_order(SCHEME);
     using V = typename Pair<T>::V;
     static_assert(ND == 2 || ND == 3, "fused12: 2-D and 3-D grids");
     static_assert(SCHEME != HJ_WENO5, "fused12: the intended WENO5 needs a global reduction between the stages");
@@ -115,9 +116,10 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                 j2 = 2 * (hh - lay * E2p);
                 j1 = (lay < W) ? (lay - W) : (E1 + lay - W);
             } else {
+                // the pair column runs fastest: consecutive lanes fetch the two ring pairs either side of ONE row
                 const int hh = a - n_intp - nring1;
-                const int lay = hh / E1;                  // 0..3: pair columns -4, -2, E2, E2+2
-                j1 = hh - lay * E1;
+                j1 = hh >> 2;
+                const int lay = hh & 3;                   // 0..3: pair columns -4, -2, E2, E2+2
                 j2 = (lay < 2) ? (2 * lay - 4) : (E2 + 2 * (lay - 2));
             }
             int oy = 0, ow = 0, g = 0;
@@ -190,8 +192,14 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                 for (int d = 1; d < ND; ++d) {
                     if (h < hbase[d] || h >= hbase[d + 1]) continue;
                     const int hh = h - hbase[d];
-                    const int lay = hh / area[d];
-                    int c = hh - lay * area[d];
+                    int lay, c;
+                    if (d == LA) {          // contiguous axis: the layer runs fastest (6 + 6 cells of one row: two cache lines)
+                        c = hh / (4 * W);
+                        lay = hh - c * (4 * W);
+                    } else {
+                        lay = hh / area[d];
+                        c = hh - lay * area[d];
+                    }
                     j[d] = (lay < 2 * W) ? (lay - 2 * W) : (A.E[d] + lay - 2 * W);
                     outside[d] = true;
                     ringlay[d] = (j[d] >= -W && j[d] < A.E[d] + W);
@@ -328,10 +336,10 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
         for (int r = 0; r < R; ++r) { yq[r][0][j] = tmp[r].x; yq[r][1][j] = tmp[r].y; }
     }
     // Prefetch: ONE register set each (256 VGPRs hold the 7-deep queue of two pairs, their Hamiltonian constants and
-    // the arithmetic of a pair; a second set spilled).  The own cells of plane q+4 are requested at the start of
-    // iteration q and join the queue at its end; the H values of plane q+1 are requested after the barrier of
-    // iteration q and staged at the start of iteration q+1.  An iteration is two stage evaluations of the whole
-    // tile (several microseconds): it covers the memory latency.
+    // the arithmetic of a pair; a second set spilled).  The own cells of plane q+4 and the H values of plane q+1 are
+    // requested right after the barrier of iteration q; the former join the queue at the end of the iteration, the
+    // latter are staged at the start of iteration q+1.  An iteration is two stage evaluations of the whole tile
+    // (several microseconds): it covers the memory latency.
     V own[R];
     T hal[KH], hin[KH];
 #pragma unroll
@@ -415,16 +423,14 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
             upwind_cd<SCHEME, T>(w + 1, A.K[LA], eps[LA], wk[LA], pc[1][LA], hd[1][LA]);
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            T H;
-            HAM::eval(A.ham, hc[c], pl, A.sc, pc[c], H, alpha[c]);
-            T diss = T(0);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) diss += hd[c][d] * alpha[c][d];
-            ydot[c] = -(H - diss);
-        }
+        for (int c = 0; c < 2; ++c) ydot[c] = lf_ydot<NP, HAM>(A.ham, hc[c], pl, A.sc, pc[c], hd[c], alpha[c]);
     };
 
+    V o2p[R];                   // stage-2 results of the previous iteration, not yet stored
+#pragma unroll
+    for (int r = 0; r < R; ++r) { o2p[r].x = T(0); o2p[r].y = T(0); }
+    bool st_pending = false;
+    unsigned st_so = 0u;
     // one iteration: stage 1 on plane q, stage 2 on plane q - W
     auto body = [&](int q) {
         V* own_c = own;
@@ -433,10 +439,6 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
         const bool s1 = s1_plane(q);
         T* bufY = ldsY + (q & 1) * ybox;
         T* bufWq = ldsW + sW[6];
-#if !(HJ_F12_ABLATE & 4)
-        if (q + W + 1 < q1 + W) load_own(q + W + 1, pw_load, own_c);
-#endif
-        pw_load = inc0(pw_load);
         if (s1) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -464,9 +466,23 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
         // lock-step; the second half of the workgroup starts late, so that one wave computes while its partner reads
         if (tid >= NT / 2) __builtin_amdgcn_s_sleep(HJ_F12_STAGGER);
 #endif
+        // ---- every vector-memory operation of the iteration is issued HERE, right after the barrier, and none is
+        // waited for before the end of the iteration (the queue rotation) or the top of the next one (the H values):
+        // the results of the PREVIOUS iteration's stage 2 go out first, then the loads.  The compiler cannot count
+        // the stores behind the wave-uniform stage-2 branches, so wherever it waits for a load it waits for
+        // vmcnt(0); with the stores issued at the end of stage 2 (first version) that wait sat right behind them
+        // and every iteration paid the store round trip (ablation, DESIGN.md 4.3: 0.36 of 1.39 ms at 513^3).
+        if (st_pending) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (w_int[r] && a_int[r]) buf_store2(o2p[r], rout, a_g[r], st_so);
+            st_pending = false;
+        }
 #if !(HJ_F12_ABLATE & 4)
+        if (q + W + 1 < q1 + W) load_own(q + W + 1, pw_load, own_c);
         if (s1_plane(q + 1) && q + 1 < q1) load_halo(pw_h, hal_c, hin_c);
 #endif
+        pw_load = inc0(pw_load);
         pw_h = inc0(pw_h);
         // ---- y1 ghost cells of plane q-1 on extrapolated in-plane boundaries (boundary rule applied to y1)
         if (tile_fix && q - 1 >= q0 && s1_plane(q - 1)) {
@@ -487,8 +503,8 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                 T ydot[2], alpha[2][ND];
                 lf_rhs2(yq[r], bufY, a_oy[r], ls1Y, hcell[r], pl1, ydot, alpha);
                 // the Euler stage as fused_substep_kernel forms it (ca = 0, cb = 1, no y0 operand)
-                y1n[r].x = T(0) * T(0) + T(1) * (yq[r][0][3] + A.dt * ydot[0]);
-                y1n[r].y = T(0) * T(0) + T(1) * (yq[r][1][3] + A.dt * ydot[1]);
+                y1n[r].x = rk_stage_out<NP>(HJ_STAGE_EULER, T(0), T(1), A.dt, T(0), yq[r][0][3], ydot[0]);
+                y1n[r].y = rk_stage_out<NP>(HJ_STAGE_EULER, T(0), T(1), A.dt, T(0), yq[r][1][3], ydot[1]);
                 if (a_w0[r] && a_w1[r]) *reinterpret_cast<V*>(bufWq + a_ow[r]) = y1n[r];
                 else if (a_w0[r]) bufWq[a_ow[r]] = y1n[r].x;
                 else if (a_w1[r]) bufWq[a_ow[r] + 1] = y1n[r].y;
@@ -555,11 +571,13 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                     for (int d = 0; d < ND; ++d)
                         if (((HAM::PLANE_DEP >> d) & 1u) && a_int[r]) amax[d] = fmax(amax[d], (double)alpha[c][d]);
                     // yq[r][c][0] is y on plane p: the y0 operand of the second stage
-                    const T o = A.ca * yq[r][c][0] + A.cb * (v0[c][3] + A.dt * ydot[c]);
+                    const T o = rk_stage_out<NP>(A.stage2, A.ca, A.cb, A.dt, yq[r][c][0], v0[c][3], ydot[c]);
                     if (c == 0) o2.x = o; else o2.y = o;
                 }
-                if (a_int[r]) buf_store2(o2, rout, a_g[r], so_out);
+                o2p[r] = o2;                              // stored after the next barrier (or after the loop)
             }
+            st_pending = true;
+            st_so = so_out;
         }
         // ---- rotate the queue and the ring
 #pragma unroll
@@ -579,6 +597,11 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
     };
 
     for (int q = q0; q < q1; ++q) body(q);
+    if (st_pending) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (w_int[r] && a_int[r]) buf_store2(o2p[r], rout, a_g[r], st_so);
+    }
 
     // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim
     const int lane = tid & 63, wv = tid >> 6;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     constexpr int LA = ND - 1;                  // the contiguous axis
     constexpr int PD = 2;
     constexpr bool GEN = (MODE == 0);
+    constexpr bool NP = np_order(SCHEME);       // ENO2 / ENO3: every operation rounded as NumPy rounds it (hj_device.h)
     using V = typename Pair<T>::V;
     const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
     extern __shared__ __align__(16) unsigned char hj_smem[];
@@ -265,8 +266,16 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             for (int d = 1; d < ND; ++d) {
                 if (h < base[d] || h >= base[d + 1]) continue;
                 const int hh = h - base[d];
-                int lay, c;
-                fdivmod(hh, fA[d], lay, c);
+                int lay, c;                            // lay 0..5: which halo layer; c: index over the other axes
+                if (d == ND - 1) {
+                    // contiguous axis: the LAYER runs fastest, so that consecutive lanes fetch the 3 + 3 cells either side
+                    // of one tile row (two cache lines) instead of one cell from each of 64 rows (64 lines per wave
+                    // instruction: round 3 found the halo columns issuing more line requests than the whole tile)
+                    c = hh / (2 * HJ_STENCIL);
+                    lay = hh - c * (2 * HJ_STENCIL);
+                } else {
+                    fdivmod(hh, fA[d], lay, c);
+                }
                 const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
                 int lo = 0, g = 0;
 #pragma unroll
@@ -449,15 +458,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             V o2;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                T H, alpha[ND];
-                HAM::eval(A.ham, hcell[r][c], pl_use, A.sc, pc[c], H, alpha);
-                T diss = T(0);
+                T alpha[ND];
+                T ydot = lf_ydot<NP, HAM>(A.ham, hcell[r][c], pl_use, A.sc, pc[c], hd[c], alpha);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    diss += hd[c][d] * alpha[d];
+                for (int d = 0; d < ND; ++d)
                     if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
-                }
-                T ydot = -(H - diss);
                 if (GEN && A.do_clamp) {
                     ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
                     ydot = (ydot > A.clamp_hi) ? A.clamp_hi : ydot;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 T o;
                 if (GEN && A.ydot_only) o = ydot;
                 else {
-                    o = A.ca * y0v + A.cb * (q[r][c][3] + A.dt * ydot);
+                    o = rk_stage_out<NP>(A.stage, A.ca, A.cb, A.dt, y0v, q[r][c][3], ydot);
                     if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0v : q[r][c][3]);
                 }
                 if (c == 0) o2.x = o; else o2.y = o;

@@ -78,6 +78,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.blocks_per_xcd = t.bpx;
     A.lds_nbuf = PAIR ? c->last_nbuf : 2;
     A.halo_ahead = (PAIR && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
+    A.stage = s.stage;
     A.ydot_only = (s.stage == HJ_STAGE_YDOT);
     A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
     switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
@@ -433,6 +434,7 @@ int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     A.blocks_per_xcd = t.bpx;
     A.nA = t.nA;
     A.nH = t.nH;
+    A.stage2 = (s.ca == 0.5) ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF;     // hj_rk_stage12 accepts exactly these two pairs
     A.ca = (T)s.ca;
     A.cb = (T)s.cb;
     A.dt = (T)s.dt;

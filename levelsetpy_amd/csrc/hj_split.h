@@ -313,6 +313,7 @@ template <typename T, int ND> struct DirectArgs {
 template <typename T, typename HAM, int SCHEME>
 __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T, HAM::ND> A) {
     constexpr int ND = HAM::ND;
+    constexpr bool NP = np_order(SCHEME);
     double amax[ND];
     T eps[ND];
     WenoK<T> wk[ND];
@@ -341,20 +342,18 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
                                   A.G.km[d], d == 0 ? A.G.halo_lo : 0, d == 0 ? A.G.halo_hi : 0);
             upwind_cd<SCHEME, T>(v, A.G.K[d], eps[d], wk[d], pc[d], hd[d]);
         }
-        T H, alpha[ND];
-        HAM::eval(A.ham, HAM::cell(A.ham, idx, A.sc), HAM::plane(A.ham, idx[0], A.sc), A.sc, pc, H, alpha);
-        T diss = T(0);
+        T alpha[ND];
+        T ydot = lf_ydot<NP, HAM>(A.ham, HAM::cell(A.ham, idx, A.sc), HAM::plane(A.ham, idx[0], A.sc), A.sc, pc, hd, alpha);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            diss += hd[d] * alpha[d];
-            amax[d] = fmax(amax[d], (double)alpha[d]);
-        }
-        T ydot = -(H - diss);
+        for (int d = 0; d < ND; ++d) amax[d] = fmax(amax[d], (double)alpha[d]);
         if (A.restrict_sign > 0) ydot = t_max(ydot, T(0));
         else if (A.restrict_sign < 0) ydot = t_min(ydot, T(0));
         T o;
         if (A.stage == HJ_STAGE_YDOT) o = ydot;
-        else {
+        else if constexpr (NP) {
+            o = rk_stage_out<true>(A.stage, T(0), T(0), A.dt, A.stage == HJ_STAGE_EULER ? T(0) : A.y0[t], A.y[t], ydot);
+            if (A.post_op) o = post_step(A.post_op, o, A.stage == HJ_STAGE_EULER ? A.y[t] : A.y0[t]);
+        } else {
             const T ye = A.y[t] + A.dt * ydot;
             if (A.stage == HJ_STAGE_EULER) o = ye;
             else if (A.stage == HJ_STAGE_RK3_HALF) o = T(0.25) * (T(3) * A.y0[t] + ye);
