@@ -298,7 +298,7 @@ VALU_F64_LANE_OPS = 39.3e12
 # fp64 VALU operations per cell-substep of the intended WENO5 kernel (Dubins, 3-D): SQ_INSTS_VALU of the substep kernel x 64
 # lanes / cells, from profiles/r03_weno5_valu.txt (all VALU instructions counted as fp64-rate ones: an upper bound on
 # the fraction)
-WENO5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_WENO5_VALU_OPS", "300"))
+WENO5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_WENO5_VALU_OPS", "335"))
 
 
 def valu_ceiling(cell_substeps_per_s):

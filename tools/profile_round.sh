@@ -3,7 +3,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (the driver's: --steps 20 --warmup 5)
 # 2. separate --pmc passes at 201^3 and 513^3: FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ issue/wait and LDS counters
 # 3. profiles/traffic.json rows (with the hash of the kernel sources they were measured on) printed at the end
-tag=${1:-r02}
+tag=${1:-r03}
 root=$PWD
 export TMPDIR=/tmp
 out=$root/gpurun_out/$tag
