@@ -293,6 +293,9 @@ const char* hj_last_error(void);
  * "fused_pair_kernel", "fused_substep_kernel", "fused12_kernel" or "direct_substep_kernel" (bench.py names the
  * kernel its roofline is about; no reference counterpart). */
 const char* hj_last_kernel(hj_ctx* ctx);
+/* LDS schedule of that launch: plane buffers in the ring (2 = double buffer) and how many planes ahead of its use the halo
+ * ring of a plane is parked in LDS (0 = staged in the iteration that consumes it); tests assert the variant that ran. */
+int hj_last_launch(hj_ctx* ctx, int* lds_nbuf_host, int* halo_ahead_host);
 const char* hj_version(void);
 
 #ifdef __cplusplus

@@ -71,6 +71,7 @@ SIGNATURES = {
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
     "hj_last_kernel": (C.c_char_p, [C.c_void_p]),
+    "hj_last_launch": (_i, [_vp, _pi, _pi]),
     "hj_version": (C.c_char_p, []),
 }
 

@@ -744,6 +744,13 @@ extern "C" {
 
 const char* hj_last_error(void) { return hjh::g_err; }
 const char* hj_last_kernel(hj_ctx* c) { return c ? c->last_kernel : ""; }
+int hj_last_launch(hj_ctx* c, int* nbuf, int* ahead) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    const bool pair = strcmp(c->last_kernel, "fused_pair_kernel") == 0;
+    if (nbuf) *nbuf = pair ? c->last_nbuf : 2;
+    if (ahead) *ahead = (pair && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
+    return HJ_OK;
+}
 const char* hj_version(void) { return "hj_mi355x 0.1 (gfx950)"; }
 
 int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,

@@ -839,6 +839,12 @@ def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch
         yd, sb = dg.empty(), C.c_double()
         _ffi.check(dg.lib.hj_lf_term(dg.ctx, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), 0., -1, dg.ptr(y), dg.ptr(yd), C.byref(sb)))
         dg.sync()
+        # the comparison must not pass vacuously: the kernel and the LDS schedule that actually ran
+        nbuf, ahead = C.c_int(), C.c_int()
+        _ffi.check(dg.lib.hj_last_launch(dg.ctx, C.byref(nbuf), C.byref(ahead)))
+        assert dg.lib.hj_last_kernel(dg.ctx) == (b"fused_substep_kernel" if flag == "0" else b"fused_pair_kernel"), flag
+        if flag != "0":
+            assert (nbuf.value, ahead.value) == ((2 + int(flag[-1]), int(flag[-1])) if "r" in flag else (2, 0)), (flag, nbuf.value, ahead.value)
         outs.append(yd)
         res[flag] = (outs, sb.value)
     for other in flags[1:]:

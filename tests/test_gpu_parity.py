@@ -363,6 +363,53 @@ def test_ode_cfl_vs_reference_golden(golden, scheme):
     cmp(y, G["rk2r_%s_y" % scheme], 1e-11)
 
 
+@pytest.mark.parametrize("ring", ["0", "1"])
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3", "WENO5_ASSHIPPED"])
+def test_reference_goldens_through_the_pair_kernel(golden, scheme, ring, monkeypatch):
+    """The dominant kernel of the large grids, fused_pair_kernel (two cells per lane; with ring = "1" its 5-plane LDS halo
+    ring), only engages by itself from 2.5 M cells up, so the golden comparisons above run fused_substep_kernel.
+    Here a slice of them -- termLaxFriedrichs on the Dubins and double-integrator goldens, five odeCFL3 steps and the
+    odeCFL2 run -- is repeated with HJ_PAIR=2 (the pair kernel at any size; fresh contexts), and the kernel that ran is
+    asserted."""
+    monkeypatch.setenv("HJ_PAIR", "2")
+    monkeypatch.setenv("HJ_PAIR_RING", ring)
+    T, Gd = golden("term.npz"), golden("ode.npz")
+
+    def ran_pair(g):
+        dg = device_grid(g, "float64")
+        nbuf, ahead = C.c_int(), C.c_int()
+        _ffi.check(dg.lib.hj_last_launch(dg.ctx, C.byref(nbuf), C.byref(ahead)))
+        assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel"
+        assert nbuf.value == (5 if ring == "1" else 2), nbuf.value
+
+    g, og = mk(T["dub_min"], T["dub_max"], T["dub_N"], 2)
+    for ub, wb in ((1, 1), (2, 3)):
+        yd, sb, _ = L.termLaxFriedrichs(0.3, T["dub_data"].reshape(-1, 1), sdata(g, L.DubinsVehicleRel(g, ub, wb), DERIV[scheme]))
+        close(yd, T["dub_u%d_w%d_%s_ydot" % (ub, wb, scheme)])
+        ref = float(T["dub_u%d_w%d_%s_sb" % (ub, wb, scheme)])
+        assert abs(sb - ref) <= 1e-13 * ref
+    ran_pair(g)
+    g2, _ = mk(T["di_min"], T["di_max"], T["di_N"], None)
+    yd, sb, _ = L.termLaxFriedrichs(0., T["di_data"].reshape(-1, 1), sdata(g2, L.DoubleIntegrator(g2, 2.5), DERIV[scheme]))
+    close(yd, T["di_u2.5_%s_ydot" % scheme])
+    ran_pair(g2)
+    g3, _ = mk(Gd["dub_min"], Gd["dub_max"], Gd["dub_N"], 2)
+    sd = sdata(g3, L.DubinsVehicleRel(g3, 1, 1), DERIV[scheme])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y, t = Gd["dub_data"].reshape(-1, 1), 0.
+    for k in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    assert abs(t - float(Gd["rk3_%s_t5" % scheme])) <= 1e-13 * t
+    if scheme.startswith("ENO"):
+        assert np.array_equal(y, Gd["rk3_%s_y5" % scheme])        # NumPy-order ENO path: bit for bit
+    else:
+        close(y, Gd["rk3_%s_y5" % scheme], 1e-11)
+    op2 = L.odeCFLset(L.Bundle(dict(factorCFL=.95, singleStep='off')))
+    t, y, _ = L.odeCFL2(L.termLaxFriedrichs, [0., 0.02], Gd["dub_data"].reshape(-1, 1), op2, sd)
+    close(y, Gd["rk2_%s_y" % scheme], 1e-11)
+    ran_pair(g3)
+
+
 def test_eno_paths_bitwise_equal_the_reference_golden(golden):
     """Round 3: with ENO2 / ENO3 the WHOLE fused substep is evaluated in the reference's operation order, contraction
     off (hj_device.h np_order: divided-difference tables and selectors, chosen candidate, Hamiltonian, dissipation sum,
