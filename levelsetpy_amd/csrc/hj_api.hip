@@ -28,7 +28,8 @@ int env_int(const char* name, int dflt) {
 // rows are E + 8 cells apart (left pad 4)
 Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf) {
     const int nd = c->ndim;
-    const int cap = k.NT * k.R * vec;
+    // HJ_TILE_CELLS (tuning): cap the tile below what the configuration holds -- more, smaller workgroups (thin slabs)
+    const int cap = c->tile_cells > 0 ? std::min(k.NT * k.R * vec, c->tile_cells) : k.NT * k.R * vec;
     Tiling best;
     best.ok = false;
     best.score = 1e300;
@@ -817,6 +818,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_kh = env_int("HJ_F12_KH", 0);
     c->f12_warm = env_int("HJ_F12_WARM", 9);
     c->f12_e2 = env_int("HJ_F12_E2", 0);
+    c->tile_cells = env_int("HJ_TILE_CELLS", 0);
     c->f12_pair = env_int("HJ_F12_PAIR", 1);
     c->f12_e1 = env_int("HJ_F12_E1", 0);
     c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on 2-D / 3-D grids of >= 2.5 M cells (0: scalar kernel everywhere, 2: pair kernel whatever the size)

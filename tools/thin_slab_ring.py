@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One rank's slab of the 513^3 grid at N = 2, 4, 8 as a PERIODIC ring through a real RCCL self send/recv on one GPU
 (a (513/N) x 513 x 513 grid, axis 0 periodic): both native schedules with their real launches, streams, events and
-RCCL calls -- only the link is missing (the 'exchange' is a device-local copy).  usage: thin_slab_ring.py [n]"""
+RCCL calls -- only the link is missing (the 'exchange' is a device-local copy).
+usage: thin_slab_ring.py [n] [worlds, e.g. 8 or 2,4,8] [schedules: deep,sub]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
@@ -16,13 +17,15 @@ from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
 steps = 30
-for world in (2, 4, 8):
+worlds = [int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 4, 8]
+scheds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["sub", "deep"]
+for world in worlds:
     n0 = (n + world - 1) // world
     g = L.createGrid(np.array([[-2., -1.25, -np.pi]]).T, np.array([[2. * (1 - 2 / n0), 1.25, np.pi * (1 - 2 / n)]]).T,
                      np.array([[n0], [n], [n]], dtype=np.int64), [0, 2], low_mem=True)
     dxs = [float(v) for v in np.asarray(g.dx).ravel()]
     d0 = torch.as_tensor(np.asarray(L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)), device="cuda")
-    for deep in (False, True):
+    for deep in [x == "deep" for x in scheds]:
         slab = SlabDecomposition(n0, 1, 0, True, self_exchange=True)
         st = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.], dxs, deep=deep)
         st.set_state(d0)
