@@ -45,6 +45,9 @@ template <typename T, int ND> struct Fused12Args {
     int stage2;                   // HJ_STAGE_RK3_HALF or HJ_STAGE_RK2_FULL: the second stage's expression
     T ca, cb, dt;
     HamTables<T> ham;
+    // diagnostic build (-DHJ_F12_STAMP, HJ_TIMING_DUMP=file): per workgroup and wave 10 words -- shader cycles of the phases of
+    // the plane loop summed over the iterations, then the loop's shader cycles and its 100 MHz wall-clock length
+    unsigned long long* timing;
 };
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC>

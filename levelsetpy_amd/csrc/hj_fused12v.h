@@ -22,6 +22,12 @@
 
 namespace hj {
 
+#ifdef HJ_F12_STAMP
+#define HJ_F12_ST(k) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[k] += now_ - st_last; st_last = now_; }
+#else
+#define HJ_F12_ST(k)
+#endif
+
 #ifndef HJ_F12_STAGGER
 #define HJ_F12_STAGGER 0
 #endif
@@ -432,7 +438,13 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
     bool st_pending = false;
     unsigned st_so = 0u;
     // one iteration: stage 1 on plane q, stage 2 on plane q - W
+#ifdef HJ_F12_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#endif
     auto body = [&](int q) {
+#ifdef HJ_F12_STAMP
+        st_last = __builtin_readcyclecounter();
+#endif
         V* own_c = own;
         T* hal_c = hal;
         T* hin_c = hin;
@@ -458,9 +470,11 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                     if (h_act[k]) bufY[h_oy[k]] = hal_c[k];
             }
         }
+        HJ_F12_ST(0)               // phase 0: wait for the H values, stage the y plane
 #if !(HJ_F12_ABLATE & 1)    // timing experiment: no barrier (results are wrong)
         __syncthreads();
 #endif
+        HJ_F12_ST(1)               // phase 1: barrier
 #if HJ_F12_STAGGER > 0
         // the waves of a SIMD leave the barrier together and would run their LDS-read bursts and their arithmetic in
         // lock-step; the second half of the workgroup starts late, so that one wave computes while its partner reads
@@ -491,6 +505,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
             for (int k = 0; k < KH; ++k)
                 if (h_fix[k]) bw[h_ow[k]] = ghost_value(bw[h_we[k]], bw[h_we[k] + h_wd[k]], h_km[k]);
         }
+        HJ_F12_ST(2)               // phase 2: stores of the previous results, loads, y1 ghost fix
         // ---- stage 1 on plane q
         V y1n[R];
 #pragma unroll
@@ -523,6 +538,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
                     *reinterpret_cast<V*>(bufWq + a_ow[r]) = y1n[r];
                 }
         }
+        HJ_F12_ST(3)               // phase 3: stage 1 (all A slots)
         if (q == n0 - 1) off_e = sW[6];
         if (q == n0 - 2) off_i = sW[6];
         if (!per0 && q == 1) {
@@ -579,6 +595,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
             st_pending = true;
             st_so = so_out;
         }
+        HJ_F12_ST(4)               // phase 4: stage 2 (interior slots)
         // ---- rotate the queue and the ring
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -594,9 +611,23 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
             sW[6] = s0;
         }
         qw = inc0(qw);
+        HJ_F12_ST(5)               // phase 5: wait for the own cells of plane q+4, rotate
     };
 
+#ifdef HJ_F12_STAMP
+    const unsigned long long lp_c0 = __builtin_readcyclecounter(), lp_w0 = wall_clock64();
+#endif
     for (int q = q0; q < q1; ++q) body(q);
+#ifdef HJ_F12_STAMP
+    if (A.timing && (tid & 63) == 0) {
+        unsigned long long* dst = A.timing + ((size_t)L * (NT / 64) + (tid >> 6)) * 10;
+        for (int k = 0; k < 6; ++k) dst[k] = st_acc[k];
+        dst[6] = __builtin_readcyclecounter() - lp_c0;
+        dst[7] = wall_clock64() - lp_w0;
+        dst[8] = (unsigned long long)(q1 - q0);
+        dst[9] = (unsigned long long)((w_int[0] ? 1 : 0) + (R > 1 && w_int[R - 1] ? 1 : 0));
+    }
+#endif
     if (st_pending) {
 #pragma unroll
         for (int r = 0; r < R; ++r)

@@ -439,8 +439,35 @@ int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     A.cb = (T)s.cb;
     A.dt = (T)s.dt;
     fill_ham<T>(c, s.par, A.ham);
+#ifdef HJ_F12_STAMP
+    const char* dump = getenv("HJ_TIMING_DUMP");    // diagnostic build: per-wave phase clocks of the pair kernel (tools/f12_stamps.py)
+    unsigned long long* tbuf = nullptr;
+    const size_t tw = (size_t)t.nblocks * (NT / 64) * 10;
+    if (PAIR && dump && *dump) {
+        HIP_TRY(hipMalloc(&tbuf, tw * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(tbuf, 0, tw * sizeof(unsigned long long), c->stream));
+        A.timing = tbuf;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, c->stream, (const T*)s.y, (T*)s.out, A);
     HIP_TRY(hipGetLastError());
+#ifdef HJ_F12_STAMP
+    if (tbuf) {
+        std::vector<unsigned long long> h(tw);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(h.data(), tbuf, tw * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(tbuf));
+        if (FILE* f = fopen(dump, "a")) {
+            fprintf(f, "# fused12_pair launch nblocks=%d waves=%d ntiles=%d chunk=%d E=(%d,%d)\n", t.nblocks, NT / 64, t.ntiles, t.chunk, t.E[1], ND > 2 ? t.E[2] : 0);
+            for (size_t i = 0; i < tw / 10; ++i) {
+                fprintf(f, "%zu %zu", i / (NT / 64), i % (NT / 64));
+                for (int k = 0; k < 10; ++k) fprintf(f, " %llu", h[i * 10 + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+#endif
     return HJ_OK;
 }
 
