@@ -76,7 +76,13 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
             // bank-friendly row pitch (E + 32) when it fits, else the minimal E + 6
             const long long rows = box / (E[nd - 1] + 6);
             int pitch = E[nd - 1] + (vec == 2 ? 8 : 6);
-            if (vec == 1 && c->lds_pad && nd >= 3 && 512 + 2 * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= c->lds_limit) pitch = E[nd - 1] + 32;
+            if (vec == 1 && c->lds_pad > 0 && nd >= 3 && 512 + 2 * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= c->lds_limit) pitch = E[nd - 1] + 32;
+            // pair kernel (HJ_LDS_PAD=1, tuning): a 16-lane group of a ds_read_b128 that straddles two tile rows is conflict free
+            // iff the row pitch in PAIRS is congruent to the row length in pairs mod 16, i.e. 32 cells of padding (round 3)
+            if (vec == 2 && c->lds_pad != 0 && nd >= 3) {
+                const size_t cap2 = nbuf > 2 ? (size_t)160 * 1024 - 1024 : c->lds_limit;
+                if (512 + (size_t)nbuf * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= cap2) pitch = E[nd - 1] + 32;
+            }
             box = rows * pitch;
             size_t lds = 512 + (size_t)nbuf * (size_t)box * c->esz;
             const size_t lds_cap = nbuf > 2 ? (size_t)160 * 1024 - 1024 : c->lds_limit;   // the ring variant may take the whole CU
@@ -797,7 +803,10 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->force_direct = env_int("HJ_FORCE_DIRECT", 0);
     c->debug = env_int("HJ_DEBUG", 0);
     c->full_rows = env_int("HJ_FULL_ROWS", 0);
-    c->lds_pad = env_int("HJ_LDS_PAD", 0);   // bank-friendly row pitch: measured +0.5 % only, off by default
+    // bank-friendly LDS row pitch: -1 (default) the pair kernel only (pitch in pairs congruent to the row length mod 16:
+    // +1 % at 201^3, +1-1.5 % for ENO3 / intended WENO5, nothing lost elsewhere, round 3), 0 never, 1 both kernels (the
+    // one-cell-per-lane kernel gained +0.5 % only in round 1)
+    c->lds_pad = env_int("HJ_LDS_PAD", -1);
     c->target_blocks = env_int("HJ_TARGET_BLOCKS", 0);   // 0 = choose from the GPU's capacity
     {
         int ncu = 0;
