@@ -828,6 +828,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_warm = env_int("HJ_F12_WARM", 9);
     c->f12_e2 = env_int("HJ_F12_E2", 0);
     c->tile_cells = env_int("HJ_TILE_CELLS", 0);
+    c->direct_below = env_int("HJ_DIRECT_BELOW", 0);
     c->f12_pair = env_int("HJ_F12_PAIR", 1);
     c->f12_e1 = env_int("HJ_F12_E1", 0);
     c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on 2-D / 3-D grids of >= 2.5 M cells (0: scalar kernel everywhere, 2: pair kernel whatever the size)

@@ -99,6 +99,7 @@ struct hj_ctx {
     int force_direct, debug, full_rows, num_cus, pd, occ_hint, cfg_from_env, lds_pad;
     int target_blocks, min_chunk, warmup_cost, no_plain;
     int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;
+    long long direct_below = 0;                     // HJ_DIRECT_BELOW: grids with fewer cells run direct_substep_kernel
     int tile_cells = 0;                             // HJ_TILE_CELLS: cap on the cells of a tile (0 = what the configuration holds)
     int f12_e1 = 0;                                 // tuning / tests: force the tile's row count (pair variant)
     int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail

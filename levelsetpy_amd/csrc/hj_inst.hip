@@ -211,7 +211,12 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
     constexpr bool tiled_ok = true;
 #endif
     if constexpr (tiled_ok) {
-        if (!c->force_direct) {
+        // small grids (round 3): the direct kernel -- one cell per thread, every stencil load issued at once, no LDS, no
+        // barrier chain -- beats a tiled launch that cannot go below ~8.5 us (a 4.5 us setup in front of a dozen plane
+        // iterations on a few dozen workgroups).  HJ_DIRECT_BELOW cells (default: see hj_ctx_create).
+        const bool small = c->direct_below > 0 && c->total < c->direct_below && HAM::ND <= 3 &&
+                           s.p0 >= 0 && s.p1 <= c->N[0] && s.q1 <= s.q0;
+        if (!c->force_direct && !small) {
             KernelCfg k = c->cfg;
             int pd = c->pd, occ = c->occ_hint;
             if (!c->cfg_from_env) {

@@ -310,6 +310,12 @@ template <typename T, int ND> struct DirectArgs {
     HamTables<T> ham;
 };
 
+// Round 3: every stencil load is issued unconditionally.  The first version went through line_value(), whose boundary
+// branches sit in front of each of the 6*ND neighbour loads: the loads were serialised behind one another (a memory round
+// trip each) and the kernel took ~40 us on a 51^3 grid.  Now the neighbour offsets are formed with selects (periodic: the
+// wrapped cell; extrapolated: the edge cell, fixed up afterwards), all loads go out back to back, and only waves that touch
+// an extrapolated edge run the ghost fix-up (two more loads per ghost value).  Same per-cell functions and stage expressions
+// as the tiled kernels: the results are theirs bit for bit.  It is also the default for SMALL grids (launch_cfg).
 template <typename T, typename HAM, int SCHEME>
 __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T, HAM::ND> A) {
     constexpr int ND = HAM::ND;
@@ -327,39 +333,76 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
             wk[d] = weno_consts<T>(eps[d], A.G.K[d]);
         }
     }
+    T ca = T(0), cb = T(1);
+    if (A.stage == HJ_STAGE_RK3_HALF) { ca = T(0.75); cb = T(0.25); }
+    else if (A.stage == HJ_STAGE_RK3_FULL) { ca = T(1.0 / 3.0); cb = T(2.0 / 3.0); }
+    else if (A.stage == HJ_STAGE_RK2_FULL) { ca = T(0.5); cb = T(0.5); }
+    const bool use_y0 = A.stage >= HJ_STAGE_RK3_HALF;
     for (long long t = A.cell_begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
          t < A.cell_end; t += (long long)gridDim.x * blockDim.x) {
         int idx[ND];
         decode<T, ND>(A.G, t, idx);
-        T pc[ND], hd[ND];
+        const T* pc0 = A.y + t;
+        T v[ND][7];
+        bool ghost = false;
+        const T centre = pc0[0];
+        const T y0v = use_y0 ? A.y0[t] : T(0);
+        const typename HAM::Cell hc = HAM::cell(A.ham, idx, A.sc);
+        const typename HAM::Plane hp = HAM::plane(A.ham, idx[0], A.sc);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const T* line = A.y + (t - (long long)idx[d] * A.G.stride[d]);
-            T v[7];
+            const int n = A.G.n[d], i = idx[d];
+            const bool per = A.G.bc[d] == HJ_BC_PERIODIC;
+            const bool hlo = d == 0 && A.G.halo_lo, hhi = d == 0 && A.G.halo_hi;
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
-                v[k] = line_value(line, A.G.stride[d], idx[d] + k - 3, A.G.n[d], A.G.bc[d],
-                                  A.G.km[d], d == 0 ? A.G.halo_lo : 0, d == 0 ? A.G.halo_hi : 0);
-            upwind_cd<SCHEME, T>(v, A.G.K[d], eps[d], wk[d], pc[d], hd[d]);
+            for (int k = 0; k < 7; ++k) {
+                if (k == 3) { v[d][k] = centre; continue; }
+                int j = i + k - 3;
+                if (j < 0 && !hlo) {
+                    if (per) j += n; else { j = 0; ghost = true; }
+                } else if (j >= n && !hhi) {
+                    if (per) j -= n; else { j = n - 1; ghost = true; }
+                }
+                v[d][k] = pc0[(long long)(j - i) * A.G.stride[d]];
+            }
         }
+        if (__any(ghost ? 1 : 0)) {
+            // ghost cells of an extrapolated boundary: edge + k*slope from the edge cell and its inner neighbour
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int n = A.G.n[d], i = idx[d];
+                if (A.G.bc[d] == HJ_BC_PERIODIC) continue;
+                const bool hlo = d == 0 && A.G.halo_lo, hhi = d == 0 && A.G.halo_hi;
+                const T* line = pc0 - (long long)i * A.G.stride[d];
+                if (i < HJ_STENCIL && !hlo) {
+                    const T e = line[0], in = line[A.G.stride[d]];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (i + k - 3 < 0) v[d][k] = ghost_value(e, in, T(3 - k - i) * A.G.km[d]);
+                }
+                if (i + HJ_STENCIL >= n && !hhi) {
+                    const T e = line[(long long)(n - 1) * A.G.stride[d]], in = line[(long long)(n - 2) * A.G.stride[d]];
+#pragma unroll
+                    for (int k = 4; k < 7; ++k)
+                        if (i + k - 3 >= n) v[d][k] = ghost_value(e, in, T(i + k - 3 - n + 1) * A.G.km[d]);
+                }
+            }
+        }
+        T pc[ND], hd[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) upwind_cd<SCHEME, T>(v[d], A.G.K[d], eps[d], wk[d], pc[d], hd[d]);
         T alpha[ND];
-        T ydot = lf_ydot<NP, HAM>(A.ham, HAM::cell(A.ham, idx, A.sc), HAM::plane(A.ham, idx[0], A.sc), A.sc, pc, hd, alpha);
+        T ydot = lf_ydot<NP, HAM>(A.ham, hc, hp, A.sc, pc, hd, alpha);
 #pragma unroll
         for (int d = 0; d < ND; ++d) amax[d] = fmax(amax[d], (double)alpha[d]);
-        if (A.restrict_sign > 0) ydot = t_max(ydot, T(0));
-        else if (A.restrict_sign < 0) ydot = t_min(ydot, T(0));
+        // termRestrictUpdate clamp, written like the tiled kernels' (a NaN stays a NaN)
+        if (A.restrict_sign > 0) ydot = (ydot < T(0)) ? T(0) : ydot;
+        else if (A.restrict_sign < 0) ydot = (ydot > T(0)) ? T(0) : ydot;
         T o;
         if (A.stage == HJ_STAGE_YDOT) o = ydot;
-        else if constexpr (NP) {
-            o = rk_stage_out<true>(A.stage, T(0), T(0), A.dt, A.stage == HJ_STAGE_EULER ? T(0) : A.y0[t], A.y[t], ydot);
-            if (A.post_op) o = post_step(A.post_op, o, A.stage == HJ_STAGE_EULER ? A.y[t] : A.y0[t]);
-        } else {
-            const T ye = A.y[t] + A.dt * ydot;
-            if (A.stage == HJ_STAGE_EULER) o = ye;
-            else if (A.stage == HJ_STAGE_RK3_HALF) o = T(0.25) * (T(3) * A.y0[t] + ye);
-            else if (A.stage == HJ_STAGE_RK3_FULL) o = (T(1) / T(3)) * (A.y0[t] + T(2) * ye);
-            else o = T(0.5) * (A.y0[t] + ye);
-            if (A.post_op) o = post_step(A.post_op, o, A.stage == HJ_STAGE_EULER ? A.y[t] : A.y0[t]);
+        else {
+            o = rk_stage_out<NP>(A.stage, ca, cb, A.dt, y0v, centre, ydot);
+            if (A.post_op) o = post_step(A.post_op, o, use_y0 ? y0v : centre);
         }
         A.out[t] = o;
     }
