@@ -230,6 +230,7 @@ def test_term_tiled_and_direct_vs_oracle_3d(scheme, n, monkeypatch):
     yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 2, 3), scheme, 0., y)
     close(yt, yo, what="tiled")
     close(yd, yo, what="direct")
+    assert np.array_equal(yt, yd) and sbt == sbd        # round 3: the two kernels agree bit for bit
     assert abs(sbt - sbo) <= 1e-13 * sbo and abs(sbd - sbo) <= 1e-13 * sbo
 
 
@@ -246,6 +247,7 @@ def test_term_tiled_and_direct_vs_oracle_2d(scheme, n, pd, monkeypatch):
     yo, sbo = O.term_lax_friedrichs(og, O.DoubleIntegrator(og, 1.5), scheme, 0., y)
     close(yt, yo, what="tiled")
     close(yd, yo, what="direct")
+    assert np.array_equal(yt, yd) and sbt == sbd        # round 3: the two kernels agree bit for bit
     assert abs(sbt - sbo) <= 1e-13 * sbo and abs(sbd - sbo) <= 1e-13 * sbo
 
 
@@ -380,7 +382,8 @@ def test_reference_goldens_through_the_pair_kernel(golden, scheme, ring, monkeyp
         nbuf, ahead = C.c_int(), C.c_int()
         _ffi.check(dg.lib.hj_last_launch(dg.ctx, C.byref(nbuf), C.byref(ahead)))
         assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel"
-        assert nbuf.value == (5 if ring == "1" else 2), nbuf.value
+        # ring: 2 + HJ_PAIR_AH plane buffers (3 ahead by default, 2 on grids below 12 M cells); else the double buffer
+        assert (nbuf.value in (4, 5) and ahead.value == nbuf.value - 2) if ring == "1" else (nbuf.value, ahead.value) == (2, 0), (nbuf.value, ahead.value)
 
     g, og = mk(T["dub_min"], T["dub_max"], T["dub_N"], 2)
     for ub, wb in ((1, 1), (2, 3)):
@@ -969,8 +972,7 @@ def test_full_size_201_cubed_properties(scheme, monkeypatch):
             assert abs(sb.value - 1 / (a0 / dx[0] + a1 / dx[1] + 2 / dx[2])) <= 1e-13 * sb.value
         dg.sync()
         outs[force] = c.cpu().numpy()
-    err = np.max(np.abs(outs["0"] - outs["1"]))
-    assert err <= 1e-12, err
+    assert np.array_equal(outs["0"], outs["1"]), np.max(np.abs(outs["0"] - outs["1"]))     # round 3: bit for bit
     assert np.isfinite(outs["0"]).all()
     # (3) H(x1, -x2, -x3; p1, -p2, -p3) = H(x; p) and the cylinder is even in x2: the solution stays
     # even under (x2, x3) -> (-x2, -x3).  x2 nodes are symmetric; x3 = -pi + k*dx3 maps k -> n-k (mod n).
@@ -1034,6 +1036,7 @@ def test_term_tiny_extents_vs_oracle(scheme, n, monkeypatch):
     yo, sbo = O.term_lax_friedrichs(og, O.DubinsRel(og, 1, 2), scheme, 0., y)
     close(yt, yo, what="tiled")
     close(yd, yo, what="direct")
+    assert np.array_equal(yt, yd) and sbt == sbd        # round 3: the two kernels agree bit for bit
     assert abs(sbt - sbo) <= 1e-13 * sbo and abs(sbd - sbo) <= 1e-13 * sbo
 
 
