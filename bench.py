@@ -421,6 +421,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HJ_BENCH_ONE_DEVICE"):      # rehearsal: every rank on GPU 0 (several processes sharing one card)
+        local = 0
     slab_leg = world > 1 or bool(os.environ.get("HJ_BENCH_FORCE_SLAB")) or (a.global_n not in (None, 0))
     cpu = None
     if rank == 0 and world == 1 and not slab_leg and not a.no_cpu_baseline:
@@ -488,8 +490,12 @@ def run(a, rank, world, local, slab_leg, cpu):
         import datetime
         import torch.distributed as dist
         # collectives that a peer never joins raise after this instead of blocking for torch's default 10 minutes x N
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local),
-                                timeout=datetime.timedelta(seconds=float(os.environ.get("HJ_BENCH_COLLECTIVE_TIMEOUT_S", "300"))))
+        tmo = datetime.timedelta(seconds=float(os.environ.get("HJ_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
+        backend = os.environ.get("HJ_BENCH_BACKEND", "nccl")       # "gloo": rehearsal of the multi-rank leg on ONE card
+        if backend == "nccl":                                      # (RCCL refuses two ranks on one device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
+        else:
+            dist.init_process_group(backend, timeout=tmo)
     import levelsetpy_amd as L
     from levelsetpy_amd import _ffi
     from levelsetpy_amd.context import DeviceGrid

@@ -477,7 +477,8 @@ def bench_slab(args, rank, world, global_n=513):
         if kind == "torch":
             be = HipSlabBackend(g, slab, sid, _ffi.HAM_DUBINS_REL, par, args.dtype)
             return SlabIntegrator(slab, be, dxs, 3, 0.8, needs_eps=(args.scheme == "WENO5")), be, \
-                "3-plane halo exchange per substep, torch.distributed P2P over RCCL, edge-first overlap"
+                "3-plane halo exchange per substep, torch.distributed P2P over %s, edge-first overlap" % (
+                    "RCCL" if dist.get_backend() == "nccl" else dist.get_backend())
         deep = {"native-deep": True, "native": False}[kind]
         it = NativeSlabStepper(g, slab, sid, _ffi.HAM_DUBINS_REL, par, dxs, args.dtype, 3, 0.8, deep=deep)
         how = ("ONE 9-plane exchange per RK3 step, stages recompute the planes beyond the slab" if deep
