@@ -343,7 +343,8 @@ def live_traffic(a, n=None, scheme=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE", None):
         # counter passes: short (every dispatch is serialised and slow under --pmc; byte counts do not depend on the
         # clocks); the duration pass: the timed leg's own spin-up, so that its kernels run at settled clocks
-        spin, warm, steps = (20, 1, 4) if ctr else (SPINUP_STEPS, 2, 20)
+        # (40 steps of spin-up: on grids of >= 40 M cells the library spends its first ~100 launches choosing a tile shape)
+        spin, warm, steps = (40, 1, 4) if ctr else (SPINUP_STEPS, 2, 20)
         nstep = spin + warm + steps
         d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin))
@@ -354,17 +355,23 @@ def live_traffic(a, n=None, scheme=None):
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
             if ctr:
-                tot, nsub = 0.0, 0
+                rows = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     with open(f) as fh:
                         for r in csv.DictReader(fh):
                             k = r["Kernel_Name"]
                             if r["Counter_Name"] == ctr and any(x in k for x in STEP_KERNELS):
-                                tot += float(r["Counter_Value"])
-                                nsub += any(x in k for x in STEP_KERNELS[:5])
+                                rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"]),
+                                             any(x in k for x in STEP_KERNELS[:5])))
+                rows.sort()
+                per_step = len(rows) // nstep if rows else 0
+                if not per_step:
+                    return None
+                tail = rows[-per_step * steps:]              # the last `steps` steps: settled tile shape
+                nsub = sum(1 for _, _, is_sub in tail if is_sub)
                 if not nsub:
                     return None
-                vals[ctr] = (tot / nstep, nsub / nstep)
+                vals[ctr] = (sum(v for _, v, _ in tail) / steps, nsub / steps)
             else:
                 # kernel-trace only: mean duration of the substep kernels over the LAST `steps` steps (clocks settled)
                 rows = []
@@ -392,8 +399,8 @@ def live_traffic(a, n=None, scheme=None):
     return {"bytes_per_launch": per_step / nsub, "bytes_per_step": per_step, "substep_launches_per_step": nsub,
             "fetch_kib_per_step": vals["FETCH_SIZE"][0], "write_kib_per_step": vals["WRITE_SIZE"][0],
             "rocprof": dur,
-            "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE over 25 RK3 steps, --kernel-trace "
-                      "over the last 20 of %d; every kernel of the step counted; %.0f s)" % (SPINUP_STEPS + 22, time.perf_counter() - t0)}
+            "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 45 RK3 steps, --kernel-trace: "
+                      "the last 20 of %d; every kernel of the step counted; %.0f s)" % (SPINUP_STEPS + 22, time.perf_counter() - t0)}
 
 
 def measured_traffic(n, scheme, dtype):

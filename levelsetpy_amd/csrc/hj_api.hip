@@ -26,8 +26,9 @@ int env_int(const char* name, int dflt) {
 // (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
 // vec = 2: the pair kernel (hj_fusedv.h) -- k.R counts PAIRS per thread, the extent of the last axis is even, its LDS
 // rows are E + 8 cells apart (left pad 4)
-Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf) {
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all) {
     const int nd = c->ndim;
+    std::map<int, Tiling> per_row;     // best tiling per extent of the last axis (autotuner candidates)
     // HJ_TILE_CELLS (tuning): cap the tile below what the configuration holds -- more, smaller workgroups (thin slabs)
     const int cap = c->tile_cells > 0 ? std::min(k.NT * k.R * vec, c->tile_cells) : k.NT * k.R * vec;
     Tiling best;
@@ -98,18 +99,23 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
                 // ~48 B per row, calibrated on the 401^3 fp64 and 129^4 fp32 tile-shape sweeps
                 const double row_cost = 1.0 + (48.0 / (double)c->esz) / (double)E[nd - 1];
                 double score = ((double)(cells + halo) / (double)cells) * row_cost * waste / util;
-                if (score < best.score) {
-                    best.ok = true;
-                    best.score = score;
-                    best.lds_bytes = lds;
-                    best.lpitch = pitch;
-                    best.ntiles = 1;
-                    for (int d = 1; d < nd; ++d) {
-                        best.E[d] = E[d];
-                        best.ntile[d] = (n[d] + E[d] - 1) / E[d];
-                        best.ntiles *= best.ntile[d];
-                    }
-                    best.E[0] = 1; best.ntile[0] = 1;
+                Tiling cur;
+                cur.ok = true;
+                cur.score = score;
+                cur.lds_bytes = lds;
+                cur.lpitch = pitch;
+                cur.ntiles = 1;
+                for (int d = 0; d < HJ_MAX_DIM; ++d) { cur.E[d] = 1; cur.ntile[d] = 1; }
+                for (int d = 1; d < nd; ++d) {
+                    cur.E[d] = E[d];
+                    cur.ntile[d] = (n[d] + E[d] - 1) / E[d];
+                    cur.ntiles *= cur.ntile[d];
+                }
+                cur.chunk = cur.nchunks = cur.nchunks1 = cur.nblocks = cur.bpx = 0;
+                if (score < best.score) best = cur;
+                if (all) {
+                    auto it = per_row.find(E[nd - 1]);
+                    if (it == per_row.end() || score < it->second.score) per_row[E[nd - 1]] = cur;
                 }
             }
         }
@@ -119,6 +125,11 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
             it[d] = 0;
         }
         if (d >= nd) break;
+    }
+    if (all) {
+        all->clear();
+        for (auto& kv : per_row) all->push_back(kv.second);
+        std::sort(all->begin(), all->end(), [](const Tiling& a, const Tiling& b) { return a.score < b.score; });
     }
     return best;
 }
@@ -828,6 +839,10 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_warm = env_int("HJ_F12_WARM", 9);
     c->f12_e2 = env_int("HJ_F12_E2", 0);
     c->tile_cells = env_int("HJ_TILE_CELLS", 0);
+    // launch-time choice of the tile shape on grids of >= HJ_AUTOTUNE_MIN_CELLS cells (hj_inst.hip, tuned_tiling)
+    c->autotune = env_int("HJ_AUTOTUNE", 1);
+    c->autotune_min_cells = (long long)env_int("HJ_AUTOTUNE_MIN_MCELLS", 40) * 1000000ll;
+    c->autotune_passes = std::max(2, env_int("HJ_AUTOTUNE_PASSES", 6));
     c->direct_below = env_int("HJ_DIRECT_BELOW", 0);
     c->f12_pair = env_int("HJ_F12_PAIR", 1);
     c->f12_e1 = env_int("HJ_F12_E1", 0);
@@ -887,6 +902,7 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->weno_vals) (void)hipFree(c->weno_vals);
     if (c->flag) (void)hipFree(c->flag);
     if (c->partials) (void)hipFree(c->partials);
+    for (int i = 0; i < 2; ++i) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
     delete c;
 }
 

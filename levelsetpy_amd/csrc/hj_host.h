@@ -47,6 +47,18 @@ struct Tiling {
 
 struct KernelCfg { int NT, R, KH; };
 
+// Launch-time choice among tile shapes (round 3).  The static score of make_tiling (halo ratio, partial cache lines) cannot see
+// how the workgroup count of a shape fills the last round of resident workgroups or how its row length suits the memory system:
+// at 513^3 the 15x130 tile beats the best-scored 27x74 by 6 %, at 481^3 and 551^3 the best-scored shape wins by 9 %
+// (profiles/r03_tile_shape_sweep.txt).  The results do not depend on the tiling (bitwise: every cell is a pure function of its
+// inputs), so the first launches of a launch shape simply take turns through the candidates, each timed with a pair of events,
+// and the fastest is kept.
+struct TuneState {
+    std::vector<Tiling> cand;
+    std::vector<float> best_ms;
+    int trial = 0, chosen = -1;
+};
+
 }  // namespace hjh
 
 struct hj_ctx {
@@ -100,6 +112,10 @@ struct hj_ctx {
     int target_blocks, min_chunk, warmup_cost, no_plain;
     int fuse12, f12_r, f12_nt, f12_kh, f12_warm, f12_e2;
     long long direct_below = 0;                     // HJ_DIRECT_BELOW: grids with fewer cells run direct_substep_kernel
+    int autotune = 1, autotune_passes = 6;          // HJ_AUTOTUNE, HJ_AUTOTUNE_PASSES
+    long long autotune_min_cells = 40000000;        // HJ_AUTOTUNE_MIN_MCELLS
+    std::map<long long, hjh::TuneState> tune;       // per launch shape (scheme, stage class, kernel configuration)
+    hipEvent_t tune_ev[2] = {nullptr, nullptr};
     int tile_cells = 0;                             // HJ_TILE_CELLS: cap on the cells of a tile (0 = what the configuration holds)
     int f12_e1 = 0;                                 // tuning / tests: force the tile's row count (pair variant)
     int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail
@@ -119,7 +135,7 @@ namespace hjh {
 using namespace hj;
 
 int env_int(const char* name, int dflt);
-Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1, int nbuf = 2);
+Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1, int nbuf = 2, std::vector<Tiling>* all = nullptr);
 void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu);
 int cfg_kh(int nd, int nt, int r);
 

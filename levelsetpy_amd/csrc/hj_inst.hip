@@ -163,6 +163,72 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
 #define HJ_CONFIGS_PAIR_4D(X)
 #endif
 
+// ---- launch-time choice of the tile shape (TuneState, hj_host.h)
+inline int stage_class(int stage) { return stage >= HJ_STAGE_RK3_HALF ? 2 : (stage == HJ_STAGE_EULER ? 1 : 0); }
+struct TuneTrial { TuneState* ts = nullptr; int cand = -1; };
+
+// The tiling of this launch: the static choice, or -- whole-grid launches of a single domain on grids of at least
+// HJ_AUTOTUNE_MIN_MCELLS cells -- the next candidate of the tuning rotation / the shape the rotation settled on.
+template <int ND>
+Tiling tune_begin(hj_ctx* c, const SubstepCall& s, const KernelCfg& k, int vec, int nbuf, long long key, TuneTrial& tr) {
+    const bool tunable = c->autotune && c->total >= c->autotune_min_cells && !c->full_rows && !c->tile_cells && !s.on_aux &&
+                         !c->launch_stop && !c->halo_lo && !c->halo_hi && s.p0 == 0 && s.p1 == c->N[0] && s.q1 <= s.q0 &&
+                         !getenv("HJ_TIMING_DUMP");
+    if (!tunable) return make_tiling(c, k, s.p0, s.p1, vec, nbuf);
+    TuneState* ts = &c->tune[key];
+    if (ts->cand.empty() && ts->chosen < 0) {
+        std::vector<Tiling> all;
+        const Tiling b0 = make_tiling(c, k, s.p0, s.p1, vec, nbuf, &all);
+        if (!b0.ok) { ts->chosen = 0; return b0; }
+        // candidate 0: the best-scored shape; then the shapes with LONGER rows within 35 % of its score (every sweep of round 3
+        // found the winner among those: 130-cell rows at 513^3 and 451^3, 134 / 102 at 401^3, 118 at 351^3), then two with
+        // shorter rows
+        constexpr int LAST = ND - 1;
+        ts->cand.push_back(b0);
+        for (const Tiling& t : all)
+            if (t.E[LAST] > b0.E[LAST] && t.score <= 1.35 * b0.score && ts->cand.size() < 7) ts->cand.push_back(t);
+        int shorter = 0;
+        for (const Tiling& t : all)
+            if (t.E[LAST] < b0.E[LAST] && t.score <= 1.35 * b0.score && shorter < 2) { ts->cand.push_back(t); ++shorter; }
+        ts->best_ms.assign(ts->cand.size(), 1e30f);
+        if (ts->cand.size() <= 1) ts->chosen = 0;
+    }
+    if (ts->cand.empty()) return make_tiling(c, k, s.p0, s.p1, vec, nbuf);
+    if (ts->chosen >= 0) return ts->cand[ts->chosen];
+    tr.ts = ts;
+    tr.cand = ts->trial % (int)ts->cand.size();
+    if (!c->tune_ev[0]) {
+        if (hipEventCreate(&c->tune_ev[0]) != hipSuccess || hipEventCreate(&c->tune_ev[1]) != hipSuccess) { tr.ts = nullptr; return ts->cand[0]; }
+    }
+    (void)hipEventRecord(c->tune_ev[0], call_stream(c, s));
+    return ts->cand[tr.cand];
+}
+
+// One timed trial (the first pass only warms up); the launch itself was a normal one: the results do not depend on the tiling.
+template <int ND>
+int tune_end(hj_ctx* c, const SubstepCall& s, TuneTrial& tr, int rc, int scheme) {
+    TuneState* ts = tr.ts;
+    if (!ts || rc != HJ_OK) return rc;
+    HIP_TRY(hipEventRecord(c->tune_ev[1], call_stream(c, s)));
+    HIP_TRY(hipEventSynchronize(c->tune_ev[1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->tune_ev[0], c->tune_ev[1]));
+    const int ncand = (int)ts->cand.size();
+    if (ts->trial >= ncand) ts->best_ms[tr.cand] = std::min(ts->best_ms[tr.cand], ms);
+    if (++ts->trial >= ncand * c->autotune_passes) {
+        ts->chosen = (int)(std::min_element(ts->best_ms.begin(), ts->best_ms.end()) - ts->best_ms.begin());
+        // the best-scored shape (candidate 0) stays unless another one beats it by more than the timing noise
+        if (ts->best_ms[ts->chosen] > 0.985f * ts->best_ms[0]) ts->chosen = 0;
+        if (getenv("HJ_DEBUG") || getenv("HJ_AUTOTUNE_LOG")) {
+            for (int i = 0; i < ncand; ++i)
+                fprintf(stderr, "[hj] autotune scheme %d stage %d: E=(%d,%d,%d) ntiles=%d score=%.3f  %.4f ms%s\n", scheme, s.stage,
+                        ts->cand[i].E[1], ND > 2 ? ts->cand[i].E[2] : 0, ND > 3 ? ts->cand[i].E[3] : 0, ts->cand[i].ntiles, ts->cand[i].score,
+                        ts->best_ms[i], i == ts->chosen ? "  <- chosen" : "");
+        }
+    }
+    return rc;
+}
+
 template <typename T, typename HAM, int SCHEME>
 int launch_direct(hj_ctx* c, const SubstepCall& s) {
     constexpr int ND = HAM::ND;
@@ -252,23 +318,33 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
                 const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
                 c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
-                const Tiling tp = make_tiling(c, kp, s.p0, s.p1, 2, c->last_nbuf);
+                const long long key = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (1ll << 35) |
+                                      ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0);
+                TuneTrial tr;
+                const Tiling tp = tune_begin<HAM::ND>(c, s, kp, 2, c->last_nbuf, key, tr);
                 if (tp.ok) {
-#define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true)) { if (kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
+                    int rc_t = -12345;
+#define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true)) { if (rc_t == -12345 && kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
                     if constexpr (HAM::ND == 4) { HJ_CONFIGS_PAIR_4D(X) }
                     else { HJ_CONFIGS_PAIR(X) }
 #undef X
+                    if (rc_t != -12345) return tune_end<HAM::ND>(c, s, tr, rc_t, SCHEME);
                     if (c->pair_nt > 0 || c->pair_r > 0 || c->pair_kh > 0 || c->pair_occ > 0)
                         return hjh::fail(HJ_EUNSUPPORTED, "pair-kernel configuration (%d,%d,%d,%d) requested through HJ_PAIR_* is not built for scheme %d",
                                          kp.NT, kp.R, kp.KH, occp, SCHEME);
                 }
             }
-            Tiling t = make_tiling(c, k, s.p0, s.p1);
+            const long long key1 = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) |
+                                   ((long long)k.NT << 20) | ((long long)k.R << 12) | ((long long)k.KH << 4) | (long long)pd;
+            TuneTrial tr1;
+            Tiling t = tune_begin<HAM::ND>(c, s, k, 1, 2, key1, tr1);
             if (t.ok) {
-#define X(NT_, R_, KH_, OCC_, PD_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, false)) { if (k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) return launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t); }
+                int rc_t = -12345;
+#define X(NT_, R_, KH_, OCC_, PD_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, false)) { if (rc_t == -12345 && k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t); }
                 if constexpr (HAM::ND == 4) { HJ_CONFIGS_4D(X) }
                 else { HJ_CONFIGS(X) }
 #undef X
+                if (rc_t != -12345) return tune_end<HAM::ND>(c, s, tr1, rc_t, SCHEME);
                 if (c->cfg_from_env)
                     return hjh::fail(HJ_EUNSUPPORTED, "kernel configuration (%d,%d,%d,%d,%d) requested through HJ_NT/HJ_R/HJ_KH/HJ_OCC/HJ_PD is not built for scheme %d",
                                      k.NT, k.R, k.KH, occ, pd, SCHEME);
