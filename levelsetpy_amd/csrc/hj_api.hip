@@ -84,6 +84,7 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
                 const size_t cap2 = nbuf > 2 ? (size_t)160 * 1024 - 1024 : c->lds_limit;
                 if (512 + (size_t)nbuf * (size_t)(rows * (E[nd - 1] + 32)) * c->esz <= cap2) pitch = E[nd - 1] + 32;
             }
+            pitch += c->lds_pitch_add;          // HJ_LDS_PITCH_ADD (tuning): extra cells of row padding
             box = rows * pitch;
             size_t lds = 512 + (size_t)nbuf * (size_t)box * c->esz;
             const size_t lds_cap = nbuf > 2 ? (size_t)160 * 1024 - 1024 : c->lds_limit;   // the ring variant may take the whole CU
@@ -854,6 +855,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // planes the ring is parked ahead: 3 aligns it exactly with the neighbours' own loads (best from 251^3 up); on the
     // 201^3-class grids 2 is 0.7 % faster (one plane less to fetch synchronously in the setup; same-box A/B r02_run43.sh)
     c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
+    c->lds_pitch_add = env_int("HJ_LDS_PITCH_ADD", 0) & ~1;
     c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) (512,2) configuration on >= 8 M cells
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);

@@ -122,6 +122,7 @@ struct hj_ctx {
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
     int last_nbuf = 2;
+    int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)
     size_t lds_limit;
@@ -214,11 +215,13 @@ inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s
 // light stencils: few enough live values that 4 cells (2 pairs) per thread fit in 256 VGPRs without scratch
 constexpr bool light_scheme(int scheme) { return scheme == HJ_WENO5_ASSHIPPED || scheme == HJ_ENO2; }
 // is configuration (NT, R) of the one-cell-per-lane / pair kernel compiled for this scheme?
-constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair) {
+constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz = 8) {
 #ifdef HJ_ALL_CONFIGS
     return true;
 #else
-    if (nd == 4) return true;
+    // 4-D (three tiled plane axes): fp32 runs 1024 single cells or -- light stencils, round 3 -- 256 threads x 2 pairs
+    // (two independent workgroups per CU); fp64 512 x 2 cells.  The other combinations spill and nobody selects them.
+    if (nd == 4) return pair ? (esz == 4 && light_scheme(scheme)) : (esz == 4 ? nt == 1024 : nt == 512);
     if (pair) return light_scheme(scheme) ? (nt == 512 && r == 2) || (nt == 256 && r == 1) : (nt == 256 && r == 1);
     return light_scheme(scheme) ? true : (nt == 256 && r == 2);
 #endif

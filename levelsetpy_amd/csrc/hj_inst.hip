@@ -160,7 +160,7 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
 // 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile): the pair kernel was measured 5-15 % slower
 // there in round 2 and every fp64 shape of it spills; built only where a tuning build defines the table
 #ifndef HJ_CONFIGS_PAIR_4D
-#define HJ_CONFIGS_PAIR_4D(X)
+#define HJ_CONFIGS_PAIR_4D(X) X(256, 2, 10, 2)
 #endif
 
 // ---- launch-time choice of the tile shape (TuneState, hj_host.h)
@@ -269,7 +269,10 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
 
 template <typename T, typename HAM, int SCHEME>
 int launch_cfg(hj_ctx* c, const SubstepCall& s) {
-#ifdef HJ_TUNE_BUILD
+#if defined(HJ_TUNE_BUILD) && HJ_TUNE_BUILD == 2
+    // quick-iteration build for C5: only the fp32 pendulum with the as-shipped WENO5 is compiled tiled
+    constexpr bool tiled_ok = std::is_same<T, float>::value && HAM::ID == HJ_HAM_DOUBLE_PENDULUM && SCHEME == HJ_WENO5_ASSHIPPED;
+#elif defined(HJ_TUNE_BUILD)
     // quick-iteration build: only fp64 Dubins with the two WENO5 arithmetics is compiled tiled
     constexpr bool tiled_ok = std::is_same<T, double>::value && HAM::ID == HJ_HAM_DUBINS_REL &&
                               (SCHEME == HJ_WENO5 || SCHEME == HJ_WENO5_ASSHIPPED);
@@ -302,13 +305,16 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 else { k.NT = 256; k.R = 2; pd = 2; occ = 2; }
                 k.KH = cfg_kh(HAM::ND, k.NT, k.R);
             }
-            if (c->pair != 0 && (HAM::ND <= 3 ? (c->total >= 2500000 || c->pair_nt > 0 || c->pair == 2) : (c->pair_nt > 0))) {
+            // 4-D: fp32 with a light stencil only (C5; round 3: 256 threads x 2 pairs, two workgroups per CU: +8 % over 1024 single cells)
+            const bool pair_dim = HAM::ND <= 3 || (sizeof(T) == 4 && light_scheme(SCHEME)) || c->pair_nt > 0;
+            if (c->pair != 0 && pair_dim && (c->total >= 2500000 || c->pair_nt > 0 || c->pair == 2)) {
                 // two cells per lane (hj_fusedv.h), round-2 A/B at 151^3 ... 513^3: the light stencils
                 // run 2 pairs per thread in 512-thread workgroups (220-232 VGPRs against 246-256 for four single
                 // cells), the heavy ones 1 pair in 256-thread workgroups
                 KernelCfg kp{512, 2, 2};
                 int occp = 2;
                 if (!(SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
+                if (HAM::ND == 4) { kp.NT = 256; kp.R = 2; kp.KH = 10; }
                 if (c->pair_nt > 0) kp.NT = c->pair_nt;
                 if (c->pair_r > 0) kp.R = c->pair_r;
                 if (c->pair_kh > 0) kp.KH = c->pair_kh;
@@ -316,7 +322,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // halo ring parked in LDS (5 plane buffers, hj_fusedv.h): pays for the two-pairs-per-thread configuration
                 // from 201^3 up (A/B tools/experiments/r02_run32.sh, r02_run33.sh: +1 % at 201^3, +3.6 % at 513^3 with
                 // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
-                const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
+                const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && HAM::ND <= 3 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
                 c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
                 const long long key = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (1ll << 35) |
                                       ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0);
@@ -324,7 +330,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 const Tiling tp = tune_begin<HAM::ND>(c, s, kp, 2, c->last_nbuf, key, tr);
                 if (tp.ok) {
                     int rc_t = -12345;
-#define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true)) { if (rc_t == -12345 && kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
+#define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true, (int)sizeof(T))) { if (rc_t == -12345 && kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
                     if constexpr (HAM::ND == 4) { HJ_CONFIGS_PAIR_4D(X) }
                     else { HJ_CONFIGS_PAIR(X) }
 #undef X
@@ -340,7 +346,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             Tiling t = tune_begin<HAM::ND>(c, s, k, 1, 2, key1, tr1);
             if (t.ok) {
                 int rc_t = -12345;
-#define X(NT_, R_, KH_, OCC_, PD_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, false)) { if (rc_t == -12345 && k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t); }
+#define X(NT_, R_, KH_, OCC_, PD_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, false, (int)sizeof(T))) { if (rc_t == -12345 && k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t); }
                 if constexpr (HAM::ND == 4) { HJ_CONFIGS_4D(X) }
                 else { HJ_CONFIGS(X) }
 #undef X

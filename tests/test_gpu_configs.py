@@ -178,9 +178,10 @@ def _pendulum_alpha_max(g, u):
 
 
 def test_c5_129_to_the_4_fp32_all_periodic_properties(monkeypatch):
-    """BASELINE C5 at full size and precision (129^4 = 277 M cells, fp32, every axis periodic): the
-    tiled kernel (three tiled plane axes, config (1024,1,3,2,2)) against the independent direct kernel on an
-    RK3 step, the last substep split into plane ranges bitwise, the CFL bound against the definition."""
+    """BASELINE C5 at full size and precision (129^4 = 277 M cells, fp32, every axis periodic): the kernel the
+    library picks (round 3: two cells per lane, 256 threads x 2 pairs, three tiled plane axes), the one-cell-per-lane
+    kernel (1024,1,3,2,2) and the independent direct kernel on an RK3 step -- bit for bit the same state; the last
+    substep split into plane ranges bitwise, the CFL bound against the definition."""
     n = 129
     g, _ = pendulum_grid(n, low_mem=True)
     xs = [torch.as_tensor(np.asarray(v).ravel(), device="cuda", dtype=torch.float64) for v in g.vs]
@@ -191,35 +192,41 @@ def test_c5_129_to_the_4_fp32_all_periodic_properties(monkeypatch):
     par = [1.0, 0., 0., 0.]
     dt = 2e-4
     outs = {}
-    for force in ("0", "1"):
+    for name, force, pair, kern in (("default", "0", None, b"fused_pair_kernel"), ("single", "0", "0", b"fused_substep_kernel"),
+                                    ("direct", "1", None, b"direct_substep_kernel")):
         monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+        if pair is None:
+            monkeypatch.delenv("HJ_PAIR", raising=False)
+        else:
+            monkeypatch.setenv("HJ_PAIR", pair)
         dg = DeviceGrid(g, "float32")
         dg.bind_stream()
         a, b, c = dg.empty(), dg.empty(), dg.empty()
         _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_EULER, dt, d0, None, a)
         _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_HALF, dt, a, d0, b)
         _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_FULL, dt, b, d0, c)
+        assert dg.lib.hj_last_kernel(dg.ctx) == kern, (name, dg.lib.hj_last_kernel(dg.ctx))
         if force == "0":
             c2 = torch.zeros_like(c)
             for k, (p0, p1) in enumerate([(0, 17), (17, 100), (100, n)]):
                 _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_FULL, dt, b, d0, c2, p0, p1, slot=4 + k)
             dg.sync()
-            assert torch.equal(c, c2), float((c - c2).abs().max())
+            assert torch.equal(c, c2), (name, float((c - c2).abs().max()))
             del c2
             sb, am = C.c_double(), (C.c_double * 4)()
             _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 3, C.byref(sb), am))
             ref = _pendulum_alpha_max(g, 1.0)
             for d in range(4):
-                assert abs(am[d] - ref[d]) <= 2e-6 * ref[d], (d, am[d], ref[d])     # fp32 tables and arithmetic
+                assert abs(am[d] - ref[d]) <= 2e-6 * ref[d], (name, d, am[d], ref[d])     # fp32 tables and arithmetic
         dg.sync()
-        outs[force] = c
-        del a, b
-    assert bool(torch.isfinite(outs["0"]).all())
-    scale = float(outs["1"].abs().max())
-    err = float((outs["0"] - outs["1"]).abs().max())
-    assert err <= 2e-5 * max(1.0, scale), (err, scale)
+        outs[name] = c
+        del a, b, dg
+    assert bool(torch.isfinite(outs["default"]).all())
+    # every cell is a pure function of its inputs through the same per-cell functions and stage expressions
+    assert torch.equal(outs["default"], outs["single"]), float((outs["default"] - outs["single"]).abs().max())
+    assert torch.equal(outs["default"], outs["direct"]), float((outs["default"] - outs["direct"]).abs().max())
     # the update moved the state (a kernel that copies its input would pass everything above)
-    assert float((outs["0"] - d0).abs().max()) > 1e-4
+    assert float((outs["default"] - d0).abs().max()) > 1e-4
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -237,10 +244,16 @@ def test_fp32_4d_tiled_and_direct_vs_fp64_oracle(scheme, n, pd, monkeypatch):
     scale = float(np.max(np.abs(yo)))
     y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
     got = {}
-    for force in ("0", "1"):
-        monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+    # "0": one cell per lane (1024,1,3,2,2); "1": direct; "pair": two cells per lane (256,2,10,2), built for the light stencils
+    variants = ("0", "1", "pair") if scheme in ("WENO5_ASSHIPPED", "ENO2") else ("0", "1")
+    for force in variants:
+        monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if force == "1" else "0")
+        monkeypatch.setenv("HJ_PAIR", "2" if force == "pair" else "0")
         g.__dict__.pop("_hj_device", None)
         yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
+        dg = g.__dict__["_hj_device"]
+        dg = dg[next(iter(dg))] if isinstance(dg, dict) else dg
+        assert dg.lib.hj_last_kernel(dg.ctx) == {"0": b"fused_substep_kernel", "1": b"direct_substep_kernel", "pair": b"fused_pair_kernel"}[force]
         assert yd.dtype == torch.float32
         assert abs(sb - sbo) <= 1e-5 * sbo
         got[force] = yd.cpu().numpy().astype(np.float64)
@@ -252,8 +265,9 @@ def test_fp32_4d_tiled_and_direct_vs_fp64_oracle(scheme, n, pd, monkeypatch):
         else:
             assert np.mean(rel > 1e-4) <= 2e-3, (force, float(np.mean(rel > 1e-4)))
             assert rel.max() <= 0.2, (force, rel.max())
-    # the two fp32 kernels share the per-cell arithmetic and (round 3) the stage expressions: bit for bit
-    assert np.array_equal(got["0"], got["1"]), np.max(np.abs(got["0"] - got["1"]))
+    # the fp32 kernels share the per-cell arithmetic and (round 3) the stage expressions: bit for bit
+    for force in variants[1:]:
+        assert np.array_equal(got["0"], got[force]), (force, np.max(np.abs(got["0"] - got[force])))
 
 
 @pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO3"])
