@@ -361,8 +361,13 @@ int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
         if ((rc = weno_eps_pass(c, s.y))) return rc;
         if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
     }
-    s.bound = next_ring(c, user_slot, &rc);
-    if (rc) return rc;
+    // user_slot < 0: nobody will read this launch's CFL bound (hj_rk_step and the slab steppers take dt from the static bound):
+    // the kernel skips its reduction and the contended atomics, and the key ring does not advance
+    s.bound = nullptr;
+    if (user_slot >= 0 || c->keep_bounds) {
+        s.bound = next_ring(c, user_slot, &rc);
+        if (rc) return rc;
+    }
     return c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
 }
 
@@ -391,8 +396,11 @@ int do_stage12(hj_ctx* c, Stage12Call& s, int user_slot) {
     if (!s.probe) {
         if (!s.y || !s.out) return fail(HJ_EINVAL, "null array argument");
         if (s.y == s.out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
-        s.bound = next_ring(c, user_slot, &rc);
-        if (rc) return rc;
+        s.bound = nullptr;
+        if (user_slot >= 0 || c->keep_bounds) {
+            s.bound = next_ring(c, user_slot, &rc);
+            if (rc) return rc;
+        }
     }
     return c->dtype == HJ_F64 ? stage12_ham<double>(c, s) : stage12_ham<float>(c, s);
 }
@@ -856,6 +864,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // 201^3-class grids 2 is 0.7 % faster (one plane less to fetch synchronously in the setup; same-box A/B r02_run43.sh)
     c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
     c->lds_pitch_add = env_int("HJ_LDS_PITCH_ADD", 0) & ~1;
+    c->keep_bounds = env_int("HJ_KEEP_BOUNDS", 0);   // 1: every launch reduces its CFL bound, read or not (round-2 behaviour; A/B)
     c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) (512,2) configuration on >= 8 M cells
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
@@ -1306,7 +1315,7 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     // deltaT = min(factorCFL*stepBound, tspan[1]-t, maxStep)  (ode_cfl_3.py:142)
     const double dt = std::min(std::min(factor_cfl * sb, tf - t0), max_step);
     const int64_t n0 = c->N[0];
-    auto slot = [&]() { int s = c->internal_slot; c->internal_slot = (s + 1) % (HJ_BOUND_SLOTS - 1); return s; };
+    auto slot = [&]() { return -1; };      // dt comes from the static bound above: no launch of a step needs its own
     double t = t0;
     const bool fuse = use_stage12(c, order, scheme, ham, par, restrict_sign);
     if (order == 1) {

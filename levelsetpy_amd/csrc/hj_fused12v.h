@@ -634,19 +634,21 @@ __global__ __launch_bounds__(NT, OCC) void fused12_pair_kernel(const T* __restri
             if (w_int[r] && a_int[r]) buf_store2(o2p[r], rout, a_g[r], st_so);
     }
 
-    // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim
-    const int lane = tid & 63, wv = tid >> 6;
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        const double m = wave_max(amax[d]) / (double)A.sc[d];
-        if (lane == 0) red[wv][d] = m;
-    }
-    __syncthreads();
-    if (tid < ND) {
-        double m = red[0][tid];
-        for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
-        if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+    if (A.bound) {
+        // ---- CFL reduction: wavefront shuffles -> LDS -> one atomicMax per block and dim
+        const int lane = tid & 63, wv = tid >> 6;
+        __syncthreads();
+    #pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const double m = wave_max(amax[d]) / (double)A.sc[d];
+            if (lane == 0) red[wv][d] = m;
+        }
+        __syncthreads();
+        if (tid < ND) {
+            double m = red[0][tid];
+            for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
+            if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+        }
     }
 }
 

@@ -505,32 +505,34 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
 
-    {   // alpha of the dimensions that do not vary along the march: column constants, taken once (any plane does)
-        T pz[ND], Hz, az[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) pz[d] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                HAM::eval(A.ham, hcell[r][c], pls[0], A.sc, pz, Hz, az);
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
-            }
-    }
+    if (A.bound) {   // a launch whose bound nobody reads (hj_rk_step: dt comes from the static bound) skips the reduction
+        {   // alpha of the dimensions that do not vary along the march: column constants, taken once (any plane does)
+            T pz[ND], Hz, az[ND];
+    #pragma unroll
+            for (int d = 0; d < ND; ++d) pz[d] = T(0);
+    #pragma unroll
+            for (int r = 0; r < R; ++r)
+    #pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    HAM::eval(A.ham, hcell[r][c], pls[0], A.sc, pz, Hz, az);
+    #pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        if (!((HAM::PLANE_DEP >> d) & 1u)) amax[d] = fmax(amax[d], (double)az[d]);
+                }
+        }
 
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        const double m = wave_max(amax[d]) / (double)A.sc[d];
-        if (lane == 0) red[wv][d] = m;
-    }
-    __syncthreads();
-    if (tid < ND) {
-        double m = red[0][tid];
-        for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
-        if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+        const int lane = tid & 63, wv = tid >> 6;
+    #pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const double m = wave_max(amax[d]) / (double)A.sc[d];
+            if (lane == 0) red[wv][d] = m;
+        }
+        __syncthreads();
+        if (tid < ND) {
+            double m = red[0][tid];
+            for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
+            if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+        }
     }
     if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
 #ifdef HJ_STAMP

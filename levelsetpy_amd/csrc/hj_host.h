@@ -122,6 +122,7 @@ struct hj_ctx {
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
     int last_nbuf = 2;
+    int keep_bounds = 0;                            // HJ_KEEP_BOUNDS: reduce the CFL bound in launches whose bound nobody reads
     int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)

@@ -407,17 +407,19 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
         A.out[t] = o;
     }
     __shared__ double red[4][ND];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        const double w = wave_max(amax[d]);
-        if (lane == 0) red[wv][d] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x < ND) {
-        const int d = threadIdx.x;
-        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        if (w > -1e299) atomicMax(A.bound + d, max_key(w / (double)A.sc[d]));
+    if (A.bound) {   // nobody reads the bound of hj_rk_step's launches (static step bound)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    #pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const double w = wave_max(amax[d]);
+            if (lane == 0) red[wv][d] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < ND) {
+            const int d = threadIdx.x;
+            const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
+            if (w > -1e299) atomicMax(A.bound + d, max_key(w / (double)A.sc[d]));
+        }
     }
 }
 

@@ -454,10 +454,16 @@ def slab_grid(L, world, n, global_n):
 def _agree(dist, ok, device):
     """Collective decision: True only if EVERY rank reports ok (a rank that failed locally must not leave
     the others inside a different collective: ADVICE r01)."""
+    return _agree3(dist, ok, device) == "all"
+
+
+def _agree3(dist, ok, device):
+    """'all' if every rank reports ok, 'none' if every rank failed, 'some' otherwise."""
     import torch
-    flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=device)
+    flag = torch.tensor([0.0 if ok else 1.0, 1.0 if ok else 0.0], dtype=torch.float64, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    return float(flag.item()) == 0.0
+    any_failed, any_ok = float(flag[0].item()) != 0.0, float(flag[1].item()) != 0.0
+    return "all" if not any_failed else ("some" if any_ok else "none")
 
 
 def bench_slab(args, rank, world, global_n=513):
@@ -488,8 +494,9 @@ def bench_slab(args, rank, world, global_n=513):
     # Transports in order of preference; each one has to reproduce the single-domain result ON THIS HARDWARE
     # before it is timed (two RK3 steps of the whole grid on every rank, untimed).  Every stage ends in a
     # collective agreement: a rank whose set-up raised reports it there instead of skipping ahead, so the
-    # ranks never sit in different collectives.  Set-up failures inside a transport's own collectives
-    # (communicator creation) cannot be recovered from and abort the run with a non-zero exit.
+    # ranks never sit in different collectives.  A set-up that failed on EVERY rank moves on to the next transport; one
+    # that failed on some ranks only (communicator creation half done) cannot be recovered from and aborts the run with
+    # a non-zero exit.
     want = os.environ.get("HJ_SLAB_TRANSPORT")
     # the deep-halo schedule pays 18 redundant planes per slab and step: only worth it on thick slabs
     thick = min(slab.counts) >= 128
@@ -506,9 +513,17 @@ def bench_slab(args, rank, world, global_n=513):
         except Exception as e:  # noqa: BLE001 -- decided collectively below
             ok, err = False, e
             sys.stderr.write("[bench_slab] rank %d: transport %s failed to set up: %r\n" % (rank, kind, e))
-        if not _agree(dist, ok, device):
+        verdict = _agree3(dist, ok, device)
+        if verdict == "some":
             # a rank that got past its communicator while another did not cannot be re-synchronised safely
             raise RuntimeError("slab transport %s could not be set up on every rank (%r)" % (kind, err))
+        if verdict == "none":
+            # every rank failed the same set-up (e.g. the RCCL library could not be opened): nobody sits in a communicator,
+            # the next transport can be tried
+            if rank == 0:
+                sys.stderr.write("[bench_slab] transport %s could not be set up on any rank (%r)\n" % (kind, err))
+            integ = None
+            continue
         bad = 0.0
         if os.environ.get("HJ_BENCH_SLAB_CHECK", "1") != "0":
             try:
