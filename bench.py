@@ -321,7 +321,7 @@ def source_hash():
 
 
 STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel",
-                "max_d1sq_kernel", "partials_to_values_kernel", "keys_to_values_kernel")
+                "max_d1sq_kernel", "partials_to_values_kernel", "keys_to_values_kernel", "eps_seam_kernel")
 
 
 def live_traffic(a, n=None, scheme=None):

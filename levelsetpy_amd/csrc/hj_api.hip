@@ -333,6 +333,43 @@ int weno_eps_to(hj_ctx* c, const void* y, void* out) {
 
 int weno_eps_pass(hj_ctx* c, const void* y) { return weno_eps_to(c, y, c->weno_vals); }
 
+// The pre-pass as ONE launch (round 3): at most 512 workgroups of 1024 threads leave their rows in c->partials and the
+// consuming substep kernel folds them in its prologue (FusedArgs::eps_rows), like the rows of eps_seam_kernel.
+// *nrows = 0: the grid has more than 512 K columns per plane -- the caller takes the two-launch form.
+int weno_eps_rows(hj_ctx* c, const void* y, int* nrows) {
+    *nrows = 0;
+    const int64_t S = c->total / c->N[0];
+    const int64_t bx = (S + 1023) / 1024;
+    if (bx > 512) return HJ_OK;
+    int by = (int)std::max<int64_t>(1, std::min<int64_t>((c->N[0] + 7) / 8, 512 / bx));
+    const int chunk = (int)((c->N[0] + by - 1) / by);
+    by = (int)((c->N[0] + chunk - 1) / chunk);
+    const int nblocks = (int)bx * by;
+    if (nblocks > c->partials_cap) {
+        if (c->partials) { HIP_TRY(hipFree(c->partials)); c->partials = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c->partials, sizeof(double) * HJ_MAX_DIM * (size_t)std::max(nblocks, 4096)));
+        c->partials_cap = std::max(nblocks, 4096);
+    }
+#define HJ_MAXD1R(T, ND)                                                                                   \
+    {                                                                                                      \
+        GridArgs<T, ND> G;                                                                                 \
+        fill_grid<T, ND>(c, G);                                                                            \
+        hipLaunchKernelGGL((max_d1sq_kernel<T, ND, 1024>), dim3((unsigned)bx, by), dim3(1024), 0, c->stream, \
+                           (const T*)y, G, c->partials, chunk);                                            \
+    }
+    if (c->dtype == HJ_F64) {
+        if (c->ndim == 2) HJ_MAXD1R(double, 2) else if (c->ndim == 3) HJ_MAXD1R(double, 3) else HJ_MAXD1R(double, 4)
+    } else {
+        if (c->ndim == 2) HJ_MAXD1R(float, 2) else if (c->ndim == 3) HJ_MAXD1R(float, 3) else HJ_MAXD1R(float, 4)
+    }
+#undef HJ_MAXD1R
+    HIP_TRY(hipGetLastError());
+    *nrows = nblocks;
+    return HJ_OK;
+}
+
+
+
 // kept for call sites that used the two-step form: the values are already in place
 int keys_to_vals(hj_ctx* c, void* out) {
     if (out != c->weno_vals)
@@ -358,9 +395,21 @@ int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
             return fail(HJ_EINVAL, "grid too small along dim %d (N=%lld)", d, (long long)c->N[d]);
     if (s.p0 == s.p1) return HJ_OK;
     if (s.scheme == HJ_WENO5 && !c->weno_src) {
-        if ((rc = weno_eps_pass(c, s.y))) return rc;
-        if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+        // inside hj_rk_step the previous launch reduced max(D1^2) of this launch's input itself (eps_ready): no pre-pass
+        if (s.eps_from_prev && c->eps_ready && c->eps_fuse) { s.eps_rows = c->eps_rows; s.eps_nrows = HJ_EPS_ROWS; }
+        else {
+            int nrows = 0;
+            if (c->eps_fuse && !s.on_aux && (rc = weno_eps_rows(c, s.y, &nrows))) return rc;
+            if (nrows > 0) { s.eps_rows = c->partials; s.eps_nrows = nrows; }
+            else {
+                if ((rc = weno_eps_pass(c, s.y))) return rc;
+                if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
+            }
+        }
+        if (s.want_eps && c->eps_fuse && !c->eps_rows)
+            HIP_TRY(hipMalloc((void**)&c->eps_rows, sizeof(double) * HJ_MAX_DIM * HJ_EPS_ROWS));
     }
+    c->eps_ready = false;          // whatever the rows described is about to be (or may have been) overwritten
     // user_slot < 0: nobody will read this launch's CFL bound (hj_rk_step and the slab steppers take dt from the static bound):
     // the kernel skips its reduction and the contended atomics, and the key ring does not advance
     s.bound = nullptr;
@@ -396,6 +445,7 @@ int do_stage12(hj_ctx* c, Stage12Call& s, int user_slot) {
     if (!s.probe) {
         if (!s.y || !s.out) return fail(HJ_EINVAL, "null array argument");
         if (s.y == s.out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
+        c->eps_ready = false;
         s.bound = nullptr;
         if (user_slot >= 0 || c->keep_bounds) {
             s.bound = next_ring(c, user_slot, &rc);
@@ -442,6 +492,15 @@ int read_ring(hj_ctx* c, int pos, double* sb, double* amax) {
 }
 
 }  // namespace
+
+int hjh::eps_rows_to_vals(hj_ctx* c, const double* rows, int nrows, hipStream_t stream) {
+    if (c->dtype == HJ_F64)
+        hipLaunchKernelGGL((partials_to_values_kernel<double>), dim3(1), dim3(256), 0, stream, rows, nrows, (double*)c->weno_vals, c->ndim);
+    else
+        hipLaunchKernelGGL((partials_to_values_kernel<float>), dim3(1), dim3(256), 0, stream, rows, nrows, (float*)c->weno_vals, c->ndim);
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
 
 static int dim_view(const hj_ctx* c, int dim, long long* outer, long long* inner) {
     long long o = 1, i = 1;
@@ -864,6 +923,8 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // 201^3-class grids 2 is 0.7 % faster (one plane less to fetch synchronously in the setup; same-box A/B r02_run43.sh)
     c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
     c->lds_pitch_add = env_int("HJ_LDS_PITCH_ADD", 0) & ~1;
+    c->eps_fuse_min_cells = (long long)env_int("HJ_EPS_FUSE_MIN_CELLS", 2000000);
+    c->eps_fuse = env_int("HJ_EPS_FUSE", 1);         // 0: the intended WENO5 always runs its two-launch epsilon pre-pass
     c->keep_bounds = env_int("HJ_KEEP_BOUNDS", 0);   // 1: every launch reduces its CFL bound, read or not (round-2 behaviour; A/B)
     c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) (512,2) configuration on >= 8 M cells
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
@@ -914,6 +975,8 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->flag) (void)hipFree(c->flag);
     if (c->partials) (void)hipFree(c->partials);
     for (int i = 0; i < 2; ++i) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
+    if (c->eps_prod) (void)hipFree(c->eps_prod);
+    if (c->eps_rows) (void)hipFree(c->eps_rows);
     delete c;
 }
 
@@ -1318,9 +1381,13 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     auto slot = [&]() { return -1; };      // dt comes from the static bound above: no launch of a step needs its own
     double t = t0;
     const bool fuse = use_stage12(c, order, scheme, ham, par, restrict_sign);
+    // intended WENO5: every stage's launch reduces max(D1^2) of its output for the next stage's epsilon (no pre-pass between
+    // the stages); across steps only inside hj_rk_integrate, where nobody else touches the state (eps_chain_*)
+    const bool chain_in = c->eps_chain_in, chain_out = c->eps_chain_out && !c->post_arr[0] && !c->post_arr[1];
     if (order == 1) {
         SubstepCall s{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, y_out, nullptr, 0, n0};
         s.post_op = c->post_step_op;
+        s.eps_from_prev = chain_in; s.want_eps = chain_out;
         if ((rc = do_substep(c, s, slot()))) return rc;
         t = t0 + dt;
     } else if (order == 2 && fuse) {
@@ -1342,19 +1409,24 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
         t = (1.0 / 3.0) * (t0 + 2 * tThreeHalf);
     } else if (order == 2) {
         SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, work0, nullptr, 0, n0};
+        a.eps_from_prev = chain_in; a.want_eps = true;
         if ((rc = do_substep(c, a, slot()))) return rc;
         SubstepCall b{scheme, ham, HJ_STAGE_RK2_FULL, restrict_sign, par, dt, work0, y_in, y_out, nullptr, 0, n0};
         b.post_op = c->post_step_op;
+        b.eps_from_prev = true; b.want_eps = chain_out;
         if ((rc = do_substep(c, b, slot()))) return rc;
         const double t1 = t0 + dt, t2 = t1 + dt;
         t = 0.5 * (t0 + t2);  // ode_cfl_2.py:200
     } else {
         SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, work0, nullptr, 0, n0};
+        a.eps_from_prev = chain_in; a.want_eps = true;
         if ((rc = do_substep(c, a, slot()))) return rc;
         SubstepCall b{scheme, ham, HJ_STAGE_RK3_HALF, restrict_sign, par, dt, work0, y_in, work1, nullptr, 0, n0};
+        b.eps_from_prev = true; b.want_eps = true;
         if ((rc = do_substep(c, b, slot()))) return rc;
         SubstepCall d{scheme, ham, HJ_STAGE_RK3_FULL, restrict_sign, par, dt, work1, y_in, y_out, nullptr, 0, n0};
         d.post_op = c->post_step_op;
+        d.eps_from_prev = true; d.want_eps = chain_out;
         if ((rc = do_substep(c, d, slot()))) return rc;
         const double t1 = t0 + dt, t2 = t1 + dt;
         const double tHalf = 0.25 * (3 * t0 + t2);       // ode_cfl_3.py:188
@@ -1389,7 +1461,18 @@ int hj_rk_plan(hj_ctx* c, int order, int scheme, int ham, const double* par, int
     int rc = check_ham(c, ham, par);
     if (rc) return rc;
     const bool f = use_stage12(c, order, scheme, ham, par, restrict_sign);
-    if (launches) *launches = (f ? order - 1 : order) * (scheme == HJ_WENO5 ? 3 : 1);
+    if (launches) {
+        *launches = f ? order - 1 : order;
+        if (scheme == HJ_WENO5) {
+            // the epsilon pre-pass (2 launches) in front of every stage -- or, when the tiled kernels reduce max(D1^2) of their
+            // own output (HJ_EPS_FUSE, whole-grid launches of a single domain), in front of the first stage only, with one
+            // seam launch behind each of the other stages' producers
+            const bool fused_eps = c->eps_fuse && !c->force_direct && !(c->direct_below > 0 && c->total < c->direct_below) &&
+                                   !c->halo_lo && !c->halo_hi && !c->weno_src && c->total >= c->eps_fuse_min_cells && c->total < (1ll << 31);
+            const bool one_launch_prepass = c->eps_fuse && !c->force_direct && (c->total / c->N[0] + 1023) / 1024 <= 512;
+            *launches = fused_eps ? 2 * order : (one_launch_prepass ? 2 * order : 3 * order);
+        }
+    }
     if (stage_fused) *stage_fused = f ? 1 : 0;
     return HJ_OK;
 }
@@ -1411,12 +1494,18 @@ int hj_rk_integrate(hj_ctx* c, int order, int scheme, int ham, const double* par
     int64_t steps = 0;
     // stop_tol < 0: the integrators' own test; stop_tol >= 0: HJIPDE_solve's `while tNow < tau[i] - small`
     auto more = [&]() { return stop_tol < 0 ? (tf - t >= small * std::fabs(tf)) : (t < tf - stop_tol); };
+    c->eps_ready = false;
     while (more() && (max_steps <= 0 || steps < max_steps)) {
         void* nxt = outs[steps & 1];
         double tn = t, dt = 0;
+        // the state stays inside this call between the steps: the last launch of a step reduces max(D1^2) for the first
+        // launch of the next one (intended WENO5)
+        c->eps_chain_in = steps > 0;
+        c->eps_chain_out = true;
         // RK3: the first stage buffer doubles as the output; RK2: `work` is the first stage buffer
         int rc = hj_rk_step(c, order, scheme, ham, par, t, tf, factor_cfl, max_step, restrict_sign, cur, nxt,
                             order == 3 ? nxt : work, work, &tn, &dt);
+        c->eps_chain_in = c->eps_chain_out = false;
         if (rc) return rc;
         if (!(tn > t)) return fail(HJ_ESTATE, "time step underflow at t=%g (dt=%g)", t, dt);
         cur = nxt;
@@ -1424,6 +1513,7 @@ int hj_rk_integrate(hj_ctx* c, int order, int scheme, int ham, const double* par
         t = tn;
         ++steps;
     }
+    c->eps_ready = false;
     if (t_out) *t_out = t;
     if (steps_out) *steps_out = steps;
     if (result_in) *result_in = which;
@@ -1445,6 +1535,7 @@ int hj_minmax_with(hj_ctx* c, int op, void* y, const void* other, int64_t n) {
     if (!c || !y || !other) return fail(HJ_EINVAL, "null argument");
     if (op < HJ_OP_MIN || op > HJ_OP_MAX_NEG) return fail(HJ_EINVAL, "unknown op %d", op);
     if (n <= 0) return HJ_OK;
+    c->eps_ready = false;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
     if (c->dtype == HJ_F64)
         hipLaunchKernelGGL((minmax_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, (double*)y, (const double*)other, (long long)n, op);

@@ -91,9 +91,64 @@ template <typename T, int ND> struct FusedArgs {
     int do_clamp;                 // termRestrictUpdate: ydot clamped to [lo, hi]
     T clamp_lo, clamp_hi;
     HamTables<T> ham;
+    // intended WENO5 (round 3): epsilon_d = 1e-6 * max(D1_d^2) of the launch's INPUT (upwind_first_weno5a.py:153-156).
+    // eps_nrows > 0: folded in the prologue from eps_rows (rows of HJ_MAX_DIM doubles: max D1^2) instead of read from max_d1sq;
+    // eps_part != null: this launch reduces its own OUTPUT for the next stage -- one row per workgroup with the largest
+    // |forward difference| per dimension over the pairs inside its tile and chunk; tile / chunk seams and periodic wrap pairs
+    // are eps_seam_kernel's (hj_split.h), which also turns the maxima into D1^2
+    double* eps_part;
+    const double* eps_rows;
+    int eps_nrows;
+    T inv_dx[ND];
     // debug (HJ_TIMING_DUMP): per logical block {start, end} of the constant 100 MHz clock, {xcc id, chunk}
     unsigned long long* timing;
 };
+
+// epsilon of the intended WENO5 from partial rows: every thread of the workgroup ends up with the ND maxima
+template <typename T, int ND, int NT>
+__device__ __forceinline__ void fold_eps_rows(const double* __restrict__ rows, int nrows, double (*red)[ND], T* eps) {
+    double m[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) m[d] = 0.0;
+    for (int i = threadIdx.x; i < nrows; i += NT)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) m[d] = fmax(m[d], rows[(size_t)i * HJ_MAX_DIM + d]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        double w = red[0][d];
+        for (int k = 1; k < NT / 64; ++k) w = fmax(w, red[k][d]);
+        eps[d] = T(1e-6) * (T)w + Lim<T>::tiny;
+    }
+    __syncthreads();          // red is the CFL reduction's scratch as well
+}
+
+// one row of partials per workgroup (eps_part): max |forward difference| per dimension, in double.  (fl(fl(K*x)^2) is
+// monotone in |x| for K > 0, so the maximum of D1^2 = (inv_dx*(a - b))^2 over pairs is that expression of the maximum
+// |a - b|: the seam kernel applies it once, after folding -- two VALU operations per pair here instead of five)
+template <int ND, int NT>
+__device__ __forceinline__ void store_eps_part(double* __restrict__ row, double (*red)[ND], const double* dmax) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double w = wave_max(dmax[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ND) {
+        double w = red[0][threadIdx.x];
+        for (int k = 1; k < NT / 64; ++k) w = fmax(w, red[k][threadIdx.x]);
+        row[threadIdx.x] = w;
+    }
+    __syncthreads();
+}
 
 // where the values of axis-0 plane `p` (possibly a ghost plane) come from: wave-uniform
 template <typename T> struct PlaneSrc {
@@ -197,12 +252,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     typename HAM::Raw hraw[R];
     // only the last round of the deal can run past the tile: shadows compute but do not write
     const bool last_real = (tid + (R - 1) * NT) < tile_cells;
+    unsigned nbv[R];              // bit d: the forward neighbour on plane axis d lies inside the tile (eps_part pairs)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int c = min(tid + r * NT, tile_cells - 1);
         int lo = 0, g = 0;
         int idx[ND];
         idx[0] = 0;
+        nbv[r] = 0u;
 #pragma unroll
         for (int d = ND - 1; d >= 1; --d) {
             int q, j;
@@ -212,6 +269,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             idx[d] = gi;
             lo += (j + HJ_STENCIL) * ls[d];
             g += gi * A.pstride[d];
+            if (j + 1 < A.E[d]) nbv[r] |= 1u << d;
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);   // byte offset within a plane
@@ -386,12 +444,23 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
     for (int d = 0; d < ND; ++d) { wk[d].c13 = T(0); wk[d].c4 = T(0); }
     if constexpr (SCHEME == HJ_WENO5) {
+        if (A.eps_nrows > 0) fold_eps_rows<T, ND, NT>(A.eps_rows, A.eps_nrows, red, eps);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            if (A.eps_nrows <= 0) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
             wk[d] = weno_consts<T>(eps[d], A.K[d]);
         }
     }
+    // max(D1^2) of the output (eps_part): the outputs of a plane are parked in one of two LDS planes behind the two
+    // input planes and meet their in-plane forward neighbours one iteration later, behind that iteration's barrier
+    const bool eps_prod = SCHEME == HJ_WENO5 && A.eps_part != nullptr;
+    T* const obuf = lds + 2 * lds_plane;
+    double dmax[ND];
+    T oprev[R];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dmax[d] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) oprev[r] = T(0);
 
     // the halo ring of a tile that touches an extrapolated edge needs two loads per slot (edge and
     // inner cell).  Both are only ISSUED here; the ghost arithmetic is done when the slot is
@@ -520,6 +589,20 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #else
             if (r < R - 1 || last_real) buf_store<HJ_AUX_ST>(o, rout, own_g[r], so_out);
 #endif
+            if constexpr (SCHEME == HJ_WENO5) {
+                if (eps_prod) {
+                    T* ob = obuf + ((p - p_begin) & 1) * lds_plane;
+                    if (p > p_begin) {
+                        dmax[0] = fmax(dmax[0], (double)t_abs(o - oprev[r]));
+                        const T* op = obuf + ((p - p_begin - 1) & 1) * lds_plane + own_lds[r];     // plane p - 1
+#pragma unroll
+                        for (int d = 1; d < ND; ++d)
+                            if ((nbv[r] >> d) & 1u) dmax[d] = fmax(dmax[d], (double)t_abs(op[ls[d]] - oprev[r]));
+                    }
+                    ob[own_lds[r]] = o;
+                    oprev[r] = o;
+                }
+            }
         }
         HJ_ST(st3);
         load_y0(p2, y0_c);
@@ -558,6 +641,21 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const unsigned long long st_loop1 = wall_clock64(), st_cyc1 = __builtin_readcyclecounter();
 #endif
 
+    if constexpr (SCHEME == HJ_WENO5) {
+        if (eps_prod) {
+            __syncthreads();
+            if (p_end > p_begin) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T* op = obuf + ((p_end - 1 - p_begin) & 1) * lds_plane + own_lds[r];
+#pragma unroll
+                    for (int d = 1; d < ND; ++d)
+                        if ((nbv[r] >> d) & 1u) dmax[d] = fmax(dmax[d], (double)t_abs(op[ls[d]] - oprev[r]));
+                }
+            }
+            store_eps_part<ND, NT>(A.eps_part + (size_t)L * HJ_MAX_DIM, red, dmax);
+        }
+    }
     if (A.bound) {   // a launch whose bound nobody reads (hj_rk_step: dt comes from the static bound) skips the reduction
         {   // alphas that are constant along the march: one max per column, taken once (any plane does)
             T pz[ND], Hz, az[ND];

@@ -145,12 +145,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     typename HAM::Cell hcell[R][2];
     typename HAM::Raw hraw[R][2];
     const bool last_real = (tid + (R - 1) * NT) < tile_slots;
+    unsigned nbv[R];              // bit d: the pair's forward neighbour on plane axis d lies inside the tile (eps_part pairs)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int c = 2 * min(tid + r * NT, tile_slots - 1);
         int lo = 0, g = 0;
         int idx[ND];
         idx[0] = 0;
+        nbv[r] = 0u;
 #pragma unroll
         for (int d = ND - 1; d >= 1; --d) {
             int qd, j;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             idx[d] = gi;
             lo += (j + pad_of(d)) * ls[d];
             g += gi * A.pstride[d];
+            if (j + (d == LA ? 2 : 1) < A.E[d]) nbv[r] |= 1u << d;
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);
@@ -319,12 +322,23 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
     for (int d = 0; d < ND; ++d) { eps[d] = T(0); wk[d].c13 = T(0); wk[d].c4 = T(0); }
     if constexpr (SCHEME == HJ_WENO5) {
+        if (A.eps_nrows > 0) fold_eps_rows<T, ND, NT>(A.eps_rows, A.eps_nrows, red, eps);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            if (A.eps_nrows <= 0) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
             wk[d] = weno_consts<T>(eps[d], A.K[d]);
         }
     }
+    // max(D1^2) of the output (eps_part, hj_fused.h): two more LDS planes behind the ring park the outputs of a plane
+    // until the next iteration's barrier
+    const bool eps_prod = SCHEME == HJ_WENO5 && A.eps_part != nullptr;
+    T* const obuf = lds + A.lds_nbuf * lds_plane;
+    double dmax[ND];
+    V oprev[R];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dmax[d] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { oprev[r].x = T(0); oprev[r].y = T(0); }
 
     auto load_halo = [&](int p, T* dst, T* dst_in) {
         const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
@@ -477,6 +491,25 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 if (c == 0) o2.x = o; else o2.y = o;
             }
             if (r < R - 1 || last_real) buf_store2(o2, rout, own_g[r], so_out);
+            if constexpr (SCHEME == HJ_WENO5) {
+                if (eps_prod) {
+                    T* ob = obuf + ((p - p_begin) & 1) * lds_plane;
+                    dmax[LA] = fmax(dmax[LA], (double)t_abs(o2.y - o2.x));      // the pair itself
+                    if (p > p_begin) {
+                        dmax[0] = fmax(dmax[0], fmax((double)t_abs(o2.x - oprev[r].x), (double)t_abs(o2.y - oprev[r].y)));
+                        const T* op = obuf + ((p - p_begin - 1) & 1) * lds_plane + own_lds[r];     // plane p - 1
+#pragma unroll
+                        for (int d = 1; d < LA; ++d)
+                            if ((nbv[r] >> d) & 1u) {
+                                const V n2 = *reinterpret_cast<const V*>(op + ls[d]);
+                                dmax[d] = fmax(dmax[d], fmax((double)t_abs(n2.x - oprev[r].x), (double)t_abs(n2.y - oprev[r].y)));
+                            }
+                        if ((nbv[r] >> LA) & 1u) dmax[LA] = fmax(dmax[LA], (double)t_abs(op[2] - oprev[r].y));
+                    }
+                    *reinterpret_cast<V*>(ob + own_lds[r]) = o2;
+                    oprev[r] = o2;
+                }
+            }
         }
 #ifdef HJ_STAMP
         const unsigned long long st3 = __builtin_readcyclecounter();
@@ -505,6 +538,25 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
 
+    if constexpr (SCHEME == HJ_WENO5) {
+        if (eps_prod) {
+            __syncthreads();
+            if (p_end > p_begin) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T* op = obuf + ((p_end - 1 - p_begin) & 1) * lds_plane + own_lds[r];
+#pragma unroll
+                    for (int d = 1; d < LA; ++d)
+                        if ((nbv[r] >> d) & 1u) {
+                            const V n2 = *reinterpret_cast<const V*>(op + ls[d]);
+                            dmax[d] = fmax(dmax[d], fmax((double)t_abs(n2.x - oprev[r].x), (double)t_abs(n2.y - oprev[r].y)));
+                        }
+                    if ((nbv[r] >> LA) & 1u) dmax[LA] = fmax(dmax[LA], (double)t_abs(op[2] - oprev[r].y));
+                }
+            }
+            store_eps_part<ND, NT>(A.eps_part + (size_t)L * HJ_MAX_DIM, red, dmax);
+        }
+    }
     if (A.bound) {   // a launch whose bound nobody reads (hj_rk_step: dt comes from the static bound) skips the reduction
         {   // alpha of the dimensions that do not vary along the march: column constants, taken once (any plane does)
             T pz[ND], Hz, az[ND];

@@ -122,6 +122,14 @@ struct hj_ctx {
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
     int last_nbuf = 2;
+    // intended WENO5: max(D1^2) of a stage's output reduced inside the producing launch (hj_fused.h, eps_part) + eps_seam_kernel
+    long long eps_fuse_min_cells = 2000000;         // HJ_EPS_FUSE_MIN_CELLS: below, launch floors make the pre-pass as fast (51^3: faster)
+    int eps_fuse = 1;                               // HJ_EPS_FUSE=0: always the two-launch pre-pass (max_d1sq_kernel)
+    double* eps_prod = nullptr;                     // one row per workgroup of the producing launch
+    size_t eps_prod_cap = 0;
+    double* eps_rows = nullptr;                     // HJ_EPS_ROWS rows of the seam kernel: what the next launch folds
+    bool eps_chain_in = false, eps_chain_out = false;   // hj_rk_integrate: the state stays inside the call between steps
+    bool eps_ready = false;                         // eps_rows describe the output of the last launch
     int keep_bounds = 0;                            // HJ_KEEP_BOUNDS: reduce the CFL bound in launches whose bound nobody reads
     int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
@@ -140,6 +148,7 @@ int env_int(const char* name, int dflt);
 Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1, int nbuf = 2, std::vector<Tiling>* all = nullptr);
 void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu);
 int cfg_kh(int nd, int nt, int r);
+int eps_rows_to_vals(hj_ctx* c, const double* rows, int nrows, hipStream_t stream);   // rows -> ctx->weno_vals (kernels that do not fold)
 
 template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
     for (int d = 0; d < HJ_MAX_DIM; ++d) H.coord[d] = (const T*)c->coord[d];
@@ -188,7 +197,13 @@ struct SubstepCall {
     int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
     int post_op = 0;          // fused post-step min/max with the state the step started from
     bool on_aux = false;      // launch on the ctx's auxiliary (edge) stream instead of the ctx stream
+    // intended WENO5 inside hj_rk_step / hj_rk_integrate: this launch's output is the next launch's input (reduce max(D1^2)
+    // of it in this launch), and this launch's input was the previous launch's output (its epsilon rows are ready)
+    bool want_eps = false, eps_from_prev = false;
+    const double* eps_rows = nullptr;   // set by do_substep: fold these rows of max D1^2 (HJ_MAX_DIM doubles each) instead of
+    int eps_nrows = 0;                  // reading weno_vals
 };
+constexpr int HJ_EPS_ROWS = 256;  // workgroups (= rows) of eps_seam_kernel
 
 inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s.on_aux ? c->edge_stream : c->stream; }
 

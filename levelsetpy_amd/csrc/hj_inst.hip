@@ -10,6 +10,14 @@
 
 namespace hjh {
 
+// does this launch reduce max(D1^2) of its own output for the next stage's epsilon (intended WENO5; FusedArgs::eps_part)?
+// Whole-grid launches of a single domain only: the seam kernel enumerates tile and chunk seams from plane 0.
+inline bool eps_producer(const hj_ctx* c, const SubstepCall& s) {
+    return s.scheme == HJ_WENO5 && s.want_eps && c->eps_fuse && s.stage != HJ_STAGE_YDOT && s.p0 == 0 && s.p1 == c->N[0] &&
+           s.q1 <= s.q0 && !c->halo_lo && !c->halo_hi && !s.on_aux && !c->weno_src && c->total >= c->eps_fuse_min_cells &&
+           c->total < (1ll << 31);
+}
+
 // PAIR: the two-cells-per-lane kernel (hj_fusedv.h; R = pairs per thread) instead of fused_substep_kernel
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE, bool PAIR>
 auto tiled_kernel() {
@@ -49,8 +57,20 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     memset(&A, 0, sizeof(A));
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
     A.bound = s.bound;
+    const bool produce = SCHEME == HJ_WENO5 && eps_producer(c, s);
+    if (produce) {
+        if ((size_t)t.nblocks > c->eps_prod_cap) {
+            if (c->eps_prod) { HIP_TRY(hipFree(c->eps_prod)); c->eps_prod = nullptr; c->eps_prod_cap = 0; }
+            const size_t cap = std::max<size_t>(4096, 2 * (size_t)t.nblocks);
+            HIP_TRY(hipMalloc((void**)&c->eps_prod, cap * HJ_MAX_DIM * sizeof(double)));
+            c->eps_prod_cap = cap;
+        }
+        A.eps_part = c->eps_prod;
+    }
+    if (SCHEME == HJ_WENO5 && s.eps_nrows > 0) { A.eps_rows = s.eps_rows; A.eps_nrows = s.eps_nrows; }
     long long st = 1;
     for (int d = ND - 1; d >= 0; --d) {
+        A.inv_dx[d] = (T)(1.0 / c->dx[d]);
         A.n[d] = (int)c->N[d];
         A.bc[d] = c->bc[d];
         A.km[d] = c->tz[d] ? T(-1) : T(1);
@@ -125,6 +145,22 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
                            (T*)s.out, A);
     }
     HIP_TRY(hipGetLastError());
+    if (produce) {
+        // tile / chunk seams and wrap pairs of the output + the fold of the launch's rows: HJ_EPS_ROWS rows for the next launch
+        SeamArgs<T, ND> S;
+        memset(&S, 0, sizeof(S));
+        S.y = (const T*)s.out;
+        fill_grid<T, ND>(c, S.G);
+        for (int d = 0; d < ND; ++d) { S.E[d] = t.E[d]; S.ntile[d] = t.ntile[d]; }
+        S.chunk = t.chunk;
+        S.nchunks = t.nchunks;
+        S.prod = c->eps_prod;
+        S.nprod = t.nblocks;
+        S.rows = c->eps_rows;
+        hipLaunchKernelGGL((eps_seam_kernel<T, ND>), dim3(HJ_EPS_ROWS), dim3(1024), 0, call_stream(c, s), S);
+        HIP_TRY(hipGetLastError());
+        c->eps_ready = true;
+    }
     if (tbuf) {
         std::vector<unsigned long long> h((size_t)t.nblocks * 12);
         HIP_TRY(hipStreamSynchronize(call_stream(c, s)));
@@ -238,6 +274,12 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.y0 = (const T*)s.y0;
     A.out = (T*)s.out;
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    if (SCHEME == HJ_WENO5 && s.eps_nrows > 0) {
+        // this kernel does not fold rows: one more (small) launch turns them into the ND values
+        int rc = eps_rows_to_vals(c, s.eps_rows, s.eps_nrows, call_stream(c, s));
+        if (rc) return rc;
+        A.max_d1sq = (const T*)c->weno_vals;
+    }
     A.bound = s.bound;
     fill_grid<T, ND>(c, A.G);
     for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
@@ -286,6 +328,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
         const bool small = c->direct_below > 0 && c->total < c->direct_below && HAM::ND <= 3 &&
                            s.p0 >= 0 && s.p1 <= c->N[0] && s.q1 <= s.q0;
         if (!c->force_direct && !small) {
+            const bool produce = SCHEME == HJ_WENO5 && eps_producer(c, s);      // two more LDS planes (hj_fused.h, eps_part)
             KernelCfg k = c->cfg;
             int pd = c->pd, occ = c->occ_hint;
             if (!c->cfg_from_env) {
@@ -325,9 +368,10 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && HAM::ND <= 3 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
                 c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
                 const long long key = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (1ll << 35) |
-                                      ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0);
+                                      ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0) |
+                                      (produce ? 2ll : 0ll);
                 TuneTrial tr;
-                const Tiling tp = tune_begin<HAM::ND>(c, s, kp, 2, c->last_nbuf, key, tr);
+                const Tiling tp = tune_begin<HAM::ND>(c, s, kp, 2, c->last_nbuf + (produce ? 2 : 0), key, tr);
                 if (tp.ok) {
                     int rc_t = -12345;
 #define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true, (int)sizeof(T))) { if (rc_t == -12345 && kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
@@ -340,10 +384,10 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                                          kp.NT, kp.R, kp.KH, occp, SCHEME);
                 }
             }
-            const long long key1 = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) |
+            const long long key1 = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (produce ? (1ll << 34) : 0ll) |
                                    ((long long)k.NT << 20) | ((long long)k.R << 12) | ((long long)k.KH << 4) | (long long)pd;
             TuneTrial tr1;
-            Tiling t = tune_begin<HAM::ND>(c, s, k, 1, 2, key1, tr1);
+            Tiling t = tune_begin<HAM::ND>(c, s, k, 1, produce ? 4 : 2, key1, tr1);
             if (t.ok) {
                 int rc_t = -12345;
 #define X(NT_, R_, KH_, OCC_, PD_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, false, (int)sizeof(T))) { if (rc_t == -12345 && k.NT == NT_ && k.R == R_ && k.KH == KH_ && pd == PD_ && occ == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, PD_>(c, s, t); }

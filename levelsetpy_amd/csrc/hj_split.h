@@ -132,9 +132,9 @@ __device__ __forceinline__ void decode(const GridArgs<T, ND>& G, long long t, in
 // plus ND-1 neighbour loads that adjacent lanes / rows also issue (L1/L2 hits), no divisions in the
 // loop.  Every workgroup leaves its ND partial maxima in partials[block][d] (no contended atomics);
 // partials_to_values_kernel folds them.
-template <typename T, int ND>
-__global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, GridArgs<T, ND> G,
-                                                       double* __restrict__ partials, int chunk) {
+template <typename T, int ND, int NT = 256>
+__global__ __launch_bounds__(NT) void max_d1sq_kernel(const T* __restrict__ y, GridArgs<T, ND> G,
+                                                      double* __restrict__ partials, int chunk) {
     double m[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) m[d] = 0.0;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, 
             }
         }
     }
-    __shared__ double red[4][ND];
+    __shared__ double red[NT / 64][ND];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
@@ -210,8 +210,98 @@ __global__ __launch_bounds__(256) void max_d1sq_kernel(const T* __restrict__ y, 
     __syncthreads();
     if (threadIdx.x < ND) {
         const int d = threadIdx.x;
-        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
+        double w = red[0][d];
+#pragma unroll
+        for (int k = 1; k < NT / 64; ++k) w = fmax(w, red[k][d]);
         partials[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * HJ_MAX_DIM + d] = w;
+    }
+}
+
+// ---- the pairs a tiled launch cannot see when it reduces max(D1^2) of its own output (FusedArgs::eps_part, hj_fused.h):
+// pairs that straddle two tiles (plane axes), two chunks (axis 0), and the periodic wrap pair of every periodic axis.
+// The same launch folds the producer's per-workgroup rows: workgroup g leaves ONE row (HJ_MAX_DIM doubles) in rows[g],
+// gridDim.x rows in all, which the next substep kernel folds in its prologue (no atomics, no second launch).
+template <typename T, int ND> struct SeamArgs {
+    const T* y;
+    GridArgs<T, ND> G;
+    int E[ND], ntile[ND];        // tiling of the producing launch (plane axes)
+    int chunk, nchunks;          // its axis-0 chunks: [k*chunk, (k+1)*chunk)
+    const double* prod;          // its rows
+    int nprod;
+    double* rows;
+};
+
+template <typename T, int ND>
+__global__ __launch_bounds__(1024) void eps_seam_kernel(const SeamArgs<T, ND> A) {
+    // m[d]: largest |forward difference| on axis d (the producer's rows hold the same quantity); D1^2 = (inv_dx*m)^2 at the end
+    double m[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) m[d] = 0.0;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    for (long long i = gtid; i < A.nprod; i += nthreads)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) m[d] = fmax(m[d], A.prod[(size_t)i * HJ_MAX_DIM + d]);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int n = A.G.n[d];
+        const int nint = (d == 0 ? A.nchunks : A.ntile[d]) - 1;            // interior seams
+        const int nface = nint + (A.G.bc[d] == HJ_BC_PERIODIC ? 1 : 0);
+        const unsigned per_face = (unsigned)(A.G.total / n);               // < 2^31: checked by the host
+        const long long items = (long long)nface * per_face;
+        // offsets of pair `it` (the cell and its forward neighbour); false if the seam coincides with the end of the axis
+        auto locate = [&](long long it, long long& off, long long& nxt) -> bool {
+            if (it >= items) return false;
+            const unsigned f = (unsigned)(it / per_face);
+            unsigned c = (unsigned)(it - (long long)f * per_face);
+            int i;
+            long long step = A.G.stride[d];
+            if ((int)f < nint) {
+                i = (d == 0) ? ((int)f + 1) * A.chunk - 1 : min((int)f * A.E[d], n - A.E[d]) + A.E[d] - 1;
+                if (i + 1 >= n) return false;
+            } else {
+                i = n - 1;
+                step = -(long long)(n - 1) * A.G.stride[d];
+            }
+            off = (long long)i * A.G.stride[d];
+#pragma unroll
+            for (int e = ND - 1; e >= 0; --e) {
+                if (e == d) continue;
+                const unsigned q = c / (unsigned)A.G.n[e];
+                off += (long long)(c - q * (unsigned)A.G.n[e]) * A.G.stride[e];
+                c = q;
+            }
+            nxt = off + step;
+            return true;
+        };
+        constexpr int U = 4;               // pairs in flight per thread
+        for (long long it = gtid; it < items; it += U * nthreads) {
+            T a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                long long off = 0, nxt = 0;
+                const bool ok = locate(it + u * nthreads, off, nxt);
+                a[u] = ok ? A.y[off] : T(0);
+                b[u] = ok ? A.y[nxt] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[d] = fmax(m[d], (double)t_abs(b[u] - a[u]));
+        }
+    }
+    __shared__ double red[16][ND];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ND) {
+        const int d = threadIdx.x;
+        double w = red[0][d];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) w = fmax(w, red[k][d]);
+        const T D1 = A.G.inv_dx[d] * (T)w;                                   // upwind_first_weno5a.py:153-156 on the largest |difference|
+        A.rows[(size_t)blockIdx.x * HJ_MAX_DIM + d] = (double)(D1 * D1);
     }
 }
 

@@ -867,3 +867,64 @@ def test_pair_kernel_bitwise_equals_scalar_kernel(scheme, n, pd, tz, monkeypatch
             assert torch.equal(a, b), "%s: max diff %g at %s" % (other, float((a - b).abs().max()),
                                                                  np.unravel_index(int((a - b).abs().argmax()), n))
     assert float((res["0"][0][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 0
+
+
+@pytest.mark.parametrize("pair", ["0", "2"])
+@pytest.mark.parametrize("case", ["dubins_odd", "dubins_big", "integrator_2d"])
+def test_weno5_epsilon_reduced_in_the_producing_launch_is_bitwise_the_pre_pass(case, pair, monkeypatch):
+    """Intended WENO5: epsilon_d = 1e-6 max(D1_d^2) of a stage's input (upwind_first_weno5a.py:153-156).  Inside hj_rk_step /
+    hj_rk_integrate the tiled kernels reduce max(D1^2) of their OUTPUT themselves (pairs inside a tile and chunk;
+    eps_seam_kernel adds tile / chunk seams and periodic wrap pairs and folds the rows), so that only the first stage of a
+    step runs the two-launch pre-pass.  A max over the same set of values: states and times must be bit for bit those of
+    HJ_EPS_FUSE=0, through both tiled kernels, step-wise and inside hj_rk_integrate, RK1 / RK2 / RK3."""
+    if case == "integrator_2d":
+        g, _ = mk([-1.3, -1.1], [1.2, 1.4], [157, 203], None)
+        ham, par = _ffi.HAM_DOUBLE_INTEGRATOR, [1.0, 0., 0., 0.]
+        rng = np.random.default_rng(5)
+        x0, x1 = np.meshgrid(np.linspace(-1.3, 1.2, 157), np.linspace(-1.1, 1.4, 203), indexing="ij")
+        data = np.sqrt(x0 ** 2 + x1 ** 2) - 0.6 + 0.01 * rng.standard_normal(x0.shape)
+    else:
+        n = (37, 29, 42) if case == "dubins_odd" else (150, 140, 130)       # 2.7 M cells: the pair kernel by default
+        g, _ = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], list(n), 2)
+        ham, par = _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0]
+        rng = np.random.default_rng(6)
+        xs = np.meshgrid(*[np.linspace(-1, 1, k) for k in n], indexing="ij")
+        data = np.sqrt(xs[0] ** 2 + xs[1] ** 2) - 0.5 + 0.1 * np.sin(3 * xs[2]) + 0.01 * rng.standard_normal(n)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("HJ_EPS_FUSE", fuse)
+        monkeypatch.setenv("HJ_EPS_FUSE_MIN_CELLS", "0")      # default: only grids of 2 M cells and more (launch floors below)
+        monkeypatch.setenv("HJ_PAIR", pair)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        y = torch.as_tensor(data, device="cuda", dtype=torch.float64).contiguous()
+        outs = []
+        for order in (3, 2, 1):
+            # two single steps through hj_rk_step ...
+            cur, t = y, 0.0
+            for _ in range(2):
+                nxt, w0, w1 = dg.empty(), dg.empty(), dg.empty()
+                tn, dt = C.c_double(), C.c_double()
+                _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, _ffi.SCHEME_IDS["WENO5"], ham, _ffi.darr(par), t, 10.0, 0.8, 1e30, 0,
+                                             dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tn), C.byref(dt)))
+                cur, t = nxt, tn.value
+            dg.sync()
+            outs.append((cur.clone(), t))
+            # ... and three steps inside one hj_rk_integrate call (the epsilon chain crosses the steps)
+            a, b, w = dg.empty(), dg.empty(), dg.empty()
+            tt, ns, which = C.c_double(), C.c_int64(), C.c_int()
+            _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, _ffi.SCHEME_IDS["WENO5"], ham, _ffi.darr(par), 0.0, 10.0, 0.8, 1e30, 0,
+                                              dg.ptr(y), dg.ptr(a), dg.ptr(b), dg.ptr(w), 3, -1.0, C.byref(tt), C.byref(ns), C.byref(which)))
+            dg.sync()
+            assert ns.value == 3
+            outs.append(((y, a, b)[which.value].clone(), tt.value))
+        assert dg.lib.hj_last_kernel(dg.ctx) == (b"fused_pair_kernel" if pair == "2" else b"fused_substep_kernel")
+        nl, fz = C.c_int(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_plan(dg.ctx, 3, _ffi.SCHEME_IDS["WENO5"], ham, _ffi.darr(par), 0, C.byref(nl), C.byref(fz)))
+        assert nl.value == (6 if fuse == "1" else 9)      # pre-pass (one launch) + 3 substep launches + 2 seam launches | 3 x 3
+        res[fuse] = outs
+        del dg
+    for (ya, ta), (yb, tb) in zip(res["0"], res["1"]):
+        assert ta == tb
+        assert torch.equal(ya, yb), float((ya - yb).abs().max())
+    assert float((res["1"][0][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 1e-6
