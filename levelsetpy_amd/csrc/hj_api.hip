@@ -655,6 +655,33 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
         if (scheme == HJ_WENO5) c->weno_src = nullptr;
         return rc;
     }
+    if (c->slab_serial) {
+        // Round 3 (HJ_SLAB_SCHEDULE=serial, default): edges_s and interior_s share the ctx stream, edges first; only the
+        // exchange runs beside them.  The "overlap" schedule below lets interior_s start as soon as interior_{s-1} is done,
+        // so that edges_s -- gated by the exchange of substep s-1 -- find every CU taken by interior_s and need 45-60 us
+        // for three planes a free GPU computes in ~10: its critical path is comm -> edges -> comm at 110-120 us per substep
+        // of a 65-plane slab (profiles/r03_thin_slab_timeline.txt).  Here edges_s run alone right after interior_{s-1}
+        // (the exchange of substep s-1 finished long before, under that interior), and the exchange of substep s hides
+        // under interior_s: the critical path is edges + interior on one stream.
+        if (c->slab_pending) HIP_TRY(hipStreamWaitEvent(main, c->ev_comm, 0));
+        {
+            SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, 0, 0};
+            if (lo_e > 0) { s.p0 = 0; s.p1 = lo_e; if (hi_b < n) { s.q0 = hi_b; s.q1 = n; } }
+            else { s.p0 = hi_b; s.p1 = n; }
+            if ((rc = do_substep(c, s, -1))) return rc;
+        }
+        HIP_TRY(hipEventRecord(c->ev_edge, main));
+        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
+        if ((rc = post_halo(c, out, c->comm_stream))) return rc;
+        HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+        c->slab_pending = 1;
+        if (hi_b > lo_e) {
+            SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, lo_e, hi_b};
+            if ((rc = do_substep(c, s, -1))) return rc;
+        }
+        if (scheme == HJ_WENO5) c->weno_src = nullptr;
+        return HJ_OK;
+    }
     // everything launched on main so far (interior_{s-1}, eps pass) gates the edges
     HIP_TRY(hipEventRecord(c->ev_start, main));
     HIP_TRY(hipStreamWaitEvent(c->edge_stream, c->ev_start, 0));
@@ -923,6 +950,13 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // 201^3-class grids 2 is 0.7 % faster (one plane less to fetch synchronously in the setup; same-box A/B r02_run43.sh)
     c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
     c->lds_pitch_add = env_int("HJ_LDS_PITCH_ADD", 0) & ~1;
+    {
+        // per-substep slab schedule: "serial" or "overlap" (rounds 1-2); default by slab thickness -- on the single-GPU self
+        // ring (profiles/r03_slab_schedule_ab.txt) serial wins on the 257-plane slab (+4 %), ties at 129 planes and loses on
+        // the 65-plane slab (-13 %: the exchange kernel finds every CU's LDS taken by the interior and starts late)
+        const char* sch = getenv("HJ_SLAB_SCHEDULE");
+        c->slab_serial = sch ? !strcmp(sch, "serial") : (N[0] >= 192);
+    }
     c->eps_fuse_min_cells = (long long)env_int("HJ_EPS_FUSE_MIN_CELLS", 2000000);
     c->eps_fuse = env_int("HJ_EPS_FUSE", 1);         // 0: the intended WENO5 always runs its two-launch epsilon pre-pass
     c->keep_bounds = env_int("HJ_KEEP_BOUNDS", 0);   // 1: every launch reduces its CFL bound, read or not (round-2 behaviour; A/B)
