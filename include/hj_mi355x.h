@@ -296,6 +296,9 @@ const char* hj_last_kernel(hj_ctx* ctx);
 /* LDS schedule of that launch: plane buffers in the ring (2 = double buffer) and how many planes ahead of its use the halo
  * ring of a plane is parked in LDS (0 = staged in the iteration that consumes it); tests assert the variant that ran. */
 int hj_last_launch(hj_ctx* ctx, int* lds_nbuf_host, int* halo_ahead_host);
+/* Tile extents of the last tiled launch on the plane axes (extents_host[0] = planes per chunk, [d] = cells on axis d, 0 beyond
+ * the grid's dimension; all 0 after a direct launch): tests assert that the launch-time tuner rotates through tile shapes. */
+int hj_last_tile(hj_ctx* ctx, int* extents_host /* HJ_MAX_DIM */);
 const char* hj_version(void);
 
 #ifdef __cplusplus

@@ -72,6 +72,7 @@ SIGNATURES = {
     "hj_last_error": (C.c_char_p, []),
     "hj_last_kernel": (C.c_char_p, [C.c_void_p]),
     "hj_last_launch": (_i, [_vp, _pi, _pi]),
+    "hj_last_tile": (_i, [_vp, _pi]),
     "hj_version": (C.c_char_p, []),
 }
 

@@ -864,6 +864,11 @@ int hj_last_launch(hj_ctx* c, int* nbuf, int* ahead) {
     if (ahead) *ahead = (pair && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
     return HJ_OK;
 }
+int hj_last_tile(hj_ctx* c, int* e) {
+    if (!c || !e) return fail(HJ_EINVAL, "null argument");
+    for (int d = 0; d < HJ_MAX_DIM; ++d) e[d] = c->last_E[d];
+    return HJ_OK;
+}
 const char* hj_version(void) { return "hj_mi355x 0.1 (gfx950)"; }
 
 int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,

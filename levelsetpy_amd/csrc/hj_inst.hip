@@ -115,6 +115,8 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     fill_ham<T>(c, s.par, A.ham);
     auto kern = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
     c->last_kernel = PAIR ? "fused_pair_kernel" : "fused_substep_kernel";
+    c->last_E[0] = t.chunk;
+    for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < ND ? t.E[d] : 0;
     if (t.lds_bytes > 64 * 1024) {
         // once per (device, kernel), raised but never lowered: the attribute belongs to the function, not to a context
         static std::mutex mu;
@@ -303,6 +305,7 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
         if (cells <= 0) continue;
         int blocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
         c->last_kernel = "direct_substep_kernel";
+        for (int d = 0; d < HJ_MAX_DIM; ++d) c->last_E[d] = 0;
         hipLaunchKernelGGL((direct_substep_kernel<T, HAM, SCHEME>), dim3(blocks), dim3(256), 0, call_stream(c, s), A);
         HIP_TRY(hipGetLastError());
     }

@@ -928,3 +928,45 @@ def test_weno5_epsilon_reduced_in_the_producing_launch_is_bitwise_the_pre_pass(c
         assert ta == tb
         assert torch.equal(ya, yb), float((ya - yb).abs().max())
     assert float((res["1"][0][0] - torch.as_tensor(data, device="cuda")).abs().max()) > 1e-6
+
+
+@pytest.mark.parametrize("scheme,pair", [("WENO5_ASSHIPPED", "2"), ("WENO5_ASSHIPPED", "0"), ("ENO3", "2"), ("WENO5", "2")])
+def test_tile_shape_rotation_of_the_launch_time_tuner_does_not_change_a_bit(scheme, pair, monkeypatch):
+    """On grids of >= 40 M cells the first launches of a launch shape take turns through candidate tile shapes, each timed
+    with a pair of events, before the fastest is kept (TuneState, hj_inst.hip).  The launches of the rotation are ordinary
+    launches: with the threshold lowered to 0 on a 96 x 90 x 100 grid, 14 RK3 steps (84 launches: through the rotation and past
+    its end) must give the state and time of HJ_AUTOTUNE=0 bit for bit, and the rotation must really have happened."""
+    n = (96, 90, 100)
+    g, _ = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], list(n), 2)
+    rng = np.random.default_rng(8)
+    xs = np.meshgrid(*[np.linspace(-1, 1, k) for k in n], indexing="ij")
+    data = np.sqrt(xs[0] ** 2 + xs[1] ** 2) - 0.5 + 0.1 * np.sin(3 * xs[2]) + 0.01 * rng.standard_normal(n)
+    par = [1.0, 1.0, 1.0, 2.0]
+    res = {}
+    for tune in ("0", "1"):
+        monkeypatch.setenv("HJ_AUTOTUNE", tune)
+        monkeypatch.setenv("HJ_AUTOTUNE_MIN_MCELLS", "0")
+        monkeypatch.setenv("HJ_AUTOTUNE_PASSES", "3")
+        monkeypatch.setenv("HJ_PAIR", pair)
+        monkeypatch.setenv("HJ_EPS_FUSE_MIN_CELLS", "0")
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        cur, t = torch.as_tensor(data, device="cuda", dtype=torch.float64).contiguous(), 0.0
+        shapes = set()
+        for _ in range(14):
+            nxt, w0, w1 = dg.empty(), dg.empty(), dg.empty()
+            tn, dt = C.c_double(), C.c_double()
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, _ffi.darr(par), t, 10.0, 0.8, 1e30, 0,
+                                         dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tn), C.byref(dt)))
+            e = (C.c_int * 4)()
+            _ffi.check(dg.lib.hj_last_tile(dg.ctx, e))
+            shapes.add(tuple(e)[1:])
+            cur, t = nxt, tn.value
+        dg.sync()
+        assert dg.lib.hj_last_kernel(dg.ctx) == (b"fused_pair_kernel" if pair == "2" else b"fused_substep_kernel")
+        res[tune] = (cur.clone(), t, shapes)
+        del dg
+    assert res["0"][1] == res["1"][1]
+    assert torch.equal(res["0"][0], res["1"][0]), float((res["0"][0] - res["1"][0]).abs().max())
+    assert len(res["0"][2]) == 1, res["0"][2]
+    assert len(res["1"][2]) >= 2, "the tuner did not rotate through tile shapes: %r" % (res["1"][2],)
