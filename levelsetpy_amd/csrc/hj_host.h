@@ -225,9 +225,10 @@ inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s
 #endif
 #endif
 
-// 4-D grids tile three plane axes: the halo cross is ~2x the tile, so more halo slots per thread
+// 4-D grids tile three plane axes: the halo cross is ~2x the tile, so more halo slots per thread (cfg_built() says which of these
+// a (dtype, scheme) really compiles)
 #ifndef HJ_CONFIGS_4D
-#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2)
+#define HJ_CONFIGS_4D(X) X(512, 2, 4, 2, 2) X(1024, 1, 3, 2, 2) X(512, 1, 4, 2, 2)
 #endif
 
 // light stencils: few enough live values that 4 cells (2 pairs) per thread fit in 256 VGPRs without scratch
@@ -238,8 +239,9 @@ constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz =
     return true;
 #else
     // 4-D (three tiled plane axes): fp32 runs 1024 single cells or -- light stencils, round 3 -- 256 threads x 2 pairs
-    // (two independent workgroups per CU); fp64 512 x 2 cells.  The other combinations spill and nobody selects them.
-    if (nd == 4) return pair ? (esz == 4 && light_scheme(scheme)) : (esz == 4 ? nt == 1024 : nt == 512);
+    // (two independent workgroups per CU); fp64 512 x 1 cell (two cells spill 68-308 B and are 20-100 % slower for every stencil
+    // but ENO2, tools/experiments/r03_run44.sh).  The other combinations spill and nobody selects them.
+    if (nd == 4) return pair ? (esz == 4 && light_scheme(scheme)) : (esz == 4 ? nt == 1024 : (nt == 512 && r == 1));
     if (pair) return light_scheme(scheme) ? (nt == 512 && r == 2) || (nt == 256 && r == 1) : (nt == 256 && r == 1);
     return light_scheme(scheme) ? true : (nt == 256 && r == 2);
 #endif

@@ -337,7 +337,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             if (!c->cfg_from_env) {
                 // round-1 sweeps (profiles/): the heavier the per-cell arithmetic, the fewer cells per
                 // thread fit in the 256-VGPR budget without scratch
-                if (HAM::ND == 4) { k.NT = sizeof(T) == 4 ? 1024 : 512; k.R = sizeof(T) == 4 ? 1 : 2; pd = 2; occ = 2; }
+                if (HAM::ND == 4) { k.NT = sizeof(T) == 4 ? 1024 : 512; k.R = 1; pd = 2; occ = 2; }
                 // the light stencils keep 4 cells per thread in registers on large grids; below ~12 M cells
                 // (201^3 = 8.1 M: 32 k cells per CU) three small independent workgroups per CU with longer
                 // chunks win (sweeps at 101^3 ... 401^3 after the deferred-ghost fix)
