@@ -195,8 +195,9 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
 #ifndef HJ_CONFIGS_PAIR
 #define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(512, 2, 2, 2)
 #endif
-// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile): the pair kernel was measured 5-15 % slower
-// there in round 2 and every fp64 shape of it spills; built only where a tuning build defines the table
+// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile, 10 halo slots per thread): fp32 with a light stencil only
+// (cfg_built): 256 threads x 2 pairs = the 1024-cell tile of the one-cell-per-lane kernel in TWO independent workgroups per CU,
+// +6 % on C5 (profiles/r03_c5_config_sweep.txt); every fp64 shape spills
 #ifndef HJ_CONFIGS_PAIR_4D
 #define HJ_CONFIGS_PAIR_4D(X) X(256, 2, 10, 2)
 #endif
