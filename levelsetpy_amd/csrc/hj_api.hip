@@ -946,7 +946,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->direct_below = env_int("HJ_DIRECT_BELOW", 0);
     c->f12_pair = env_int("HJ_F12_PAIR", 1);
     c->f12_e1 = env_int("HJ_F12_E1", 0);
-    c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on 2-D / 3-D grids of >= 2.5 M cells (0: scalar kernel everywhere, 2: pair kernel whatever the size)
+    c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on grids of >= 6.5 M cells (light stencils) / 2.5 M (heavy stencils, fp32 4-D) (0: scalar kernel everywhere, 2: pair kernel whatever the size)
     c->pair_nt = env_int("HJ_PAIR_NT", 0);
     c->pair_r = env_int("HJ_PAIR_R", 0);
     c->pair_kh = env_int("HJ_PAIR_KH", 0);
@@ -965,7 +965,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->eps_fuse_min_cells = (long long)env_int("HJ_EPS_FUSE_MIN_CELLS", 2000000);
     c->eps_fuse = env_int("HJ_EPS_FUSE", 1);         // 0: the intended WENO5 always runs its two-launch epsilon pre-pass
     c->keep_bounds = env_int("HJ_KEEP_BOUNDS", 0);   // 1: every launch reduces its CFL bound, read or not (round-2 behaviour; A/B)
-    c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) (512,2) configuration on >= 8 M cells
+    c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) with the (512,2) configuration
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);
     if (getenv("HJ_KH")) c->cfg.KH = env_int("HJ_KH", c->cfg.KH);
     c->pd = env_int("HJ_PD", 2);

@@ -354,7 +354,10 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             }
             // 4-D: fp32 with a light stencil only (C5; round 3: 256 threads x 2 pairs, two workgroups per CU: +8 % over 1024 single cells)
             const bool pair_dim = HAM::ND <= 3 || (sizeof(T) == 4 && light_scheme(SCHEME)) || c->pair_nt > 0;
-            if (c->pair != 0 && pair_dim && (c->total >= 2500000 || c->pair_nt > 0 || c->pair == 2)) {
+            // light stencils on 2-D / 3-D grids: from 6.5 M cells (191^3 up the (512,2) shape + ring wins; 141^3 ... 181^3 run 3-10 % faster as
+            // three 256-thread workgroups per CU of the one-cell-per-lane kernel, tools/experiments/r03_run50.sh, r03_run51.sh)
+            const long long pair_from = (HAM::ND <= 3 && light_scheme(SCHEME)) ? 6500000 : 2500000;
+            if (c->pair != 0 && pair_dim && (c->total >= pair_from || c->pair_nt > 0 || c->pair == 2)) {
                 // two cells per lane (hj_fusedv.h), round-2 A/B at 151^3 ... 513^3: the light stencils
                 // run 2 pairs per thread in 512-thread workgroups (220-232 VGPRs against 246-256 for four single
                 // cells), the heavy ones 1 pair in 256-thread workgroups
@@ -369,7 +372,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // halo ring parked in LDS (5 plane buffers, hj_fusedv.h): pays for the two-pairs-per-thread configuration
                 // from 201^3 up (A/B tools/experiments/r02_run32.sh, r02_run33.sh: +1 % at 201^3, +3.6 % at 513^3 with
                 // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
-                const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && HAM::ND <= 3 && kp.NT == 512 && kp.R == 2 && c->total >= 8000000);
+                const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && HAM::ND <= 3 && kp.NT == 512 && kp.R == 2 && c->total >= 6500000);
                 c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
                 const long long key = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (1ll << 35) |
                                       ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0) |

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 3, run 51: 191^3 ... 241^3: the default pair (512,2)+ring against the 256-thread shapes that win at 141^3 ... 181^3
+out=gpurun_out/r03ay; mkdir -p $out; rm -rf $out/*
+run() { echo "== n=$N $*" >> $out/ab.txt; env "$@" HJ_DEBUG=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-live-traffic --no-also --steps 40 --repeats 5 --n $N >> $out/ab.txt 2> $out/last.err || { tail -3 $out/last.err >> $out/ab.txt; }; grep -E "tiling" $out/last.err | sort | uniq -c | sort -rn | head -1 >> $out/ab.txt; }
+for N in 191 201 221 241; do
+  run HJ_X=0
+  run HJ_PAIR=0 HJ_NT=256 HJ_R=2 HJ_KH=2 HJ_OCC=2 HJ_PD=2
+  run HJ_PAIR=2 HJ_PAIR_NT=256 HJ_PAIR_R=1 HJ_PAIR_KH=2
+  run HJ_PAIR=2 HJ_PAIR_NT=256 HJ_PAIR_R=1 HJ_PAIR_KH=2 HJ_PAIR_RING=1
+  run HJ_X=1
+done
+python - <<'PY'
+import json
+n = None
+for ln in open("gpurun_out/r03ay/ab.txt"):
+    if ln.startswith("=="): n = ln.strip(); continue
+    if ln.startswith("{"):
+        d = json.loads(ln); print("%-78s %.4e  frac %.3f  us/step %.1f" % (n, d["value"], d["roofline"]["frac"], d["ms_per_step"] * 1e3), end="  ")
+    elif "tiling" in ln: print(ln.strip()[2:][5:100])
+    else: print(n, ln.strip()[:100])
+PY
