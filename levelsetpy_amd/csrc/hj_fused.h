@@ -30,6 +30,16 @@
 #pragma once
 #include "hj_device.h"
 
+// Surplus halo slots shadow slot 0 (same source, same LDS cell, same value).  In 4-D (10 slots per thread, 2-3 % of them
+// surplus) their LDS stores go out unpredicated -- a benign duplicate write instead of an exec save + branch per slot and
+// plane: C5 +3 % (tools/experiments/r03_run54.sh).  In 2-D / 3-D most slots of the last round are surplus (2-D: 506 of 512)
+// and whole waves would store to ONE LDS address, which the LDS serialises (C3 -9 %): there the predicate stays.
+// -DHJ_PRED_HALO (tuning builds): the predicate everywhere.
+#ifdef HJ_PRED_HALO
+#define HJ_SLOT_PRED(k) if (h_real[k])
+#else
+#define HJ_SLOT_PRED(k) if (ND < 4 ? h_real[k] : true)
+#endif
 namespace hj {
 
 // cache policies of the streams (tuning macros): y0 and the output are touched once
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         for (int k = 0; k < KH; ++k) {
             int h = tid + k * NT;
             h_real[k] = h < base[ND];
-            if (!h_real[k]) h = 0;                    // shadow of slot 0: loads it, never writes LDS
+            if (!h_real[k]) h = 0;                    // shadow of slot 0: loads it; writes LDS only in 4-D (HJ_SLOT_PRED)
             h_lds[k] = 0; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
             // static loop over the axis the slot belongs to (runtime-indexed local arrays
             // would be demoted to scratch)
@@ -519,11 +529,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             // h_km = 0 for in-domain slots: edge + 0*slope = edge
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) buf[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
+                HJ_SLOT_PRED(k) buf[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) buf[h_lds[k]] = hal_c[k];
+                HJ_SLOT_PRED(k) buf[h_lds[k]] = hal_c[k];
         }
         HJ_ST(st1);
         __syncthreads();

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         for (int k = 0; k < KH; ++k) {
             int h = tid + k * NT;
             h_real[k] = h < base[ND];
-            if (!h_real[k]) h = 0;
+            if (!h_real[k]) h = 0;                    // shadow of slot 0 (HJ_SLOT_PRED, hj_fused.h)
             h_lds[k] = 0; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
 #pragma unroll
             for (int d = 1; d < ND; ++d) {
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             T* bufa = lds + a * lds_plane;
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) bufa[h_lds[k]] = tile_ghost ? ghost_value(th[k], ti[k], h_km[k]) : th[k];
+                HJ_SLOT_PRED(k) bufa[h_lds[k]] = tile_ghost ? ghost_value(th[k], ti[k], h_km[k]) : th[k];
         }
     }
 #pragma unroll
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (tile_ghost) {
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) bufh[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
+                HJ_SLOT_PRED(k) bufh[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < KH; ++k)
-                if (h_real[k]) bufh[h_lds[k]] = hal_c[k];
+                HJ_SLOT_PRED(k) bufh[h_lds[k]] = hal_c[k];
         }
 #ifdef HJ_STAMP
         const unsigned long long st1 = __builtin_readcyclecounter();
