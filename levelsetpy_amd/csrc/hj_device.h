@@ -402,6 +402,11 @@ template <typename T> struct HamDubinsRel {
     __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {
         return Raw{P.aux[0][idx[2]], P.aux[1][idx[2]], P.coord[1][idx[1]]};
     }
+    // the next cell along the CONTIGUOUS axis (pair kernel): what does not depend on that axis is taken over from the first
+    // cell, so that the compiler sees ONE value and shares everything derived from it between the two cells of a pair
+    __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw& first) {
+        return Raw{P.aux[0][idx[2]], P.aux[1][idx[2]], first.x1};
+    }
     __device__ static __forceinline__ Cell cell_fin(const HamTables<T>& P, const Raw& r, const T* sc) {
         // contraction off (once per thread, in the setup): v_e - v_p cos x3 rounded as NumPy rounds it
         // (dubins_relative.py:84,108), so that alpha -- and with it stepBound and deltaT -- is the reference's bit for bit
@@ -453,6 +458,7 @@ template <typename T> struct HamDoubleIntegrator {
     struct Plane { int unused; };
     struct Raw { T x1; };
     __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) { return Raw{P.coord[1][idx[1]]}; }
+    __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw&) { return cell_raw(P, idx); }
     __device__ static __forceinline__ Cell cell_fin(const HamTables<T>&, const Raw& r, const T* sc) {
         Cell c;
         c.x1 = sc[0] * r.x1;
@@ -497,6 +503,13 @@ template <typename T> struct HamDoublePendulum {
         c.c2 = P.aux[3][idx[2]];
         return c;
     }
+    // next cell along axis 3: only w2 changes -- sin/cos of the angle difference, the denominator and its reciprocal are then
+    // computed once per PAIR in eval() (common subexpressions of the two inlined calls)
+    __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw& first) {
+        Cell c = first;
+        c.w2 = P.coord[3][idx[3]];
+        return c;
+    }
     __device__ static __forceinline__ Cell cell_fin(const HamTables<T>&, const Raw& r, const T*) { return r; }
     __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
         return cell_fin(P, cell_raw(P, idx), sc);
@@ -520,11 +533,21 @@ template <typename T> struct HamDoublePendulum {
         const T sd = s2 * c1 - c2 * s1;  // sin(th2-th1)
         const T cd = c2 * c1 + s2 * s1;  // cos(th2-th1)
         const T den1 = (M1 + M2) * L1 - M2 * L1 * cd * cd;
+        // ONE division for both accelerations (den2 = (L2/L1)*den1 = den1 here): an IEEE fp32 division is ~10 VALU
+        // instructions, two of them were a fifth of the C5 loop's arithmetic (round 3)
+#ifdef HJ_PENDULUM_TWO_DIV
         const T f1 = (M2 * L1 * w1 * w1 * sd * cd + M2 * G * s2 * cd + M2 * L2 * w2 * w2 * sd
                       - (M1 + M2) * G * s1) / den1;
         const T den2 = (L2 / L1) * den1;
         const T f3 = (-M2 * L2 * w2 * w2 * sd * cd + (M1 + M2) * G * s1 * cd
                       - (M1 + M2) * L1 * w1 * w1 * sd - (M1 + M2) * G * s2) / den2;
+#else
+        const T rden = T(1) / den1;
+        const T f1 = (M2 * L1 * w1 * w1 * sd * cd + M2 * G * s2 * cd + M2 * L2 * w2 * w2 * sd
+                      - (M1 + M2) * G * s1) * rden;
+        const T f3 = (-M2 * L2 * w2 * w2 * sd * cd + (M1 + M2) * G * s1 * cd
+                      - (M1 + M2) * L1 * w1 * w1 * sd - (M1 + M2) * G * s2) * ((L1 / L2) * rden);
+#endif
         H = p[0] * w1 + p[1] * f1 + p[2] * w2 + p[3] * f3 + u * (t_abs(p[1]) + t_abs(p[3]));
         alpha[0] = sc[0] * t_abs(w1);
         alpha[1] = sc[1] * (t_abs(f1) + u);

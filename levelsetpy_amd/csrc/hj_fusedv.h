@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         // for them later waits for nothing else); the arithmetic on them follows the halo setup
         hraw[r][0] = HAM::cell_raw(A.ham, idx);
         idx[LA] += 1;
-        hraw[r][1] = HAM::cell_raw(A.ham, idx);
+        hraw[r][1] = HAM::cell_raw_next(A.ham, idx, hraw[r][0]);
     }
 
     // ---- loaders of the own pairs, issued ahead of the rest of the setup (as in the scalar kernel)
