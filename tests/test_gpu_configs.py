@@ -922,6 +922,16 @@ def test_weno5_epsilon_reduced_in_the_producing_launch_is_bitwise_the_pre_pass(c
         nl, fz = C.c_int(), C.c_int()
         _ffi.check(dg.lib.hj_rk_plan(dg.ctx, 3, _ffi.SCHEME_IDS["WENO5"], ham, _ffi.darr(par), 0, C.byref(nl), C.byref(fz)))
         assert nl.value == (6 if fuse == "1" else 9)      # pre-pass (one launch) + 3 substep launches + 2 seam launches | 3 x 3
+        # the runtime-flag instantiation (MODE 0): termRestrictUpdate clamp + fused post-step minimum, four steps in one call --
+        # the epsilon of a step's first stage then comes from the CLAMPED, MINIMISED output of the previous step's last launch
+        _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, 1))
+        a, b, w = dg.empty(), dg.empty(), dg.empty()
+        tt, ns, which = C.c_double(), C.c_int64(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, 3, _ffi.SCHEME_IDS["WENO5"], ham, _ffi.darr(par), 0.0, 10.0, 0.8, 1e30, 1,
+                                          dg.ptr(y), dg.ptr(a), dg.ptr(b), dg.ptr(w), 4, -1.0, C.byref(tt), C.byref(ns), C.byref(which)))
+        dg.sync()
+        outs.append(((y, a, b)[which.value].clone(), tt.value))
+        _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, 0))
         res[fuse] = outs
         del dg
     for (ya, ta), (yb, tb) in zip(res["0"], res["1"]):
