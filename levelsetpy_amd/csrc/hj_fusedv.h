@@ -342,6 +342,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 
     auto load_halo = [&](int p, T* dst, T* dst_in) {
         const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 8)          // timing experiment (tuning builds; HJ_ABLATE bits: 1 no Hamiltonian arithmetic,
+        (void)so;                                  // 2 no stencil LDS reads, 8 no halo loads, 16 no halo LDS stores)
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < KH; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
         if (tile_ghost) {
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 c2.y = q[r][1][3];
                 *reinterpret_cast<V*>(buf + own_lds[r]) = c2;
             }
+#if !(defined(HJ_ABLATE) && (HJ_ABLATE & 16))
         if (tile_ghost) {
 #pragma unroll
             for (int k = 0; k < KH; ++k)
@@ -423,6 +428,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             for (int k = 0; k < KH; ++k)
                 HJ_SLOT_PRED(k) bufh[h_lds[k]] = hal_c[k];
         }
+#else
+#pragma unroll
+        for (int k = 0; k < KH; ++k) asm volatile("" ::"v"(hal_c[k]));
+#endif
 #ifdef HJ_STAMP
         const unsigned long long st1 = __builtin_readcyclecounter();
 #endif
@@ -450,15 +459,23 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
                     if (j == 3) { va[j] = q[r][0][3]; vb[j] = q[r][1][3]; continue; }
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 2)
+                    va[j] = q[r][0][j]; vb[j] = q[r][1][j];
+#else
                     const V n2 = *reinterpret_cast<const V*>(base + (j - 3) * ls[d]);
                     va[j] = n2.x;
                     vb[j] = n2.y;
+#endif
                 }
                 upwind_cd<SCHEME, T>(va, A.K[d], eps[d], wk[d], pc[0][d], hd[0][d]);
                 upwind_cd<SCHEME, T>(vb, A.K[d], eps[d], wk[d], pc[1][d], hd[1][d]);
             }
             {   // the contiguous axis: cells j-3 .. j+4 = [b64][b128][own pair][b128][b64]
                 T w[8];
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 2)
+                w[0] = q[r][0][0]; w[1] = q[r][0][1]; w[2] = q[r][0][2]; w[5] = q[r][1][4]; w[6] = q[r][1][5]; w[7] = q[r][1][6];
+                w[3] = q[r][0][3]; w[4] = q[r][1][3];
+#else
                 w[0] = base[-3];
                 const V l2 = *reinterpret_cast<const V*>(base - 2);
                 w[1] = l2.x; w[2] = l2.y;
@@ -466,6 +483,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 const V r2 = *reinterpret_cast<const V*>(base + 2);
                 w[5] = r2.x; w[6] = r2.y;
                 w[7] = base[4];
+#endif
                 upwind_cd<SCHEME, T>(w, A.K[LA], eps[LA], wk[LA], pc[0][LA], hd[0][LA]);
                 upwind_cd<SCHEME, T>(w + 1, A.K[LA], eps[LA], wk[LA], pc[1][LA], hd[1][LA]);
             }
@@ -473,7 +491,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 T alpha[ND];
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 1)
+                T ydot = pc[c][0] + hd[c][ND - 1];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { alpha[d] = pc[c][d]; ydot += hd[c][d]; }
+#else
                 T ydot = lf_ydot<NP, HAM>(A.ham, hcell[r][c], pl_use, A.sc, pc[c], hd[c], alpha);
+#endif
 #pragma unroll
                 for (int d = 0; d < ND; ++d)
                     if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
