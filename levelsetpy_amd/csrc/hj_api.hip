@@ -88,7 +88,14 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
             box = rows * pitch;
             size_t lds = 512 + (size_t)nbuf * (size_t)box * c->esz;
             const size_t lds_cap = nbuf > 2 ? (size_t)160 * 1024 - 1024 : c->lds_limit;   // the ring variant may take the whole CU
-            if (!odd_row && halo <= (long long)k.KH * k.NT && lds <= lds_cap) {
+            // slots the kernel has for the halo: KH single cells per thread -- or, pair kernel in 4-D (hj_fusedv.h, HP), KH - 1 pair
+            // slots for the layers of the non-contiguous plane axes and one single slot for the 3 + 3 cells either side of a row
+            bool halo_fits = halo <= (long long)k.KH * k.NT;
+            if (vec == 2 && nd == 4) {
+                const long long singles = 6 * (cells / E[nd - 1]);
+                halo_fits = (halo - singles) / 2 <= (long long)(k.KH - 1) * k.NT && singles <= k.NT;
+            }
+            if (!odd_row && halo_fits && lds <= lds_cap) {
                 double util = (double)cells / (double)(((cells + k.NT - 1) / k.NT) * k.NT);
                 // cells recomputed by the shifted last tile on each axis
                 double waste = 1.0;

@@ -242,11 +242,84 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     }
 
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 1] = wall_clock64();
-    // ---- halo slots (single cells): the cross around the tile, as in the scalar kernel
-    int h_lds[KH], h_dlt[KH];
-    unsigned h_src[KH];
-    T h_km[KH];
-    bool h_real[KH];
+    // ---- halo slots (single cells): the cross around the tile, as in the scalar kernel.
+    // 4-D (HP, round 3): the halo layers of the plane axes OTHER than the contiguous one are rows of the tile's own row structure,
+    // so they are dealt as PAIRS (8 / 16-byte loads and LDS stores, KP = KH - 1 slots per thread); only the 3 + 3 cells either
+    // side of a row stay single cells (KS = 1 slot per thread).  Halves the halo's load / store instructions and slot registers:
+    // the halo loads were 22 % of the C5 launch (tools/experiments/r03_run60.sh).
+    constexpr bool HP = (ND == 4);
+    constexpr int KS = HP ? 1 : KH;               // single-cell slots per thread
+    constexpr int KP = HP ? KH - 1 : 1;           // pair slots per thread (unused unless HP)
+    int h_lds[KS], h_dlt[KS];
+    unsigned h_src[KS];
+    T h_km[KS];
+    bool h_real[KS];
+    int hp_lds[KP], hp_dlt[KP];
+    unsigned hp_src[KP];
+    T hp_km[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { hp_lds[k] = 0; hp_dlt[k] = 0; hp_src[k] = 0; hp_km[k] = T(0); }
+    if constexpr (HP) {
+        // pair slots: axes d = 1 .. LA-1, 6 layers each, over the tile's extent on the other axes with the contiguous axis in pairs
+        int areap[ND], basep[ND + 1];
+        basep[1] = 0;
+        FDiv fAp[ND];
+        const int half = A.E[LA] >> 1;
+        const FDiv fHalf = fdiv_make(half);
+#pragma unroll
+        for (int d = 1; d < LA; ++d) {
+            areap[d] = half;
+#pragma unroll
+            for (int e = 1; e < LA; ++e) if (e != d) areap[d] *= A.E[e];
+            basep[d + 1] = basep[d] + 2 * HJ_STENCIL * areap[d];
+            fAp[d] = fdiv_make(areap[d]);
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            int h = tid + k * NT;
+            if (h >= basep[LA]) h = 0;                // surplus slots shadow slot 0: same source, same LDS cells, same values
+#pragma unroll
+            for (int d = 1; d < LA; ++d) {
+                if (h < basep[d] || h >= basep[d + 1]) continue;
+                int lay, c;
+                fdivmod(h - basep[d], fAp[d], lay, c);
+                const int jd = (lay < HJ_STENCIL) ? (lay - HJ_STENCIL) : (A.E[d] + lay - HJ_STENCIL);
+                int lo = 0, g = 0;
+                {
+                    int qe, j;
+                    fdivmod(c, fHalf, qe, j);
+                    c = qe;
+                    lo += (2 * j + pad_of(LA)) * ls[LA];
+                    g += (org[LA] + 2 * j) * A.pstride[LA];
+                }
+#pragma unroll
+                for (int e = LA - 1; e >= 1; --e) {
+                    if (e == d) continue;
+                    int qe, j;
+                    fdivmod(c, fE[e], qe, j);
+                    c = qe;
+                    lo += (j + pad_of(e)) * ls[e];
+                    g += (org[e] + j) * A.pstride[e];
+                }
+                lo += (jd + pad_of(d)) * ls[d];
+                int gi = org[d] + jd;
+                const int nd = A.n[d];
+                int dlt = 0;
+                T km = T(0);
+                if (gi < 0) {
+                    if (A.bc[d] == HJ_BC_PERIODIC) gi += nd;
+                    else { km = T(-gi) * A.km[d]; dlt = A.pstride[d]; gi = 0; }
+                } else if (gi >= nd) {
+                    if (A.bc[d] == HJ_BC_PERIODIC) gi -= nd;
+                    else { km = T(gi - nd + 1) * A.km[d]; dlt = -A.pstride[d]; gi = nd - 1; }
+                }
+                hp_lds[k] = lo;
+                hp_src[k] = (unsigned)(g + gi * A.pstride[d]) * (unsigned)sizeof(T);
+                hp_dlt[k] = dlt * (int)sizeof(T);
+                hp_km[k] = km;
+            }
+        }
+    }
     {
         int area[ND], base[ND + 1];
         base[1] = 0;
@@ -259,11 +332,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             base[d + 1] = base[d] + 2 * HJ_STENCIL * area[d];
             fA[d] = fdiv_make(area[d]);
         }
+        // HP: the single slots cover the contiguous axis only (the other axes' layers are the pair slots above)
+        const int first = HP ? base[LA] : 0;
 #pragma unroll
-        for (int k = 0; k < KH; ++k) {
-            int h = tid + k * NT;
+        for (int k = 0; k < KS; ++k) {
+            int h = first + tid + k * NT;
             h_real[k] = h < base[ND];
-            if (!h_real[k]) h = 0;                    // shadow of slot 0 (HJ_SLOT_PRED, hj_fused.h)
+            if (!h_real[k]) h = first;                // shadow of the first slot (HJ_SLOT_PRED, hj_fused.h)
             h_lds[k] = 0; h_src[k] = 0; h_dlt[k] = 0; h_km[k] = T(0);
 #pragma unroll
             for (int d = 1; d < ND; ++d) {
@@ -340,21 +415,66 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
     for (int r = 0; r < R; ++r) { oprev[r].x = T(0); oprev[r].y = T(0); }
 
-    auto load_halo = [&](int p, T* dst, T* dst_in) {
+    auto load_halo = [&](int p, T* dst, T* dst_in, V* dstp, V* dstp_in) {
         const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #if defined(HJ_ABLATE) && (HJ_ABLATE & 8)          // timing experiment (tuning builds; HJ_ABLATE bits: 1 no Hamiltonian arithmetic,
         (void)so;                                  // 2 no stencil LDS reads, 8 no halo loads, 16 no halo LDS stores)
         return;
 #endif
+        if constexpr (HP) {
 #pragma unroll
-        for (int k = 0; k < KH; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
+            for (int k = 0; k < KP; ++k) dstp[k] = buf_load2(ry, hp_src[k], so, T());
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) dst[k] = buf_load(ry, h_src[k], so, T());
         if (tile_ghost) {
+            if constexpr (HP) {
 #pragma unroll
-            for (int k = 0; k < KH; ++k) {
+                for (int k = 0; k < KP; ++k) {
+                    dstp_in[k].x = T(0); dstp_in[k].y = T(0);
+                    if (hp_dlt[k] != 0) dstp_in[k] = buf_load2(ry, hp_src[k] + (unsigned)hp_dlt[k], so, T());
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
                 dst_in[k] = T(0);
                 if (h_dlt[k] != 0) dst_in[k] = buf_load(ry, h_src[k] + (unsigned)h_dlt[k], so, T());
             }
         }
+    };
+    // the ring of one plane -> its LDS buffer
+    auto park_halo = [&](T* bufh, const T* hv, const T* hi, const V* pv, const V* pi) {
+#if !(defined(HJ_ABLATE) && (HJ_ABLATE & 16))
+        if (tile_ghost) {
+            if constexpr (HP) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    V gv;
+                    gv.x = ghost_value(pv[k].x, pi[k].x, hp_km[k]);
+                    gv.y = ghost_value(pv[k].y, pi[k].y, hp_km[k]);
+                    *reinterpret_cast<V*>(bufh + hp_lds[k]) = gv;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                HJ_SLOT_PRED(k) bufh[h_lds[k]] = ghost_value(hv[k], hi[k], h_km[k]);
+        } else {
+            if constexpr (HP) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) *reinterpret_cast<V*>(bufh + hp_lds[k]) = pv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                HJ_SLOT_PRED(k) bufh[h_lds[k]] = hv[k];
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < KS; ++k) asm volatile("" ::"v"(hv[k]));
+        if constexpr (HP) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) asm volatile("" ::"v"(pv[k]));
+        }
+#endif
     };
     // Halo ring schedule.  AH = 0: the ring of plane P is requested PD planes ahead and written to LDS in iteration P.
     // AH = 3 (large grids, HJ_PAIR_RING): it is requested PD + 3 = 5 planes ahead -- in the very iteration in which
@@ -363,26 +483,30 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     // iteration through a 4 MB L2) -- and parked in the LDS buffer of plane P, a ring of NB = 5 plane buffers, from
     // iteration P - 3 on.  Same values either way.
     const int NB = A.lds_nbuf, AH = A.halo_ahead;
-    T hal[PD][KH], hin[PD][KH];
+    T hal[PD][KS], hin[PD][KS];
+    V halp[PD][KP], hinp[PD][KP];
 #pragma unroll
-    for (int s = 0; s < PD; ++s)
+    for (int s = 0; s < PD; ++s) {
 #pragma unroll
-        for (int k = 0; k < KH; ++k) { hal[s][k] = T(0); hin[s][k] = T(0); }
+        for (int k = 0; k < KS; ++k) { hal[s][k] = T(0); hin[s][k] = T(0); }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { halp[s][k].x = T(0); halp[s][k].y = T(0); hinp[s][k].x = T(0); hinp[s][k].y = T(0); }
+    }
     if (AH > 0) {
         // the rings of the first AH planes go straight to their LDS buffers (the first barrier of the loop orders them)
         for (int a = 0; a < AH; ++a) {
-            T th[KH], ti[KH];
+            T th[KS], ti[KS];
+            V tp[KP], tq[KP];
 #pragma unroll
-            for (int k = 0; k < KH; ++k) { th[k] = T(0); ti[k] = T(0); }
-            load_halo(min(p_begin + a, p_last), th, ti);
-            T* bufa = lds + a * lds_plane;
+            for (int k = 0; k < KS; ++k) { th[k] = T(0); ti[k] = T(0); }
 #pragma unroll
-            for (int k = 0; k < KH; ++k)
-                HJ_SLOT_PRED(k) bufa[h_lds[k]] = tile_ghost ? ghost_value(th[k], ti[k], h_km[k]) : th[k];
+            for (int k = 0; k < KP; ++k) { tp[k].x = T(0); tp[k].y = T(0); tq[k].x = T(0); tq[k].y = T(0); }
+            load_halo(min(p_begin + a, p_last), th, ti, tp, tq);
+            park_halo(lds + a * lds_plane, th, ti, tp, tq);
         }
     }
 #pragma unroll
-    for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s]);
+    for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s], halp[s], hinp[s]);
 
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 3] = wall_clock64();
     // the arithmetic on the Hamiltonian tables, now that every load of the setup is in flight
@@ -399,7 +523,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
     int ring_c = 0;                                            // LDS buffer of the plane the next iteration computes
-    auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* y0_c, typename HAM::Plane& pl_c) {
+    auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
 #ifdef HJ_STAMP
         const unsigned long long st0 = __builtin_readcyclecounter();
 #endif
@@ -418,20 +542,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 c2.y = q[r][1][3];
                 *reinterpret_cast<V*>(buf + own_lds[r]) = c2;
             }
-#if !(defined(HJ_ABLATE) && (HJ_ABLATE & 16))
-        if (tile_ghost) {
-#pragma unroll
-            for (int k = 0; k < KH; ++k)
-                HJ_SLOT_PRED(k) bufh[h_lds[k]] = ghost_value(hal_c[k], hin_c[k], h_km[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < KH; ++k)
-                HJ_SLOT_PRED(k) bufh[h_lds[k]] = hal_c[k];
-        }
-#else
-#pragma unroll
-        for (int k = 0; k < KH; ++k) asm volatile("" ::"v"(hal_c[k]));
-#endif
+        park_halo(bufh, hal_c, hin_c, halp_c, hinp_c);
 #ifdef HJ_STAMP
         const unsigned long long st1 = __builtin_readcyclecounter();
 #endif
@@ -442,7 +553,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         const unsigned long long st2 = __builtin_readcyclecounter();
 #endif
         const int p2 = min(p + PD, p_last);
-        load_halo(min(p + PD + AH, p_last), hal_c, hin_c);
+        load_halo(min(p + PD + AH, p_last), hal_c, hin_c, halp_c, hinp_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
         pl_c = HAM::plane(A.ham, p2, A.sc);
@@ -556,8 +667,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 5] = wall_clock64();   // loop start
     for (int p = p_begin; p < p_end; p += PD) {
-        body(p, own[0], own[1], hal[0], hin[0], y0s[0], pls[0]);
-        if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], hin[1], y0s[1], pls[1]);
+        body(p, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
+        if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
         if (A.timing && tid == 0 && p == p_begin) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 7] = wall_clock64();
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end

@@ -195,11 +195,11 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
 #ifndef HJ_CONFIGS_PAIR
 #define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(512, 2, 2, 2)
 #endif
-// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile, 10 halo slots per thread): fp32 with a light stencil only
+// 4-D grids (three plane axes: the halo cross is 1.7-2.4x the tile; 5 pair + 1 single halo slots per thread): fp32 with a light stencil only
 // (cfg_built): 256 threads x 2 pairs = the 1024-cell tile of the one-cell-per-lane kernel in TWO independent workgroups per CU,
 // +6 % on C5 (profiles/r03_c5_config_sweep.txt); every fp64 shape spills
 #ifndef HJ_CONFIGS_PAIR_4D
-#define HJ_CONFIGS_PAIR_4D(X) X(256, 2, 10, 2)
+#define HJ_CONFIGS_PAIR_4D(X) X(256, 2, 6, 2)
 #endif
 
 // ---- launch-time choice of the tile shape (TuneState, hj_host.h)
@@ -364,7 +364,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 KernelCfg kp{512, 2, 2};
                 int occp = 2;
                 if (!(SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
-                if (HAM::ND == 4) { kp.NT = 256; kp.R = 2; kp.KH = 10; }
+                if (HAM::ND == 4) { kp.NT = 256; kp.R = 2; kp.KH = 6; }      // 5 pair slots + 1 single slot per thread (hj_fusedv.h, HP)
                 if (c->pair_nt > 0) kp.NT = c->pair_nt;
                 if (c->pair_r > 0) kp.R = c->pair_r;
                 if (c->pair_kh > 0) kp.KH = c->pair_kh;

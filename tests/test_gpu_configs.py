@@ -244,7 +244,7 @@ def test_fp32_4d_tiled_and_direct_vs_fp64_oracle(scheme, n, pd, monkeypatch):
     scale = float(np.max(np.abs(yo)))
     y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
     got = {}
-    # "0": one cell per lane (1024,1,3,2,2); "1": direct; "pair": two cells per lane (256,2,10,2), built for the light stencils
+    # "0": one cell per lane (1024,1,3,2,2); "1": direct; "pair": two cells per lane (256,2,6,2: 5 pair + 1 single halo slots per thread), built for the light stencils
     variants = ("0", "1", "pair") if scheme in ("WENO5_ASSHIPPED", "ENO2") else ("0", "1")
     for force in variants:
         monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if force == "1" else "0")
