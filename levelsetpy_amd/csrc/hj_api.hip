@@ -695,6 +695,9 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
     if (c->slab_pending && c->comm_stream != c->edge_stream) HIP_TRY(hipStreamWaitEvent(c->edge_stream, c->ev_comm, 0));
     // interior_s reads the edges written by substep s-1
     if (c->slab_pending) HIP_TRY(hipStreamWaitEvent(main, c->ev_edge, 0));
+    // HJ_SLAB_SCHEDULE=overlap2 (experiment): interior_s also waits for the exchange of substep s-1, so that edges_s (launched
+    // first, high-priority stream) find the CUs free instead of taken by an interior launch that started 20-30 us earlier
+    if (c->slab_pending && c->slab_overlap2) HIP_TRY(hipStreamWaitEvent(main, c->ev_comm, 0));
     {   // both edge ranges in ONE launch on the edge stream
         SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, 0, 0};
         if (lo_e > 0) { s.p0 = 0; s.p1 = lo_e; if (hi_b < n) { s.q0 = hi_b; s.q1 = n; } }
@@ -968,6 +971,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         // the 65-plane slab (-13 %: the exchange kernel finds every CU's LDS taken by the interior and starts late)
         const char* sch = getenv("HJ_SLAB_SCHEDULE");
         c->slab_serial = sch ? !strcmp(sch, "serial") : (N[0] >= 192);
+        c->slab_overlap2 = sch && !strcmp(sch, "overlap2");
     }
     c->eps_fuse_min_cells = (long long)env_int("HJ_EPS_FUSE_MIN_CELLS", 2000000);
     c->eps_fuse = env_int("HJ_EPS_FUSE", 1);         // 0: the intended WENO5 always runs its two-launch epsilon pre-pass

@@ -99,6 +99,7 @@ struct hj_ctx {
     hipEvent_t ev_start, ev_edge, ev_edge2, ev_comm;
     hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
     int slab_pending;
+    int slab_overlap2 = 0;             // HJ_SLAB_SCHEDULE=overlap2 (experiment)
     int slab_serial = 1;               // HJ_SLAB_SCHEDULE: edges and interior of a substep on ONE stream, edges first (round 3)
     int external_exchange;             // hj_comm_init_external: the caller fills the pad planes itself
     hipEvent_t launch_stop;            // if set, the next tiled launch signals this event on completion
