@@ -842,10 +842,19 @@ def test_native_rccl_slab_stepper_self_ring():
             y, t_ref = data.reshape(-1, 1), 0.
             for _ in range(4):
                 t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
-            for deep in (True, False):      # one 9-plane exchange per step / one 3-plane exchange per substep
-                slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
-                nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
-                                        [float(v) for v in np.asarray(g.dx).ravel()], deep=deep)
+            # one 9-plane exchange per step / one 3-plane exchange per substep in each of its three stream schedules
+            # (HJ_SLAB_SCHEDULE is read when the stepper creates its context; the default depends on the slab thickness)
+            for deep, sched in ((True, None), (False, "overlap"), (False, "overlap2"), (False, "serial")):
+                if sched is None:
+                    os.environ.pop("HJ_SLAB_SCHEDULE", None)
+                else:
+                    os.environ["HJ_SLAB_SCHEDULE"] = sched
+                try:
+                    slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
+                    nat = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.],
+                                            [float(v) for v in np.asarray(g.dx).ravel()], deep=deep)
+                finally:
+                    os.environ.pop("HJ_SLAB_SCHEDULE", None)
                 nat.set_state(torch.as_tensor(data, device="cuda"))
                 t = 0.
                 for _ in range(4):
@@ -853,7 +862,7 @@ def test_native_rccl_slab_stepper_self_ring():
                 got = nat.state().cpu().numpy()
                 nat.close()
                 assert abs(t - t_ref) <= 1e-14
-                (close if scheme.startswith("WENO") else close_eno)(got, y.reshape(n), 1e-12, what="%s deep=%s" % (scheme, deep))
+                (close if scheme.startswith("WENO") else close_eno)(got, y.reshape(n), 1e-12, what="%s deep=%s %s" % (scheme, deep, sched))
     finally:
         if created:
             dist.destroy_process_group()
