@@ -975,6 +975,10 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     }
     c->eps_fuse_min_cells = (long long)env_int("HJ_EPS_FUSE_MIN_CELLS", 2000000);
     c->eps_fuse = env_int("HJ_EPS_FUSE", 1);         // 0: the intended WENO5 always runs its two-launch epsilon pre-pass
+    {
+        const char* td = getenv("HJ_TIMING_DUMP");
+        if (td && *td) { c->timing_dump_path = td; c->timing_dump = c->timing_dump_path.c_str(); }
+    }
     c->keep_bounds = env_int("HJ_KEEP_BOUNDS", 0);   // 1: every launch reduces its CFL bound, read or not (round-2 behaviour; A/B)
     c->pair_ring = env_int("HJ_PAIR_RING", -1);  // halo ring parked in LDS 3 planes ahead: 0 never, 1 always, -1 (default) with the (512,2) configuration
     c->cfg.KH = cfg_kh(ndim, c->cfg.NT, c->cfg.R);

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -133,6 +134,8 @@ struct hj_ctx {
     double* eps_rows = nullptr;                     // HJ_EPS_ROWS rows of the seam kernel: what the next launch folds
     bool eps_chain_in = false, eps_chain_out = false;   // hj_rk_integrate: the state stays inside the call between steps
     bool eps_ready = false;                         // eps_rows describe the output of the last launch
+    std::string timing_dump_path;                   // HJ_TIMING_DUMP=file, read once when the ctx is created (debug)
+    const char* timing_dump = nullptr;              // = timing_dump_path.c_str() or null
     int keep_bounds = 0;                            // HJ_KEEP_BOUNDS: reduce the CFL bound in launches whose bound nobody reads
     int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)

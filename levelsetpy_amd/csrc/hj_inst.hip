@@ -129,7 +129,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
             granted = t.lds_bytes;
         }
     }
-    const char* dump = getenv("HJ_TIMING_DUMP");    // debug: per-workgroup start/end clocks of every launch
+    const char* dump = c->timing_dump;              // HJ_TIMING_DUMP (read at ctx creation): per-workgroup start/end clocks of every launch
     unsigned long long* tbuf = nullptr;
     if (dump && *dump) {
         HIP_TRY(hipMalloc(&tbuf, (size_t)t.nblocks * 12 * sizeof(unsigned long long)));
@@ -212,7 +212,7 @@ template <int ND>
 Tiling tune_begin(hj_ctx* c, const SubstepCall& s, const KernelCfg& k, int vec, int nbuf, long long key, TuneTrial& tr) {
     const bool tunable = c->autotune && c->total >= c->autotune_min_cells && !c->full_rows && !c->tile_cells && !s.on_aux &&
                          !c->launch_stop && !c->halo_lo && !c->halo_hi && s.p0 == 0 && s.p1 == c->N[0] && s.q1 <= s.q0 &&
-                         !getenv("HJ_TIMING_DUMP");
+                         !c->timing_dump;
     if (!tunable) return make_tiling(c, k, s.p0, s.p1, vec, nbuf);
     TuneState* ts = &c->tune[key];
     if (ts->cand.empty() && ts->chosen < 0) {
@@ -578,7 +578,7 @@ int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     A.dt = (T)s.dt;
     fill_ham<T>(c, s.par, A.ham);
 #ifdef HJ_F12_STAMP
-    const char* dump = getenv("HJ_TIMING_DUMP");    // diagnostic build: per-wave phase clocks of the pair kernel (tools/f12_stamps.py)
+    const char* dump = c->timing_dump;              // diagnostic build: per-wave phase clocks of the pair kernel (tools/f12_stamps.py)
     unsigned long long* tbuf = nullptr;
     const size_t tw = (size_t)t.nblocks * (NT / 64) * 10;
     if (PAIR && dump && *dump) {
