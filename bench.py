@@ -6,8 +6,8 @@ on the Dubins-relative 3-D problem, fp64 (BASELINE.json).
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one odeCFL3 time step = 3 RK substeps over the whole grid; inputs are resident in HBM
-before the timed region; K steps are timed between synchronisations, R times (--repeats, default 5),
-and `value` is the MEDIAN repeat (the spread is reported in "repeats").
+before the timed region; a window of exactly K steps is timed between synchronisations, R times (--repeats,
+default 25), and `value` is the MEDIAN window (inter-quartile range and min/max in "repeats").
 
 N = 1 (default): BASELINE C2, the 201^3 grid.  The same run also times, each with its own spin-up and
 reported under "also" with its own roofline fraction: the intended WENO5 arithmetic at 201^3, the
@@ -55,18 +55,24 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated this many times; value = median")
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="the window of EXACTLY K timed steps (synchronised on both sides) is repeated this many times; "
+                         "value = the median window, the inter-quartile range is reported beside it")
     ap.add_argument("--n", type=int, default=201, help="grid points per axis of the single-GPU / weak-scaling leg")
     ap.add_argument("--global-n", type=int, default=None,
                     help="strong scaling: an n^3 grid slab-decomposed over the ranks (default 513 when N > 1; "
                          "0 = weak scaling with --n planes per rank)")
+    ap.add_argument("--workload", default=None, choices=["C4", "C5"],
+                    help="slab leg only: C4 = Dubins 3-D fp64 (default for N > 1), C5 = double pendulum 4-D fp32, all axes "
+                         "periodic, ring of slabs (BASELINE configs[4]; --global-n = points per axis, default 129)")
     ap.add_argument("--scheme", default="WENO5_ASSHIPPED", choices=["WENO5", "WENO5_ASSHIPPED", "ENO3", "ENO2"],
                     help="WENO5_ASSHIPPED = what the reference's upwindFirstWENO5 computes (parity-pinned; "
                          "headline); WENO5 = the intended nonlinear scheme (reported in 'also')")
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported under 'also'")
-    ap.add_argument("--also", default="WENO5,513,C3,C5", help="comma list of the extra workloads to time")
+    ap.add_argument("--also", default="WENO5,513,C3,C5,CFL,API", help="comma list of the extra workloads to time (API = the 201^3 / "
+                    "51^3 workloads through odeCFL3 / HJIPDE_solve, the reference's own call protocol)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -78,13 +84,18 @@ def parse():
 # on this pool) and sit blocked on stdin until the GPU legs are over, so they do not disturb the timing.
 def cpu_worker(spec):
     """Child process: the NumPy oracle (a port of the reference's array path; 18x faster than the reference
-    import itself, which materialises 519 fancy-index gathers per step) on n^3 for `steps` RK3 steps."""
-    n, steps, scheme = spec.split(":")
-    n, steps = int(n), int(steps)
+    import itself, which materialises 519 fancy-index gathers per step) on n^3 for `steps` RK3 steps.  With a
+    fourth field (a path prefix) the initial data and the state after the steps are saved as .npy there: the GPU leg
+    integrates the SAME data through the drop-in API and the bench line carries the difference ("parity")."""
+    parts = spec.split(":")
+    n, steps, scheme = int(parts[0]), int(parts[1]), parts[2]
+    save = parts[3] if len(parts) > 3 and parts[3] else None
     from oracle import hj_oracle as O
     og = O.Grid([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n)], [n] * 3, [2])
     osys = O.DubinsRel(og, 1, 1)
     y = O.shape_cylinder(og, 2, None, .5).reshape(-1, 1)
+    if save:
+        np.save(save + "_y0.npy", y)
     term = lambda tt, yy: O.term_lax_friedrichs(og, osys, scheme, tt, yy)  # noqa: E731
     sys.stdout.write("ready\n")
     sys.stdout.flush()
@@ -95,19 +106,64 @@ def cpu_worker(spec):
     for _ in range(steps):
         t, y = O.ode_cfl_3(term, [t, 10.], y, 0.8, single_step=True)
     sec = time.perf_counter() - t0
-    sys.stdout.write(json.dumps({"n": n, "steps": steps, "sec": sec, "finite": bool(np.isfinite(y).all())}) + "\n")
+    if save:
+        np.save(save + "_y.npy", y)
+    sys.stdout.write(json.dumps({"n": n, "steps": steps, "sec": sec, "finite": bool(np.isfinite(y).all()), "t": float(t),
+                                 "state": save}) + "\n")
     sys.stdout.flush()
 
 
+PARITY_TOL = 1e-11      # HIP fp64 vs the CPU restatement, absolute, O(1) data
+
+
+def gpu_parity(L, torch, c2, scheme):
+    """The `parity` object of the bench line: the oracle's state after its timed steps at the HEADLINE size (saved by the
+    cpu_baseline worker) against the product path run from the same initial data through the drop-in API --
+    odeCFL3(termLaxFriedrichs, ...) with singleStep='on', device tensor in/out (the reference call being replaced:
+    ValueFuncs/hji_solver.py:542).  Raises if the tolerance is exceeded: a fast wrong kernel must not print a value."""
+    pre, n, steps = c2["state"], c2["n"], c2["steps"]
+    y0, yref = np.load(pre + "_y0.npy"), np.load(pre + "_y.npy")
+    for suf in ("_y0.npy", "_y.npy"):
+        try:
+            os.remove(pre + suf)
+        except OSError:
+            pass
+    g = dubins_grid(L, n, n)
+    sysd = L.DubinsVehicleRel(g, 1, 1)
+    calc = {"WENO5_ASSHIPPED": L.upwindFirstWENO5, "ENO3": L.upwindFirstENO3, "ENO2": L.upwindFirstENO2}.get(scheme)
+    if calc is None:
+        calc = L.upwindFirstWENO5Intended
+    sd = L.Bundle(dict(grid=g, hamFunc=sysd.hamiltonian, partialFunc=sysd.dissipation,
+                       dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y = torch.from_numpy(y0).to("cuda")
+    t = 0.
+    for _ in range(steps):
+        t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    kern = L.context.device_grid(g).lib.hj_last_kernel(L.context.device_grid(g).ctx)
+    diff = float(np.max(np.abs(y.cpu().numpy() - yref)))
+    dt = abs(float(t) - c2["t"])
+    ok = diff <= PARITY_TOL and dt <= 1e-14 and c2["finite"]
+    out = {"config": "%d^3" % n, "steps": steps, "scheme": scheme, "max_abs_diff": diff, "tol": PARITY_TOL, "t_abs_diff": dt,
+           "ok": bool(ok), "kernel": kern.decode() if kern else "?",
+           "path": "odeCFL3(termLaxFriedrichs, singleStep='on') on a device tensor vs oracle/hj_oracle.py on the same initial data",
+           "max_abs_state": float(np.max(np.abs(yref)))}
+    if not ok:
+        raise RuntimeError("parity at the headline size FAILED: %r" % (out,))
+    return out
+
+
 class CpuBaseline(object):
-    def __init__(self, scheme):
-        self.scheme = scheme
+    def __init__(self, scheme, n=201):
+        self.scheme, self.n = scheme, n
         try:
             self.cores_avail = len(os.sched_getaffinity(0))
         except AttributeError:
             self.cores_avail = os.cpu_count() or 1
         self.pool_size = max(1, min(self.cores_avail, 16))
-        self.specs = [("c2", "201:2:%s" % scheme), ("c1", "51:10:%s" % scheme)] + \
+        import tempfile
+        self.state_prefix = os.path.join(tempfile.gettempdir(), "hj_bench_parity_%d" % os.getpid())
+        self.specs = [("c2", "%d:2:%s:%s" % (n, scheme, self.state_prefix)), ("c1", "51:10:%s" % scheme)] + \
                      [("all%d" % i, "101:4:%s" % scheme) for i in range(self.pool_size)]
         self.procs = []
         for name, spec in self.specs:
@@ -138,11 +194,12 @@ class CpuBaseline(object):
             model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
         except Exception:  # noqa: BLE001
             model = "?"
+        self.c2 = c2
         return {"value": rate(c2), "unit": "cell-substeps/s", "cores": 1, "kind": "port",
-                "sample": "%d RK3 steps of Dubins-relative 201^3 %s+GLF fp64 (the GPU workload itself) with "
+                "sample": "%d RK3 steps of Dubins-relative %d^3 %s+GLF fp64 (the GPU workload itself) with "
                           "oracle/hj_oracle.py (NumPy restatement pinned to the reference's outputs, single-threaded) "
                           "in %.1f s on one core of %s (%d cores visible, %d in this process's affinity); %s"
-                          % (c2["steps"], self.scheme, c2["sec"], model, os.cpu_count(), self.cores_avail, REF_IMPORT),
+                          % (c2["steps"], self.n, self.scheme, c2["sec"], model, os.cpu_count(), self.cores_avail, REF_IMPORT),
                 "c1_51cubed": {"value": rate(c1), "cores": 1, "sample": "%d RK3 steps at 51^3 in %.2f s" % (c1["steps"], c1["sec"])},
                 "all_cores": {"value": units / wall, "cores": len(allr),
                               "sample": "%d processes, each %d RK3 steps at 101^3 on its own grid, wall %.1f s"
@@ -249,6 +306,79 @@ def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
             "launches_per_step": int(launches), "stage_fused": int(fused.value), "kernel": kern.decode() if kern else "?"}
 
 
+def quartiles(xs):
+    """(q1, median, q3) by linear interpolation."""
+    v = sorted(xs)
+    def at(f):
+        x = f * (len(v) - 1)
+        i = int(x)
+        return v[i] if i + 1 >= len(v) else v[i] + (x - i) * (v[i + 1] - v[i])
+    return at(0.25), at(0.5), at(0.75)
+
+
+def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
+    """The same workload through the reference's own call protocol (what a user of LevelSetPy switches to; the raw C loop
+    of time_single is the floor these are compared with):
+      "odeCFL3"  K calls of odeCFL3(termLaxFriedrichs, [t, tf], y, options(singleStep='on'), schemeData), device tensor
+                 in / tensor out -- the call HJIPDE_solve makes per step (reference ValueFuncs/hji_solver.py:542)
+      "solve"    ONE HJIPDE_solve(data0, [0, T], schemeData, 'none', keepLast) call per window with T = (K - 1/2) dt,
+                 i.e. exactly K steps (the last one clipped), tensor in / tensor out
+    Every window is synchronised on both sides; one window = K RK3 steps."""
+    g = dubins_grid(L, n, n)
+    sysd = L.DubinsVehicleRel(g, 1, 1)
+    calc = {"WENO5_ASSHIPPED": L.upwindFirstWENO5, "ENO3": L.upwindFirstENO3, "ENO2": L.upwindFirstENO2,
+            "WENO5": L.upwindFirstWENO5Intended}[scheme]
+    sd = L.Bundle(dict(grid=g, hamFunc=sysd.hamiltonian, partialFunc=sysd.dissipation,
+                       dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
+    d0 = device_sdf(torch, g, 0.5, ignore=(2,))
+    cells = d0.numel()
+    st = {"y": d0.reshape(-1, 1), "t": 0.0}
+    if kind == "odeCFL3":
+        op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+
+        def window(k):
+            for _ in range(k):
+                st["t"], st["y"], _sd = L.odeCFL3(L.termLaxFriedrichs, [st["t"], 1e9], st["y"], op, sd)
+    else:
+        dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+        # static stepBound of the Dubins system (dubins_relative.py:106-111, artificial_diss_glf.py:107-109), v = w = 1
+        x1 = max(abs(float(np.asarray(g.vs[0]).ravel()[0])), abs(float(np.asarray(g.vs[0]).ravel()[-1])))
+        x2 = max(abs(float(np.asarray(g.vs[1]).ravel()[0])), abs(float(np.asarray(g.vs[1]).ravel()[-1])))
+        c3 = np.cos(np.asarray(g.vs[2]).ravel())
+        s3 = np.sin(np.asarray(g.vs[2]).ravel())
+        a0 = float(np.max(np.abs(1.0 - c3))) + x2
+        a1 = float(np.max(np.abs(s3))) + x1
+        dt = 0.8 / (a0 / dxs[0] + a1 / dxs[1] + 2.0 / dxs[2])
+        ex = L.Bundle(dict(keepLast=True, quiet=True))
+        st["y"] = d0
+
+        def window(k):
+            data, _tau, _e = L.HJIPDE_solve(st["y"], [0.0, (k - 0.5) * dt], sd, 'none', ex)
+            st["y"] = data
+    window(max(1, min(spinup, 60)))
+    for _ in range(max(1, warmup // max(1, steps)) + 1):
+        window(steps)
+    walls = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        window(steps)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    assert bool(torch.isfinite(st["y"]).all())
+    med = statistics.median(walls)
+    q = quartiles(walls)
+    bps = BYTES_PER_SUBSTEP["float64"]
+    val = cells * 3 * steps / med
+    return {"value": val, "ms_per_step": 1e3 * med / steps, "steps": steps, "dtype": "f64",
+            "roofline_frac": val * bps / 1e9 / HBM_PEAK_GBS,
+            "repeats": {"n": len(walls), "iqr_over_median": (q[2] - q[0]) / med,
+                        "value_min": cells * 3 * steps / max(walls), "value_max": cells * 3 * steps / min(walls)},
+            "workload": "Dubins-relative %d^3 %s + GLF through %s" % (n, scheme, {
+                "odeCFL3": "odeCFL3(termLaxFriedrichs, ..., singleStep='on') calls, device tensor in / out",
+                "solve": "one HJIPDE_solve(keepLast) call per window of K steps, device tensor in / out"}[kind])}
+
+
 def summarize(r, steps):
     """value from the MEDIAN repeat, spread, and the roofline numbers of the step's launches."""
     med = statistics.median(r["walls"])
@@ -259,7 +389,9 @@ def summarize(r, steps):
     achieved = r["cells"] * 3 * bps / (dev_step_ms * 1e-3) / 1e9
     return {"value": per_s(med), "ms_per_step": 1e3 * med / steps,
             "repeats": {"n": len(r["walls"]), "value_min": per_s(max(r["walls"])), "value_max": per_s(min(r["walls"])),
-                        "spread": (max(r["walls"]) - min(r["walls"])) / med},
+                        "value_q1": per_s(quartiles(r["walls"])[2]), "value_q3": per_s(quartiles(r["walls"])[0]),
+                        "spread": (max(r["walls"]) - min(r["walls"])) / med,
+                        "iqr_over_median": (quartiles(r["walls"])[2] - quartiles(r["walls"])[0]) / med},
             "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "dev_step_ms": dev_step_ms}
 
 
@@ -420,20 +552,105 @@ def measured_traffic(n, scheme, dtype):
     return None
 
 
+def error_json(a, world, msg):
+    """The ONE line a failed run prints instead of a result: no `value`, an `error`, non-zero exit code follows."""
+    return json.dumps({"metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI, %d MI355X" % world, "value": None,
+                       "unit": "cell-substeps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                       "higher_is_better": True, "error": msg})
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a, argv, script=None, visible_devices=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks from HERE, one process per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment, exactly what
+    torch.distributed.run would set), BEFORE this process makes any GPU call -- it never does: it only waits, relays rank 0's
+    single JSON line and returns the worst exit code.  A rank that dies takes the others down (their exact PIDs), and when
+    rank 0 printed no line of its own an `error` line is printed instead.  Returns the exit code."""
+    n = a.gpus
+    if visible_devices is None:
+        import torch                                    # device_count() does not initialise HIP on this image
+        visible_devices = torch.cuda.device_count()
+    if not os.environ.get("HJ_BENCH_ONE_DEVICE") and visible_devices < n:
+        print(error_json(a, n, "--gpus %d asked for, %d GPU(s) visible: refusing to report a %d-GPU figure from fewer "
+                               "devices (HJ_BENCH_ONE_DEVICE=1 rehearses all ranks on GPU 0)" % (n, visible_devices, n)))
+        return 2
+    env0 = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(free_port()), HJ_BENCH_LAUNCHED="1")
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=os.getcwd(), text=True,
+                                      stdout=subprocess.PIPE if r == 0 else 2))   # other ranks' stdout -> fd 2
+    limit = float(os.environ.get("HJ_BENCH_WATCHDOG_S", "900")) + 120.0
+    t0, rcs, out0 = time.time(), [None] * n, []
+    import threading
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = "rank %d exited with code %d" % (r, rcs[r])
+        if failed is None and time.time() - t0 > limit:
+            failed = "the %d ranks did not finish within %.0f s" % (n, limit)
+        if failed is not None:
+            t1 = time.time()
+            # give the surviving ranks a moment to report by themselves (collective time-outs), then end exactly the
+            # processes started here
+            while time.time() - t1 < 20 and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for r, p in enumerate(procs):
+                rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    rd.join(timeout=10)
+    lines = [ln.strip() for ln in out0 if ln.strip().startswith("{")]
+    rc = max((abs(c) for c in rcs if c), default=0)
+    if lines and (rc == 0 or '"error"' in lines[-1]):
+        print(lines[-1])
+    else:
+        print(error_json(a, n, failed or "rank 0 printed no result line"))
+        rc = rc or 1
+    sys.stdout.flush()
+    return min(rc, 255)
+
+
 def main():
     a = parse()
     if a.cpu_worker:
         cpu_worker(a.cpu_worker)
         return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
+        sys.exit(launch_ranks(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("HJ_BENCH_ONE_DEVICE"):      # rehearsal: every rank on GPU 0 (several processes sharing one card)
         local = 0
-    slab_leg = world > 1 or bool(os.environ.get("HJ_BENCH_FORCE_SLAB")) or (a.global_n not in (None, 0))
+    if world != a.gpus:
+        # a figure labelled N GPUs must come from N ranks: refuse anything else (torchrun with a different
+        # --nproc-per-node, a stale WORLD_SIZE in the environment)
+        if rank == 0:
+            print(error_json(a, a.gpus, "--gpus %d but WORLD_SIZE=%d: the launcher started a different number of ranks" % (a.gpus, world)))
+        sys.exit(2)
+    slab_leg = world > 1 or bool(os.environ.get("HJ_BENCH_FORCE_SLAB")) or (a.global_n not in (None, 0)) or a.workload is not None
     cpu = None
     if rank == 0 and world == 1 and not slab_leg and not a.no_cpu_baseline:
-        cpu = CpuBaseline(a.scheme)          # before the GPU is touched; idle until the GPU legs are done
+        cpu = CpuBaseline(a.scheme, a.n)     # before the GPU is touched; idle until the GPU legs are done
     a.live, a.live_also = None, {}
     # (quick runs -- --no-also -- and runs that are themselves being profiled skip the passes)
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -516,8 +733,14 @@ def run(a, rank, world, local, slab_leg, cpu):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
-        gn = 513 if a.global_n is None else a.global_n
-        res = hjdist.bench_slab(a, rank, world, global_n=gn)
+        wname = a.workload or "C4"
+        gn = (513 if wname == "C4" else 129) if a.global_n is None else a.global_n
+        res = hjdist.bench_slab(a, rank, world, global_n=gn, workload=wname)
+        if res.get("nranks") != world:
+            raise RuntimeError("the slab transport spans %r ranks, --gpus says %d" % (res.get("nranks"), world))
+        wl = res["workload"]
+        bps = BYTES_PER_SUBSTEP[wl["dtype"]]
+        dt_tag = "f64" if wl["dtype"] == "float64" else "f32"
         walls = res["walls"]
         tw = torch.tensor(walls, dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)           # per repeat: the slowest rank
@@ -529,24 +752,32 @@ def run(a, rank, world, local, slab_leg, cpu):
         dev_step_ms = res["devs"][k] / a.steps
         # roofline of the step's launches on THIS rank (rank 0): its own cells over its own device time
         achieved = res["local_cells"] * 3 * bps / (dev_step_ms * 1e-3) / 1e9
-        strong = gn > 0
-        grid_txt = ("%d x %d x %d" % (gn, gn, gn)) if strong else ("%dx%d x %d x %d" % (world, a.n, a.n, a.n))
+        strong = gn > 0 or wname != "C4"
+        if wname == "C4":
+            grid_txt = ("%d x %d x %d" % (gn, gn, gn)) if strong else ("%dx%d x %d x %d" % (world, a.n, a.n, a.n))
+            what = "Dubins-3D HJI %s %s" % ("%d^3" % gn if strong else "%d^3 per GPU" % a.n, "fp64" if dt_tag == "f64" else "fp32")
+        else:
+            grid_txt, what = wl["grid_txt"], "double-pendulum 4-D HJI %s fp32 periodic" % wl["grid_txt"]
+        q = quartiles(walls)
         out = {
-            "metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI %s %s, slab-decomposed over %d MI355X"
-                      % ("%d^3" % gn if strong else "%d^3 per GPU" % a.n, "fp64" if a.dtype == "float64" else "fp32", world),
+            "metric": "grid-cell RK-substep updates/sec, %s, slab-decomposed over %d MI355X" % (what, world),
             "value": value, "unit": "cell-substeps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * med / a.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": dt_tag, "data": "synthetic",
-            "config": {"workload": "Dubins-relative (air3D) 3-D HJI, %s grid slab-decomposed over %d along axis 0 (%s planes "
-                                   "per rank), %s + GLF, odeCFL3 (factorCFL 0.8), cylinder r=0.5 initial data"
-                                   % (grid_txt, world, res["planes"], a.scheme),
-                       "scheme": a.scheme, "parallelism": res["parallelism"], "substeps_per_step": 3,
-                       "spinup_steps": SPINUP_STEPS, "rccl_nranks": res.get("nranks")},
+            "config": {"workload": "%s; %s grid slab-decomposed over %d along axis 0 (%s planes per rank)"
+                                   % (wl["desc"], grid_txt, world, res["planes"]),
+                       "scheme": wl["scheme"], "parallelism": res["parallelism"], "substeps_per_step": 3,
+                       "spinup_steps": SPINUP_STEPS, "rccl_nranks": res.get("nranks"), "world_size": world,
+                       "launched_by": "bench.py itself (one child process per rank)" if os.environ.get("HJ_BENCH_LAUNCHED")
+                                      else "an external launcher (torch.distributed.run)" if world > 1 else "single process"},
             "repeats": {"n": len(walls), "value_min": total_cells * 3 * a.steps / max(walls),
-                        "value_max": total_cells * 3 * a.steps / min(walls), "spread": (max(walls) - min(walls)) / med},
+                        "value_max": total_cells * 3 * a.steps / min(walls), "spread": (max(walls) - min(walls)) / med,
+                        "iqr_over_median": (q[2] - q[0]) / med},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "fused_substep_kernel (rank 0's launches of one RK3 step: interior + edge planes)",
+                         "traffic_note": "counters are not collected in the slab leg (rocprofv3 --pmc serialises the "
+                                         "streams the overlap depends on); the undivided grid's traffic is in the N=1 line",
+                         "kernel": "%s (rank 0's launches of one RK3 step on its slab: %s)" % (res["kernel"], res["launches"]),
                          "kernel_ms": dev_step_ms, "algorithmic_bytes_per_launch": res["local_cells"] * 3 * bps},
             "per_gpu_value": value / world,
             "also": {"slab_check_max_abs_diff": res.get("slab_check_max_abs_diff")},
@@ -570,7 +801,10 @@ def run(a, rank, world, local, slab_leg, cpu):
         "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dt_tag, "data": "synthetic",
         "config": {"workload": r["desc"], "scheme": a.scheme, "parallelism": "single", "substeps_per_step": 3,
-                   "launches_per_step": r["launches_per_step"], "spinup_steps": SPINUP_STEPS},
+                   "launches_per_step": r["launches_per_step"], "spinup_steps": SPINUP_STEPS,
+                   "cfl_reduction": "static bound, skipped in launch (alpha is data independent: dt = factorCFL * "
+                                    "hj_static_step_bound, equal to the reduced bound by test; value with the reduction kept "
+                                    "in every launch: config.cfl_reduction_kept_value)"},
         "repeats": s["repeats"],
         # the step's launches as one unit: algorithmic bytes of an RK3 step (8 words per cell) over the HIP-event
         # time of a step's launches, back to back on the ctx stream (median repeat)
@@ -581,6 +815,31 @@ def run(a, rank, world, local, slab_leg, cpu):
     if not a.no_also:
         for name in [x for x in a.also.split(",") if x]:
             try:
+                if name == "CFL":
+                    # the headline launches skip the in-kernel CFL reduction (alpha of the native Hamiltonians is data
+                    # independent: hj_rk_step takes dt from hj_static_step_bound, identical by test); this is the same
+                    # step with every launch reducing its bound anyway (HJ_KEEP_BOUNDS=1, read when a ctx is created)
+                    os.environ["HJ_KEEP_BOUNDS"] = "1"
+                    try:
+                        wl2 = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n)
+                        r2 = time_single(torch, _ffi, DeviceGrid, wl2, a.steps, a.warmup, min(15, a.repeats), SPINUP_STEPS)
+                    finally:
+                        del os.environ["HJ_KEEP_BOUNDS"]
+                    s2 = summarize(r2, a.steps)
+                    also["%d^3 with the CFL reduction kept in every launch" % a.n] = {
+                        "value": s2["value"], "ms_per_step": s2["ms_per_step"], "roofline_frac": s2["frac"], "repeats": s2["repeats"],
+                        "vs_headline": s2["value"] / s["value"]}
+                    out["config"]["cfl_reduction_kept_value"] = s2["value"]
+                    del r2, wl2
+                    continue
+                if name == "API":
+                    rep = min(15, a.repeats)
+                    also["%d^3 via odeCFL3 (tensor)" % a.n] = time_api(L, torch, a.n, "odeCFL3", a.scheme, a.steps, a.warmup, rep, SPINUP_STEPS)
+                    also["%d^3 via HJIPDE_solve" % a.n] = time_api(L, torch, a.n, "solve", a.scheme, a.steps, a.warmup, rep, SPINUP_STEPS)
+                    also["51^3 singleStep"] = time_api(L, torch, 51, "odeCFL3", a.scheme, max(a.steps, 200), a.warmup, rep, SPINUP_STEPS)
+                    for k in ("%d^3 via odeCFL3 (tensor)" % a.n, "%d^3 via HJIPDE_solve" % a.n):
+                        also[k]["vs_raw_c_loop"] = also[k]["value"] / s["value"]
+                    continue
                 if name in ("WENO5", "ENO3", "ENO2", "WENO5_ASSHIPPED"):
                     if name == a.scheme:
                         continue
@@ -589,7 +848,7 @@ def run(a, rank, world, local, slab_leg, cpu):
                     wl2, st, key = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, int(name)), max(10, a.steps // 4), "%s^3 %s" % (name, a.scheme)
                 else:
                     wl2, st, key = workload(L, _ffi, torch, name, None, None, 0), max(10, a.steps // 4), name
-                r2 = time_single(torch, _ffi, DeviceGrid, wl2, st, max(2, a.warmup // 2), min(3, a.repeats), max(20, SPINUP_STEPS // 3))
+                r2 = time_single(torch, _ffi, DeviceGrid, wl2, st, max(2, a.warmup // 2), min(9, a.repeats), max(20, SPINUP_STEPS // 3))
                 s2 = summarize(r2, st)
                 lt = getattr(a, "live_also", {}).get(name)
                 ro = roofline_obj(r2, s2, lt, r2["cells"] * 3 * BYTES_PER_SUBSTEP[r2["dtype"]])
@@ -607,6 +866,8 @@ def run(a, rank, world, local, slab_leg, cpu):
         out["also"] = also
     if cpu is not None:
         out["cpu_baseline"] = cpu.run()
+        # the oracle's state at the headline size, already paid for by the baseline leg, checks the product path
+        out["parity"] = gpu_parity(L, torch, cpu.c2, a.scheme)
     return out
 
 

@@ -396,7 +396,7 @@ class NativeSlabStepper(object):
         _ffi.check(self.dg.lib.hj_comm_destroy(self.dg.ctx))
 
 
-def _slab_self_check(L, g, slab, integ, args, tdtype, device, steps=2):
+def _slab_self_check(g, slab, integ, wl, tdtype, device, steps=2):
     """max |slab result - single-domain result| over this rank's planes after `steps` RK3 steps."""
     import torch
     from .context import DeviceGrid
@@ -406,16 +406,16 @@ def _slab_self_check(L, g, slab, integ, args, tdtype, device, steps=2):
     mine = integ.state().clone()
     torch.cuda.synchronize(device)
     n0 = slab.n0
-    dg = DeviceGrid(g, args.dtype)
+    dg = DeviceGrid(g, wl["dtype"])
     dg.bind_stream()
-    cur = _cylinder_planes(torch, g, 0, n0, tdtype, device)
+    cur = wl["planes"](torch, g, 0, n0, tdtype, device)
     assert cur.shape[0] == n0
     nxt, w1 = torch.empty_like(cur), torch.empty_like(cur)
     tout, dtout = C.c_double(), C.c_double()
-    par = _ffi.darr([1.0, 1.0, 1.0, 2.0])
+    par = _ffi.darr(wl["par"])
     ts = 0.0
     for _ in range(steps):
-        _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, _ffi.SCHEME_IDS[args.scheme], _ffi.HAM_DUBINS_REL, par, ts, 1e9, 0.8,
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, _ffi.SCHEME_IDS[wl["scheme"]], wl["ham"], par, ts, 1e9, 0.8,
                                      1e300, 0, dg.ptr(cur), dg.ptr(nxt), dg.ptr(nxt), dg.ptr(w1),
                                      C.byref(tout), C.byref(dtout)))
         cur, nxt = nxt, cur
@@ -437,6 +437,21 @@ def _cylinder_planes(torch, g, b, e, tdtype, device):
     return d.expand(e - b, x1.shape[1], n2).to(tdtype).contiguous()
 
 
+def _sphere_planes(torch, g, b, e, tdtype, device, radius=0.5):
+    """shapeSphere(g, 0, radius) restricted to axis-0 planes [b, e), built on the device (sphere.py:50-57)."""
+    dim = int(g.dim)
+    acc = None
+    for i, v in enumerate(g.vs):
+        v = np.asarray(v).ravel()
+        if i == 0:
+            v = v[b:e]
+        view = [1] * dim
+        view[i] = -1
+        sq = torch.as_tensor(v, device=device).reshape(view) ** 2
+        acc = sq if acc is None else acc + sq
+    return (acc.sqrt() - radius).to(tdtype).contiguous()
+
+
 def slab_grid(L, world, n, global_n):
     """The bench grid: strong scaling (global_n > 0) integrates the global_n^3 Dubins grid of BASELINE C4
     whatever the rank count; weak scaling gives every rank an n^3 slab of an (world*n) x n x n grid."""
@@ -449,6 +464,30 @@ def slab_grid(L, world, n, global_n):
     gmin = np.array([[-.75, -1.25, -np.pi]]).T
     gmax = np.array([[gmax0, 1.25, np.pi * (1 - 2 / n)]]).T
     return L.createGrid(gmin, gmax, np.array([[n0], [n], [n]], dtype=np.int64), 2, low_mem=True), n0, n
+
+
+def slab_workload(L, name, world, args, global_n):
+    """What bench.py's slab leg integrates.  "C4": BASELINE config 4, the Dubins-relative 3-D grid (fp64, axis 0
+    extrapolated: the end ranks synthesise their ghosts).  "C5": BASELINE config 5, the double-pendulum 4-D grid, fp32,
+    ALL axes periodic -- the slab ring closes rank P-1 <-> 0 and the drift's sin/cos tables of the axis-0 node are
+    per-slab (context.py); `global_n` is the points per axis (129)."""
+    if name == "C4":
+        g, n0, n = slab_grid(L, world, args.n, global_n)
+        return {"name": "C4", "grid": g, "n0": n0, "plane": n * n, "periodic0": False, "ham": _ffi.HAM_DUBINS_REL,
+                "par": [1.0, 1.0, 1.0, 2.0], "scheme": args.scheme, "dtype": args.dtype, "planes": _cylinder_planes,
+                "grid_txt": ("%d x %d x %d" % (n0, n, n)),
+                "desc": "Dubins-relative (air3D) 3-D HJI, %s + GLF, odeCFL3 (factorCFL 0.8), cylinder r=0.5 initial data" % args.scheme}
+    if name == "C5":
+        n = int(global_n) if global_n and global_n > 0 else 129
+        gmin = np.array([[-np.pi, -8, -np.pi, -8]]).T
+        gmax = np.array([[np.pi * (1 - 2 / n), 8 * (1 - 2 / n), np.pi * (1 - 2 / n), 8 * (1 - 2 / n)]]).T
+        g = L.createGrid(gmin, gmax, n * np.ones((4, 1), dtype=np.int64), [0, 1, 2, 3], low_mem=True)
+        return {"name": "C5", "grid": g, "n0": n, "plane": n ** 3, "periodic0": True, "ham": _ffi.HAM_DOUBLE_PENDULUM,
+                "par": [1.0, 0.0, 0.0, 0.0], "scheme": "WENO5_ASSHIPPED", "dtype": "float32", "planes": _sphere_planes,
+                "grid_txt": "%d^4" % n,
+                "desc": "double pendulum 4-D HJI, fp32, all axes periodic (slab ring closed), WENO5_ASSHIPPED + GLF, odeCFL3 "
+                        "(factorCFL 0.8), sphere r=0.5 initial data"}
+    raise ValueError("unknown slab workload %r (C4, C5)" % (name,))
 
 
 def _agree(dist, ok, device):
@@ -466,27 +505,31 @@ def _agree3(dist, ok, device):
     return "all" if not any_failed else ("some" if any_ok else "none")
 
 
-def bench_slab(args, rank, world, global_n=513):
-    """bench.py's slab leg.  global_n > 0: STRONG scaling of the global_n^3 grid (BASELINE C4: 513^3, slabs of
-    65/64 planes at 8 ranks); global_n == 0: weak scaling, every rank owns an n^3 slab."""
+def bench_slab(args, rank, world, global_n=513, workload="C4"):
+    """bench.py's slab leg.  Workload C4 (default) -- global_n > 0: STRONG scaling of the global_n^3 Dubins grid (BASELINE
+    C4: 513^3, slabs of 65/64 planes at 8 ranks); global_n == 0: weak scaling, every rank owns an n^3 slab.  Workload C5:
+    the 4-D double-pendulum grid (129^4 fp32, all axes periodic; 17/16-plane slabs at 8 ranks), strong scaling."""
     import time
     import torch
     import torch.distributed as dist
     import levelsetpy_amd as L
-    g, n0, n = slab_grid(L, world, args.n, global_n)
-    slab = SlabDecomposition(n0, world, rank, False)
+    wl = slab_workload(L, workload, world, args, global_n)
+    g, n0 = wl["grid"], wl["n0"]
+    # one rank with a periodic axis 0: the ring closes rank 0 <-> rank 0 through the transport, so that N = 1 of the
+    # slab leg runs the same exchange code as N > 1
+    slab = SlabDecomposition(n0, world, rank, wl["periodic0"], self_exchange=wl["periodic0"])
     dxs = [float(v) for v in np.asarray(g.dx).ravel()]
-    sid, par = _ffi.SCHEME_IDS[args.scheme], [1.0, 1.0, 1.0, 2.0]
+    sid, par, ham, dtype = _ffi.SCHEME_IDS[wl["scheme"]], wl["par"], wl["ham"], wl["dtype"]
     device = torch.device("cuda", torch.cuda.current_device())
 
     def make(kind):
         if kind == "torch":
-            be = HipSlabBackend(g, slab, sid, _ffi.HAM_DUBINS_REL, par, args.dtype)
-            return SlabIntegrator(slab, be, dxs, 3, 0.8, needs_eps=(args.scheme == "WENO5")), be, \
+            be = HipSlabBackend(g, slab, sid, ham, par, dtype)
+            return SlabIntegrator(slab, be, dxs, 3, 0.8, needs_eps=(wl["scheme"] == "WENO5")), be, \
                 "3-plane halo exchange per substep, torch.distributed P2P over %s, edge-first overlap" % (
                     "RCCL" if dist.get_backend() == "nccl" else dist.get_backend())
         deep = {"native-deep": True, "native": False}[kind]
-        it = NativeSlabStepper(g, slab, sid, _ffi.HAM_DUBINS_REL, par, dxs, args.dtype, 3, 0.8, deep=deep)
+        it = NativeSlabStepper(g, slab, sid, ham, par, dxs, dtype, 3, 0.8, deep=deep)
         how = ("ONE 9-plane exchange per RK3 step, stages recompute the planes beyond the slab" if deep
                else "3-plane exchange per substep, edge-first overlap")
         return it, it, how + ", ncclSend/ncclRecv over RCCL inside the C library"
@@ -499,19 +542,31 @@ def bench_slab(args, rank, world, global_n=513):
     # a non-zero exit.
     want = os.environ.get("HJ_SLAB_TRANSPORT")
     # the deep-halo schedule pays 18 redundant planes per slab and step: only worth it on thick slabs
-    thick = min(slab.counts) >= 128
+    thick = min(slab.counts) >= 128 and wl["name"] == "C4"
     order = [want] if want else ((["native-deep"] if thick else []) + ["native", "torch"])
     integ = be = how = None
     check = float("inf")
     y_init = None
+    last_err = None
+
+    def drop(it):
+        # a stepper that is given up owns an RCCL communicator and side streams: release them before the next one
+        if it is not None and hasattr(it, "close"):
+            try:
+                it.close()
+            except Exception:  # noqa: BLE001
+                pass
+
     for kind in order:
         ok, err = True, None
+        integ = None
         try:
             integ, be, how = make(kind)
-            y_init = _cylinder_planes(torch, g, slab.begin, slab.end, be.dg.tdtype, be.device)
+            y_init = wl["planes"](torch, g, slab.begin, slab.end, be.dg.tdtype, be.device)
             integ.set_state(y_init)
         except Exception as e:  # noqa: BLE001 -- decided collectively below
             ok, err = False, e
+            last_err = e
             sys.stderr.write("[bench_slab] rank %d: transport %s failed to set up: %r\n" % (rank, kind, e))
         verdict = _agree3(dist, ok, device)
         if verdict == "some":
@@ -522,31 +577,30 @@ def bench_slab(args, rank, world, global_n=513):
             # the next transport can be tried
             if rank == 0:
                 sys.stderr.write("[bench_slab] transport %s could not be set up on any rank (%r)\n" % (kind, err))
+            drop(integ)        # make() may have succeeded (communicator, streams) before a later set-up step raised
             integ = None
             continue
         bad = 0.0
         if os.environ.get("HJ_BENCH_SLAB_CHECK", "1") != "0":
             try:
-                bad = _slab_self_check(L, g, slab, integ, args, be.dg.tdtype, be.device)
+                bad = _slab_self_check(g, slab, integ, wl, be.dg.tdtype, be.device)
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("[bench_slab] rank %d: self check of %s raised: %r\n" % (rank, kind, e))
                 bad = float("inf")
         worst = torch.tensor([bad], dtype=torch.float64, device=device)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         check = float(worst.item())
-        if check <= 1e-12:
+        if check <= (1e-12 if dtype == "float64" else 0.0):    # (fp32: the decomposition is bitwise or it is wrong)
             integ.set_state(y_init)
             dist.barrier()
             break
         if rank == 0:
             sys.stderr.write("[bench_slab] transport %s rejected: max |slab - single domain| = %g\n" % (kind, check))
-        if hasattr(integ, "close"):
-            try:
-                integ.close()
-            except Exception:  # noqa: BLE001
-                pass
+        drop(integ)
         integ = None
     if integ is None:
+        if check == float("inf") and last_err is not None:
+            raise RuntimeError("no slab transport could be set up (last error: %r)" % (last_err,))
         raise RuntimeError("no slab transport reproduced the single-domain result (last diff %g)" % check)
     t = 0.0
     # untimed device spin-up (clock ramp), as in bench.py's single-GPU leg
@@ -568,12 +622,19 @@ def bench_slab(args, rank, world, global_n=513):
         walls.append(time.perf_counter() - t0)
         devs.append(e0.elapsed_time(e1))
     ok = bool(torch.isfinite(integ.state()).all())
-    nranks = getattr(integ, "nranks", world)
+    # ranks of the transport that moved the halos: RCCL's own count (ncclCommCount) for the native steppers, the
+    # process group's for the torch.distributed one
+    nranks = integ.nranks if hasattr(integ, "nranks") else dist.get_world_size()
+    kern = be.dg.lib.hj_last_kernel(be.dg.ctx)
     if hasattr(integ, "close"):
         integ.close()
     assert ok, "non-finite state after the timed steps"
-    plane = n * n
+    plane = wl["plane"]
+    deep = bool(getattr(integ, "deep", False))
     return {"walls": walls, "devs": devs, "total_cells": n0 * plane, "local_cells": slab.n_local * plane,
             "planes": "/".join(str(c) for c in sorted(set(slab.counts), reverse=True)),
-            "slab_check_max_abs_diff": check, "nranks": nranks,
+            "slab_check_max_abs_diff": check, "nranks": nranks, "workload": wl,
+            "kernel": kern.decode() if kern else "?",
+            "launches": "3 whole-slab launches incl. the redundant pad planes" if deep else
+                        "per substep one launch for the edge planes and one for the interior",
             "parallelism": "slab%d (axis-0 slabs; %s)" % (world, how)}

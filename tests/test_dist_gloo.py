@@ -23,7 +23,7 @@ class OracleSlabBackend(object):
     """Test double for HipSlabBackend: padded CPU buffers, arithmetic by the NumPy oracle."""
     device = torch.device("cpu")
 
-    def __init__(self, og_global, slab, scheme):
+    def __init__(self, og_global, slab, scheme, make_sys=None):
         self.slab, self.scheme = slab, scheme
         b, e = slab.begin, slab.end
         g = O.Grid(og_global.min, og_global.max, og_global.N.ravel(), None)
@@ -33,7 +33,7 @@ class OracleSlabBackend(object):
         g.xs = np.meshgrid(*g.vs, indexing='ij')
         g.shape = (e - b,) + og_global.shape[1:]
         self.g = g
-        self.sys = O.DubinsRel(g, 1, 1)
+        self.sys = make_sys(g) if make_sys is not None else O.DubinsRel(g, 1, 1)
         self.n = e - b
         self.eps = None
 
@@ -63,11 +63,11 @@ class OracleSlabBackend(object):
         out[HALO + p0:HALO + p1] = torch.from_numpy(np.ascontiguousarray(o[p0:p1]))
 
     def local_alpha_max(self):
-        return [float(np.max(self.sys.dissipation(0, None, None, None, None, d))) for d in range(3)]
+        return [float(np.max(self.sys.dissipation(0, None, None, None, None, d))) for d in range(self.g.dim)]
 
     def max_d1sq(self, y):
         yi = y[HALO:HALO + self.n].numpy()
-        v = [O.max_d1_squared(self.g, yi, d, self._halo(y) if d == 0 else None) for d in range(3)]
+        v = [O.max_d1_squared(self.g, yi, d, self._halo(y) if d == 0 else None) for d in range(self.g.dim)]
         return torch.tensor(v, dtype=torch.float64)
 
     def set_weno_eps(self, v):
@@ -190,6 +190,77 @@ def test_eight_rank_uneven_slabs_equal_single_domain():
             assert abs(t - t_ref) <= 1e-14
             assert abs(sb - sb_ref) <= 1e-14 * sb_ref
         assert np.max(np.abs(got - y_ref)) <= 1e-12, (scheme, periodic0, order)
+
+
+# ---------------------------------------------------------------- BASELINE C5 as decomposed: 4-D, every axis periodic
+N4 = (13, 5, 6, 5)
+CASES4 = [("WENO5_ASSHIPPED", 3), ("WENO5", 2)]
+
+
+def _grid4(N=N4):
+    gmin = [-np.pi, -8., -np.pi, -8.]
+    gmax = [np.pi * (1 - 2 / N[0]), 8 * (1 - 2 / N[1]), np.pi * (1 - 2 / N[2]), 8 * (1 - 2 / N[3])]
+    return O.Grid(gmin, gmax, N, [0, 1, 2, 3])
+
+
+def _data4(og):
+    return O.shape_sphere(og, None, .5) + 0.05 * np.random.default_rng(4).standard_normal(og.shape)
+
+
+def _worker4(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for ci, (scheme, order) in enumerate(CASES4):
+            og = _grid4()
+            data = _data4(og)
+            slab = SlabDecomposition(N4[0], world, rank, True)
+            be = OracleSlabBackend(og, slab, scheme, make_sys=lambda g: O.DoublePendulum4D(g, 1.0))
+            integ = SlabIntegrator(slab, be, [float(v) for v in og.dx.ravel()], order, 0.8, needs_eps=(scheme == "WENO5"))
+            integ.set_state(torch.from_numpy(np.ascontiguousarray(data[slab.begin:slab.end])))
+            t = 0.0
+            for _ in range(NSTEPS):
+                t, _dt = integ.step(t)
+            q.put((ci, rank, slab.begin, slab.end, t, integ.step_bound, integ.state().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_c5_four_d_all_periodic_ring_of_slabs_equals_single_domain(world):
+    """The double-pendulum 4-D grid with every axis periodic (BASELINE configs[4]) over `world` gloo ranks: the ring of
+    slabs closes rank world-1 <-> 0 (world 2: both neighbours are the same peer), the drift depends on the axis-0
+    coordinate of the slab (the per-slab alpha maxima are all-reduced), slabs of 4 / 3 planes at world 4."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world * len(CASES4))]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    og = _grid4()
+    data = _data4(og)
+    sys_ = O.DoublePendulum4D(og, 1.0)
+    for ci, (scheme, order) in enumerate(CASES4):
+        term = lambda t, y: O.term_lax_friedrichs(og, sys_, scheme, t, y)  # noqa: E731
+        ode = {2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
+        y, t_ref = data.reshape(-1, 1), 0.0
+        for _ in range(NSTEPS):
+            t_ref, y = ode(term, [t_ref, 10.], y, 0.8, single_step=True)
+        sb_ref = term(0., data.reshape(-1, 1))[1]
+        got = np.full(N4, np.nan)
+        parts = [r for r in res if r[0] == ci]
+        assert len(parts) == world
+        for (_ci, _rank, b, e, t, sb, ys) in parts:
+            got[b:e] = ys
+            assert abs(t - t_ref) <= 1e-14
+            assert abs(sb - sb_ref) <= 1e-14 * sb_ref
+        assert np.max(np.abs(got - y.reshape(N4))) <= 1e-11, (scheme, order, world)
 
 
 def test_slab_decomposition_bookkeeping():

@@ -1,0 +1,368 @@
+"""GPU tests added in round 4 ("next" items 2 and 3):
+
+  * FULL-ARRAY parity with the oracle at BASELINE sizes -- 51^3 (C1) five RK3 steps with every scheme, 201^3 (C2) one
+    RK3 step through odeCFL3 (the pair kernel's instantiations), 4096^2 (C3) one ENO3 term evaluation; ENO2 / ENO3
+    comparisons are bit for bit (the fused ENO substep is evaluated in the reference's operation order);
+  * the stand-alone artificialDissipationGLF golden of the reference against the DEVICE function;
+  * BASELINE C5 as decomposed: the double-pendulum 4-D grid, fp32, all axes periodic, split into a ring of axis-0 slabs
+    -- deep-halo and per-substep schedules with 2 / 3 / 8 virtual ranks (one of them at the full 129^4 over 8), and the
+    native RCCL stepper as a one-rank self ring -- all bitwise against the undivided grid.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import levelsetpy_amd as L  # noqa: E402
+from levelsetpy_amd import _ffi  # noqa: E402
+from levelsetpy_amd.context import DeviceGrid, device_grid  # noqa: E402
+from oracle import hj_oracle as O  # noqa: E402
+
+from test_gpu_parity import mk, sdata, DERIV, SCHEMES, close, dubins  # noqa: E402
+from test_gpu_configs import pendulum_grid  # noqa: E402
+
+PAR_PENDULUM = [1.0, 0.0, 0.0, 0.0]
+
+
+# ------------------------------------------------------------------------------ oracle parity at BASELINE sizes
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_c1_51_cubed_full_array_vs_oracle_five_rk3_steps(scheme):
+    """BASELINE C1 (configs[0]): the whole 51^3 state after five odeCFL3 steps against the oracle, not five scalars.
+    ENO2 / ENO3: bit for bit; the two WENO5 arithmetics: 1e-11 absolute."""
+    g, og = dubins(51)
+    d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+    assert np.array_equal(d0, O.shape_cylinder(og, 2, None, .5))
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), DERIV[scheme])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    osys = O.DubinsRel(og, 1, 1)
+    term = lambda tt, yy: O.term_lax_friedrichs(og, osys, scheme, tt, yy)  # noqa: E731
+    y, t = d0.reshape(-1, 1), 0.
+    yo, to = d0.reshape(-1, 1), 0.
+    for _ in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+        to, yo = O.ode_cfl_3(term, [to, 10.], yo, 0.8, single_step=True)
+    assert abs(t - to) <= 1e-14
+    if scheme.startswith("ENO"):
+        assert t == to
+        assert np.array_equal(y, yo), "%s: %d cells differ, max %.3e" % (scheme, int((y != yo).sum()), float(np.abs(y - yo).max()))
+    else:
+        close(y, yo, 1e-11, what=scheme)
+
+
+def test_c2_201_cubed_one_rk3_step_vs_oracle_through_odecfl3():
+    """BASELINE C2 at full size: one odeCFL3 step of the 201^3 Dubins problem through the drop-in API (the launches
+    are the pair kernel's EULER / RK3_HALF / RK3_FULL instantiations, asserted) against the oracle's full array."""
+    n = 201
+    g, og = dubins(n)
+    d0 = O.shape_cylinder(og, 2, None, .5)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y0 = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y0, op, sd)
+    dg = device_grid(g)
+    assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel"
+    osys = O.DubinsRel(og, 1, 1)
+    to, yo = O.ode_cfl_3(lambda tt, yy: O.term_lax_friedrichs(og, osys, "WENO5_ASSHIPPED", tt, yy), [0., 10.],
+                         d0.reshape(-1, 1), 0.8, single_step=True)
+    assert abs(float(t) - to) <= 1e-15
+    close(y.cpu().numpy(), yo, 1e-11, what="201^3 RK3 step")
+    assert torch.equal(y0, torch.as_tensor(d0.reshape(-1, 1), device="cuda"))      # the input is never written
+
+
+def test_c3_4096_squared_eno3_term_vs_oracle_bitwise():
+    """BASELINE C3 at full size: termLaxFriedrichs (ENO3 + GLF, double integrator) on the 4096^2 grid against the
+    oracle -- array_equal, stepBound equal (the NumPy-ordered ENO arithmetic is claimed bit-faithful: here on
+    16.8 M cells with the pair kernel), then one Euler substep of the state."""
+    n = 4096
+    g, og = mk([-1, -1], [1, 1], [n, n], None)
+    d0 = O.shape_sphere(og, None, .25)
+    y0 = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    sd = sdata(g, L.DoubleIntegrator(g, 1), L.upwindFirstENO3)
+    yd, sb, _ = L.termLaxFriedrichs(0., y0, sd)
+    dg = device_grid(g)
+    assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel"
+    yo, sbo = O.term_lax_friedrichs(og, O.DoubleIntegrator(og, 1), "ENO3", 0., d0.reshape(-1, 1))
+    assert sb == sbo
+    got = yd.cpu().numpy()
+    assert np.array_equal(got, yo), "%d cells differ, max %.3e" % (int((got != yo).sum()), float(np.abs(got - yo).max()))
+    # one odeCFL1 step (y + dt*ydot, ode_cfl_1.py / ode_cfl_3.py:151) of the whole state
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t1, y1, _ = L.odeCFL1(L.termLaxFriedrichs, [0., 10.], y0, op, sd)
+    dt = 0.8 * sbo
+    assert float(t1) == dt
+    assert np.array_equal(y1.cpu().numpy(), d0.reshape(-1, 1) + dt * yo)
+
+
+def test_glf_dissipation_reference_golden_on_device(golden):
+    """The reference's stand-alone artificialDissipationGLF output (tests/golden/term.npz: glf_diss, glf_sb for the
+    reference's own derivL / derivR arrays) against the DEVICE function fed device tensors (round 3 only checked the
+    oracle against it), and against the NumPy-in / NumPy-out form of the same call."""
+    G = golden("term.npz")
+    n = tuple(int(v) for v in np.asarray(G["dub_N"]).ravel())
+    g, og = mk(np.asarray(G["dub_min"]).ravel(), np.asarray(G["dub_max"]).ravel(), n, 2)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstENO3)
+    dl = [torch.as_tensor(G["glf_dL%d" % i], device="cuda") for i in range(3)]
+    dr = [torch.as_tensor(G["glf_dR%d" % i], device="cuda") for i in range(3)]
+    data = torch.as_tensor(G["dub_data"], device="cuda")
+    diss, sb = L.artificialDissipationGLF(0., data, dl, dr, sd)
+    assert type(diss).__module__.startswith("torch") and diss.is_cuda
+    close(diss.cpu().numpy().reshape(G["glf_diss"].shape), G["glf_diss"], 1e-12, what="glf diss (device)")
+    assert abs(sb - float(G["glf_sb"])) <= 1e-14 * sb
+    diss_np, sb_np = L.artificialDissipationGLF(0., G["dub_data"], [G["glf_dL%d" % i] for i in range(3)],
+                                                [G["glf_dR%d" % i] for i in range(3)], sd)
+    assert isinstance(diss_np, np.ndarray)
+    close(diss_np.reshape(G["glf_diss"].shape), G["glf_diss"], 1e-12, what="glf diss (NumPy)")
+    assert abs(sb_np - float(G["glf_sb"])) <= 1e-14 * sb
+
+
+# ------------------------------------------------------------------------------ C5 as decomposed: 4-D fp32 periodic ring
+def sphere4(g, noise=0.0, seed=0):
+    """4-D sphere r = .5 (+ optional smooth and random perturbation) in fp32 on the device."""
+    xs = [torch.as_tensor(np.asarray(v).ravel(), device="cuda", dtype=torch.float64) for v in g.vs]
+    r2 = (xs[0] ** 2).reshape(-1, 1, 1, 1) + (xs[1] ** 2).reshape(1, -1, 1, 1) + (xs[2] ** 2).reshape(1, 1, -1, 1) \
+        + (xs[3] ** 2).reshape(1, 1, 1, -1)
+    d = r2.sqrt() - 0.5
+    if noise:
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        d = d + 0.1 * torch.sin(xs[0]).reshape(-1, 1, 1, 1) * torch.cos(xs[2]).reshape(1, 1, -1, 1) \
+            + noise * torch.randn(d.shape, generator=gen, device="cuda", dtype=torch.float64)
+    return d.to(torch.float32).contiguous()
+
+
+def undivided_steps(g, full, scheme, order, steps, dt):
+    dg = DeviceGrid(g, "float32")
+    dg.bind_stream()
+    sid = _ffi.SCHEME_IDS[scheme]
+    cur, nxt, w0, w1 = full.clone(), torch.empty_like(full), torch.empty_like(full), torch.empty_like(full)
+    tout, dtout = C.c_double(), C.c_double()
+    t = 0.
+    for _ in range(steps):
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, _ffi.HAM_DOUBLE_PENDULUM, _ffi.darr(PAR_PENDULUM), t, 1e9, 0.8, dt, 0,
+                                     dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+        cur, nxt = nxt, cur
+        t = float(tout.value)
+        assert dtout.value == dt
+    torch.cuda.synchronize()
+    return t, cur
+
+
+@pytest.mark.parametrize("scheme,world,n,order", [("WENO5_ASSHIPPED", 2, (40, 9, 10, 11), 3), ("WENO5_ASSHIPPED", 3, (57, 8, 9, 12), 3),
+                                                  ("ENO3", 2, (38, 7, 12, 9), 2), ("WENO5_ASSHIPPED", 8, (150, 6, 7, 8), 3)])
+def test_c5_ring_deep_halo_virtual_ranks_bitwise(scheme, world, n, order):
+    """hj_slab_rk_step_deep on the 4-D all-periodic pendulum grid in fp32: `world` virtual ranks in one process, the ring
+    closed rank world-1 <-> 0 (two ranks: both neighbours are the same rank), pad planes (3*order deep, with their own
+    sin/cos tables of the axis-0 node: hj_ctx_set_axis0_pad) moved by the test.  Bitwise equal to the undivided grid."""
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    g, _ = pendulum_grid(n, low_mem=True)
+    full = sphere4(g, noise=0.01, seed=world)
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    sid = _ffi.SCHEME_IDS[scheme]
+    steppers = []
+    for r in range(world):
+        slab = SlabDecomposition(n[0], world, r, True)
+        assert slab.lo == (r - 1) % world and slab.hi == (r + 1) % world
+        steppers.append(NativeSlabStepper(g, slab, sid, _ffi.HAM_DOUBLE_PENDULUM, PAR_PENDULUM, dxs, "float32", order=order,
+                                          deep=True, external=lambda st: None))
+    amax = [max(st.alpha_local[d] for st in steppers) for d in range(4)]
+    for st in steppers:
+        st.set_alpha_max(amax)
+
+    def move_pads():
+        torch.cuda.synchronize()
+        for st in steppers:
+            D, nl, sl = st.pad, st.n, st.slab
+            nb = steppers[sl.hi]
+            st.buf["cur"][D + nl:D + nl + D].copy_(nb.buf["cur"][nb.pad:nb.pad + D])
+            nb = steppers[sl.lo]
+            st.buf["cur"][0:D].copy_(nb.buf["cur"][nb.pad + nb.n - D:nb.pad + nb.n])
+        torch.cuda.synchronize()
+
+    for st in steppers:
+        st.set_state(full[st.slab.begin:st.slab.end])
+    move_pads()
+    t = 0.
+    for _ in range(3):
+        ts = [st.step(t) for st in steppers]
+        move_pads()
+        assert all(a == ts[0] for a in ts)
+        t, dt = ts[0]
+    t_ref, ref = undivided_steps(g, full, scheme, order, 3, dt)
+    assert abs(t_ref - t) <= 1e-15
+    for st in steppers:
+        got, want = st.state(), ref[st.slab.begin:st.slab.end]
+        assert torch.equal(got, want), "rank %d differs by %g" % (st.slab.rank, float((got - want).abs().max()))
+        st.close()
+
+
+class ThreadRing(object):
+    """`world` in-process ranks (threads, one stream each) for SlabIntegrator + HipSlabBackend: 3-plane halo exchange per
+    substep and the all-reduce through shared tensors and a barrier (the transport of test_gpu_parity._LocalTransport,
+    for any world size and the closed ring)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.box = {}
+
+    def exchanger(self, slab):
+        tr = self
+
+        class Ex(object):
+            def start(self, buf):
+                n = slab.n_local
+                torch.cuda.current_stream().synchronize()
+                tr.box[(slab.rank, "low")] = buf[3:6].clone()
+                tr.box[(slab.rank, "high")] = buf[n:n + 3].clone()
+                torch.cuda.current_stream().synchronize()
+                tr.bar.wait()
+                if slab.hi is not None:
+                    buf[n + 3:n + 6].copy_(tr.box[(slab.hi, "low")])
+                if slab.lo is not None:
+                    buf[0:3].copy_(tr.box[(slab.lo, "high")])
+                torch.cuda.current_stream().synchronize()
+                tr.bar.wait()
+                return []
+
+            @staticmethod
+            def finish(reqs):
+                pass
+
+            def exchange(self, buf):
+                self.start(buf)
+        return Ex()
+
+    def allreduce_max(self, rank):
+        tr = self
+
+        def f(t):
+            torch.cuda.current_stream().synchronize()
+            tr.box[(rank, "ar")] = t.clone()
+            torch.cuda.current_stream().synchronize()
+            tr.bar.wait()
+            m = tr.box[(0, "ar")]
+            for r in range(1, tr.world):
+                m = torch.maximum(m, tr.box[(r, "ar")])
+            torch.cuda.current_stream().synchronize()
+            tr.bar.wait()
+            t.copy_(m)
+        return f
+
+
+def run_ring_per_substep(g, n, world, scheme, full, steps):
+    from levelsetpy_amd.dist import SlabDecomposition, SlabIntegrator, HipSlabBackend
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    tr = ThreadRing(world)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                slab = SlabDecomposition(n[0], world, rank, True, self_exchange=True)
+                be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS[scheme], _ffi.HAM_DOUBLE_PENDULUM, PAR_PENDULUM, "float32")
+                integ = SlabIntegrator(slab, be, dxs, 3, 0.8, exchanger=tr.exchanger(slab), allreduce_max=tr.allreduce_max(rank))
+                integ.set_state(full[slab.begin:slab.end])
+                t = 0.
+                for _ in range(steps):
+                    t, dt = integ.step(t)
+                be.sync()
+                out[rank] = (slab.begin, slab.end, t, dt, integ.state().clone())
+                be.sync()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            tr.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errs, errs
+    assert len(out) == world
+    return out
+
+
+@pytest.mark.parametrize("scheme,world,n", [("WENO5_ASSHIPPED", 2, (14, 9, 10, 11)), ("WENO5_ASSHIPPED", 3, (19, 8, 9, 12)),
+                                            ("ENO3", 2, (12, 7, 12, 9)), ("WENO5_ASSHIPPED", 8, (43, 6, 7, 40)),
+                                            ("WENO5_ASSHIPPED", 1, (13, 6, 7, 9))])
+def test_c5_ring_per_substep_virtual_ranks_bitwise(scheme, world, n):
+    """SlabIntegrator + HipSlabBackend (edge planes, 3-plane exchange per substep, interior) on the 4-D all-periodic
+    pendulum grid in fp32, ring closed across the last and the first rank (world 1: rank 0 <-> rank 0 through the
+    transport); slabs as thin as 5 planes (43 = 8*5 + 3).  Bitwise equal to the undivided grid."""
+    g, _ = pendulum_grid(n, low_mem=True)
+    full = sphere4(g, noise=0.01, seed=7)
+    out = run_ring_per_substep(g, n, world, scheme, full, 2)
+    t, dt = out[0][2], out[0][3]
+    t_ref, ref = undivided_steps(g, full, scheme, 3, 2, dt)
+    for r in range(world):
+        b, e, tr_, dtr, ys = out[r]
+        assert tr_ == t and dtr == dt and abs(t - t_ref) <= 1e-15
+        assert torch.equal(ys, ref[b:e]), "rank %d differs by %g" % (r, float((ys - ref[b:e]).abs().max()))
+
+
+def test_c5_129_to_the_4_over_eight_virtual_ranks_bitwise():
+    """BASELINE C5 as BASELINE.json decomposes it: 129^4 fp32, all axes periodic, 8 ranks -> slabs of 17 / 16 planes
+    (thinner than the 18 the deep-halo stepper needs: the per-substep schedule is the one that runs), ring closed 7 <-> 0.
+    One RK3 step, bitwise against the undivided 129^4 grid; the pair kernel runs on the slabs."""
+    from levelsetpy_amd.dist import SlabDecomposition
+    n, world = (129, 129, 129, 129), 8
+    counts = SlabDecomposition(129, world, 0, True).counts
+    assert counts == [17] + [16] * 7 and min(counts) < 2 * 3 * 3
+    g, _ = pendulum_grid(n, low_mem=True)
+    full = sphere4(g, noise=0.0)
+    out = run_ring_per_substep(g, n, world, "WENO5_ASSHIPPED", full, 1)
+    t, dt = out[0][2], out[0][3]
+    t_ref, ref = undivided_steps(g, full, "WENO5_ASSHIPPED", 3, 1, dt)
+    assert abs(t - t_ref) <= 1e-15
+    for r in range(world):
+        b, e, _t, _dt, ys = out[r]
+        assert torch.equal(ys, ref[b:e]), "rank %d differs by %g" % (r, float((ys - ref[b:e]).abs().max()))
+
+
+def test_c5_native_rccl_stepper_self_ring_4d_fp32():
+    """hj_slab_rk_step (ncclSend/ncclRecv inside the C library) on the 4-D fp32 pendulum grid as a one-rank ring: axis 0
+    closed through a self send/recv instead of the in-kernel wrap, every per-substep schedule + the deep-halo one."""
+    import torch.distributed as dist
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29593")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        n = (24, 7, 9, 10)
+        g, _ = pendulum_grid(n, low_mem=True)
+        full = sphere4(g, noise=0.01, seed=11)
+        dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+        ref = None
+        for deep, sched in ((True, None), (False, "overlap"), (False, "serial")):
+            if sched is None:
+                os.environ.pop("HJ_SLAB_SCHEDULE", None)
+            else:
+                os.environ["HJ_SLAB_SCHEDULE"] = sched
+            try:
+                slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
+                nat = NativeSlabStepper(g, slab, _ffi.WENO5_ASSHIPPED, _ffi.HAM_DOUBLE_PENDULUM, PAR_PENDULUM, dxs, "float32", deep=deep)
+            finally:
+                os.environ.pop("HJ_SLAB_SCHEDULE", None)
+            assert nat.nranks == 1
+            nat.set_state(full)
+            t = 0.
+            for _ in range(3):
+                t, dt = nat.step(t)
+            got = nat.state().clone()
+            torch.cuda.synchronize()
+            nat.close()
+            if ref is None:
+                t_ref, ref = undivided_steps(g, full, "WENO5_ASSHIPPED", 3, 3, dt)
+            assert abs(t - t_ref) <= 1e-15
+            assert torch.equal(got, ref), "deep=%s %s differs by %g" % (deep, sched, float((got - ref).abs().max()))
+    finally:
+        if created:
+            dist.destroy_process_group()
