@@ -333,8 +333,11 @@ def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
     d0 = device_sdf(torch, g, 0.5, ignore=(2,))
     cells = d0.numel()
     st = {"y": d0.reshape(-1, 1), "t": 0.0}
-    if kind == "odeCFL3":
+    if kind in ("odeCFL3", "numpy"):
         op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+        if kind == "numpy":
+            # the reference's own driver loop: a NumPy array in, whatever comes back fed into the next call
+            st["y"] = d0.reshape(-1, 1).cpu().numpy()
 
         def window(k):
             for _ in range(k):
@@ -365,7 +368,11 @@ def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
         window(steps)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
-    assert bool(torch.isfinite(st["y"]).all())
+    yfin = st["y"]
+    if kind == "numpy":
+        kind_out = type(yfin).__name__
+        yfin = torch.as_tensor(np.asarray(yfin))
+    assert bool(torch.isfinite(yfin).all())
     med = statistics.median(walls)
     q = quartiles(walls)
     bps = BYTES_PER_SUBSTEP["float64"]
@@ -376,6 +383,8 @@ def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
                         "value_min": cells * 3 * steps / max(walls), "value_max": cells * 3 * steps / min(walls)},
             "workload": "Dubins-relative %d^3 %s + GLF through %s" % (n, scheme, {
                 "odeCFL3": "odeCFL3(termLaxFriedrichs, ..., singleStep='on') calls, device tensor in / out",
+                "numpy": "odeCFL3(termLaxFriedrichs, ..., singleStep='on') calls, a NumPy array in, every result fed back into the next call "
+                         "(the reference's driver loop; results are lazy.HostView handles that stay in HBM until somebody looks)",
                 "solve": "one HJIPDE_solve(keepLast) call per window of K steps, device tensor in / out"}[kind])}
 
 
@@ -395,7 +404,7 @@ def summarize(r, steps):
             "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "dev_step_ms": dev_step_ms}
 
 
-def roofline_obj(r, s, tr, step_bytes):
+def roofline_obj(r, s, tr, step_bytes, ach=None):
     """The `roofline` object of one workload.  achieved = algorithmic bytes of an RK3 step / the time of the step's
     launches, with that time taken as the LARGER of (a) the HIP-event time of the step on the launch stream, median
     repeat, and (b) the sum of the kernels' durations in the rocprofv3 kernel-trace child pass of this run (VERDICT r02:
@@ -410,8 +419,17 @@ def roofline_obj(r, s, tr, step_bytes):
     step_ms = max(ev_ms, rp_ms) if rp_ms else ev_ms
     achieved = step_bytes / (step_ms * 1e-3) / 1e9
     working_set = 3 * r["cells"] * (8 if r["dtype"] == "float64" else 4)
+    regime = "hbm" if working_set > 256 * 2 ** 20 else "infinity_cache"
+    # what a plain streaming kernel reaches on this box in the step's access mix (one 1R:1W launch + two 2R:1W launches per
+    # RK3 step: bytes-weighted harmonic mix of the copy and triad rates), in the memory regime of this working set
+    ach_gbs = None
+    if ach and ach.get(regime):
+        c, t3 = ach[regime]["copy"] * 1e3, ach[regime]["triad"] * 1e3
+        ach_gbs = 8.0 / (2.0 / c + 6.0 / t3) if (nl == 3 and c > 0 and t3 > 0) else t3
     return {"bound": "hbm" if working_set > 256 * 2 ** 20 else "infinity-cache/fabric",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "achievable": ach_gbs, "frac_of_achievable": (achieved / ach_gbs) if ach_gbs else None,
+            "achievable_source": (ach["source"] + "; regime: " + regime) if ach_gbs else None,
             # measured fabric bytes per launch / per step (null unless counters were collected on these kernel sources)
             "traffic": tr["bytes_per_launch"] if tr else None,
             "traffic_per_step": tr["bytes_per_step"] if tr else None,
@@ -475,8 +493,10 @@ def live_traffic(a, n=None, scheme=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE", None):
         # counter passes: short (every dispatch is serialised and slow under --pmc; byte counts do not depend on the
         # clocks); the duration pass: the timed leg's own spin-up, so that its kernels run at settled clocks
-        # (40 steps of spin-up: on grids of >= 40 M cells the library spends its first ~100 launches choosing a tile shape)
-        spin, warm, steps = (40, 1, 4) if ctr else (SPINUP_STEPS, 2, 20)
+        # (60 steps of spin-up in the counter passes: on grids of >= 40 M cells the library spends up to 9 x 6 = 54 launches per
+        # (scheme, stage class) choosing a tile shape, and the stage-1 class sees ONE launch per step -- the counted steps must
+        # run the settled shape: ADVICE r03)
+        spin, warm, steps = (60, 1, 4) if ctr else (SPINUP_STEPS, 2, 20)
         nstep = spin + warm + steps
         d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin))
@@ -531,8 +551,27 @@ def live_traffic(a, n=None, scheme=None):
     return {"bytes_per_launch": per_step / nsub, "bytes_per_step": per_step, "substep_launches_per_step": nsub,
             "fetch_kib_per_step": vals["FETCH_SIZE"][0], "write_kib_per_step": vals["WRITE_SIZE"][0],
             "rocprof": dur,
-            "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 45 RK3 steps, --kernel-trace: "
+            "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 65 RK3 steps, --kernel-trace: "
                       "the last 20 of %d; every kernel of the step counted; %.0f s)" % (SPINUP_STEPS + 22, time.perf_counter() - t0)}
+
+
+def achievable_rates():
+    """Streaming rates this box achieves in the substep's access mixes (tools/ubench/bw2 --quick, a child process run BEFORE
+    this one touches the GPU): TB/s of a 16-byte-per-lane copy (1R:1W) and triad (2R:1W, the mix of RK stages 2 and 3) on
+    1 GiB arrays (HBM) and on 64 MiB arrays (three of them resident in the 256 MiB Infinity Cache: the regime of the 201^3
+    headline, 65 MB per array).  None if the binary is not built (build() compiles it)."""
+    exe = os.path.join(ROOT, "tools", "ubench", "bw2")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=120, cwd="/tmp")
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"hbm": d["hbm_1GiB"], "infinity_cache": d["infinity_cache_64MiB"], "unit": "TB/s",
+                "source": "tools/ubench/bw2 --quick in this run: best of the grid-stride copy / triad shapes, 16 B per lane, "
+                          "1 GiB arrays (hbm) and 64 MiB arrays (infinity_cache)"}
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def measured_traffic(n, scheme, dtype):
@@ -652,8 +691,11 @@ def main():
     if rank == 0 and world == 1 and not slab_leg and not a.no_cpu_baseline:
         cpu = CpuBaseline(a.scheme, a.n)     # before the GPU is touched; idle until the GPU legs are done
     a.live, a.live_also = None, {}
+    a.achievable = None
     # (quick runs -- --no-also -- and runs that are themselves being profiled skip the passes)
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rank == 0 and world == 1 and not slab_leg and not a.no_also and not profiled:
+        a.achievable = achievable_rates()    # a child process, before this one touches the GPU
     if rank == 0 and world == 1 and not slab_leg and not a.no_live_traffic and not a.no_also and not profiled:
         a.live = live_traffic(a)             # two rocprofv3 child passes, also before this process touches the GPU
         # the same for the digit entries of --also (513^3: the point where the arrays do not fit the Infinity Cache)
@@ -808,9 +850,11 @@ def run(a, rank, world, local, slab_leg, cpu):
         "repeats": s["repeats"],
         # the step's launches as one unit: algorithmic bytes of an RK3 step (8 words per cell) over the HIP-event
         # time of a step's launches, back to back on the ctx stream (median repeat)
-        "roofline": roofline_obj(r, s, tr, cells * 3 * bps),
+        "roofline": roofline_obj(r, s, tr, cells * 3 * bps, a.achievable),
         "per_gpu_value": s["value"],
     }
+    if a.achievable:
+        out["achievable_streaming_rates"] = a.achievable
     also = {}
     if not a.no_also:
         for name in [x for x in a.also.split(",") if x]:
@@ -837,7 +881,9 @@ def run(a, rank, world, local, slab_leg, cpu):
                     also["%d^3 via odeCFL3 (tensor)" % a.n] = time_api(L, torch, a.n, "odeCFL3", a.scheme, a.steps, a.warmup, rep, SPINUP_STEPS)
                     also["%d^3 via HJIPDE_solve" % a.n] = time_api(L, torch, a.n, "solve", a.scheme, a.steps, a.warmup, rep, SPINUP_STEPS)
                     also["51^3 singleStep"] = time_api(L, torch, 51, "odeCFL3", a.scheme, max(a.steps, 200), a.warmup, rep, SPINUP_STEPS)
-                    for k in ("%d^3 via odeCFL3 (tensor)" % a.n, "%d^3 via HJIPDE_solve" % a.n):
+                    also["%d^3 NumPy-in loop" % a.n] = time_api(L, torch, a.n, "numpy", a.scheme, a.steps, a.warmup, rep, SPINUP_STEPS)
+                    also["%d^3 NumPy-in loop" % a.n]["vs_tensor_in"] = also["%d^3 NumPy-in loop" % a.n]["value"] / also["%d^3 via odeCFL3 (tensor)" % a.n]["value"]
+                    for k in ("%d^3 via odeCFL3 (tensor)" % a.n, "%d^3 via HJIPDE_solve" % a.n, "%d^3 NumPy-in loop" % a.n):
                         also[k]["vs_raw_c_loop"] = also[k]["value"] / s["value"]
                     continue
                 if name in ("WENO5", "ENO3", "ENO2", "WENO5_ASSHIPPED"):
@@ -851,7 +897,7 @@ def run(a, rank, world, local, slab_leg, cpu):
                 r2 = time_single(torch, _ffi, DeviceGrid, wl2, st, max(2, a.warmup // 2), min(9, a.repeats), max(20, SPINUP_STEPS // 3))
                 s2 = summarize(r2, st)
                 lt = getattr(a, "live_also", {}).get(name)
-                ro = roofline_obj(r2, s2, lt, r2["cells"] * 3 * BYTES_PER_SUBSTEP[r2["dtype"]])
+                ro = roofline_obj(r2, s2, lt, r2["cells"] * 3 * BYTES_PER_SUBSTEP[r2["dtype"]], a.achievable)
                 also[key] = {"workload": r2["desc"], "dtype": "f64" if r2["dtype"] == "float64" else "f32", "steps": st,
                              "value": s2["value"], "ms_per_step": s2["ms_per_step"], "roofline_frac": ro["frac"],
                              "achieved_GBps": ro["achieved"], "repeats": s2["repeats"], "kernel": r2["kernel"], "roofline": ro}

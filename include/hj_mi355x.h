@@ -152,7 +152,13 @@ int hj_read_step_bound(hj_ctx* ctx, int bound_slot, double* step_bound_host, dou
  * with a native Hamiltonian whose alpha does not depend on the data (all HJ_HAM_* above): ONE step,
  * `order` fused substeps, no host synchronisation.  dt = min(factor_cfl*stepBound, tf-t0, max_step)
  * (ode_cfl_3.py:142).  work0/work1: caller scratch, same size as y (work1 unused for order<3,
- * may be NULL).  y_out must not alias y_in (stencil).  t_out/dt_out: host. */
+ * may be NULL).  y_out must not alias y_in (stencil).  t_out/dt_out: host.
+ * Host synchronisation: none in steady state.  EXCEPTION (grids of >= HJ_AUTOTUNE_MIN_MCELLS = 40 M cells, whole-grid
+ * launches of a single domain, HJ_AUTOTUNE=1 = default): the first ncand * HJ_AUTOTUNE_PASSES (at most 9 x 6) launches per
+ * (scheme, stage class, kernel configuration) take turns through candidate tile shapes and each ends in a
+ * hipEventSynchronize on the ctx stream (hj_rk_substep / hj_rk_step / hj_rk_integrate alike); results do not depend on
+ * the shape.  Launches issued while the stream is being CAPTURED never tune (they take the shape chosen so far).
+ * HJ_AUTOTUNE=0 turns the rotation off. */
 int hj_rk_step(hj_ctx* ctx, int order, int scheme, int ham_id, const double* ham_params, double t0,
                double tf, double factor_cfl, double max_step, int restrict_sign, const void* y_in,
                void* y_out, void* work0, void* work1, double* t_out, double* dt_out);

@@ -11,6 +11,8 @@ import weakref
 import numpy as np
 
 from . import _ffi
+from . import lazy as _lazy
+from .lazy import HostView
 
 
 def _torch():
@@ -18,12 +20,28 @@ def _torch():
     return torch
 
 
+_GPU_OK = [None]       # torch, once torch.cuda.is_available() has answered True (it does not change within a process)
+
+
 def require_gpu():
+    torch = _GPU_OK[0]
+    if torch is not None:
+        return torch
     torch = _torch()
     if not torch.cuda.is_available():
         raise RuntimeError("levelsetpy_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is "
                            "False and there is no CPU fallback")
+    _GPU_OK[0] = torch
     return torch
+
+
+def _raw_stream_getter(torch):
+    """torch's current HIP stream of a device as an integer handle: the private fast accessor when this torch has it
+    (0.3 us), else through torch.cuda.current_stream (6 us: it builds a Stream object)."""
+    fast = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None)
+    if fast is not None:
+        return fast
+    return lambda index: torch.cuda.current_stream(index).cuda_stream
 
 
 def is_tensor(x):
@@ -112,6 +130,9 @@ class DeviceGrid(object):
                     a0, a1 = t0.ctypes.data_as(_ffi._pd), t1.ctypes.data_as(_ffi._pd)
                 _ffi.check(self.lib.hj_ctx_set_axis0_pad(ctx, int(pad), vs0_ext.ctypes.data_as(_ffi._pd), a0, a1))
         self._work = {}
+        self._raw_stream = _raw_stream_getter(torch)
+        self._stream_bound = None       # stream handle the ctx was last bound to (bind_stream skips the C call when unchanged)
+        self.bound_state = None         # (dissipation kind, post-step state) last written by term._Plan.bind
 
     def _aux(self, slot, tab):
         tab = np.ascontiguousarray(tab, dtype=np.float64)
@@ -119,12 +140,18 @@ class DeviceGrid(object):
 
     # ------------------------------------------------------------------ marshalling
     def bind_stream(self):
-        s = self.torch.cuda.current_stream(self.device)
-        _ffi.check(self.lib.hj_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)))
+        """Launch on torch's CURRENT stream of this device (asked every call: the caller may have switched streams)."""
+        s = self._raw_stream(self.device.index)
+        if s != self._stream_bound:
+            _ffi.check(self.lib.hj_ctx_set_stream(self.ctx, C.c_void_p(s)))
+            self._stream_bound = s
 
     def to_device(self, a):
         """NumPy array or torch tensor -> contiguous device tensor of the ctx dtype (flat view ok)."""
         torch = self.torch
+        if isinstance(a, HostView):
+            # a result of this package handed straight back (the NumPy caller's loop): consumed where it lives
+            a = a.device_tensor() if a.device_tensor() is not None else a.__array__()
         if is_tensor(a):
             t = a
             if t.device != self.device or t.dtype != self.tdtype:
@@ -134,8 +161,11 @@ class DeviceGrid(object):
         # a page-locked source (e.g. an array this package returned) goes over at the DMA rate
         return h.to(device=self.device, dtype=self.tdtype, non_blocking=False)
 
-    def like(self, t, proto, shape=None):
+    def like(self, t, proto, shape=None, lazy=False):
         """Return `t` in the array type of `proto` (NumPy in -> NumPy out, tensor in -> tensor out).
+        lazy=True (the state / ydot results of the fused path): a NumPy caller gets a HostView -- an ndarray-compatible
+        handle that is copied to the host when somebody looks at it and is consumed on the device when it is passed
+        back in (lazy.py; HJ_LAZY_NUMPY=0 restores the eager copy).
         The NumPy result lives in page-locked host memory from torch's caching host allocator (the D2H copy
         runs at the DMA rate instead of through a pageable bounce buffer, and an array handed back to the next
         call is recognised as pinned by to_device)."""
@@ -143,6 +173,8 @@ class DeviceGrid(object):
             t = t.reshape(shape)
         if is_tensor(proto):
             return t
+        if lazy and _lazy.LAZY and t.is_cuda:
+            return HostView(t.detach())
         t = t.detach()
         nbytes = t.numel() * t.element_size()
         # HJ_PIN_RESULTS=0 turns the page-locked results off; HJ_PIN_MAX_MB caps a single pinned result (default 2048:
@@ -178,6 +210,11 @@ _PIN_RESULTS = os.environ.get("HJ_PIN_RESULTS", "1") != "0"
 _PIN_MAX_BYTES = int(float(os.environ.get("HJ_PIN_MAX_MB", "2048")) * (1 << 20))
 
 
+def _current_device(torch):
+    f = getattr(getattr(torch, "_C", None), "_cuda_getDevice", None)
+    return f() if f is not None else torch.cuda.current_device()
+
+
 def device_grid(grid, dtype="float64"):
     """Cached DeviceGrid of a grid Bundle (kept on the Bundle itself)."""
     cache = grid.__dict__.get("_hj_device")
@@ -185,7 +222,7 @@ def device_grid(grid, dtype="float64"):
         cache = {}
         object.__setattr__(grid, "_hj_device", cache)
     torch = require_gpu()
-    key = (dtype, torch.cuda.current_device())
+    key = (dtype, _current_device(torch))
     dg = cache.get(key)
     if dg is None:
         dg = cache[key] = DeviceGrid(grid, dtype)
@@ -195,6 +232,8 @@ def device_grid(grid, dtype="float64"):
 def array_dtype_name(a):
     """'float32' only when the caller hands float32 data explicitly; the reference path is fp64
     (ghost functions force float64: add_ghost_extrapolate.py:77)."""
-    if is_tensor(a):
+    if isinstance(a, HostView):
+        a = a.device_tensor() if a.device_tensor() is not None else None
+    if a is not None and is_tensor(a):
         return "float32" if str(a.dtype) == "torch.float32" else "float64"
     return "float64"

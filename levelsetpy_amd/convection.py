@@ -54,12 +54,14 @@ def termConvection(t, y, schemeData):
         phi = dg.to_device(data)
         arrs, scal = [], []
         for v in velocity:
-            if np.isscalar(v) or (isinstance(v, np.ndarray) and v.ndim == 0):
+            if np.isscalar(v) or (isinstance(v, np.ndarray) and v.ndim == 0) or (is_tensor(v) and v.dim() == 0):
                 arrs.append(None)
-                scal.append(float(v))
+                scal.append(float(v))          # (a 0-dim tensor is a scalar speed as well: ADVICE r03)
             else:
                 if is_tensor(v):
-                    a = v.reshape(grid.shape)
+                    # broadcast-shaped components (e.g. (N0,1,1)) are accepted like NumPy ones; to_device materialises them
+                    import torch
+                    a = v.reshape(grid.shape) if v.numel() == int(np.prod(grid.shape)) else torch.broadcast_to(v, grid.shape)
                 else:
                     a = np.broadcast_to(np.asarray(v, dtype=np.float64), grid.shape)
                 arrs.append(dg.to_device(a))

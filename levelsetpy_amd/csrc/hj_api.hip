@@ -26,7 +26,17 @@ int env_int(const char* name, int dflt) {
 // (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
 // vec = 2: the pair kernel (hj_fusedv.h) -- k.R counts PAIRS per thread, the extent of the last axis is even, its LDS
 // rows are E + 8 cells apart (left pad 4)
+static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all);
+
 Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all) {
+    if (all) return make_tiling_uncached(c, k, p0, p1, vec, nbuf, all);
+    const long long key = ((long long)k.NT << 40) | ((long long)k.R << 32) | ((long long)k.KH << 24) | ((long long)vec << 16) | (long long)nbuf;
+    auto it = c->tiling_cache.find(key);
+    if (it == c->tiling_cache.end()) it = c->tiling_cache.emplace(key, make_tiling_uncached(c, k, p0, p1, vec, nbuf, nullptr)).first;
+    return it->second;
+}
+
+static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all) {
     const int nd = c->ndim;
     std::map<int, Tiling> per_row;     // best tiling per extent of the last axis (autotuner candidates)
     // HJ_TILE_CELLS (tuning): cap the tile below what the configuration holds -- more, smaller workgroups (thin slabs)
@@ -343,11 +353,14 @@ int weno_eps_pass(hj_ctx* c, const void* y) { return weno_eps_to(c, y, c->weno_v
 // The pre-pass as ONE launch (round 3): at most 512 workgroups of 1024 threads leave their rows in c->partials and the
 // consuming substep kernel folds them in its prologue (FusedArgs::eps_rows), like the rows of eps_seam_kernel.
 // *nrows = 0: the grid has more than 512 K columns per plane -- the caller takes the two-launch form.
+// (one helper for the launch code and for hj_rk_plan's launch count: ADVICE r03)
+static inline bool weno_rows_fit(const hj_ctx* c) { return (c->total / c->N[0] + 1023) / 1024 <= 512; }
+
 int weno_eps_rows(hj_ctx* c, const void* y, int* nrows) {
     *nrows = 0;
     const int64_t S = c->total / c->N[0];
     const int64_t bx = (S + 1023) / 1024;
-    if (bx > 512) return HJ_OK;
+    if (!weno_rows_fit(c)) return HJ_OK;
     int by = (int)std::max<int64_t>(1, std::min<int64_t>((c->N[0] + 7) / 8, 512 / bx));
     const int chunk = (int)((c->N[0] + by - 1) / by);
     by = (int)((c->N[0] + chunk - 1) / chunk);
@@ -1523,8 +1536,12 @@ int hj_rk_plan(hj_ctx* c, int order, int scheme, int ham, const double* par, int
             // seam launch behind each of the other stages' producers
             const bool fused_eps = c->eps_fuse && !c->force_direct && !(c->direct_below > 0 && c->total < c->direct_below) &&
                                    !c->halo_lo && !c->halo_hi && !c->weno_src && c->total >= c->eps_fuse_min_cells && c->total < (1ll << 31);
-            const bool one_launch_prepass = c->eps_fuse && !c->force_direct && (c->total / c->N[0] + 1023) / 1024 <= 512;
-            *launches = fused_eps ? 2 * order : (one_launch_prepass ? 2 * order : 3 * order);
+            // launches of one epsilon pre-pass, decided exactly as do_substep / weno_eps_rows decide it: ONE launch whose rows the
+            // consumer folds when the plane has at most 512 K columns (and HJ_EPS_FUSE is on), else the two-launch form
+            const int prepass = (c->eps_fuse && weno_rows_fit(c)) ? 1 : 2;
+            // hj_rk_step with fused epsilon: a pre-pass in front of the first stage, then `order` substep launches with a seam
+            // launch behind each producer (all stages but the last); without: a pre-pass in front of every stage
+            *launches = fused_eps ? prepass + order + (order - 1) : order * (1 + prepass);
         }
     }
     if (stage_fused) *stage_fused = f ? 1 : 0;

@@ -82,6 +82,15 @@ __device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsr
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(W, v), r, off, soff, 0);
 }
 
+// prologue experiments of round 4 (A/B through tune builds): HJ_EARLY_ARGS batches the kernel-argument loads,
+// HJ_PROLOGUE_V2 issues every load of the setup before the first wait (the rings of the first AH planes were requested and
+// waited for one after the other: two serialised memory round trips in front of the plane loop)
+#ifndef HJ_EARLY_ARGS
+#define HJ_EARLY_ARGS 1
+#endif
+#ifndef HJ_PROLOGUE_V2
+#define HJ_PROLOGUE_V2 1
+#endif
 constexpr int HJ_VPAD = 4;      // left pad of an LDS row (cells): even, so that tile cell 0 of a row is 16-byte aligned
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int MODE = 0>
@@ -99,6 +108,18 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     T* lds = reinterpret_cast<T*>(hj_smem + 512);
     static_assert((NT / 64) * ND * 8 <= 512, "reduction scratch");
 
+#if HJ_EARLY_ARGS
+    // Round 4: the setup below reads ~45 fields of the 700-byte kernel-argument block.  The compiler places each scalar load next to
+    // its first use, so the prologue was a chain of 6-8 dependent s_load -> s_waitcnt round trips before the first
+    // buffer_load went out (1.8 us after the workgroup started: profiles/r04_prologue.txt).  Naming the fields as inputs of
+    // one empty asm statement makes them all live HERE: the loads are issued back to back and waited for once.
+    asm volatile("" ::"s"(A.nblocks), "s"(A.ntiles), "s"(A.blocks_per_xcd), "s"(A.ntile[1]), "s"(A.ntile[ND - 1]), "s"(A.E[1]),
+                 "s"(A.E[ND - 1]), "s"(A.n[0]), "s"(A.n[1]), "s"(A.n[ND - 1]), "s"(A.nchunks1), "s"(A.plane_begin), "s"(A.plane_end),
+                 "s"(A.plane_begin2), "s"(A.plane_end2), "s"(A.chunk), "s"(A.lpitch), "s"(A.pstride[1]), "s"(A.pstride[ND - 1]),
+                 "s"(A.stride0), "s"(A.halo_lo), "s"(A.halo_hi), "s"(A.lds_nbuf), "s"(A.halo_ahead), "s"(A.timing));
+    asm volatile("" ::"s"(y), "s"(y0), "s"(out), "s"(A.ham.coord[0]), "s"(A.ham.coord[1]), "s"(A.ham.coord[ND - 1]), "s"(A.ham.aux[0]),
+                 "s"(A.ham.aux[1]), "s"(A.bc[1]), "s"(A.bc[ND - 1]), "s"(A.use_y0));
+#endif
     const int b = blockIdx.x;
     const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
     if (L >= A.nblocks) return;
@@ -224,6 +245,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         for (int r = 0; r < R; ++r) { q[r][0][j] = tmp[r].x; q[r][1][j] = tmp[r].y; }
     }
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 0] = wall_clock64();
+#if !HJ_PROLOGUE_V2
     V own[PD][R], y0s[PD][R];
     typename HAM::Plane pls[PD];
 #pragma unroll
@@ -241,6 +263,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         pls[s] = HAM::plane(A.ham, ps, A.sc);
     }
 
+#endif
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 1] = wall_clock64();
     // ---- halo slots (single cells): the cross around the tile, as in the scalar kernel.
     // 4-D (HP, round 3): the halo layers of the plane axes OTHER than the contiguous one are rows of the tile's own row structure,
@@ -492,6 +515,41 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < KP; ++k) { halp[s][k].x = T(0); halp[s][k].y = T(0); hinp[s][k].x = T(0); hinp[s][k].y = T(0); }
     }
+#if HJ_PROLOGUE_V2
+    // every load of the setup goes out before anything waits: the rings of the first AH planes (parked in LDS below, after
+    // the Hamiltonian constants: by then they have landed), the two rings the loop consumes from registers, then the
+    // prefetched own plane and the y0 planes -- in the order the loop needs them (loads return in order)
+    constexpr int AHM = HP ? 1 : 3;                 // 4-D runs without the parked ring (AH = 0)
+    T th[AHM][KS], ti[AHM][KS];
+    V tp[AHM][KP], tq[AHM][KP];
+#pragma unroll
+    for (int a = 0; a < AHM; ++a) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) { th[a][k] = T(0); ti[a][k] = T(0); }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { tp[a][k].x = T(0); tp[a][k].y = T(0); tq[a][k].x = T(0); tq[a][k].y = T(0); }
+        if (a < AH) load_halo(min(p_begin + a, p_last), th[a], ti[a], tp[a], tq[a]);
+    }
+#pragma unroll
+    for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s], halp[s], hinp[s]);
+    V own[PD][R], y0s[PD][R];
+    typename HAM::Plane pls[PD];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { own[s][r].x = T(0); own[s][r].y = T(0); }
+        if (s < PD - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { y0s[s][r].x = T(0); y0s[s][r].y = T(0); }
+        const int ps = min(p_begin + s, p_last);
+        load_y0(ps, y0s[s]);
+        pls[s] = HAM::plane(A.ham, ps, A.sc);
+    }
+
+#else
     if (AH > 0) {
         // the rings of the first AH planes go straight to their LDS buffers (the first barrier of the loop orders them)
         for (int a = 0; a < AH; ++a) {
@@ -507,6 +565,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     }
 #pragma unroll
     for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s], halp[s], hinp[s]);
+#endif
 
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 3] = wall_clock64();
     // the arithmetic on the Hamiltonian tables, now that every load of the setup is in flight
@@ -515,6 +574,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         hcell[r][0] = HAM::cell_fin(A.ham, hraw[r][0], A.sc);
         hcell[r][1] = HAM::cell_fin(A.ham, hraw[r][1], A.sc);
     }
+#if HJ_PROLOGUE_V2
+    // the rings of the first AH planes -> their LDS buffers (the first barrier of the loop orders them)
+#pragma unroll
+    for (int a = 0; a < AHM; ++a)
+        if (a < AH) park_halo(lds + a * lds_plane, th[a], ti[a], tp[a], tq[a]);
+#endif
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;

@@ -144,6 +144,9 @@ struct hj_ctx {
     // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device
     std::map<std::pair<const void*, size_t>, int> occ_cache;
     std::map<int, bool> f12_ok;        // (scheme, Hamiltonian) -> the stage-fused kernel has a tiling for this grid
+    // make_tiling's answer per (NT, R, KH, vec, nbuf): it depends on nothing else that changes after hj_ctx_create, and the
+    // enumeration it runs (64 row extents in 3-D, 64^2 in 4-D) was paid on EVERY launch (round 4: host cost of small grids)
+    mutable std::map<long long, hjh::Tiling> tiling_cache;
 };
 
 namespace hjh {

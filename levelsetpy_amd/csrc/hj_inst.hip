@@ -210,11 +210,20 @@ struct TuneTrial { TuneState* ts = nullptr; int cand = -1; };
 // HJ_AUTOTUNE_MIN_MCELLS cells -- the next candidate of the tuning rotation / the shape the rotation settled on.
 template <int ND>
 Tiling tune_begin(hj_ctx* c, const SubstepCall& s, const KernelCfg& k, int vec, int nbuf, long long key, TuneTrial& tr) {
-    const bool tunable = c->autotune && c->total >= c->autotune_min_cells && !c->full_rows && !c->tile_cells && !s.on_aux &&
-                         !c->launch_stop && !c->halo_lo && !c->halo_hi && s.p0 == 0 && s.p1 == c->N[0] && s.q1 <= s.q0 &&
-                         !c->timing_dump;
+    bool tunable = c->autotune && c->total >= c->autotune_min_cells && !c->full_rows && !c->tile_cells && !s.on_aux &&
+                   !c->launch_stop && !c->halo_lo && !c->halo_hi && s.p0 == 0 && s.p1 == c->N[0] && s.q1 <= s.q0 &&
+                   !c->timing_dump;
     if (!tunable) return make_tiling(c, k, s.p0, s.p1, vec, nbuf);
     TuneState* ts = &c->tune[key];
+    if (ts->chosen < 0) {
+        // a trial ends in hipEventSynchronize: never while the stream is being captured into a graph -- such a
+        // launch takes the shape chosen so far (or the best-scored one) and leaves the rotation where it is
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(call_stream(c, s), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return ts->cand.empty() ? make_tiling(c, k, s.p0, s.p1, vec, nbuf) : ts->cand[0];
+        }
+    }
     if (ts->cand.empty() && ts->chosen < 0) {
         std::vector<Tiling> all;
         const Tiling b0 = make_tiling(c, k, s.p0, s.p1, vec, nbuf, &all);

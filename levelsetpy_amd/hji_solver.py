@@ -187,15 +187,24 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
     startTime = cputime()
 
     # ---- initial data (hji_solver.py:474-507; time axis FIRST in store-all mode)
-    data0_np = data0.detach().cpu().numpy() if is_tensor(data0) else np.asarray(data0)
-    if data0_np.ndim == gDim:
-        first = data0_np
+    # A device tensor stays on the device: the host copy is only made when something needs it (store-all mode, an
+    # SDModFunc, the NumPy path) -- a keepLast solve on a tensor never touches PCIe
+    dev_in = is_tensor(data0) and data0.is_cuda
+    nd0 = data0.dim() if is_tensor(data0) else np.ndim(data0)
+    host = {}
+
+    def data0_host():
+        if "a" not in host:
+            host["a"] = data0.detach().cpu().numpy() if is_tensor(data0) else np.asarray(data0)
+        return host["a"]
+    if nd0 == gDim:
+        first = data0 if dev_in else data0_host()
         istart = 1
         hist = None
-    elif data0_np.ndim == gDim + 1:
-        first = data0_np[-1]
-        istart = int(_get(extraArgs, 'istart', data0_np.shape[0]))
-        hist = data0_np
+    elif nd0 == gDim + 1:
+        first = data0[-1] if dev_in else data0_host()[-1]
+        istart = int(_get(extraArgs, 'istart', data0.shape[0]))
+        hist = data0_host()
     else:
         error('Inconsistent initial condition dimension!')
     if tuple(first.shape) != tuple(g.shape):
@@ -206,26 +215,30 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
         if hist is not None:
             data[:hist.shape[0]] = hist
         else:
-            data[0] = first
-    cur_np = first
+            data[0] = data0_host()
+    cur_np = None if dev_in else first        # host copy of the current state: kept only where it is consumed (SDModFunc)
 
     plan = native_plan(schemeData)
     dg = device_grid(g, "float64") if plan is not None else None
     ops = _Ops(dg)
     col = (int(np.prod(g.shape)), 1) if schemeFunc is termLaxFriedrichs else (int(np.prod(g.shape)),)
     if dg is not None:
-        y = dg.to_device(cur_np).reshape(col).clone()
+        y = dg.to_device(first).reshape(col).clone()
     else:
-        y = np.array(cur_np, dtype=np.float64).reshape(col)
-    y_init = ops.prep(data0_np if data0_np.ndim == gDim else data0_np[0], y)
-    if dg is not None and y_init is not None:
-        y_init = y_init.clone()
+        y = np.array(first.detach().cpu().numpy() if is_tensor(first) else first, dtype=np.float64).reshape(col)
+    first0 = first if nd0 == gDim else (data0[0] if dev_in else data0_host()[0])
+    if dg is not None:
+        y_init = dg.to_device(first0).reshape(col).clone()
+    else:
+        y_init = np.asarray(first0.detach().cpu().numpy() if is_tensor(first0) else first0).reshape(col)
 
     for i in range(istart, len(tau)):
         if not quiet:
             info('Computing value function at time tau[%d]: %.4f' % (i, tau[i]))
         if isfield(extraArgs, 'SDModFunc'):
             paramsIn = _get(extraArgs, 'SDModParams', [])
+            if cur_np is None:
+                cur_np = y.detach().cpu().numpy().reshape(g.shape) if is_tensor(y) else np.asarray(y).reshape(g.shape)
             schemeData = extraArgs.SDModFunc(schemeData, i, tau, cur_np, obstacles, paramsIn)
             # the reference hands the reassigned Bundle straight to the integrator (hji_solver.py:512-542):
             # re-apply the defaults and rebuild what was derived from the old Bundle
@@ -251,7 +264,8 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
                     y_init = dg.to_device(y_init).reshape(col).clone() if y_init is not None else None
                 ops = _Ops(dg)
             plan = new_plan
-        y_start = y.clone() if is_tensor(y) else y.copy()
+        # the state the interval started from: only the convergence test reads it (the integrators never write their input)
+        y_start = y if stopConverge else None
         tNow = tau[i - 1]
         target_i = ops.prep(targets[i] if targ_tv else targets, y)
         obstacle_i = ops.prep(obstacles[i] if obs_tv else obstacles, y)

@@ -143,7 +143,7 @@ def _device_plan(schemeFunc, schemeData, y0):
 def _check_shape(schemeFunc, y0):
     # termLaxFriedrichs returns an (N,1) column, termRestrictUpdate an (N,) vector; the reference
     # silently broadcasts the mixed case to (N,N) -- reject it instead.
-    nd = y0.dim() if is_tensor(y0) else np.ndim(y0)
+    nd = y0.dim() if is_tensor(y0) else (len(y0.shape) if hasattr(y0, 'shape') else np.ndim(y0))
     if schemeFunc is termLaxFriedrichs and nd != 2:
         raise ValueError('termLaxFriedrichs needs y0 as an (N,1) column (got %d-D)' % nd)
     if schemeFunc is termRestrictUpdate and nd != 1:
@@ -180,6 +180,7 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     dg.bind_stream()
     plan.bind(dg)
     shape0 = tuple(y0.shape)
+    lib, ctx, ptr = dg.lib, dg.ctx, dg.ptr
     # the input is only ever read (hj_rk_step never writes y_in), so it is used in place; results go
     # to buffers allocated here (A/B ping-pong for multi-step spans), so nothing is cloned and the
     # caller's array is never mutated
@@ -190,7 +191,7 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     # stage reads the first stage buffer as its stencil input, so it needs its own
     w0_own = dg.work('rk_w0') if order == 2 else None
     w1 = dg.work('rk_w1') if order == 3 else None
-    parv = _ffi.darr(par)
+    parv = plan.parv
     t = float(tspan[0])
     tf = float(tspan[1])
     steps = 0
@@ -198,53 +199,55 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     post = _post_hook(options)
     tout, dtout = C.c_double(), C.c_double()
     eventValueOld = None
+    factorCFL, maxStep = float(options.factorCFL), float(options.maxStep)
+    single = strcmp(options.singleStep, 'on')
+    terminal = getattr(options, 'terminalEvent', None)
     # the native Hamiltonians have a data-independent alpha, so stepBound is the same at every
     # substep: the reference's CFL warning (ode_cfl_3.py:173-175,215-217) can only fire when
     # factorCFL > min(1, 1.2 factorCFL), and it is decided on the host without a device read
-    safetyFactorCFL = min(1.0, 1.2 * float(options.factorCFL))
-    sb_static = C.c_double()
-    _ffi.check(dg.lib.hj_static_step_bound(dg.ctx, ham, parv, C.byref(sb_static), None))
+    safetyFactorCFL = min(1.0, 1.2 * factorCFL)
+    sb_static = plan.static_step_bound(dg)
     # no per-step callbacks and nothing to warn about: the whole span is one native call
     # (hj_rk_integrate runs the same loop in C; no Python and no host synchronisation per step)
-    if (not post and not getattr(options, 'terminalEvent', None) and not strcmp(options.singleStep, 'on')
-            and float(options.factorCFL) <= safetyFactorCFL and tf - t >= small * abs(tf)):
+    if (not post and not terminal and not single and factorCFL <= safetyFactorCFL and tf - t >= small * abs(tf)):
         buf_b = dg.empty()
         work = dg.work('rk_w1')
         nsteps, where = C.c_int64(), C.c_int()
-        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
-                                          float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt), dg.ptr(buf_b),
-                                          dg.ptr(work), 0, -1.0, C.byref(tout), C.byref(nsteps), C.byref(where)))
+        _ffi.check(lib.hj_rk_integrate(ctx, order, sid, ham, parv, t, tf, factorCFL, maxStep, rs, ptr(cur), ptr(nxt), ptr(buf_b),
+                                       ptr(work), 0, -1.0, C.byref(tout), C.byref(nsteps), C.byref(where)))
         cur = (cur, nxt, buf_b)[where.value]
+        if where.value == 1:
+            nxt = buf_b                # never step in place should the loop below still have something to do
         t = float(tout.value)
         steps = int(nsteps.value)
     while tf - t >= small * abs(tf):
         tOld = t
-        _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, parv, t, tf, float(options.factorCFL),
-                                     float(options.maxStep), rs, dg.ptr(cur), dg.ptr(nxt),
-                                     dg.ptr(nxt if order == 3 else w0_own),
-                                     dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+        _ffi.check(lib.hj_rk_step(ctx, order, sid, ham, parv, t, tf, factorCFL, maxStep, rs, ptr(cur), ptr(nxt),
+                                  ptr(nxt if order == 3 else w0_own), ptr(w1), C.byref(tout), C.byref(dtout)))
         yOld = cur
         prev = cur
         cur = nxt
-        # next output buffer: recycle the one two steps back if it is ours, never the caller's input
-        nxt = spare if spare is not None else dg.empty()
-        spare = prev if steps >= 1 else None
         t = float(tout.value)
         steps += 1
-        if order > 1 and dtout.value > safetyFactorCFL * sb_static.value:
+        if order > 1 and dtout.value > safetyFactorCFL * sb_static:
             for which in ('Second', 'Third')[:order - 1]:
-                warn('%s substep violated CFL effective number %s' % (which, dtout.value / sb_static.value))
+                warn('%s substep violated CFL effective number %s' % (which, dtout.value / sb_static))
+        if single and not post:
+            break                      # the common drop-in call (hji_solver.py:542): one step, nothing else to prepare
+        # next output buffer: recycle the one two steps back if it is ours, never the caller's input
+        nxt = spare if spare is not None else dg.empty()
+        spare = prev if steps >= 2 else None
         if post:
             yv = dg.like(cur.reshape(shape0), y0)
             yv, schemeData = odeCFLcallPostTimestep(t, yv, schemeData, options)
             cur = dg.to_device(yv).reshape(dg.shape)
             if cur.data_ptr() == nxt.data_ptr() or (spare is not None and cur.data_ptr() == spare.data_ptr()):
                 cur = cur.clone()
-        if strcmp(options.singleStep, 'on'):
+        if single:
             break
-        if getattr(options, 'terminalEvent', None):
+        if terminal:
             # the old state lives in `nxt` until the next step overwrites it
-            eventValue, schemeData = options.terminalEvent(
+            eventValue, schemeData = terminal(
                 t, dg.like(cur.reshape(shape0), y0), tOld, dg.like(yOld.reshape(shape0), y0), schemeData)
             if steps > 1 and np.any(np.sign(eventValue) != np.sign(eventValueOld)):
                 break
@@ -255,7 +258,7 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     out = cur.reshape(shape0)
     if is_tensor(y0) and steps == 0:
         out = out.clone()          # zero steps taken: do not hand the caller's own tensor back
-    return np.float64(t), dg.like(out, y0), schemeData
+    return np.float64(t), dg.like(out, y0, lazy=True), schemeData
 
 
 def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, post_op=0, order=3,
@@ -276,7 +279,7 @@ def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, 
         a, b, w = dg.empty(), dg.empty(), dg.work('rk_w1')
         tout, nsteps, where = C.c_double(), C.c_int64(), C.c_int()
         options = _options(options)
-        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, sid, ham, _ffi.darr(par), float(t0), float(tf),
+        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, order, sid, ham, plan.parv, float(t0), float(tf),
                                           float(options.factorCFL), float(options.maxStep), rs, dg.ptr(cur),
                                           dg.ptr(a), dg.ptr(b), dg.ptr(w), 0, float(stop_tol),
                                           C.byref(tout), C.byref(nsteps), C.byref(where)))

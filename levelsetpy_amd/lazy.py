@@ -1,0 +1,216 @@
+"""HostView: what the fused path hands back to a NumPy caller -- an ndarray-compatible handle on a result that
+still lives in HBM.
+
+The reference's drivers are NumPy in / NumPy out and feed every result straight back into the next call
+(ValueFuncs/hji_solver.py:542, Notes/rcbrt.ipynb cell 4):
+
+    t, y, schemeData = odeCFL3(termRestrictUpdate, [t, t_plot], y, options, schemeData)
+
+A literal drop-in pays PCIe both ways per call (2.5 ms per step at 201^3 against 0.12 ms of GPU work).  A HostView
+keeps the device tensor the kernels wrote and copies it to (page-locked) host memory only when somebody LOOKS at the
+values: `np.asarray(y)`, indexing, any NumPy function or ufunc, any ndarray attribute.  Passed back into
+odeCFLn / termLaxFriedrichs / termRestrictUpdate it is consumed on the device, so the loop above touches PCIe once
+per plot, not twice per step.
+
+What it promises: same shape / dtype / values as the ndarray the reference would have returned (`np.asarray(y)` is
+exact and cached); results of arithmetic and NumPy functions are plain ndarrays; inputs are never mutated (kernels
+only read their inputs).  Where it differs from an ndarray: `isinstance(y, np.ndarray)` is False; `reshape` /
+`flatten` / `ravel` / `squeeze` / `copy` return independent HostViews (not memory-sharing views); the cached host copy
+is read-only while the device tensor is attached (write through the view itself, `y[i] = v`, which detaches it from
+the device first).  `HJ_LAZY_NUMPY=0` turns the handles off: plain ndarrays, a D2H copy per call, as in rounds 1-3.
+"""
+import os
+
+import numpy as np
+
+LAZY = os.environ.get("HJ_LAZY_NUMPY", "1") != "0"
+
+
+def set_lazy(on):
+    """Switch HostView results for NumPy callers on / off at run time (default: on unless HJ_LAZY_NUMPY=0)."""
+    global LAZY
+    LAZY = bool(on)
+
+
+def _host_copy(t):
+    """device tensor -> ndarray in page-locked host memory when it is large (the D2H copy then runs at the DMA rate and
+    an array handed back later is uploaded at the DMA rate too); context.DeviceGrid.like's policy."""
+    from . import context
+    import torch
+    t = t.detach()
+    nbytes = t.numel() * t.element_size()
+    if t.is_cuda and nbytes >= (1 << 20) and context._PIN_RESULTS and nbytes <= context._PIN_MAX_BYTES:
+        try:
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t)
+            return host.numpy()
+        except RuntimeError:
+            pass
+    return t.cpu().numpy()
+
+
+def _unwrap(x):
+    if isinstance(x, HostView):
+        return x.__array__()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_unwrap(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _unwrap(v) for k, v in x.items()}
+    return x
+
+
+class HostView(np.lib.mixins.NDArrayOperatorsMixin):
+    """ndarray-compatible, lazily materialised view of a device tensor (module docstring)."""
+
+    __slots__ = ("_t", "_h")
+    __array_priority__ = 1000.0
+
+    def __init__(self, tensor, host=None):
+        object.__setattr__(self, "_t", tensor)      # device tensor (None once detached)
+        object.__setattr__(self, "_h", host)        # cached host ndarray (None until somebody looks)
+
+    # ------------------------------------------------------------------ what the package itself asks for
+    def device_tensor(self):
+        """The tensor the kernels wrote, or None if this view was written to from the host."""
+        return self._t
+
+    # ------------------------------------------------------------------ cheap metadata (no copy)
+    @property
+    def shape(self):
+        return tuple(self._t.shape) if self._t is not None else self._h.shape
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def dtype(self):
+        if self._h is not None:
+            return self._h.dtype
+        return np.dtype(str(self._t.dtype).replace("torch.", ""))
+
+    @property
+    def itemsize(self):
+        return self.dtype.itemsize
+
+    @property
+    def nbytes(self):
+        return self.size * self.itemsize
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of unsized object")
+        return self.shape[0]
+
+    # ------------------------------------------------------------------ materialisation
+    def __array__(self, dtype=None, copy=None):
+        h = self._h
+        if h is None:
+            h = _host_copy(self._t)
+            h.flags.writeable = False       # the device copy is still what the next call consumes: no silent divergence
+            object.__setattr__(self, "_h", h)
+        if dtype is not None and np.dtype(dtype) != h.dtype:
+            return h.astype(dtype)
+        if copy:
+            return h.copy()
+        return h
+
+    def _detach(self):
+        """Before a write from the host: a private writable host copy, and the device tensor is let go."""
+        h = np.array(self.__array__(), copy=True)
+        object.__setattr__(self, "_h", h)
+        object.__setattr__(self, "_t", None)
+        return h
+
+    # ------------------------------------------------------------------ NumPy protocols: results are plain ndarrays
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if "out" in kwargs:
+            outs = kwargs["out"]
+            kwargs["out"] = tuple(o._detach() if isinstance(o, HostView) else o for o in outs)
+        return getattr(ufunc, method)(*_unwrap(inputs), **_unwrap(kwargs))
+
+    def __array_function__(self, func, types, args, kwargs):
+        # metadata questions are answered without looking at the values (np.ndim / np.shape / np.size dispatch here too)
+        if func in _META and len(args) == 1 and not kwargs and isinstance(args[0], HostView):
+            return _META[func](args[0])
+        return func(*_unwrap(args), **_unwrap(kwargs))
+
+    # ------------------------------------------------------------------ shape changes stay on the device
+    def _lazy(self, fn_t, fn_h):
+        if self._t is not None:
+            return HostView(fn_t(self._t))
+        return fn_h(self._h)
+
+    def reshape(self, *shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        if kw.get("order", "C") not in ("C", "A") or self._t is None:
+            return self.__array__().reshape(*shape, **kw)
+        return HostView(self._t.reshape(tuple(int(v) for v in shape)))
+
+    def flatten(self, order="C"):
+        if order not in ("C", "A"):
+            return self.__array__().flatten(order)
+        return self._lazy(lambda t: t.reshape(-1), lambda h: h.flatten())
+
+    def ravel(self, order="C"):
+        if order not in ("C", "A"):
+            return self.__array__().ravel(order)
+        return self._lazy(lambda t: t.reshape(-1), lambda h: h.ravel())
+
+    def squeeze(self, axis=None):
+        if axis is not None:
+            return self.__array__().squeeze(axis)
+        return self._lazy(lambda t: t.squeeze(), lambda h: h.squeeze())
+
+    def copy(self, order="C"):
+        return self._lazy(lambda t: t, lambda h: h.copy())     # the device tensor is never written: sharing it IS a copy
+
+    def __copy__(self):
+        return HostView(self._t, self._h)
+
+    def __deepcopy__(self, memo):
+        return self._lazy(lambda t: t, lambda h: h.copy())
+
+    # ------------------------------------------------------------------ element access
+    def __getitem__(self, idx):
+        return self.__array__()[idx]
+
+    def __setitem__(self, idx, value):
+        self._detach()[idx] = _unwrap(value)
+
+    def __iter__(self):
+        return iter(self.__array__())
+
+    def __float__(self):
+        return float(self.__array__())
+
+    def __int__(self):
+        return int(self.__array__())
+
+    def __bool__(self):
+        return bool(self.__array__())
+
+    def __repr__(self):
+        where = "device" if self._t is not None else "host"
+        return "HostView(%s, shape=%s, dtype=%s)" % (where, self.shape, self.dtype)
+
+    def __getattr__(self, name):
+        # every other ndarray attribute / method (sum, min, T, astype, tolist, ...): look, then delegate
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.__array__(), name)
+
+    def __reduce__(self):
+        return (np.array, (self.__array__(),))      # pickles as the ndarray it stands for
+
+
+_META = {np.ndim: lambda v: v.ndim, np.shape: lambda v: v.shape, np.size: lambda v: v.size}
+
+
+def is_lazy(x):
+    return isinstance(x, HostView)

@@ -366,3 +366,83 @@ def test_c5_native_rccl_stepper_self_ring_4d_fp32():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ NumPy callers stay in HBM (lazy.HostView)
+def test_numpy_loop_stays_on_the_device_and_equals_the_tensor_loop():
+    """The reference's driver loop (NumPy in, NumPy out, every result fed back: hji_solver.py:542, Notes/rcbrt.ipynb cell 4)
+    through odeCFL3 + termRestrictUpdate: results are HostViews consumed on the device by the next call; np.asarray() of
+    them equals the tensor-in loop bit for bit, inputs are never mutated, writes through a view detach it."""
+    from levelsetpy_amd.lazy import HostView
+    g, og = dubins([33, 31, 29])
+    d0 = O.shape_cylinder(og, 2, None, .5) + 0.02 * np.random.default_rng(1).standard_normal(og.shape)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+    sdr = L.Bundle(dict(innerFunc=L.termLaxFriedrichs, innerData=sd, positive=0))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y_np = d0.flatten()
+    keep = y_np.copy()
+    y_t = torch.as_tensor(y_np, device="cuda")
+    t1 = t2 = 0.
+    seen = []
+    for k in range(4):
+        t1, y_np, _ = L.odeCFL3(L.termRestrictUpdate, [t1, 10.], y_np, op, sdr)
+        t2, y_t, _ = L.odeCFL3(L.termRestrictUpdate, [t2, 10.], y_t, op, sdr)
+        assert isinstance(y_np, HostView) and y_np.device_tensor() is not None and y_np.shape == (og.shape[0] * og.shape[1] * og.shape[2],)
+        seen.append(y_np)
+        if k == 1:
+            looked = np.asarray(y_np)           # looking does not break the chain
+            assert looked.shape == y_np.shape and not looked.flags.writeable
+    assert t1 == t2 and np.array_equal(keep, d0.flatten())
+    assert seen[0]._h is None and seen[2]._h is None and seen[3]._h is None      # nobody looked: nothing crossed PCIe
+    assert np.array_equal(np.asarray(y_np), y_t.cpu().numpy())
+    assert np.array_equal(np.asarray(seen[1]), looked)                  # earlier results stay valid (nothing is recycled)
+    vr = y_np.reshape(og.shape)
+    assert isinstance(vr, HostView) and vr.shape == og.shape and float(vr[3, 4, 5]) == float(y_t.reshape(og.shape)[3, 4, 5])
+    # termLaxFriedrichs alone: (N,1) column in, HostView column out, arithmetic gives ndarrays
+    yd, sb, _ = L.termLaxFriedrichs(0., d0.reshape(-1, 1), sd)
+    ydt, sbt, _ = L.termLaxFriedrichs(0., torch.as_tensor(d0.reshape(-1, 1), device="cuda"), sd)
+    assert isinstance(yd, HostView) and yd.shape == (d0.size, 1) and sb == sbt
+    e = d0.reshape(-1, 1) + 0.5 * sb * yd
+    assert isinstance(e, np.ndarray) and np.array_equal(e, d0.reshape(-1, 1) + 0.5 * sb * ydt.cpu().numpy())
+    # a write through the view detaches it; the next call uploads the modified values
+    y_mod = seen[-1]
+    y_mod[0] = 123.0
+    assert y_mod.device_tensor() is None
+    t3, y3, _ = L.odeCFL3(L.termRestrictUpdate, [0., 10.], y_mod, op, sdr)
+    ref_in = y_t.clone()
+    ref_in[0] = 123.0
+    t4, y4, _ = L.odeCFL3(L.termRestrictUpdate, [0., 10.], ref_in, op, sdr)
+    assert np.array_equal(np.asarray(y3), y4.cpu().numpy())
+
+
+def test_numpy_callers_get_plain_ndarrays_with_lazy_off():
+    from levelsetpy_amd import lazy
+    g, og = dubins([17, 15, 13])
+    d0 = O.shape_cylinder(og, 2, None, .5)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstENO3)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t1, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], d0.reshape(-1, 1), op, sd)
+    lazy.set_lazy(False)
+    try:
+        t2, y2, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], d0.reshape(-1, 1), op, sd)
+    finally:
+        lazy.set_lazy(True)
+    assert isinstance(y2, np.ndarray) and not isinstance(y1, np.ndarray) and np.array_equal(y1, y2) and t1 == t2
+
+
+def test_term_convection_tensor_velocity_forms():
+    """termConvection with torch velocity components that are not full arrays: a 0-dim tensor is a scalar
+    speed, a broadcast-shaped tensor (N0,1,1) is expanded like its NumPy twin."""
+    g, og = dubins((15, 14, 12))
+    data = O.shape_cylinder(og, 2, None, .5) + 0.05 * np.random.default_rng(3).standard_normal(g.shape)
+    prof = np.sin(2 * np.asarray(og.vs[0]).ravel()).reshape(-1, 1, 1) + 0.3
+    vel_np = [0.7, prof, -0.4 * np.ones(g.shape)]
+    vel_t = [torch.tensor(0.7, dtype=torch.float64, device="cuda"), torch.as_tensor(prof, device="cuda"),
+             torch.as_tensor(vel_np[2], device="cuda")]
+    y = torch.as_tensor(data.reshape(-1, 1), device="cuda")
+    ref, sb0, _ = L.termConvection(0., y, L.Bundle(dict(grid=g, velocity=vel_np, derivFunc=L.upwindFirstENO3)))
+    got, sb1, _ = L.termConvection(0., y, L.Bundle(dict(grid=g, velocity=vel_t, derivFunc=L.upwindFirstENO3)))
+    assert sb0 == sb1 and torch.equal(ref, got)
+    yo, sbo = O.term_convection(og, [0.7, np.broadcast_to(prof, g.shape), vel_np[2]], "ENO3", 0., data.reshape(-1, 1))
+    close(got.cpu().numpy(), yo)
+    assert abs(sb1 - sbo) <= 1e-14 * sbo

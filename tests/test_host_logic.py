@@ -72,3 +72,83 @@ def test_float_reciprocal_index_division_is_exact_below_2_pow_22():
             hi = rem >= d
             q = q + hi; rem = rem - hi * d
             assert np.array_equal(q, a // d) and np.array_equal(rem, a % d), (d, float(r))
+
+
+# ---------------------------------------------------------------- HostView (lazy.py): ndarray-compatible handle
+def _hv(a):
+    import torch
+    from levelsetpy_amd.lazy import HostView
+    return HostView(torch.from_numpy(np.array(a, dtype=np.float64)))
+
+
+def test_hostview_looks_like_the_ndarray_it_stands_for():
+    from levelsetpy_amd.lazy import HostView
+    a = np.arange(24, dtype=np.float64).reshape(6, 4) - 7.5
+    v = _hv(a)
+    assert v.shape == (6, 4) and v.ndim == 2 and v.size == 24 and v.dtype == np.float64 and len(v) == 6 and v.nbytes == 192
+    assert v._h is None                                   # nothing copied by asking for metadata
+    assert np.array_equal(np.asarray(v), a) and np.asarray(v) is np.asarray(v)     # exact, cached
+    assert isinstance(v + 1, np.ndarray) and np.array_equal(v + 1, a + 1) and np.array_equal(2 * v - v, a)
+    assert np.array_equal(np.abs(v), np.abs(a)) and np.array_equal(np.minimum(v, 0), np.minimum(a, 0))
+    assert v.sum() == a.sum() and v.min() == a.min() and np.linalg.norm(v) == np.linalg.norm(a)
+    assert np.array_equal(v[2:4, 1], a[2:4, 1]) and v[0, 0] == a[0, 0] and np.array_equal(v.T, a.T)
+    assert np.array_equal(np.concatenate([v, v]), np.concatenate([a, a]))
+    assert [float(x[0]) for x in v] == [float(x[0]) for x in a]
+    r = v.reshape(-1, 1)
+    assert isinstance(r, HostView) and r.shape == (24, 1) and np.array_equal(r, a.reshape(-1, 1))
+    assert isinstance(v.flatten(), HostView) and v.flatten().shape == (24,) and v.reshape(4, 6).reshape((2, 12)).shape == (2, 12)
+    assert isinstance(r.squeeze(), HostView) and r.squeeze().shape == (24,)
+    assert np.array_equal(v.reshape(4, 6, order="F"), a.reshape(4, 6, order="F"))      # non-C orders: through the host
+    assert float(_hv([2.5]).reshape(())) == 2.5
+    import copy as _copy
+    import pickle
+    assert np.array_equal(_copy.copy(v), a) and np.array_equal(_copy.deepcopy(v), a)
+    assert np.array_equal(pickle.loads(pickle.dumps(v)), a)
+    assert "HostView(device" in repr(v)
+
+
+def test_hostview_writes_detach_and_never_touch_the_tensor():
+    a = np.linspace(-1, 1, 12).reshape(3, 4)
+    v = _hv(a)
+    t = v.device_tensor()
+    host = np.asarray(v)
+    assert not host.flags.writeable                      # the device copy is what the next call consumes
+    with pytest.raises(ValueError):
+        host[0, 0] = 9.0
+    w = v.reshape(12)
+    v[0, 1] = 5.0                                        # write through the view: private host copy, device let go
+    assert v.device_tensor() is None and v[0, 1] == 5.0 and np.asarray(v).flags.writeable
+    assert w.device_tensor() is not None and w.device_tensor().data_ptr() == t.data_ptr() and w[1] == a[0, 1]    # other views unaffected
+    assert float(t[0, 1]) == a[0, 1]                     # the tensor itself was never written
+    out = _hv(np.zeros(12))
+    np.add(w, 1.0, out=out)
+    assert out.device_tensor() is None and np.array_equal(out, a.reshape(12) + 1)
+
+
+def test_hostview_is_what_numpy_callers_get_and_can_be_switched_off(monkeypatch):
+    import torch
+    from levelsetpy_amd import lazy
+    from levelsetpy_amd.context import DeviceGrid, array_dtype_name
+
+    class FakeDG(object):       # DeviceGrid.like without a GPU: only the branch taken for a host tensor matters here
+        pass
+    FakeDG.torch = torch
+    t = torch.arange(6, dtype=torch.float64)
+    got = DeviceGrid.like(FakeDG(), t, np.zeros(6), (6, 1), lazy=True)
+    assert isinstance(got, np.ndarray) and got.shape == (6, 1)      # a CPU tensor is simply converted (no device to stay on)
+    assert array_dtype_name(lazy.HostView(torch.zeros(3, dtype=torch.float32))) == "float32"
+    assert array_dtype_name(lazy.HostView(torch.zeros(3, dtype=torch.float64))) == "float64"
+    lazy.set_lazy(False)
+    assert lazy.LAZY is False
+    lazy.set_lazy(True)
+
+
+def test_hostview_metadata_functions_do_not_copy():
+    v = _hv(np.zeros((5, 1)))
+    assert np.ndim(v) == 2 and np.shape(v) == (5, 1) and np.size(v) == 5 and v._h is None
+    from levelsetpy_amd import integration
+    import levelsetpy_amd as L
+    integration._check_shape(L.termLaxFriedrichs, v)
+    with pytest.raises(ValueError):
+        integration._check_shape(L.termRestrictUpdate, v)
+    assert v._h is None                                   # the integrators' own checks never look at the values

@@ -1,0 +1,132 @@
+// What can this memory system stream, in the access mixes of the RK substep?  (round 4)
+//
+// The substep kernel's roofline is quoted against the 8 TB/s HBM spec; this program measures the ACHIEVABLE rate on the
+// box it runs on, so that bench.py can report roofline.frac_of_achievable beside roofline.frac:
+//   copy   1R:1W   (the guide's reference shape: 16 B per lane, 6.29 TB/s quoted)
+//   triad  2R:1W   (RK stages 2 and 3: y, y0 -> out)
+//   euler  1R:1W through the same code path as triad (RK stage 1)
+//   read   1R:0W   (sum into a register, one store per thread at the end)
+//   write  0R:1W
+// each as (a) a grid-stride loop over the whole array and (b) "slab" form: every workgroup streams ONE contiguous slab
+// (what a persistent tile-column march does), with U independent 16-byte accesses in flight per lane, for several grid
+// sizes; at two array sizes: 1 GiB per array (HBM) and 64 MiB per array (three arrays resident in the 256 MiB Infinity
+// Cache, the regime of the 201^3 headline: 65 MB per array).
+// Build: hipcc -O3 --offload-arch=gfx950 bw2.hip -o bw2        Output: one line per measurement + a JSON summary line.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+#include <string>
+
+typedef double v2 __attribute__((ext_vector_type(2)));
+
+enum Mode { COPY = 0, TRIAD = 1, READ = 2, WRITE = 3 };
+
+template <int MODE, int U>
+__global__ __launch_bounds__(256) void slab_kernel(const v2* __restrict__ a, const v2* __restrict__ b, v2* __restrict__ c,
+                                                   size_t n, size_t per_block) {
+    // block `blk` owns [blk*per_block, (blk+1)*per_block): contiguous, 256 lanes x 16 B = 4 KiB per wave-front sweep
+    const size_t lo = (size_t)blockIdx.x * per_block;
+    const size_t hi = lo + per_block < n ? lo + per_block : n;
+    v2 acc = {0.0, 0.0};
+    for (size_t i = lo + threadIdx.x; i < hi; i += (size_t)256 * U) {
+        v2 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + (size_t)u * 256;
+            if (MODE != WRITE) x[u] = j < hi ? a[j] : acc;
+            if (MODE == TRIAD) y[u] = j < hi ? b[j] : acc;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + (size_t)u * 256;
+            if (MODE == COPY) { if (j < hi) c[j] = x[u]; }
+            if (MODE == TRIAD) { if (j < hi) c[j] = x[u] * 0.75 + y[u] * 0.25; }
+            if (MODE == READ) acc += x[u];
+            if (MODE == WRITE) { if (j < hi) c[j] = acc; }
+        }
+    }
+    if (MODE == READ && acc.x == 12345.678) c[lo] = acc;       // never true: keeps the loads alive
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void stride_kernel(const v2* __restrict__ a, const v2* __restrict__ b, v2* __restrict__ c, size_t n) {
+    v2 acc = {0.0, 0.0};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (MODE == COPY) c[i] = a[i];
+        if (MODE == TRIAD) c[i] = a[i] * 0.75 + b[i] * 0.25;
+        if (MODE == READ) acc += a[i];
+        if (MODE == WRITE) c[i] = acc;
+    }
+    if (MODE == READ && acc.x == 12345.678) c[0] = acc;
+}
+
+static hipEvent_t e0, e1;
+template <typename F> static float best_ms(F f, int reps) {
+    float best = 1e30f;
+    for (int it = 0; it < reps; ++it) {
+        hipEventRecord(e0);
+        f();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float t;
+        hipEventElapsedTime(&t, e0, e1);
+        if (it > 0 && t < best) best = t;
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    // --quick: copy and triad only, the shapes that won on MI355X (bench.py runs this before its timed legs: ~2 s)
+    const bool quick = argc > 1 && std::string(argv[1]) == "--quick";
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const char* mname[4] = {"copy 1R:1W", "triad 2R:1W", "read 1R:0W", "write 0R:1W"};
+    const double bytes_per_elem[4] = {32, 48, 16, 16};
+    std::string json = "{";
+    for (int big = 1; big >= 0; --big) {
+        const size_t n = big ? ((size_t)1 << 26) : ((size_t)1 << 22);      // v2 elements: 1 GiB / 64 MiB per array
+        v2 *a, *b, *c;
+        hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&c, n * 16);
+        hipMemset(a, 0, n * 16); hipMemset(b, 0, n * 16); hipMemset(c, 0, n * 16);
+        const int reps = quick ? (big ? 4 : 12) : (big ? 8 : 40);
+        double top[4] = {0, 0, 0, 0};
+        for (int mode = 0; mode < (quick ? 2 : 4); ++mode) {
+            for (int blocks : {256, 512, 1024, 2048, 4096, 8192}) {
+                if (quick && blocks != 512 && blocks != 1024 && blocks != 2048) continue;   // the shapes that won (profiles/r04_ubench_bw2.txt)
+                float ms = 0;
+                switch (mode) {
+                    case 0: ms = best_ms([&] { stride_kernel<COPY><<<blocks, 256>>>(a, b, c, n); }, reps); break;
+                    case 1: ms = best_ms([&] { stride_kernel<TRIAD><<<blocks, 256>>>(a, b, c, n); }, reps); break;
+                    case 2: ms = best_ms([&] { stride_kernel<READ><<<blocks, 256>>>(a, b, c, n); }, reps); break;
+                    case 3: ms = best_ms([&] { stride_kernel<WRITE><<<blocks, 256>>>(a, b, c, n); }, reps); break;
+                }
+                const double tbs = bytes_per_elem[mode] * n / ms / 1e9;
+                top[mode] = std::max(top[mode], tbs);
+                printf("%s MiB/array %-12s grid-stride blocks=%5d          %.4f ms  %.2f TB/s\n", big ? "1024" : "  64", mname[mode], blocks, ms, tbs);
+            }
+            for (int blocks : {256, 512, 1024, 2048}) {
+                const size_t per = (n + blocks - 1) / blocks;
+                for (int u : {2, 4, 8}) {
+                    if (quick) continue;
+                    float ms = 0;
+#define RUN(M, U_) ms = best_ms([&] { slab_kernel<M, U_><<<blocks, 256>>>(a, b, c, n, per); }, reps)
+#define RUNU(M) if (u == 2) RUN(M, 2); else if (u == 4) RUN(M, 4); else RUN(M, 8)
+                    if (mode == 0) { RUNU(COPY); } else if (mode == 1) { RUNU(TRIAD); } else if (mode == 2) { RUNU(READ); } else { RUNU(WRITE); }
+                    const double tbs = bytes_per_elem[mode] * n / ms / 1e9;
+                    top[mode] = std::max(top[mode], tbs);
+                    printf("%s MiB/array %-12s slab blocks=%5d in-flight=%d      %.4f ms  %.2f TB/s\n", big ? "1024" : "  64", mname[mode], blocks, u, ms, tbs);
+                }
+            }
+        }
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s\"%s\": {\"copy\": %.3f, \"triad\": %.3f, \"read\": %.3f, \"write\": %.3f}", big ? "" : ", ",
+                 big ? "hbm_1GiB" : "infinity_cache_64MiB", top[0], top[1], top[2], top[3]);
+        json += buf;
+        hipFree(a); hipFree(b); hipFree(c);
+    }
+    json += ", \"unit\": \"TB/s, best shape per mix\"}";
+    printf("%s\n", json.c_str());
+    return 0;
+}
