@@ -675,6 +675,32 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
         if (scheme == HJ_WENO5) c->weno_src = nullptr;
         return rc;
     }
+    if (c->slab_gated && hi_b > lo_e && c->gate) {
+        // Round 4 (HJ_SLAB_SCHEDULE=gated, opt-in): edges_s and interior_s are ONE launch.
+        // The edge chunks are its first workgroups (dispatched first, spread over the XCDs); each adds 1 to ctx->gate when its
+        // planes are in memory, and the exchange stream waits for that count (hipStreamWaitValue64 on plain device memory:
+        // the gated kernel starts 1.5 us after the last publication, profiles/r04_stream_gate_probe.txt) -- no separate 25 us
+        // edge launch, no event hop, and the short edge workgroups fill the CUs the interior's last round leaves idle
+        // (133 tiles x 2 chunks = 266 workgroups on 256 CUs was 2 rounds for 1.04 rounds of work).
+        if (c->slab_pending) HIP_TRY(hipStreamWaitEvent(main, c->ev_comm, 0));       // y's pads: the exchange of substep s-1
+        SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, lo_e, hi_b};
+        s.gated = true;
+        if (lo_e > 0) { s.e0[0] = 0; s.e1[0] = lo_e; }
+        if (hi_b < n) { const int w = lo_e > 0 ? 1 : 0; s.e0[w] = hi_b; s.e1[w] = n; }
+        if ((rc = do_substep(c, s, -1))) return rc;
+        HIP_TRY(hipEventRecord(c->ev_edge, main));            // what hj_slab_join waits for besides the exchange
+        if (c->gate_posted > 0) {
+            c->gate_count += (unsigned long long)c->gate_posted;
+            HIP_TRY(hipStreamWaitValue64(c->comm_stream, c->gate, c->gate_count, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));   // the launch could not gate (direct kernel)
+        }
+        if ((rc = post_halo(c, out, c->comm_stream))) return rc;
+        HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+        c->slab_pending = 1;
+        if (scheme == HJ_WENO5) c->weno_src = nullptr;
+        return HJ_OK;
+    }
     if (c->slab_serial) {
         // Round 3 (HJ_SLAB_SCHEDULE=serial, default): edges_s and interior_s share the ctx stream, edges first; only the
         // exchange runs beside them.  The "overlap" schedule below lets interior_s start as soon as interior_{s-1} is done,
@@ -746,6 +772,16 @@ int slab_streams_create(hj_ctx* c) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_edge2, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_int[i], hipEventDisableTiming));
+    if (!c->gate) {
+        // the counter of the gated schedule: plain device memory (signal memory opened the gate 33 us late in the probe)
+        int can = 0;
+        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+        if (can) {
+            HIP_TRY(hipMalloc((void**)&c->gate, sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(c->gate, 0, sizeof(unsigned long long)));
+            c->gate_count = 0;
+        }
+    }
     return HJ_OK;
 }
 
@@ -985,6 +1021,12 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         const char* sch = getenv("HJ_SLAB_SCHEDULE");
         c->slab_serial = sch ? !strcmp(sch, "serial") : (N[0] >= 192);
         c->slab_overlap2 = sch && !strcmp(sch, "overlap2");
+        // round 4: "gated" -- edges and interior in ONE launch, the exchange gated on a counter the edge workgroups publish.
+        // Opt-in: on the self ring it wins on the 257-plane slab (0.503 against 0.492 serial / 0.481 overlap) and loses on the
+        // 65-plane one (0.338 against 0.379 overlap): there the launch itself is the problem -- 133 tiles x 3 chunks of 20 + 6
+        // warm-up planes plus 266 edge workgroups of 3 + 6 planes are 96 plane loads per tile column for 65 planes of output
+        // (profiles/r04_thin_slab_gated.txt)
+        c->slab_gated = sch && !strcmp(sch, "gated");
     }
     c->eps_fuse_min_cells = (long long)env_int("HJ_EPS_FUSE_MIN_CELLS", 2000000);
     c->eps_fuse = env_int("HJ_EPS_FUSE", 1);         // 0: the intended WENO5 always runs its two-launch epsilon pre-pass
@@ -1688,6 +1730,7 @@ int hj_comm_destroy(hj_ctx* c) {
     for (int i = 0; i < 3; ++i) { if (c->ev_int[i]) (void)hipEventDestroy(c->ev_int[i]); c->ev_int[i] = nullptr; }
     c->comm_stream = c->edge_stream = nullptr;
     c->ev_start = c->ev_edge = c->ev_edge2 = c->ev_comm = nullptr;
+    if (c->gate) { (void)hipFree(c->gate); c->gate = nullptr; c->gate_count = 0; }
     c->slab_pending = 0;
     c->external_exchange = 0;
     return HJ_OK;

@@ -89,6 +89,15 @@ template <typename T, int ND> struct FusedArgs {
     int plane_begin, plane_end;
     int plane_begin2, plane_end2, nchunks1;   // optional second plane range (slab edges): chunks >= nchunks1
     int nblocks, blocks_per_xcd;
+    // Gated slab launch (round 4; hj_api.hip, slab_substep): the EDGE plane ranges of a slab ride in the same launch as its
+    // interior.  Their chunks (echunk planes each) come first in the chunk order -- eplane[0] (nchunks_e1 chunks), then
+    // eplane[1], nchunks_e in all -- and first in the dispatch order (the first edge_blocks workgroups, mapped XCD-aware among
+    // themselves); every one of their workgroups adds 1 to *gate once its planes are stored and released, and the stream
+    // that posts the halo exchange waits on that count (hipStreamWaitValue64).  nchunks_e = 0: an ordinary launch.
+    int eplane[2][2];
+    int echunk, nchunks_e1, nchunks_e;
+    int edge_blocks, edge_count, edge_bpx;
+    unsigned long long* gate;
     // pair kernel only: LDS plane buffers (2 = double buffer) and how many planes ahead of its use the halo ring
     // of a plane is parked in LDS (0 = written in the iteration that consumes it)
     int lds_nbuf, halo_ahead;
@@ -113,6 +122,49 @@ template <typename T, int ND> struct FusedArgs {
     // debug (HJ_TIMING_DUMP): per logical block {start, end} of the constant 100 MHz clock, {xcc id, chunk}
     unsigned long long* timing;
 };
+
+// Logical block of this workgroup, -1 for the padding blocks of the launch.  Blocks b, b + 8, b + 16 ... share an XCD
+// (round-robin dispatch): every XCD gets a contiguous run of logical blocks.  In a gated slab launch the first edge_blocks
+// workgroups are the edge chunks (logical blocks [0, edge_count)), mapped the same way among themselves.
+template <typename ARGS> __device__ __forceinline__ int logical_block(const ARGS& A) {
+    const int b = blockIdx.x;
+    if (b < A.edge_blocks) {
+        const int L = (b & 7) * A.edge_bpx + (b >> 3);
+        return L < A.edge_count ? L : -1;
+    }
+    const int b2 = b - A.edge_blocks;
+    const int L = A.edge_count + (b2 & 7) * A.blocks_per_xcd + (b2 >> 3);
+    return L < A.nblocks ? L : -1;
+}
+
+// planes [p_begin, p_end) of chunk `chunk_id`: edge ranges first (gated launches), then the main range, then the optional
+// second range (low and high edge planes of a slab in one launch)
+template <typename ARGS> __device__ __forceinline__ void chunk_planes(const ARGS& A, int chunk_id, int& p_begin, int& p_end) {
+    if (chunk_id < A.nchunks_e) {
+        const int w = chunk_id >= A.nchunks_e1 ? 1 : 0;
+        p_begin = A.eplane[w][0] + (chunk_id - (w ? A.nchunks_e1 : 0)) * A.echunk;
+        p_end = min(p_begin + A.echunk, A.eplane[w][1]);
+        return;
+    }
+    const int cm = chunk_id - A.nchunks_e;
+    const bool second = cm >= A.nchunks1;
+    p_begin = second ? A.plane_begin2 + (cm - A.nchunks1) * A.chunk : A.plane_begin + cm * A.chunk;
+    p_end = min(p_begin + A.chunk, second ? A.plane_end2 : A.plane_end);
+}
+
+// end of an edge chunk's workgroup in a gated launch: its planes are in memory (every wave's stores drained, L2 written
+// back at system scope: the exchange kernel may run on any XCD, or be a peer's DMA) before the count moves
+template <typename ARGS> __device__ __forceinline__ void publish_gate(const ARGS& A, int chunk_id) {
+    if (A.gate != nullptr && chunk_id < A.nchunks_e) {          // workgroup-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the compiler may drop the wait behind buffer_wbl2 (MI355X guide)
+            __hip_atomic_fetch_add(A.gate, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // epsilon of the intended WENO5 from partial rows: every thread of the workgroup ends up with the ND maxima
 template <typename T, int ND, int NT>
@@ -214,8 +266,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // ---- XCD-aware block order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch),
     // give each XCD a contiguous run of logical blocks.
     const int b = blockIdx.x;
-    const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
-    if (L >= A.nblocks) return;
+    const int L = logical_block(A);
+    if (L < 0) return;
     int chunk_id, rem;
     fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);     // index divisions through a float reciprocal (hj_device.h)
     if (A.timing && threadIdx.x == 0) {
@@ -235,10 +287,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         rem = q;
         fE[d] = fdiv_make(A.E[d]);
     }
-    // two plane ranges may share a launch (the low and high edge planes of a slab)
-    const bool second = chunk_id >= A.nchunks1;
-    const int p_begin = second ? A.plane_begin2 + (chunk_id - A.nchunks1) * A.chunk : A.plane_begin + chunk_id * A.chunk;
-    const int p_end = min(p_begin + A.chunk, second ? A.plane_end2 : A.plane_end);
+    // several plane ranges may share a launch (the low and high edge planes of a slab; edges + interior: chunk_planes)
+    int p_begin, p_end;
+    chunk_planes(A, chunk_id, p_begin, p_end);
 
     // ---- LDS geometry: halo'd box, last axis contiguous
     // rows of the last axis are A.lpitch apart: E + 6, or E + 32 when LDS allows -- then the jump a
@@ -694,6 +745,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
         }
     }
+    publish_gate(A, chunk_id);
     if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
 #ifdef HJ_STAMP
     // phases of wave 0 and of the last wave, after the 4*nblocks words of the start/end records

@@ -116,13 +116,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     asm volatile("" ::"s"(A.nblocks), "s"(A.ntiles), "s"(A.blocks_per_xcd), "s"(A.ntile[1]), "s"(A.ntile[ND - 1]), "s"(A.E[1]),
                  "s"(A.E[ND - 1]), "s"(A.n[0]), "s"(A.n[1]), "s"(A.n[ND - 1]), "s"(A.nchunks1), "s"(A.plane_begin), "s"(A.plane_end),
                  "s"(A.plane_begin2), "s"(A.plane_end2), "s"(A.chunk), "s"(A.lpitch), "s"(A.pstride[1]), "s"(A.pstride[ND - 1]),
-                 "s"(A.stride0), "s"(A.halo_lo), "s"(A.halo_hi), "s"(A.lds_nbuf), "s"(A.halo_ahead), "s"(A.timing));
+                 "s"(A.stride0), "s"(A.halo_lo), "s"(A.halo_hi), "s"(A.lds_nbuf), "s"(A.halo_ahead), "s"(A.timing), "s"(A.edge_blocks), "s"(A.edge_count),
+                 "s"(A.nchunks_e));
     asm volatile("" ::"s"(y), "s"(y0), "s"(out), "s"(A.ham.coord[0]), "s"(A.ham.coord[1]), "s"(A.ham.coord[ND - 1]), "s"(A.ham.aux[0]),
                  "s"(A.ham.aux[1]), "s"(A.bc[1]), "s"(A.bc[ND - 1]), "s"(A.use_y0));
 #endif
-    const int b = blockIdx.x;
-    const int L = (b & 7) * A.blocks_per_xcd + (b >> 3);
-    if (L >= A.nblocks) return;
+    const int L = logical_block(A);
+    if (L < 0) return;
     int chunk_id, rem;
     fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);
     if (A.timing && threadIdx.x == 0) {         // HJ_TIMING_DUMP: start clock, XCC the hardware put us on, chunk, HW_ID
@@ -141,9 +141,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         rem = qd;
         fE[d] = fdiv_make(A.E[d]);
     }
-    const bool second = chunk_id >= A.nchunks1;
-    const int p_begin = second ? A.plane_begin2 + (chunk_id - A.nchunks1) * A.chunk : A.plane_begin + chunk_id * A.chunk;
-    const int p_end = min(p_begin + A.chunk, second ? A.plane_end2 : A.plane_end);
+    int p_begin, p_end;
+    chunk_planes(A, chunk_id, p_begin, p_end);
 
     // ---- LDS geometry: rows of the last axis are A.lpitch (even) apart, cell j of a row sits at j + HJ_VPAD;
     // the other plane axes keep the 3-cell pad
@@ -786,6 +785,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
         }
     }
+    publish_gate(A, chunk_id);
     if (A.timing && tid == 0) A.timing[4 * L + 1] = wall_clock64();
 #ifdef HJ_STAMP
     if (A.timing && tid == 0)

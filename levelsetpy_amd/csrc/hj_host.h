@@ -101,6 +101,11 @@ struct hj_ctx {
     hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
     int slab_pending;
     int slab_overlap2 = 0;             // HJ_SLAB_SCHEDULE=overlap2 (experiment)
+    int slab_gated = 0;                // HJ_SLAB_SCHEDULE=gated (round 4): edges + interior in ONE launch, exchange gated on a counter
+    unsigned long long* gate = nullptr;           // device counter the edge workgroups of gated launches add to
+    unsigned long long gate_count = 0;            // its value once every gated launch issued so far has published
+    int gate_posted = 0;                          // workgroups of the last launch that publish (0: it did not gate)
+    hipStream_t compute_stream = nullptr;         // HJ_SLAB_RESERVE_CUS > 0: CU-masked stream the slab launches run on
     int slab_serial = 1;               // HJ_SLAB_SCHEDULE: edges and interior of a substep on ONE stream, edges first (round 3)
     int external_exchange;             // hj_comm_init_external: the caller fills the pad planes itself
     hipEvent_t launch_stop;            // if set, the next tiled launch signals this event on completion
@@ -204,6 +209,11 @@ struct SubstepCall {
     unsigned long long* bound;
     int64_t p0, p1;
     int64_t q0 = 0, q1 = 0;   // optional second plane range in the same launch (tiled kernel only)
+    // gated slab launch (round 4): up to two EDGE plane ranges ride in this launch, ahead of [p0, p1) in chunk and dispatch
+    // order; each of their workgroups adds 1 to ctx->gate when its planes are in memory.  The launch code reports how many
+    // will (ctx->gate_posted); 0 = the launch could not gate (direct kernel): the caller orders the exchange with an event
+    int64_t e0[2] = {0, 0}, e1[2] = {0, 0};
+    bool gated = false;
     int post_op = 0;          // fused post-step min/max with the state the step started from
     bool on_aux = false;      // launch on the ctx's auxiliary (edge) stream instead of the ctx stream
     // intended WENO5 inside hj_rk_step / hj_rk_integrate: this launch's output is the next launch's input (reduce max(D1^2)

@@ -28,6 +28,7 @@ auto tiled_kernel() {
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE, bool PAIR = false>
 int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     constexpr int ND = HAM::ND;
+    int echunk = 0, ne[2] = {0, 0}, edge_count = 0;
     {
         auto kern0 = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
         const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
@@ -46,6 +47,15 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
             t.nblocks = t.nchunks * t.ntiles;
             t.bpx = (t.nblocks + 7) / 8;
         }
+        if (s.gated) {
+            // edge chunks of HJ_STENCIL planes each, ahead of everything else (hj_fused.h: logical_block, chunk_planes)
+            echunk = HJ_STENCIL;
+            for (int w = 0; w < 2; ++w) ne[w] = (int)((s.e1[w] - s.e0[w] + echunk - 1) / echunk);
+            const int main_blocks = t.nblocks;
+            edge_count = (ne[0] + ne[1]) * t.ntiles;
+            t.nblocks = main_blocks + edge_count;
+            t.bpx = (main_blocks + 7) / 8;
+        }
         if (c->debug) {
             fprintf(stderr, "[hj] %stiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
                     PAIR ? "pair " : "", NT, R, KH, PD, OCC, t.E[1], c->ndim > 2 ? t.E[2] : 0, c->ndim > 3 ? t.E[3] : 0, t.lpitch, t.ntiles, t.chunk,
@@ -53,6 +63,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
             c->debug = 0;
         }
     }
+    if (c->debug > 1 && s.gated) fprintf(stderr, "[hj] gated launch: %d edge workgroups + %d, chunk %d, %d tiles\n", edge_count, t.nblocks - edge_count, t.chunk, t.ntiles);
     FusedArgs<T, ND> A;
     memset(&A, 0, sizeof(A));
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
@@ -96,6 +107,16 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     A.nblocks = t.nblocks;
     if (t.nblocks >= (1 << 22)) return hjh::fail(HJ_EUNSUPPORTED, "more than 4 M workgroups in one launch (index arithmetic of the kernels)");
     A.blocks_per_xcd = t.bpx;
+    A.echunk = echunk;
+    A.nchunks_e1 = ne[0];
+    A.nchunks_e = ne[0] + ne[1];
+    for (int w = 0; w < 2; ++w) { A.eplane[w][0] = (int)s.e0[w]; A.eplane[w][1] = (int)s.e1[w]; }
+    A.edge_count = edge_count;
+    A.edge_bpx = (edge_count + 7) / 8;
+    A.edge_blocks = 8 * A.edge_bpx;
+    A.gate = (s.gated && edge_count > 0) ? c->gate : nullptr;
+    c->gate_posted = A.gate ? edge_count : 0;
+    const unsigned grid_blocks = (unsigned)(A.edge_blocks + t.bpx * 8);
     A.lds_nbuf = PAIR ? c->last_nbuf : 2;
     A.halo_ahead = (PAIR && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
     A.stage = s.stage;
@@ -139,11 +160,11 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     if (c->launch_stop) {
         // completion signal attached to the dispatch packet itself: a separate hipEventRecord costs a
         // marker packet and ~6 us of bubble before the next kernel of the stream (slab timeline)
-        hipExtLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
+        hipExtLaunchKernelGGL(kern, dim3(grid_blocks), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
                               (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
         c->launch_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(kern, dim3(t.bpx * 8), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0,
+        hipLaunchKernelGGL(kern, dim3(grid_blocks), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0,
                            (T*)s.out, A);
     }
     HIP_TRY(hipGetLastError());
@@ -297,6 +318,8 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
     if (s.p0 < 0 || s.p1 > c->N[0] || (s.q1 > s.q0 && (s.q0 < 0 || s.q1 > c->N[0])))
         return hjh::fail(HJ_EUNSUPPORTED, "pad planes need the tiled kernel");
+    for (int w = 0; w < 2; ++w)
+        if (s.gated && s.e1[w] > s.e0[w] && (s.e0[w] < 0 || s.e1[w] > c->N[0])) return hjh::fail(HJ_EUNSUPPORTED, "pad planes need the tiled kernel");
     const long long plane = c->total / c->N[0];
     A.cell_begin = s.p0 * plane;
     A.cell_end = s.p1 * plane;
@@ -305,11 +328,17 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.restrict_sign = s.restrict_sign;
     A.dt = (T)s.dt;
     fill_ham<T>(c, s.par, A.ham);
-    for (int pass = 0; pass < 2; ++pass) {
+    c->gate_posted = 0;            // the direct kernel never publishes: the caller orders the exchange with an event
+    for (int pass = 0; pass < 4; ++pass) {
         if (pass == 1) {
-            if (s.q1 <= s.q0) break;
+            if (s.q1 <= s.q0) continue;
             A.cell_begin = s.q0 * plane;
             A.cell_end = s.q1 * plane;
+        }
+        if (pass >= 2) {               // edge ranges of a gated call
+            if (!s.gated || s.e1[pass - 2] <= s.e0[pass - 2]) continue;
+            A.cell_begin = s.e0[pass - 2] * plane;
+            A.cell_end = s.e1[pass - 2] * plane;
         }
         const long long cells = A.cell_end - A.cell_begin;
         if (cells <= 0) continue;

@@ -844,7 +844,7 @@ def test_native_rccl_slab_stepper_self_ring():
                 t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
             # one 9-plane exchange per step / one 3-plane exchange per substep in each of its three stream schedules
             # (HJ_SLAB_SCHEDULE is read when the stepper creates its context; the default depends on the slab thickness)
-            for deep, sched in ((True, None), (False, "overlap"), (False, "overlap2"), (False, "serial")):
+            for deep, sched in ((True, None), (False, "overlap"), (False, "overlap2"), (False, "serial"), (False, "gated")):
                 if sched is None:
                     os.environ.pop("HJ_SLAB_SCHEDULE", None)
                 else:

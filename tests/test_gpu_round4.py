@@ -341,7 +341,7 @@ def test_c5_native_rccl_stepper_self_ring_4d_fp32():
         full = sphere4(g, noise=0.01, seed=11)
         dxs = [float(v) for v in np.asarray(g.dx).ravel()]
         ref = None
-        for deep, sched in ((True, None), (False, "overlap"), (False, "serial")):
+        for deep, sched in ((True, None), (False, "overlap"), (False, "serial"), (False, "gated")):
             if sched is None:
                 os.environ.pop("HJ_SLAB_SCHEDULE", None)
             else:
@@ -446,3 +446,60 @@ def test_term_convection_tensor_velocity_forms():
     yo, sbo = O.term_convection(og, [0.7, np.broadcast_to(prof, g.shape), vel_np[2]], "ENO3", 0., data.reshape(-1, 1))
     close(got.cpu().numpy(), yo)
     assert abs(sb1 - sbo) <= 1e-14 * sbo
+
+
+@pytest.mark.parametrize("n,scheme", [((65, 120, 110), "WENO5_ASSHIPPED"), ((23, 40, 300), "ENO3"), ((9, 64, 64), "WENO5")])
+def test_gated_slab_schedule_self_ring_bitwise(n, scheme):
+    """HJ_SLAB_SCHEDULE=gated (round 4): edge chunks and interior in ONE launch, the RCCL exchange gated on the counter the
+    edge workgroups publish (hipStreamWaitValue64).  One-rank periodic ring through a real self send/recv: several tiles
+    per plane, several interior chunks, slabs down to 9 planes; five RK3 steps bitwise equal to the in-kernel wrap."""
+    import torch.distributed as dist
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29594")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        g, og = mk([-2., -1.25, -np.pi], [2. * (1 - 2 / n[0]), 1.25, np.pi * (1 - 2 / n[2])], n, (0, 2))
+        x0 = torch.as_tensor(np.asarray(g.vs[0]).ravel(), device="cuda").reshape(-1, 1, 1)
+        x1 = torch.as_tensor(np.asarray(g.vs[1]).ravel(), device="cuda").reshape(1, -1, 1)
+        x2 = torch.as_tensor(np.asarray(g.vs[2]).ravel(), device="cuda").reshape(1, 1, -1)
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        full = ((x0 * x0 + x1 * x1).sqrt() - 0.5 + 0.1 * torch.sin(3 * x0) * torch.cos(2 * x2)
+                + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)).contiguous()
+        dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+        sid = _ffi.SCHEME_IDS[scheme]
+        os.environ["HJ_SLAB_SCHEDULE"] = "gated"
+        try:
+            slab = SlabDecomposition(n[0], 1, 0, True, self_exchange=True)
+            nat = NativeSlabStepper(g, slab, sid, _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.], dxs, deep=False)
+        finally:
+            os.environ.pop("HJ_SLAB_SCHEDULE", None)
+        nat.set_state(full)
+        t = 0.
+        for _ in range(5):
+            t, dt = nat.step(t)
+        got = nat.state().clone()
+        torch.cuda.synchronize()
+        nat.close()
+        dg = DeviceGrid(g)
+        dg.bind_stream()
+        cur, nxt, w0, w1 = full.clone(), torch.empty_like(full), torch.empty_like(full), torch.empty_like(full)
+        tout, dtout = C.c_double(), C.c_double()
+        tr = 0.
+        for _ in range(5):
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, sid, _ffi.HAM_DUBINS_REL, _ffi.darr([1., 1., 1., 2.]), tr, 1e9, 0.8, dt, 0,
+                                         dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+            cur, nxt = nxt, cur
+            tr = float(tout.value)
+        torch.cuda.synchronize()
+        assert abs(t - tr) <= 1e-15
+        if scheme == "WENO5":
+            assert float((got - cur).abs().max()) <= 1e-12        # the all-reduced epsilon is reduced in another order
+        else:
+            assert torch.equal(got, cur), float((got - cur).abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
