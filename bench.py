@@ -459,6 +459,25 @@ def valu_ceiling(cell_substeps_per_s):
                       "78.6 TFLOP/s fp64 vector / 2 flop per FMA lane-op"}
 
 
+# C5 (4-D, fp32): 130 VALU lane-operations per cell-substep (SQ_INSTS_VALU x 64 / cells, profiles/r03_c5_counters_single_vs_pair.txt)
+# against 10.67 algorithmic bytes -- beyond the ridge of the roofline (78.6e12 / 8e12 = 9.8 lane-ops per byte): the vector
+# ceiling of this workload (6.0e11 cell-substeps/s) is LOWER than its HBM ceiling (7.5e11).  fp32 vector peak 157.3 TFLOP/s
+# = 78.6e12 lane-operations/s (a packed v_pk_fma_f32 counts as one instruction here: the fraction is a lower bound on the
+# arithmetic actually retired)
+VALU_F32_LANE_OPS = 78.6e12
+C5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C5_VALU_OPS", "130"))
+
+
+def valu_ceiling_c5(cell_substeps_per_s):
+    achieved = cell_substeps_per_s * C5_VALU_OPS_PER_CELL
+    return {"bound": "valu-fp32", "ops_per_cell_substep": C5_VALU_OPS_PER_CELL, "achieved": achieved / 1e12,
+            "peak": VALU_F32_LANE_OPS / 1e12, "unit": "Tera fp32 lane-ops/s", "frac": achieved / VALU_F32_LANE_OPS,
+            "ceiling_cell_substeps_per_s": VALU_F32_LANE_OPS / C5_VALU_OPS_PER_CELL,
+            "source": "SQ_INSTS_VALU x 64 / cells of the substep kernel (profiles/r03_c5_counters_single_vs_pair.txt) x measured rate; "
+                      "peak = 157.3 TFLOP/s fp32 vector / 2 flop per FMA lane-op; this workload's vector ceiling is below its HBM ceiling "
+                      "(profiles/r04_c5_tile_order.txt)"}
+
+
 def source_hash():
     """Hash of every kernel / host source of the library (csrc/*.h, *.hip)."""
     import glob
@@ -904,6 +923,8 @@ def run(a, rank, world, local, slab_leg, cpu):
                 if name == "WENO5":
                     # the intended WENO5 is fp64-VALU bound, not HBM bound: its own ceiling
                     also[key]["roofline_valu"] = valu_ceiling(s2["value"])
+                if name == "C5":
+                    also[key]["roofline_valu"] = valu_ceiling_c5(s2["value"])
                 del r2, wl2
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001 -- an extra workload must not take the headline down

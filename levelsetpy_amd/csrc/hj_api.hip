@@ -998,6 +998,8 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_warm = env_int("HJ_F12_WARM", 9);
     c->f12_e2 = env_int("HJ_F12_E2", 0);
     c->tile_cells = env_int("HJ_TILE_CELLS", 0);
+    c->tile_block[0] = env_int("HJ_TB1", 4);      // 4 x 4 positions x the 4 axis-3 tiles = the 64 workgroups an XCD holds (C5)
+    c->tile_block[1] = env_int("HJ_TB2", 4);
     // launch-time choice of the tile shape on grids of >= HJ_AUTOTUNE_MIN_CELLS cells (hj_inst.hip, tuned_tiling)
     c->autotune = env_int("HJ_AUTOTUNE", 1);
     c->autotune_min_cells = (long long)env_int("HJ_AUTOTUNE_MIN_MCELLS", 40) * 1000000ll;

@@ -131,14 +131,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         A.timing[4 * L + 3] = (unsigned long long)chunk_id;
         A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
-    int org[ND];
+    int org[ND], tc[ND];
     FDiv fE[ND];
+    tile_coords<ND>(A, rem, tc);
 #pragma unroll
     for (int d = ND - 1; d >= 1; --d) {
-        int qd, rd;
-        fdivmod(rem, fdiv_make(A.ntile[d]), qd, rd);
-        org[d] = min(rd * A.E[d], A.n[d] - A.E[d]);
-        rem = qd;
+        org[d] = min(tc[d] * A.E[d], A.n[d] - A.E[d]);
         fE[d] = fdiv_make(A.E[d]);
     }
     int p_begin, p_end;

@@ -93,6 +93,8 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
         A.E[d] = t.E[d];
         A.ntile[d] = t.ntile[d];
     }
+    for (int d = 0; d < ND; ++d) A.tb[d] = 0;
+    if (ND == 4 && c->tile_block[0] > 0 && c->tile_block[1] > 0) { A.tb[1] = c->tile_block[0]; A.tb[2] = c->tile_block[1]; }
     A.halo_lo = c->halo_lo;
     A.halo_hi = c->halo_hi;
     A.ntiles = t.ntiles;
