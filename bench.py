@@ -71,8 +71,9 @@ def parse():
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported under 'also'")
-    ap.add_argument("--also", default="WENO5,513,C3,C5,CFL,API", help="comma list of the extra workloads to time (API = the 201^3 / "
-                    "51^3 workloads through odeCFL3 / HJIPDE_solve, the reference's own call protocol)")
+    ap.add_argument("--also", default="WENO5,513,C3,C5,CFL,API,RTC", help="comma list of the extra workloads to time (API = the 201^3 / "
+                    "51^3 workloads through odeCFL3 / HJIPDE_solve, the reference's own call protocol; RTC = the same system as a "
+                    "Hamiltonian compiled at run time with hipRTC, and as Python callbacks on the split path)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -386,6 +387,60 @@ def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
                 "numpy": "odeCFL3(termLaxFriedrichs, ..., singleStep='on') calls, a NumPy array in, every result fed back into the next call "
                          "(the reference's driver loop; results are lazy.HostView handles that stay in HBM until somebody looks)",
                 "solve": "one HJIPDE_solve(keepLast) call per window of K steps, device tensor in / out"}[kind])}
+
+
+DUBINS_REL_SRC = """
+    const T c3 = cos(x[2]), s3 = sin(x[2]);
+    H = p[0] * (par[0] - par[1] * c3) - p[1] * (par[1] * s3) - par[2] * fabs(p[0] * x[1] - p[1] * x[0] - p[2]) + par[2] * fabs(p[2]);
+    alpha[0] = fabs(par[0] - par[1] * c3) + fabs(par[2] * x[1]);
+    alpha[1] = fabs(par[1] * s3) + fabs(par[2] * x[0]);
+    alpha[2] = par[3];
+"""
+
+
+def time_runtime_ham(L, torch, _ffi, DeviceGrid, a, s_head):
+    """The headline system written by a USER: (1) as a device expression registered at run time (hj_ham_register: the fused
+    pair kernel compiled with hipRTC, one pair per thread in 256-thread workgroups) through the same raw C loop as the
+    headline; (2) as plain Python callbacks on device tensors (the split path every foreign hamFunc / partialFunc takes:
+    derivative kernels -> callbacks -> dissipation kernel -> hj_rk_combine) through odeCFL3."""
+    out = {}
+    reg = L.register_native_hamiltonian("bench_dubins_rel", 3, DUBINS_REL_SRC, nparams=4)
+    wl = list(workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n))
+    wl[0] = wl[0].replace("Dubins-relative", "Dubins-relative as a run-time (hipRTC) Hamiltonian")
+    wl[2] = reg.ham_id
+    t0 = time.perf_counter()
+    r = time_single(torch, _ffi, DeviceGrid, tuple(wl), a.steps, a.warmup, min(15, a.repeats), SPINUP_STEPS)
+    s = summarize(r, a.steps)
+    out["%d^3 run-time Hamiltonian (hipRTC)" % a.n] = {
+        "workload": r["desc"], "value": s["value"], "ms_per_step": s["ms_per_step"], "roofline_frac": s["frac"], "repeats": s["repeats"],
+        "kernel": r["kernel"], "vs_builtin": s["value"] / s_head["value"], "leg_wall_s_incl_compile": time.perf_counter() - t0}
+    # split path: the same formulas as Python callbacks on device tensors
+    g = dubins_grid(L, a.n, a.n)
+    sysd = L.DubinsVehicleRel(g, 1, 1)
+    calc = {"WENO5_ASSHIPPED": L.upwindFirstWENO5, "ENO3": L.upwindFirstENO3, "ENO2": L.upwindFirstENO2, "WENO5": L.upwindFirstWENO5Intended}[a.scheme]
+    sd = L.Bundle(dict(grid=g, hamFunc=lambda t, d, p, sd_: sysd.hamiltonian(t, d, p, sd_),
+                       partialFunc=lambda t, d, lo, hi, sd_, dim: sysd.dissipation(t, d, lo, hi, sd_, dim),
+                       dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y, t = device_sdf(torch, g, 0.5, ignore=(2,)).reshape(-1, 1), 0.0
+    for _ in range(3):
+        t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+    k = max(3, min(10, a.steps))
+    walls = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t1)
+    med = statistics.median(walls)
+    cells = y.numel()
+    out["%d^3 foreign Python callbacks (split path)" % a.n] = {
+        "workload": "the same system as Python hamFunc / partialFunc callbacks on device tensors through odeCFL3 (split path)",
+        "value": cells * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k,
+        "vs_run_time_hamiltonian": (cells * 3 * k / med) / s["value"]}
+    return out
 
 
 def summarize(r, steps):
@@ -894,6 +949,9 @@ def run(a, rank, world, local, slab_leg, cpu):
                         "vs_headline": s2["value"] / s["value"]}
                     out["config"]["cfl_reduction_kept_value"] = s2["value"]
                     del r2, wl2
+                    continue
+                if name == "RTC":
+                    also.update(time_runtime_ham(L, torch, _ffi, DeviceGrid, a, s))
                     continue
                 if name == "API":
                     rep = min(15, a.repeats)

@@ -25,7 +25,11 @@
 #ifndef HJ_MI355X_H
 #define HJ_MI355X_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else        /* hipRTC has no system headers: the kernels of a user Hamiltonian only need the enums below */
+typedef signed long long int64_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -51,7 +55,8 @@ enum {
 enum {
     HJ_HAM_DUBINS_REL = 0,        /* DynamicalSystems/dubins_relative.py:63-111; params {v_e, v_p, w, w_e+w_p}; aux0=cos(vs[2]) aux1=sin(vs[2]) */
     HJ_HAM_DOUBLE_INTEGRATOR = 1, /* DynamicalSystems/double_integrator.py:49-89; params {u_bound} */
-    HJ_HAM_DOUBLE_PENDULUM = 2    /* build-defined 4-D stress case (BASELINE C5); params {u_max}; aux0..3 = sin th1, cos th1, sin th2, cos th2 */
+    HJ_HAM_DOUBLE_PENDULUM = 2,   /* build-defined 4-D stress case (BASELINE C5); params {u_max}; aux0..3 = sin th1, cos th1, sin th2, cos th2 */
+    HJ_HAM_USER_BASE = 100        /* ids >= this: Hamiltonians registered at run time (hj_ham_register) */
 };
 
 enum { HJ_F64 = 0, HJ_F32 = 1 };
@@ -292,6 +297,23 @@ int hj_term_reinit(hj_ctx* ctx, int scheme, const void* y, const void* initial, 
                    double* step_bound);
 int hj_term_convection(hj_ctx* ctx, int scheme, const void* y, const void* const* velocity, const double* velocity_scalar,
                        void* ydot, double* step_bound);
+
+/* ---- a user's hamFunc / partialFunc pair as a fused kernel (round 4).  The reference takes ARBITRARY Python callables
+ * (ExplicitIntegration/Term/term_lax_friedrich.py:111 hamFunc(t, data, derivC, schemeData);
+ * Dissipation/artificial_diss_glf.py:98 partialFunc(t, data, derivMin, derivMax, schemeData, dim)).  `body` is the same
+ * pair written once as a device expression: C++ statements that read x[d] (node coordinates), p[d] (costates,
+ * = derivC), par[k] (the ham_params of a call, k < nparams <= 4) and assign  H  and  alpha[d]  for d = 0..ndim-1
+ * (alpha must not depend on p -- true of every system the reference ships).  The library wraps it in a Hamiltonian
+ * type, compiles the fused substep kernel for it with hipRTC (gfx950; on first use of a scheme, 1-2 s) and returns an id
+ * that every entry point taking ham_id accepts (fp64, 2-D / 3-D grids).  include_dir: directory of the library's kernel
+ * headers (levelsetpy_amd/csrc); hiprtc_path: the libhiprtc.so to load (NULL: the loader's default).
+ * Registering the same (name, ndim, nparams, body) again returns the same id.  A body that does not compile fails at
+ * first use (or in hj_ham_compile_check) with the compiler's message in hj_last_error(). */
+int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* include_dir,
+                    const char* hiprtc_path, int* ham_id);
+int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built);
+/* compile the substep kernel of `scheme` and the alpha-bound kernel WITHOUT launching (needs no GPU) */
+int hj_ham_compile_check(int ham_id, int scheme);
 
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);

@@ -15,6 +15,7 @@ DISS_GLF, DISS_LOCAL = 0, 1
 POST_NONE, POST_MIN_PREV, POST_MAX_PREV = 0, 1, 2
 ENO2, ENO3, WENO5, WENO5_ASSHIPPED = 0, 1, 2, 3
 HAM_DUBINS_REL, HAM_DOUBLE_INTEGRATOR, HAM_DOUBLE_PENDULUM = 0, 1, 2
+HAM_USER_BASE = 100
 F64, F32 = 0, 1
 STAGE_YDOT, STAGE_EULER, STAGE_RK3_HALF, STAGE_RK3_FULL, STAGE_RK2_FULL = 0, 1, 2, 3, 4
 OP_MIN, OP_MAX, OP_MAX_NEG = 0, 1, 2
@@ -68,6 +69,9 @@ SIGNATURES = {
     "hj_term_normal": (_i, [_vp, _i, _vp, _vp, _d, _vp, _pd]),
     "hj_term_reinit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _pd]),
     "hj_term_convection": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _pd]),
+    "hj_ham_register": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, C.c_char_p, _pi]),
+    "hj_ham_info": (_i, [_i, _pi, _pi, _pi]),
+    "hj_ham_compile_check": (_i, [_i, _i]),
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
     "hj_last_kernel": (C.c_char_p, [C.c_void_p]),

@@ -6,7 +6,7 @@
 
 namespace hjh {
 
-thread_local char g_err[512] = "";
+thread_local char g_err[4096] = "";      // (room for a hipRTC compiler message)
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -217,7 +217,7 @@ int ham_ndim(int ham) {
         case HJ_HAM_DOUBLE_INTEGRATOR: return 2;
         case HJ_HAM_DOUBLE_PENDULUM: return 4;
     }
-    return -1;
+    return user_ham_ndim(ham);       // -1 unless registered at run time (hj_rtc.hip)
 }
 int ham_npar(int ham) {
     switch (ham) {
@@ -225,7 +225,7 @@ int ham_npar(int ham) {
         case HJ_HAM_DOUBLE_INTEGRATOR: return 1;
         case HJ_HAM_DOUBLE_PENDULUM: return 1;
     }
-    return 0;
+    return user_ham_npar(ham);
 }
 
 template <typename T>
@@ -234,6 +234,7 @@ int launch_ham(hj_ctx* c, const SubstepCall& s) {
         case HJ_HAM_DUBINS_REL: return launch_scheme<T, HamDubinsRel<T>>(c, s);
         case HJ_HAM_DOUBLE_INTEGRATOR: return launch_scheme<T, HamDoubleIntegrator<T>>(c, s);
         case HJ_HAM_DOUBLE_PENDULUM: return launch_scheme<T, HamDoublePendulum<T>>(c, s);
+        default: if (user_ham_valid(s.ham)) return launch_user(c, s);
     }
     return fail(HJ_EINVAL, "unknown Hamiltonian id %d", s.ham);
 }
@@ -477,7 +478,7 @@ int do_stage12(hj_ctx* c, Stage12Call& s, int user_slot) {
 
 // does hj_rk_step fuse the first two stages on this ctx?  (cached per scheme / Hamiltonian)
 bool use_stage12(hj_ctx* c, int order, int scheme, int ham, const double* par, int restrict_sign) {
-    if (order < 2 || c->fuse12 == 0 || restrict_sign != 0) return false;
+    if (order < 2 || c->fuse12 == 0 || restrict_sign != 0 || ham >= HJ_HAM_USER_BASE) return false;
     if (order == 2 && c->post_step_op != 0) return false;     // the fused post-step operator rides on the LAST stage
     if (c->fuse12 < 0) {
         // auto: the fusion trades HBM traffic for redundant ring / warm-up work; it pays once the arrays are
@@ -1423,7 +1424,9 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         hipLaunchKernelGGL((alpha_bound_kernel<T, HAM<T>>), dim3(blocks), dim3(256), 0,          \
                            c->stream, G, P, c->keys, DX);                                        \
     }
-    if (c->dtype == HJ_F64) {
+    if (ham >= HJ_HAM_USER_BASE) {
+        if ((rc = user_alpha_bound(c, ham, par, c->keys))) return rc;
+    } else if (c->dtype == HJ_F64) {
         if (ham == HJ_HAM_DUBINS_REL) HJ_AB(double, HamDubinsRel)
         else if (ham == HJ_HAM_DOUBLE_INTEGRATOR) HJ_AB(double, HamDoubleIntegrator)
         else HJ_AB(double, HamDoublePendulum)

@@ -12,7 +12,9 @@
 // operation order so that results agree to rounding (not bit-for-bit: the compiler may
 // contract a*b+c into FMAs here; ghost_value is the exception and is bit-exact).
 #pragma once
+#ifndef __HIPCC_RTC__      // hipRTC (user Hamiltonians, hj_rtc.hip) brings the HIP device declarations itself
 #include <hip/hip_runtime.h>
+#endif
 #include "../../include/hj_mi355x.h"
 
 namespace hj {

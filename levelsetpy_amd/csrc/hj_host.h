@@ -265,6 +265,13 @@ constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz =
 #endif
 }
 
+// Hamiltonians compiled at run time (hj_rtc.hip)
+bool user_ham_valid(int ham);
+int user_ham_ndim(int ham);
+int user_ham_npar(int ham);
+int launch_user(hj_ctx* c, const SubstepCall& s);
+int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys);
+
 // the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
 // instantiated in hj_inst.hip
 template <typename T, typename HAM> int launch_scheme(hj_ctx* c, const SubstepCall& s);

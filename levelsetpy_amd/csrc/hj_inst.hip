@@ -7,6 +7,7 @@
 #include "hj_fused12.h"
 #include "hj_fusedv.h"
 #include "hj_fused12v.h"
+#include "hj_launch.h"
 
 namespace hjh {
 
@@ -28,7 +29,7 @@ auto tiled_kernel() {
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int PD, int MODE, bool PAIR = false>
 int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
     constexpr int ND = HAM::ND;
-    int echunk = 0, ne[2] = {0, 0}, edge_count = 0;
+    EdgePlan ep;
     {
         auto kern0 = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
         const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
@@ -39,22 +40,9 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
             it = c->occ_cache.emplace(key, nb).first;
         }
         const int occ_blocks = it->second;
-        choose_chunks(c, t, s.p0, s.p1, occ_blocks);
-        if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
-        t.nchunks1 = t.nchunks;
-        if (s.q1 > s.q0) {     // second range: same chunk length
-            t.nchunks += (int)((s.q1 - s.q0 + t.chunk - 1) / t.chunk);
-            t.nblocks = t.nchunks * t.ntiles;
-            t.bpx = (t.nblocks + 7) / 8;
-        }
-        if (s.gated) {
-            // edge chunks of HJ_STENCIL planes each, ahead of everything else (hj_fused.h: logical_block, chunk_planes)
-            echunk = HJ_STENCIL;
-            for (int w = 0; w < 2; ++w) ne[w] = (int)((s.e1[w] - s.e0[w] + echunk - 1) / echunk);
-            const int main_blocks = t.nblocks;
-            edge_count = (ne[0] + ne[1]) * t.ntiles;
-            t.nblocks = main_blocks + edge_count;
-            t.bpx = (main_blocks + 7) / 8;
+        {
+            const int rc_plan = plan_chunks(c, s, t, occ_blocks, ep);
+            if (rc_plan) return rc_plan;
         }
         if (c->debug) {
             fprintf(stderr, "[hj] %stiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
@@ -63,7 +51,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
             c->debug = 0;
         }
     }
-    if (c->debug > 1 && s.gated) fprintf(stderr, "[hj] gated launch: %d edge workgroups + %d, chunk %d, %d tiles\n", edge_count, t.nblocks - edge_count, t.chunk, t.ntiles);
+    if (c->debug > 1 && s.gated) fprintf(stderr, "[hj] gated launch: %d edge workgroups + %d, chunk %d, %d tiles\n", ep.edge_count, t.nblocks - ep.edge_count, t.chunk, t.ntiles);
     FusedArgs<T, ND> A;
     memset(&A, 0, sizeof(A));
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
@@ -79,63 +67,11 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
         A.eps_part = c->eps_prod;
     }
     if (SCHEME == HJ_WENO5 && s.eps_nrows > 0) { A.eps_rows = s.eps_rows; A.eps_nrows = s.eps_nrows; }
-    long long st = 1;
-    for (int d = ND - 1; d >= 0; --d) {
-        A.inv_dx[d] = (T)(1.0 / c->dx[d]);
-        A.n[d] = (int)c->N[d];
-        A.bc[d] = c->bc[d];
-        A.km[d] = c->tz[d] ? T(-1) : T(1);
-        fill_stencil_constants<T>(c->dx[d], A.K[d]);
-        A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
-        A.pstride[d] = (d >= 1) ? (int)st : 0;
-        if (d == 0) A.stride0 = st;
-        st *= c->N[d];
-        A.E[d] = t.E[d];
-        A.ntile[d] = t.ntile[d];
+    unsigned grid_blocks = 0;
+    {
+        const int rc_fill = fill_fused_args<T, ND>(c, s, t, ep, SCHEME, PAIR, A, grid_blocks);
+        if (rc_fill) return rc_fill;
     }
-    for (int d = 0; d < ND; ++d) A.tb[d] = 0;
-    if (ND == 4 && c->tile_block[0] > 0 && c->tile_block[1] > 0) { A.tb[1] = c->tile_block[0]; A.tb[2] = c->tile_block[1]; }
-    A.halo_lo = c->halo_lo;
-    A.halo_hi = c->halo_hi;
-    A.ntiles = t.ntiles;
-    A.lpitch = t.lpitch;
-    A.chunk = t.chunk;
-    A.nchunks = t.nchunks;
-    A.plane_begin = (int)s.p0;
-    A.plane_end = (int)s.p1;
-    A.plane_begin2 = (int)s.q0;
-    A.plane_end2 = (int)s.q1;
-    A.nchunks1 = t.nchunks1;
-    A.nblocks = t.nblocks;
-    if (t.nblocks >= (1 << 22)) return hjh::fail(HJ_EUNSUPPORTED, "more than 4 M workgroups in one launch (index arithmetic of the kernels)");
-    A.blocks_per_xcd = t.bpx;
-    A.echunk = echunk;
-    A.nchunks_e1 = ne[0];
-    A.nchunks_e = ne[0] + ne[1];
-    for (int w = 0; w < 2; ++w) { A.eplane[w][0] = (int)s.e0[w]; A.eplane[w][1] = (int)s.e1[w]; }
-    A.edge_count = edge_count;
-    A.edge_bpx = (edge_count + 7) / 8;
-    A.edge_blocks = 8 * A.edge_bpx;
-    A.gate = (s.gated && edge_count > 0) ? c->gate : nullptr;
-    c->gate_posted = A.gate ? edge_count : 0;
-    const unsigned grid_blocks = (unsigned)(A.edge_blocks + t.bpx * 8);
-    A.lds_nbuf = PAIR ? c->last_nbuf : 2;
-    A.halo_ahead = (PAIR && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
-    A.stage = s.stage;
-    A.ydot_only = (s.stage == HJ_STAGE_YDOT);
-    A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);
-    switch (s.stage) {                          // out = ca*y0 + cb*(y + dt*ydot)
-        case HJ_STAGE_RK3_HALF: A.ca = T(0.75); A.cb = T(0.25); break;           // ode_cfl_3.py:184,193
-        case HJ_STAGE_RK3_FULL: A.ca = T(1.0 / 3.0); A.cb = T(2.0 / 3.0); break; // :226,241
-        case HJ_STAGE_RK2_FULL: A.ca = T(0.5); A.cb = T(0.5); break;             // ode_cfl_2.py:184,201
-        default: A.ca = T(0); A.cb = T(1); break;
-    }
-    A.dt = (T)s.dt;
-    A.post_op = s.post_op;
-    A.do_clamp = s.restrict_sign != 0;
-    A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
-    A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
-    fill_ham<T>(c, s.par, A.ham);
     auto kern = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
     c->last_kernel = PAIR ? "fused_pair_kernel" : "fused_substep_kernel";
     c->last_E[0] = t.chunk;

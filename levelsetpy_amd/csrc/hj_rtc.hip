@@ -1,0 +1,320 @@
+// Hamiltonians compiled at RUN time (round 4): the fused substep kernel for a user-supplied H(x, p) / alpha(x).
+//
+// The reference's hamFunc / partialFunc are arbitrary Python callables (ExplicitIntegration/Term/term_lax_friedrich.py:111,
+// Dissipation/artificial_diss_glf.py:98); the library fuses the three systems it was built with, everything else took the
+// split path (derivative kernels -> Python callbacks -> dissipation kernel: 25x the fused step at 201^3).  Here the caller
+// hands over the BODY of the Hamiltonian as a device expression once (hj_ham_register); the library wraps it in the
+// interface the kernels expect from a Hamiltonian type (hj_device.h: Cell / Plane / eval), compiles
+// fused_pair_kernel<double, HamUser, SCHEME, ...> and alpha_bound_kernel<double, HamUser> with hipRTC for gfx950 (1-2 s per
+// scheme, on first use) and launches them through the module API with the very FusedArgs block the built-in
+// instantiations get (hj_launch.h).  Every consumer of a Hamiltonian id -- hj_lf_term, hj_rk_substep, hj_rk_step,
+// hj_rk_integrate, the slab steppers -- then works with the new id.
+//
+// What the expression may use:  x[d] (node coordinates, d = 0 .. ND-1), p[d] (costates), par[k] (the ham_params of the
+// call), t-independent device math (sin, cos, fabs, sqrt, fmin, fmax ...); what it must set:  H  and  alpha[d] for every d.
+// alpha must not depend on p (true of every system the reference ships: dubins_relative.py:106-111,
+// dubins_absolute.py:150-170, double_integrator.py:84-89, bird.py:346): the CFL bound is then a property of the grid
+// (hj_static_step_bound) and a time step needs no host synchronisation.  fp64, 2-D and 3-D grids.
+#include <dlfcn.h>
+#include <sstream>
+#include "hj_launch.h"
+#include "hj_fusedv.h"
+
+namespace hjh {
+
+typedef struct _hiprtcProgram* rtcProgram;
+struct Rtc {
+    void* handle = nullptr;
+    int (*CreateProgram)(rtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*CompileProgram)(rtcProgram, int, const char**) = nullptr;
+    int (*AddNameExpression)(rtcProgram, const char*) = nullptr;
+    int (*GetLoweredName)(rtcProgram, const char*, const char**) = nullptr;
+    int (*GetCodeSize)(rtcProgram, size_t*) = nullptr;
+    int (*GetCode)(rtcProgram, char*) = nullptr;
+    int (*GetProgramLogSize)(rtcProgram, size_t*) = nullptr;
+    int (*GetProgramLog)(rtcProgram, char*) = nullptr;
+    int (*DestroyProgram)(rtcProgram*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rtc g_rtc;
+
+static int rtc_load(const char* path) {
+    if (g_rtc.handle) return HJ_OK;
+    const char* names[] = {path, "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(HJ_ESTATE, "cannot dlopen hipRTC: %s", dlerror());
+#define HJ_SYM(field, name)                                                     \
+    *(void**)(&g_rtc.field) = dlsym(h, name);                                   \
+    if (!g_rtc.field) return fail(HJ_ESTATE, "hipRTC symbol %s missing", name);
+    HJ_SYM(CreateProgram, "hiprtcCreateProgram")
+    HJ_SYM(CompileProgram, "hiprtcCompileProgram")
+    HJ_SYM(AddNameExpression, "hiprtcAddNameExpression")
+    HJ_SYM(GetLoweredName, "hiprtcGetLoweredName")
+    HJ_SYM(GetCodeSize, "hiprtcGetCodeSize")
+    HJ_SYM(GetCode, "hiprtcGetCode")
+    HJ_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize")
+    HJ_SYM(GetProgramLog, "hiprtcGetProgramLog")
+    HJ_SYM(DestroyProgram, "hiprtcDestroyProgram")
+    HJ_SYM(GetErrorString, "hiprtcGetErrorString")
+#undef HJ_SYM
+    g_rtc.handle = h;
+    return HJ_OK;
+}
+
+struct UserKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; int occ = 0; size_t lds_granted = 0; };
+struct UserHam {
+    std::string name, body, include_dir, rtc_path;
+    int ndim = 0, nparams = 0;
+    std::map<int, UserKernel> substep;      // key: scheme * 4 + MODE
+    UserKernel alpha;
+};
+static std::vector<UserHam> g_user;
+
+static UserHam* user_of(int ham) {
+    const int i = ham - HJ_HAM_USER_BASE;
+    return (i >= 0 && i < (int)g_user.size()) ? &g_user[(size_t)i] : nullptr;
+}
+bool user_ham_valid(int ham) { return user_of(ham) != nullptr; }
+int user_ham_ndim(int ham) { const UserHam* u = user_of(ham); return u ? u->ndim : -1; }
+int user_ham_npar(int ham) { const UserHam* u = user_of(ham); return u ? u->nparams : 0; }
+
+// the translation unit hipRTC compiles: the kernel headers + the Hamiltonian type around the caller's expression
+static std::string user_source(const UserHam& u, int id) {
+    std::ostringstream o;
+    o << "#include \"hj_fusedv.h\"\n#include \"hj_split.h\"\nnamespace hj {\n"
+         "template <typename T> struct HamUser {\n"
+         "    static constexpr int ND = " << u.ndim << ";\n"
+         "    static constexpr int ID = " << id << ";\n"
+         "    static constexpr unsigned PLANE_DEP = 0xFu;     // any alpha may vary along the march\n"
+         "    struct Cell { T x[ND]; };\n    struct Plane { T x0; };\n    using Raw = Cell;\n"
+         "    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {\n"
+         "        Cell c; c.x[0] = T(0);\n"
+         "        for (int d = 1; d < ND; ++d) c.x[d] = P.coord[d][idx[d]];\n        return c;\n    }\n"
+         "    __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw& first) {\n"
+         "        Cell c = first; c.x[ND - 1] = P.coord[ND - 1][idx[ND - 1]]; return c;\n    }\n"
+         "    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>&, const Raw& r, const T*) { return r; }\n"
+         "    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) { return cell_fin(P, cell_raw(P, idx), sc); }\n"
+         "    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T*) { Plane u; u.x0 = P.coord[0][i0]; return u; }\n"
+         "    template <bool NP = false>\n"
+         "    __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& pl, const T* sc, const T* q, T& H, T* alpha) {\n"
+         "        T x[ND], p[ND];\n        x[0] = pl.x0;\n"
+         "        for (int d = 1; d < ND; ++d) x[d] = c.x[d];\n"
+         "        for (int d = 0; d < ND; ++d) { p[d] = sc[d] * q[d]; alpha[d] = T(0); }\n"
+         "        const T* par = P.par;\n        H = T(0);\n"
+         "        {\n#line 1 \"" << u.name << "\"\n" << u.body << "\n        }\n"
+         "        for (int d = 0; d < ND; ++d) alpha[d] = sc[d] * alpha[d];     // the kernels carry alpha in the stencil's scale\n"
+         "    }\n};\n}\n";
+    return o.str();
+}
+
+static int rtc_build(UserHam& u, int id, const std::string& name_expr, UserKernel& out) {
+    int rc = rtc_load(u.rtc_path.empty() ? nullptr : u.rtc_path.c_str());
+    if (rc) return rc;
+    const std::string src = user_source(u, id);
+    rtcProgram prog = nullptr;
+    int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);
+    if (e) return fail(HJ_EHIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(e));
+    e = g_rtc.AddNameExpression(prog, name_expr.c_str());
+    const std::string inc1 = "-I" + u.include_dir, inc2 = "-I" + u.include_dir + "/../../include";
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", inc1.c_str(), inc2.c_str(), "-DHJ_RTC=1"};
+    if (!e) e = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    if (e) {
+        size_t n = 0;
+        std::string log;
+        if (g_rtc.GetProgramLogSize(prog, &n) == 0 && n > 1) { log.resize(n); (void)g_rtc.GetProgramLog(prog, &log[0]); }
+        (void)g_rtc.DestroyProgram(&prog);
+        if (log.size() > 3000) log = log.substr(0, 3000) + " ...";
+        return fail(HJ_EINVAL, "the Hamiltonian '%s' does not compile (%s):\n%s", u.name.c_str(), g_rtc.GetErrorString(e), log.c_str());
+    }
+    const char* lowered = nullptr;
+    e = g_rtc.GetLoweredName(prog, name_expr.c_str(), &lowered);
+    size_t n = 0;
+    if (!e) e = g_rtc.GetCodeSize(prog, &n);
+    std::vector<char> code(n);
+    if (!e) e = g_rtc.GetCode(prog, code.data());
+    const std::string kname = lowered ? lowered : "";
+    (void)g_rtc.DestroyProgram(&prog);
+    if (e) return fail(HJ_EHIP, "hipRTC: %s", g_rtc.GetErrorString(e));
+    HIP_TRY(hipModuleLoadData(&out.mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&out.fn, out.mod, kname.c_str()));
+    return HJ_OK;
+}
+
+// kernel-argument block of fused_pair_kernel(const T* y, const T* y0, T* out, const FusedArgs<T, ND> A)
+template <typename T, int ND> struct PairKernArgs {
+    const T* y;
+    const T* y0;
+    T* out;
+    FusedArgs<T, ND> A;
+};
+template <typename T, int ND> struct AlphaKernArgs {
+    GridArgs<T, ND> G;
+    HamTables<T> P;
+    unsigned long long* keys;
+    DxArgs DX;
+};
+
+static int module_launch(hipFunction_t fn, unsigned grid, unsigned block, size_t lds, hipStream_t st, void* args, size_t nbytes) {
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)lds, st, nullptr, cfg));
+    return HJ_OK;
+}
+
+// (threads, pairs per thread, halo slots per thread, waves/SIMD hint) of the run-time instantiation: the shape the heavy
+// built-in stencils use -- one pair per thread leaves ~120 VGPRs for an arbitrary Hamiltonian expression
+constexpr int U_NT = 256, U_R = 1, U_KH = 2, U_OCC = 2;
+
+template <int ND>
+static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
+    using T = double;
+    // MODE 1 / 2: the flag-free instantiations of plain RK stages (hj_inst.hip, launch_tiled); 0: every run-time flag
+    const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0;
+    const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
+    UserKernel& k = u.substep[s.scheme * 4 + mode];
+    if (!k.fn) {
+        std::ostringstream nm;
+        nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << s.scheme << ", " << U_NT << ", " << U_R << ", " << U_KH << ", "
+           << U_OCC << ", " << mode << ">";
+        int rc = rtc_build(u, s.ham, nm.str(), k);
+        if (rc) return rc;
+    }
+    KernelCfg kc{U_NT, U_R, U_KH};
+    c->last_nbuf = 2;
+    Tiling t = make_tiling(c, kc, s.p0, s.p1, 2, 2);
+    if (!t.ok) return fail(HJ_EUNSUPPORTED, "no tiling of this grid for the run-time kernel");
+    if (!k.occ) {
+        int nb = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, U_NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+        k.occ = nb;
+    }
+    EdgePlan ep;
+    int rc = plan_chunks(c, s, t, k.occ, ep);
+    if (rc) return rc;
+    PairKernArgs<T, ND> K;
+    memset(&K, 0, sizeof(K));
+    K.y = (const T*)s.y;
+    K.y0 = (const T*)s.y0;
+    K.out = (T*)s.out;
+    K.A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
+    K.A.bound = s.bound;
+    if (s.scheme == HJ_WENO5 && s.eps_nrows > 0) { K.A.eps_rows = s.eps_rows; K.A.eps_nrows = s.eps_nrows; }
+    unsigned grid_blocks = 0;
+    if ((rc = fill_fused_args<T, ND>(c, s, t, ep, s.scheme, true, K.A, grid_blocks))) return rc;
+    if (t.lds_bytes > 64 * 1024) return fail(HJ_EUNSUPPORTED, "tile of the run-time kernel needs %zu bytes of LDS", t.lds_bytes);
+    c->last_kernel = "fused_pair_kernel (hipRTC)";
+    c->last_E[0] = t.chunk;
+    for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < ND ? t.E[d] : 0;
+    return module_launch(k.fn, grid_blocks, U_NT, t.lds_bytes, call_stream(c, s), &K, sizeof(K));
+}
+
+int launch_user(hj_ctx* c, const SubstepCall& s) {
+    UserHam* u = user_of(s.ham);
+    if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", s.ham);
+    if (c->dtype != HJ_F64) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians are compiled for fp64 grids");
+    if (c->ndim == 2) return launch_user_nd<2>(c, s, *u);
+    if (c->ndim == 3) return launch_user_nd<3>(c, s, *u);
+    return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D and 3-D grids");
+}
+
+template <int ND>
+static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long long* keys, UserHam& u) {
+    using T = double;
+    if (!u.alpha.fn) {
+        int rc = rtc_build(u, ham, "hj::alpha_bound_kernel<double, hj::HamUser<double>>", u.alpha);
+        if (rc) return rc;
+    }
+    AlphaKernArgs<T, ND> K;
+    memset(&K, 0, sizeof(K));
+    fill_grid<T, ND>(c, K.G);
+    fill_ham<T>(c, par, K.P);
+    K.keys = keys;
+    for (int d = 0; d < HJ_MAX_DIM; ++d) K.DX.dx[d] = c->dx[d];
+    const unsigned blocks = (unsigned)std::min<int64_t>((c->total + 255) / 256, 256 * 2);
+    return module_launch(u.alpha.fn, blocks, 256, 0, c->stream, &K, sizeof(K));
+}
+
+int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys) {
+    UserHam* u = user_of(ham);
+    if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham);
+    if (c->dtype != HJ_F64) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians are compiled for fp64 grids");
+    if (c->ndim == 2) return alpha_user_nd<2>(c, ham, par, keys, *u);
+    if (c->ndim == 3) return alpha_user_nd<3>(c, ham, par, keys, *u);
+    return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D and 3-D grids");
+}
+
+}  // namespace hjh
+
+using namespace hjh;
+
+extern "C" {
+
+int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* include_dir, const char* hiprtc_path,
+                    int* ham_id) {
+    if (!name || !body || !include_dir || !ham_id) return fail(HJ_EINVAL, "null argument");
+    if (ndim < 2 || ndim > 3) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: grid.dim must be 2 or 3, got %d", ndim);
+    if (nparams < 0 || nparams > 4) return fail(HJ_EINVAL, "a Hamiltonian takes 0..4 parameters, got %d", nparams);
+    for (size_t i = 0; i < g_user.size(); ++i)
+        if (g_user[i].name == name && g_user[i].ndim == ndim && g_user[i].nparams == nparams && g_user[i].body == body) {
+            *ham_id = HJ_HAM_USER_BASE + (int)i;        // registering the same expression again: the same id, nothing recompiled
+            return HJ_OK;
+        }
+    UserHam u;
+    u.name = name;
+    u.body = body;
+    u.include_dir = include_dir;
+    u.rtc_path = hiprtc_path ? hiprtc_path : "";
+    u.ndim = ndim;
+    u.nparams = nparams;
+    g_user.push_back(u);
+    *ham_id = HJ_HAM_USER_BASE + (int)g_user.size() - 1;
+    return HJ_OK;
+}
+
+int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built) {
+    const UserHam* u = user_of(ham_id);
+    if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
+    if (ndim) *ndim = u->ndim;
+    if (nparams) *nparams = u->nparams;
+    if (kernels_built) {
+        int n = u->alpha.fn ? 1 : 0;
+        for (const auto& kv : u->substep) n += kv.second.fn ? 1 : 0;
+        *kernels_built = n;
+    }
+    return HJ_OK;
+}
+
+// compile without launching (needs no GPU: hipRTC cross-compiles for gfx950) -- the check a registration can run up front
+int hj_ham_compile_check(int ham_id, int scheme) {
+    UserHam* u = user_of(ham_id);
+    if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
+    if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    int rc = rtc_load(u->rtc_path.empty() ? nullptr : u->rtc_path.c_str());
+    if (rc) return rc;
+    std::ostringstream nm;
+    nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << scheme << ", " << U_NT << ", " << U_R << ", " << U_KH << ", " << U_OCC << ", 0>";
+    const std::string src = user_source(*u, ham_id);
+    rtcProgram prog = nullptr;
+    int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);
+    if (e) return fail(HJ_EHIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(e));
+    e = g_rtc.AddNameExpression(prog, nm.str().c_str());
+    if (!e) e = g_rtc.AddNameExpression(prog, "hj::alpha_bound_kernel<double, hj::HamUser<double>>");
+    const std::string inc1 = "-I" + u->include_dir, inc2 = "-I" + u->include_dir + "/../../include";
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", inc1.c_str(), inc2.c_str(), "-DHJ_RTC=1"};
+    if (!e) e = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    std::string log;
+    if (e) {
+        size_t n = 0;
+        if (g_rtc.GetProgramLogSize(prog, &n) == 0 && n > 1) { log.resize(n); (void)g_rtc.GetProgramLog(prog, &log[0]); }
+        if (log.size() > 3000) log = log.substr(0, 3000) + " ...";
+    }
+    (void)g_rtc.DestroyProgram(&prog);
+    if (e) return fail(HJ_EINVAL, "the Hamiltonian '%s' does not compile (%s):\n%s", u->name.c_str(), g_rtc.GetErrorString(e), log.c_str());
+    return HJ_OK;
+}
+
+}  // extern "C"

@@ -13,7 +13,16 @@ import numpy as np
 from . import _ffi
 from .context import is_tensor
 
-__all__ = ["DubinsVehicleRel", "DoubleIntegrator", "DoublePendulum4D", "native_of"]
+__all__ = ["DubinsVehicleRel", "DoubleIntegrator", "DoublePendulum4D", "native_of", "native_again"]
+
+
+def native_again(system):
+    """(ham_id, params) of a system object as of NOW (its speeds / parameters may have been changed in place), None if it
+    is not native any more: what a cached plan is re-validated with (term.native_plan)."""
+    att = getattr(system, "_hj_native", None)
+    if att is not None:
+        return att.reg.ham_id, att.params(system)
+    return system.native()
 
 
 def _xs(grid, i, like):
@@ -168,6 +177,12 @@ def native_of(hamFunc, partialFunc):
     sys_p = getattr(partialFunc, "__self__", None)
     if sys_h is None or sys_h is not sys_p:
         return None
+    att = getattr(sys_h, "_hj_native", None)
+    if att is not None:
+        # a Hamiltonian registered at run time (user_ham.py): the methods must be the ones the registration saw
+        if getattr(hamFunc, "__func__", None) is not att.ham_func or getattr(partialFunc, "__func__", None) is not att.diss_func:
+            return None
+        return sys_h, att.reg.ham_id, att.params(sys_h)
     owner = next((k for k in (DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D) if isinstance(sys_h, k)), None)
     if owner is None:
         return None

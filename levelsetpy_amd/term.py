@@ -17,7 +17,7 @@ from . import _ffi
 from .context import device_grid, array_dtype_name, is_tensor
 from . import dissipation as _diss
 from .dissipation import artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF, glf_device
-from .dynamics import native_of
+from .dynamics import native_of, native_again
 from .spatial import scheme_id_of, upwind_all_dims
 from .utilities import isfield, iscell
 
@@ -93,7 +93,7 @@ def native_plan(schemeData):
                 and src[3] is d.get('partialFunc') and src[4] is fn:
             if plan is None:
                 return None
-            nat = plan.system.native()
+            nat = native_again(plan.system)
             if nat is not None and nat[0] == plan[2] and nat[1] == plan[3] and scheme_id_of(fn) == plan[1]:
                 return plan
     plan = _classify(sd, fn)

@@ -1,0 +1,117 @@
+"""A user's hamFunc / partialFunc pair as a fused HIP kernel, compiled at run time (C ABI: hj_ham_register).
+
+The reference's termLaxFriedrichs calls arbitrary Python callables on whole arrays
+(ExplicitIntegration/Term/term_lax_friedrich.py:111, Dissipation/artificial_diss_glf.py:98); this package fuses the
+systems of dynamics.py and sends everything else down the split path (derivative kernels -> the callbacks -> a
+dissipation kernel: 25x the fused step at 201^3).  `register_native_hamiltonian` closes that gap for any system whose
+alpha does not depend on the costate (every system the reference ships): write H and alpha ONCE more, as a device
+expression, and the schemeData that carries the system's own bound methods runs fused -- selected by callable
+identity, exactly as the built-in systems are (dynamics.native_of).
+
+    DubinsAbs = register_native_hamiltonian("dubins_abs", 3, '''
+        H = p[0] * par[0] * cos(x[2]) + p[1] * par[0] * sin(x[2]) + par[1] * fabs(p[2]);
+        alpha[0] = fabs(par[0] * cos(x[2]));  alpha[1] = fabs(par[0] * sin(x[2]));  alpha[2] = par[1];
+    ''', nparams=2)
+    DubinsAbs.attach(vehicle, params=lambda v: [v.v, v.w])     # an EXISTING object with .hamiltonian / .dissipation / .grid
+    # or: sys_ = DubinsAbs(grid, [1.0, 1.0], hamiltonian=py_ham, dissipation=py_diss)   # a new object around Python callbacks
+
+In the expression: x[d] node coordinates, p[d] costates (the reference's derivC), par[k] parameters; assign H and every
+alpha[d].  fp64, 2-D and 3-D grids; the kernels are built with hipRTC on first use (1-2 s per scheme).
+"""
+import ctypes as C
+import os
+
+from . import _ffi
+
+__all__ = ["register_native_hamiltonian", "NativeRegistration", "RegisteredSystem"]
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _hiprtc_path():
+    """The libhiprtc.so next to the HIP runtime this process uses (torch's wheel bundles both), else the loader's default."""
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")
+        if os.path.exists(cand):
+            return cand
+    except ImportError:
+        pass
+    return None
+
+
+class _Attached(object):
+    """What native_of needs to recognise an object's bound methods: the registration, the functions the methods must be,
+    and where the parameters come from (a list, or a callable of the object: re-read at every call, like system.native())."""
+
+    def __init__(self, reg, params, ham_func, diss_func):
+        self.reg, self._params, self.ham_func, self.diss_func = reg, params, ham_func, diss_func
+
+    def params(self, obj):
+        p = self._params(obj) if callable(self._params) else self._params
+        p = [float(v) for v in p]
+        if len(p) != self.reg.nparams:
+            raise ValueError("Hamiltonian '%s' takes %d parameters, got %d" % (self.reg.name, self.reg.nparams, len(p)))
+        return p
+
+
+class RegisteredSystem(object):
+    """A system object around a registration: the reference's callback protocol (.hamiltonian / .dissipation, from the
+    Python callables given -- they serve the split path and parity checks) plus the native kernel."""
+
+    def __init__(self, reg, grid, params, hamiltonian=None, dissipation=None):
+        if int(grid.dim) != reg.dim:
+            raise ValueError("Hamiltonian '%s' is %d-dimensional, the grid has dim %d" % (reg.name, reg.dim, grid.dim))
+        self.grid = grid
+        self.params = [float(v) for v in params]
+        self._py_ham, self._py_diss = hamiltonian, dissipation
+        self._hj_native = _Attached(reg, lambda s: s.params, RegisteredSystem.hamiltonian, RegisteredSystem.dissipation)
+
+    def hamiltonian(self, t, data, value_derivs, finite_diff_bundle=None):
+        if self._py_ham is None:
+            raise NotImplementedError("no Python hamFunc was given for '%s': it only runs fused" % self._hj_native.reg.name)
+        return self._py_ham(self, t, data, value_derivs, finite_diff_bundle)
+
+    def dissipation(self, t, data, derivMin, derivMax, schemeData, dim):
+        if self._py_diss is None:
+            raise NotImplementedError("no Python partialFunc was given for '%s': it only runs fused" % self._hj_native.reg.name)
+        return self._py_diss(self, t, data, derivMin, derivMax, schemeData, dim)
+
+
+class NativeRegistration(object):
+    def __init__(self, name, dim, device_src, nparams=0):
+        self.name, self.dim, self.nparams, self.device_src = str(name), int(dim), int(nparams), str(device_src)
+        ham = C.c_int()
+        rtc = _hiprtc_path()
+        _ffi.check(_ffi.lib().hj_ham_register(self.name.encode(), self.dim, self.nparams, self.device_src.encode(),
+                                              os.path.join(HERE, "csrc").encode(), rtc.encode() if rtc else None, C.byref(ham)))
+        self.ham_id = int(ham.value)
+
+    def check(self, scheme="WENO5_ASSHIPPED"):
+        """Compile now (no GPU needed): raises ValueError with the compiler's message if the expression is wrong."""
+        _ffi.check(_ffi.lib().hj_ham_compile_check(self.ham_id, _ffi.SCHEME_IDS[scheme]))
+        return self
+
+    def __call__(self, grid, params=(), hamiltonian=None, dissipation=None):
+        return RegisteredSystem(self, grid, params, hamiltonian, dissipation)
+
+    def attach(self, obj, params=()):
+        """Mark an existing system object (it must have .grid and bound .hamiltonian / .dissipation methods): a schemeData
+        whose hamFunc / partialFunc are THOSE methods then runs fused.  params: a list, or a callable of the object."""
+        cls = type(obj)
+        if not hasattr(obj, "grid"):
+            raise ValueError("the system object needs a .grid (the fused path checks that schemeData.grid is the same grid)")
+        if int(obj.grid.dim) != self.dim:
+            raise ValueError("Hamiltonian '%s' is %d-dimensional, the object's grid has dim %d" % (self.name, self.dim, obj.grid.dim))
+        att = _Attached(self, params, getattr(cls, "hamiltonian", None), getattr(cls, "dissipation", None))
+        if att.ham_func is None or att.diss_func is None:
+            raise ValueError("the system object's class needs hamiltonian() and dissipation() methods")
+        att.params(obj)                      # validates the count now
+        obj._hj_native = att
+        return obj
+
+
+def register_native_hamiltonian(name, dim, device_src, nparams=0):
+    """Register H / alpha as a device expression (module docstring); returns a NativeRegistration: call it to make a
+    system object, or .attach() it to an existing one."""
+    return NativeRegistration(name, dim, device_src, nparams)

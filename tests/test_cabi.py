@@ -1,5 +1,6 @@
 """CPU-only: the C-ABI library loads and exports every symbol include/hj_mi355x.h declares, and
 the host-side mirror of the reference interface behaves (no compute calls)."""
+import ctypes as C
 import os
 import re
 
@@ -123,3 +124,65 @@ def test_wide_store_hazard_rule_holds_in_built_library():
 @pytest.mark.gpu
 def test_wide_store_hazard_rule_holds_in_loaded_library():
     _check_wide_store_hazard()
+
+
+def test_runtime_hamiltonian_registration_and_compile_check():
+    """hj_ham_register / hj_ham_compile_check (round 4): a user's H / alpha expression becomes a Hamiltonian id; hipRTC
+    cross-compiles the fused kernel for gfx950 without a GPU; a wrong expression fails with the compiler's message, which
+    points into the user's own text."""
+    import levelsetpy_amd as L
+    src = """
+        H = p[0] * par[0] * cos(x[2]) + p[1] * par[0] * sin(x[2]) + par[1] * fabs(p[2]);
+        alpha[0] = fabs(par[0] * cos(x[2]));  alpha[1] = fabs(par[0] * sin(x[2]));  alpha[2] = par[1];
+    """
+    reg = L.register_native_hamiltonian("cabi_dubins_abs", 3, src, nparams=2)
+    assert reg.ham_id >= _ffi.HAM_USER_BASE
+    assert L.register_native_hamiltonian("cabi_dubins_abs", 3, src, nparams=2).ham_id == reg.ham_id      # same text, same id
+    assert L.register_native_hamiltonian("cabi_dubins_abs", 3, src + " ", nparams=2).ham_id != reg.ham_id
+    nd, npar, built = C.c_int(), C.c_int(), C.c_int()
+    _ffi.check(_ffi.lib().hj_ham_info(reg.ham_id, C.byref(nd), C.byref(npar), C.byref(built)))
+    assert (nd.value, npar.value, built.value) == (3, 2, 0)
+    reg.check("ENO3")
+    reg.check("WENO5")
+    bad = L.register_native_hamiltonian("cabi_bad", 2, "H = p[0] * no_such_symbol;\nalpha[0] = 1; alpha[1] = 1;", nparams=0)
+    with pytest.raises(ValueError) as e:
+        bad.check()
+    assert "no_such_symbol" in str(e.value) and "cabi_bad:1" in str(e.value)
+    with pytest.raises(ValueError):
+        L.register_native_hamiltonian("cabi_4d", 4, "H = 0;", nparams=0)          # 2-D / 3-D only
+    with pytest.raises(ValueError):
+        _ffi.check(_ffi.lib().hj_ham_info(9999, None, None, None))
+
+
+def test_runtime_hamiltonian_is_selected_by_callable_identity():
+    import levelsetpy_amd as L
+    from levelsetpy_amd.dynamics import native_of
+    from levelsetpy_amd.term import native_plan
+    reg = L.register_native_hamiltonian("cabi_di", 2, "H = -(p[0] * x[1]) + par[0] * fabs(p[1]); alpha[0] = fabs(x[1]); alpha[1] = par[0];", nparams=1)
+    g = L.createGrid(-np.ones((2, 1)), np.ones((2, 1)), 17 * np.ones((2, 1), dtype=np.int64), None)
+    s = reg(g, [1.5])
+    sd = L.Bundle(dict(grid=g, hamFunc=s.hamiltonian, partialFunc=s.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=L.upwindFirstENO3))
+    nat = native_of(sd.hamFunc, sd.partialFunc)
+    assert nat[0] is s and nat[1] == reg.ham_id and nat[2] == [1.5]
+    plan = native_plan(sd)
+    assert plan is not None and plan[2] == reg.ham_id and plan[3] == [1.5] and native_plan(sd) is plan      # cached
+    s.params[0] = 2.0                       # changed in place: the cached plan is re-validated, like system.native()
+    assert native_plan(sd)[3] == [2.0]
+    with pytest.raises(NotImplementedError):
+        s.hamiltonian(0., None, None)       # no Python callback was given: fused only
+
+    class Mine(object):                     # an EXISTING object of the caller's own class
+        def __init__(self, grid):
+            self.grid, self.u = grid, 0.5
+
+        def hamiltonian(self, t, data, derivs, sd=None):
+            return -(derivs[0] * self.grid.xs[1]) + self.u * np.abs(derivs[1])
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            return np.abs(self.grid.xs[1]) if dim == 0 else self.u
+    m = reg.attach(Mine(g), params=lambda o: [o.u])
+    nat = native_of(m.hamiltonian, m.dissipation)
+    assert nat[1] == reg.ham_id and nat[2] == [0.5]
+    assert native_of(m.hamiltonian, Mine(g).dissipation) is None          # methods of two different objects
+    with pytest.raises(ValueError):
+        reg.attach(Mine(g), params=[1.0, 2.0])                            # wrong parameter count
