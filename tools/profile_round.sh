@@ -3,11 +3,11 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (the driver's: --steps 20 --warmup 5)
 # 2. separate --pmc passes at 201^3 and 513^3: FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ issue/wait and LDS counters
 # 3. profiles/traffic.json rows (with the hash of the kernel sources they were measured on) printed at the end
-tag=${1:-r03}
+tag=${1:-r04}
 root=$PWD
 export TMPDIR=/tmp
 out=$root/gpurun_out/$tag
-rm -rf $out; mkdir -p $out
+mkdir -p $out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $out/stats_bench.json 2> $out/stats.err
 # 1b. the headline workload alone (201^3, the default K/W): this stats file's average for the dominant kernel is the
