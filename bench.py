@@ -283,7 +283,24 @@ def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
 
     # device spin-up (untimed, reported as config.spinup_steps): the GPU's clocks need a few tens of
     # milliseconds of load to reach their steady state; without it a short --steps run measures the ramp
-    for _ in range(spinup + warmup):
+    for _ in range(spinup):
+        one()
+    # ... and until the clocks have SETTLED: untimed blocks of K steps until three in a row agree within 0.5 % (at most
+    # HJ_BENCH_SETTLE_BLOCKS = 60 blocks).  A fixed 300-step spin-up (33 ms at 201^3) was not always enough after the child passes
+    # that precede this leg: a run whose 25 windows drifted by 2 % reported the headline 5 % below what the later legs of the
+    # SAME run measured with the same kernels (profiles/r04_bench_default.json vs gpurun r04_run12)
+    settle, last = 0, []
+    for _ in range(int(os.environ.get("HJ_BENCH_SETTLE_BLOCKS", "60"))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        last.append(time.perf_counter() - t0)
+        settle += steps
+        if len(last) >= 3 and max(last[-3:]) - min(last[-3:]) <= 0.005 * min(last[-3:]):
+            break
+    for _ in range(warmup):
         one()
     walls, devs = [], []
     for _ in range(repeats):
@@ -303,7 +320,7 @@ def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
         raise RuntimeError(lib.hj_last_error().decode())
     launches = nl.value                      # launches of one RK3 step as hj_rk_step issues it on this ctx
     kern = lib.hj_last_kernel(dg.ctx)
-    return {"desc": desc, "cells": dg.numel, "dtype": dtype, "scheme": scheme, "walls": walls, "devs": devs,
+    return {"desc": desc, "cells": dg.numel, "dtype": dtype, "scheme": scheme, "walls": walls, "devs": devs, "settle_steps": settle,
             "launches_per_step": int(launches), "stage_fused": int(fused.value), "kernel": kern.decode() if kern else "?"}
 
 
@@ -523,6 +540,22 @@ VALU_F32_LANE_OPS = 78.6e12
 C5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C5_VALU_OPS", "130"))
 
 
+# C3 (4096^2, ENO3 in the reference's operation order, fp64): 135 VALU instructions per cell and plane in the plane loop of
+# fused_pair_kernel<double, HamDoubleIntegrator, ENO3, 256, 1, 2, 2, 2> (101 fp64 + 34 selects / moves; tools/kernel_isa_stats.py
+# on the built library, profiles/r04_isa_mix.txt) against 21.33 algorithmic bytes = 6.3 per byte; balance 39.3e12 / 8e12 = 4.9:
+# beyond the ridge as well -- vector ceiling 2.9e11 cell-substeps/s, HBM ceiling 3.75e11
+C3_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C3_VALU_OPS", "135"))
+
+
+def valu_ceiling_c3(cell_substeps_per_s):
+    achieved = cell_substeps_per_s * C3_VALU_OPS_PER_CELL
+    return {"bound": "valu-fp64", "ops_per_cell_substep": C3_VALU_OPS_PER_CELL, "achieved": achieved / 1e12,
+            "peak": VALU_F64_LANE_OPS / 1e12, "unit": "Tera fp64 lane-ops/s", "frac": achieved / VALU_F64_LANE_OPS,
+            "ceiling_cell_substeps_per_s": VALU_F64_LANE_OPS / C3_VALU_OPS_PER_CELL,
+            "source": "VALU instructions per cell of the kernel's plane loop (static count on the built library, profiles/r04_isa_mix.txt) x "
+                      "measured rate; peak = 78.6 TFLOP/s fp64 vector / 2 flop per FMA lane-op"}
+
+
 def valu_ceiling_c5(cell_substeps_per_s):
     achieved = cell_substeps_per_s * C5_VALU_OPS_PER_CELL
     return {"bound": "valu-fp32", "ops_per_cell_substep": C5_VALU_OPS_PER_CELL, "achieved": achieved / 1e12,
@@ -573,7 +606,7 @@ def live_traffic(a, n=None, scheme=None):
         spin, warm, steps = (60, 1, 4) if ctr else (SPINUP_STEPS, 2, 20)
         nstep = spin + warm + steps
         d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin))
+        env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin), HJ_BENCH_SETTLE_BLOCKS="0")   # (fixed step count: the rows are dealt to steps by position)
         cmd = [exe] + (["--pmc", ctr] if ctr else []) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also", "--no-live-traffic",
                "--steps", str(steps), "--warmup", str(warm), "--repeats", "1", "--n", str(n or a.n), "--scheme", scheme,
@@ -917,7 +950,9 @@ def run(a, rank, world, local, slab_leg, cpu):
         "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dt_tag, "data": "synthetic",
         "config": {"workload": r["desc"], "scheme": a.scheme, "parallelism": "single", "substeps_per_step": 3,
-                   "launches_per_step": r["launches_per_step"], "spinup_steps": SPINUP_STEPS,
+                   "launches_per_step": r["launches_per_step"], "spinup_steps": SPINUP_STEPS + r["settle_steps"],
+                   "spinup_note": "untimed: %d fixed steps + %d steps in blocks of K until three blocks in a row agreed within 0.5 %% (clock "
+                                  "ramp), then the W warm-up steps" % (SPINUP_STEPS, r["settle_steps"]),
                    "cfl_reduction": "static bound, skipped in launch (alpha is data independent: dt = factorCFL * "
                                     "hj_static_step_bound, equal to the reduced bound by test; value with the reduction kept "
                                     "in every launch: config.cfl_reduction_kept_value)"},
@@ -983,6 +1018,8 @@ def run(a, rank, world, local, slab_leg, cpu):
                     also[key]["roofline_valu"] = valu_ceiling(s2["value"])
                 if name == "C5":
                     also[key]["roofline_valu"] = valu_ceiling_c5(s2["value"])
+                if name == "C3":
+                    also[key]["roofline_valu"] = valu_ceiling_c3(s2["value"])
                 del r2, wl2
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001 -- an extra workload must not take the headline down

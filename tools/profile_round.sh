@@ -18,7 +18,7 @@ find $out/stats201 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/k
 for n in 201 513; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
     name=$(echo $ctr | cut -d' ' -f1)
-    HJ_BENCH_SPINUP=60 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${n}_$name -- python3 $root/bench.py --no-cpu-baseline --no-also --steps 4 --warmup 1 --repeats 1 --n $n > /dev/null 2> $out/pmc_${n}_$name.err
+    HJ_BENCH_SPINUP=60 HJ_BENCH_SETTLE_BLOCKS=0 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${n}_$name -- python3 $root/bench.py --no-cpu-baseline --no-also --steps 4 --warmup 1 --repeats 1 --n $n > /dev/null 2> $out/pmc_${n}_$name.err
     echo "== n=$n $ctr" >> $out/pmc_summary.txt
     python3 $root/tools/pmc_summary.py $out/pmc_${n}_$name >> $out/pmc_summary.txt 2>&1
   done
