@@ -603,7 +603,9 @@ def live_traffic(a, n=None, scheme=None):
         # (60 steps of spin-up in the counter passes: on grids of >= 40 M cells the library spends up to 9 x 6 = 54 launches per
         # (scheme, stage class) choosing a tile shape, and the stage-1 class sees ONE launch per step -- the counted steps must
         # run the settled shape: ADVICE r03)
-        spin, warm, steps = (60, 1, 4) if ctr else (SPINUP_STEPS, 2, 20)
+        # (the duration pass spins up 4x longer than the timed leg's fixed part: it cannot use the leg's settle loop -- its rows
+        # are dealt to steps by position -- and has to reach the same clocks)
+        spin, warm, steps = (60, 1, 4) if ctr else (4 * SPINUP_STEPS, 2, 20)
         nstep = spin + warm + steps
         d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin), HJ_BENCH_SETTLE_BLOCKS="0")   # (fixed step count: the rows are dealt to steps by position)
@@ -659,7 +661,7 @@ def live_traffic(a, n=None, scheme=None):
             "fetch_kib_per_step": vals["FETCH_SIZE"][0], "write_kib_per_step": vals["WRITE_SIZE"][0],
             "rocprof": dur,
             "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 65 RK3 steps, --kernel-trace: "
-                      "the last 20 of %d; every kernel of the step counted; %.0f s)" % (SPINUP_STEPS + 22, time.perf_counter() - t0)}
+                      "the last 20 of %d; every kernel of the step counted; %.0f s)" % (4 * SPINUP_STEPS + 22, time.perf_counter() - t0)}
 
 
 def achievable_rates():
@@ -931,6 +933,28 @@ def run(a, rank, world, local, slab_leg, cpu):
             "per_gpu_value": value / world,
             "also": {"slab_check_max_abs_diff": res.get("slab_check_max_abs_diff")},
         }
+        # The companion point of the scaling curve, same ranks, same communicator set-up: BASELINE's metric names 201^3 and
+        # configs[3] names 513^3, so the strong-scaling line also carries the WEAK-scaling figure (a 201-plane slab of an
+        # (N*201) x 201 x 201 grid per rank: per-GPU work fixed) and vice versa.  Any failure of this extra leg is reported in
+        # place of its number; it cannot take the main figure down (it runs after it) unless a rank hangs (watchdog).
+        if world > 1 and wname == "C4" and not a.no_also:
+            try:
+                import copy as _copy
+                a2 = _copy.copy(a)
+                a2.steps, a2.repeats = max(10, a.steps // 2), min(9, a.repeats)
+                other_gn = 0 if strong else 513
+                r2 = hjdist.bench_slab(a2, rank, world, global_n=other_gn, workload="C4")
+                tw2 = torch.tensor(r2["walls"], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tw2, op=dist.ReduceOp.MAX)
+                med2 = statistics.median([float(v) for v in tw2.cpu()])
+                v2 = r2["total_cells"] * 3 * a2.steps / med2
+                key = ("weak scaling: %d^3 per GPU" % a.n if other_gn == 0 else "strong scaling: 513^3") + " over %d MI355X" % world
+                out["also"][key] = {"value": v2, "per_gpu_value": v2 / world, "ms_per_step": 1e3 * med2 / a2.steps, "steps": a2.steps,
+                                    "scaling": "weak" if other_gn == 0 else "strong", "planes_per_rank": r2["planes"],
+                                    "parallelism": r2["parallelism"], "slab_check_max_abs_diff": r2.get("slab_check_max_abs_diff"),
+                                    "roofline_frac_per_gpu": (v2 / world) * bps / 1e9 / HBM_PEAK_GBS}
+            except Exception as e:  # noqa: BLE001
+                out["also"]["companion_leg_error"] = repr(e)
         dist.destroy_process_group()
         return out
 

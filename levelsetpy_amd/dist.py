@@ -75,6 +75,14 @@ class HaloExchanger(object):
         self.dist = dist
         self.slab = slab
         self.group = group
+        # gloo moves device tensors through host staging buffers with copies of its own that are NOT ordered after the
+        # caller's current stream: a send could read edge planes whose kernel had not finished (seen in the two-rank rehearsal
+        # on one card: one stale halo plane now and then).  With gloo the stream is drained before the sends are posted and
+        # after the receives have completed; RCCL ("nccl") is stream-ordered and needs neither.
+        try:
+            self.host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl"
+        except Exception:  # noqa: BLE001
+            self.host_staged = True
 
     def start(self, buf):
         """Post the sends/receives for `buf`; returns the request list (wait with finish())."""
@@ -91,12 +99,18 @@ class HaloExchanger(object):
             ops.append(dist.P2POp(dist.irecv, buf[0:HALO], s.lo, group=self.group, tag=1))
         if not ops:
             return []
+        if self.host_staged and buf.is_cuda:
+            import torch
+            torch.cuda.current_stream(buf.device).synchronize()
         return dist.batch_isend_irecv(ops)
 
-    @staticmethod
-    def finish(reqs):
+    def finish(self, reqs):
         for r in reqs:
             r.wait()
+        if self.host_staged and reqs:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     def exchange(self, buf):
         self.finish(self.start(buf))
@@ -422,6 +436,12 @@ def _slab_self_check(g, slab, integ, wl, tdtype, device, steps=2):
         ts = float(tout.value)
     torch.cuda.synchronize(device)
     diff = float((cur[slab.begin:slab.end] - mine).abs().max())
+    if os.environ.get("HJ_DEBUG_SLABCHECK") and diff > 0:
+        d = (cur[slab.begin:slab.end] - mine).abs()
+        per_plane = d.reshape(d.shape[0], -1).max(dim=1).values
+        bad = [int(i) for i in torch.nonzero(per_plane > 0).ravel()[:12]]
+        sys.stderr.write("[slabcheck] rank %d planes [%d,%d) n_local %d: diff %g, first bad local planes %s, t slab %r ref %r, dt %r, "
+                         "step_bound %r\n" % (slab.rank, slab.begin, slab.end, slab.n_local, diff, bad, t, ts, _dt, getattr(integ, "step_bound", None)))
     if abs(ts - t) > 1e-14 * max(1.0, abs(t)):
         diff = max(diff, abs(ts - t))
     del cur, nxt, w1

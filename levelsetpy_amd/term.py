@@ -43,7 +43,6 @@ class _Plan(tuple):
         self.diss = diss
         self.system = system
         self.parv = _ffi.darr(items[3])
-        self._sb = {}
         return self
 
     def bind(self, dg, post_op=0, post_a=None, post_b=None):
@@ -62,12 +61,14 @@ class _Plan(tuple):
 
     def static_step_bound(self, dg):
         """stepBound of this (grid, system, dissipation kind): data independent for the native systems, one C call per ctx."""
-        key = (id(dg), self.diss)
-        sb = self._sb.get(key)
+        # kept ON the DeviceGrid (an id(dg) key could be reused by a later object once this one is collected)
+        cache = dg.__dict__.setdefault("_sb_cache", {})
+        key = (self[2], tuple(self[3]), self.diss)
+        sb = cache.get(key)
         if sb is None:
             v = C.c_double()
             _ffi.check(dg.lib.hj_static_step_bound(dg.ctx, self[2], self.parv, C.byref(v), None))
-            sb = self._sb[key] = float(v.value)
+            sb = cache[key] = float(v.value)
         return sb
 
 
