@@ -828,6 +828,13 @@ def main():
         def bark():
             sys.stderr.write("[bench] rank %d: no result after %.0f s -- a rank is stuck (communicator set-up or a "
                              "collective); aborting\n" % (rank, limit))
+            part = getattr(a, "_partial", None)
+            if part is not None:
+                # the main figure was complete; only the companion leg (the other scaling point, run after it) is stuck
+                if rank == 0:
+                    part["also"]["companion_leg_error"] = "watchdog: the companion leg did not finish within %.0f s" % limit
+                    os.write(json_fd, (json.dumps(part) + "\n").encode())
+                os._exit(0)
             if rank == 0:
                 err = {"metric": "grid-cell RK-substep updates/sec, Dubins-3D HJI, slab-decomposed over %d MI355X" % world,
                        "value": None, "unit": "cell-substeps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -837,6 +844,14 @@ def main():
         dog = threading.Timer(limit, bark)
         dog.daemon = True
         dog.start()
+
+        def arm_companion():
+            # the companion leg gets its own, shorter deadline: it must not hold the finished main figure back for long
+            t2 = threading.Timer(float(os.environ.get("HJ_BENCH_COMPANION_S", "240")), bark)
+            t2.daemon = True
+            t2.start()
+            a._dog2 = t2
+        a._arm_companion = arm_companion
     try:
         out = run(a, rank, world, local, slab_leg, cpu)
     except BaseException as e:
@@ -938,6 +953,9 @@ def run(a, rank, world, local, slab_leg, cpu):
         # (N*201) x 201 x 201 grid per rank: per-GPU work fixed) and vice versa.  Any failure of this extra leg is reported in
         # place of its number; it cannot take the main figure down (it runs after it) unless a rank hangs (watchdog).
         if world > 1 and wname == "C4" and not a.no_also:
+            a._partial = out          # from here on a stuck rank costs the companion figure only (watchdog in main())
+            if hasattr(a, "_arm_companion"):
+                a._arm_companion()
             try:
                 import copy as _copy
                 a2 = _copy.copy(a)
@@ -955,6 +973,9 @@ def run(a, rank, world, local, slab_leg, cpu):
                                     "roofline_frac_per_gpu": (v2 / world) * bps / 1e9 / HBM_PEAK_GBS}
             except Exception as e:  # noqa: BLE001
                 out["also"]["companion_leg_error"] = repr(e)
+            if getattr(a, "_dog2", None) is not None:
+                a._dog2.cancel()
+            a._partial = None
         dist.destroy_process_group()
         return out
 
