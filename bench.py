@@ -406,8 +406,9 @@ def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
                 "solve": "one HJIPDE_solve(keepLast) call per window of K steps, device tensor in / out"}[kind])}
 
 
+DUBINS_REL_COL = "col[0] = cos(x[2]); col[1] = sin(x[2]);"      # once per grid column, outside the march
 DUBINS_REL_SRC = """
-    const T c3 = cos(x[2]), s3 = sin(x[2]);
+    const T c3 = col[0], s3 = col[1];
     H = p[0] * (par[0] - par[1] * c3) - p[1] * (par[1] * s3) - par[2] * fabs(p[0] * x[1] - p[1] * x[0] - p[2]) + par[2] * fabs(p[2]);
     alpha[0] = fabs(par[0] - par[1] * c3) + fabs(par[2] * x[1]);
     alpha[1] = fabs(par[1] * s3) + fabs(par[2] * x[0]);
@@ -421,7 +422,7 @@ def time_runtime_ham(L, torch, _ffi, DeviceGrid, a, s_head):
     headline; (2) as plain Python callbacks on device tensors (the split path every foreign hamFunc / partialFunc takes:
     derivative kernels -> callbacks -> dissipation kernel -> hj_rk_combine) through odeCFL3."""
     out = {}
-    reg = L.register_native_hamiltonian("bench_dubins_rel", 3, DUBINS_REL_SRC, nparams=4)
+    reg = L.register_native_hamiltonian("bench_dubins_rel", 3, DUBINS_REL_SRC, nparams=4, column_src=DUBINS_REL_COL, ncol=2)
     wl = list(workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n))
     wl[0] = wl[0].replace("Dubins-relative", "Dubins-relative as a run-time (hipRTC) Hamiltonian")
     wl[2] = reg.ham_id

@@ -303,14 +303,18 @@ int hj_term_convection(hj_ctx* ctx, int scheme, const void* y, const void* const
  * Dissipation/artificial_diss_glf.py:98 partialFunc(t, data, derivMin, derivMax, schemeData, dim)).  `body` is the same
  * pair written once as a device expression: C++ statements that read x[d] (node coordinates), p[d] (costates,
  * = derivC), par[k] (the ham_params of a call, k < nparams <= 4) and assign  H  and  alpha[d]  for d = 0..ndim-1
- * (alpha must not depend on p -- true of every system the reference ships).  The library wraps it in a Hamiltonian
+ * (alpha must not depend on p -- true of every system the reference ships).  Optional `column_body` (ncol <= 8 values):
+ * statements assigning col[k] from x[1..] and par, evaluated ONCE per grid column outside the march along axis 0 and
+ * readable in `body` as col[k] -- where trigonometric functions of the in-plane coordinates belong (the built-in Dubins
+ * kernel reads such values from tables; an expression that calls cos / sin per cell and plane runs 8 % slower).
+ * The library wraps it in a Hamiltonian
  * type, compiles the fused substep kernel for it with hipRTC (gfx950; on first use of a scheme, 1-2 s) and returns an id
  * that every entry point taking ham_id accepts (fp64, 2-D / 3-D grids).  include_dir: directory of the library's kernel
  * headers (levelsetpy_amd/csrc); hiprtc_path: the libhiprtc.so to load (NULL: the loader's default).
  * Registering the same (name, ndim, nparams, body) again returns the same id.  A body that does not compile fails at
  * first use (or in hj_ham_compile_check) with the compiler's message in hj_last_error(). */
-int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* include_dir,
-                    const char* hiprtc_path, int* ham_id);
+int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol,
+                    const char* include_dir, const char* hiprtc_path, int* ham_id);
 int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built);
 /* compile the substep kernel of `scheme` and the alpha-bound kernel WITHOUT launching (needs no GPU) */
 int hj_ham_compile_check(int ham_id, int scheme);

@@ -69,7 +69,7 @@ SIGNATURES = {
     "hj_term_normal": (_i, [_vp, _i, _vp, _vp, _d, _vp, _pd]),
     "hj_term_reinit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _pd]),
     "hj_term_convection": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _pd]),
-    "hj_ham_register": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, C.c_char_p, _pi]),
+    "hj_ham_register": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _i, C.c_char_p, C.c_char_p, _pi]),
     "hj_ham_info": (_i, [_i, _pi, _pi, _pi]),
     "hj_ham_compile_check": (_i, [_i, _i]),
     "hj_sync": (_i, [_vp]),

@@ -68,9 +68,11 @@ static int rtc_load(const char* path) {
 
 struct UserKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; int occ = 0; size_t lds_granted = 0; };
 struct UserHam {
-    std::string name, body, include_dir, rtc_path;
-    int ndim = 0, nparams = 0;
-    std::map<int, UserKernel> substep;      // key: scheme * 4 + MODE
+    std::string name, body, column_body, include_dir, rtc_path;
+    int ndim = 0, nparams = 0, ncol = 0;
+    std::map<int, UserKernel> substep;      // key: (scheme * 4 + MODE) * 2 + (big shape ? 1 : 0)
+    std::map<int, bool> big_spills;         // key: scheme * 4 + MODE -- the big shape needed scratch for this expression
+    bool no_big_lds = false;                // the runtime refused > 64 KB of dynamic LDS for a module function
     UserKernel alpha;
 };
 static std::vector<UserHam> g_user;
@@ -91,13 +93,22 @@ static std::string user_source(const UserHam& u, int id) {
          "    static constexpr int ND = " << u.ndim << ";\n"
          "    static constexpr int ID = " << id << ";\n"
          "    static constexpr unsigned PLANE_DEP = 0xFu;     // any alpha may vary along the march\n"
-         "    struct Cell { T x[ND]; };\n    struct Plane { T x0; };\n    using Raw = Cell;\n"
+         "    static constexpr int NCOL = " << (u.ncol > 0 ? u.ncol : 1) << ";\n"
+         "    struct Cell { T x[ND]; T col[NCOL]; };\n    struct Plane { T x0; };\n    using Raw = Cell;\n"
          "    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {\n"
          "        Cell c; c.x[0] = T(0);\n"
-         "        for (int d = 1; d < ND; ++d) c.x[d] = P.coord[d][idx[d]];\n        return c;\n    }\n"
+         "        for (int d = 1; d < ND; ++d) c.x[d] = P.coord[d][idx[d]];\n"
+         "        for (int k = 0; k < NCOL; ++k) c.col[k] = T(0);\n        return c;\n    }\n"
          "    __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw& first) {\n"
          "        Cell c = first; c.x[ND - 1] = P.coord[ND - 1][idx[ND - 1]]; return c;\n    }\n"
-         "    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>&, const Raw& r, const T*) { return r; }\n"
+         "    // once per grid COLUMN, outside the march: the caller's column expression (col[k] from x[1..], par)\n"
+         "    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>& P, const Raw& r, const T*) {\n"
+         "        Cell c = r;\n        T x[ND], col[NCOL];\n        x[0] = T(0);\n"
+         "        for (int d = 1; d < ND; ++d) x[d] = r.x[d];\n"
+         "        for (int k = 0; k < NCOL; ++k) col[k] = T(0);\n"
+         "        const T* par = P.par;\n        (void)par; (void)x;\n"
+         "        {\n#line 1 \"" << u.name << " (column)\"\n" << u.column_body << "\n        }\n"
+         "        for (int k = 0; k < NCOL; ++k) c.col[k] = col[k];\n        return c;\n    }\n"
          "    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) { return cell_fin(P, cell_raw(P, idx), sc); }\n"
          "    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T*) { Plane u; u.x0 = P.coord[0][i0]; return u; }\n"
          "    template <bool NP = false>\n"
@@ -105,7 +116,7 @@ static std::string user_source(const UserHam& u, int id) {
          "        T x[ND], p[ND];\n        x[0] = pl.x0;\n"
          "        for (int d = 1; d < ND; ++d) x[d] = c.x[d];\n"
          "        for (int d = 0; d < ND; ++d) { p[d] = sc[d] * q[d]; alpha[d] = T(0); }\n"
-         "        const T* par = P.par;\n        H = T(0);\n"
+         "        const T* par = P.par;\n        const T* col = c.col;\n        (void)col; (void)par;\n        H = T(0);\n"
          "        {\n#line 1 \"" << u.name << "\"\n" << u.body << "\n        }\n"
          "        for (int d = 0; d < ND; ++d) alpha[d] = sc[d] * alpha[d];     // the kernels carry alpha in the stencil's scale\n"
          "    }\n};\n}\n";
@@ -165,9 +176,13 @@ static int module_launch(hipFunction_t fn, unsigned grid, unsigned block, size_t
     return HJ_OK;
 }
 
-// (threads, pairs per thread, halo slots per thread, waves/SIMD hint) of the run-time instantiation: the shape the heavy
-// built-in stencils use -- one pair per thread leaves ~120 VGPRs for an arbitrary Hamiltonian expression
-constexpr int U_NT = 256, U_R = 1, U_KH = 2, U_OCC = 2;
+// (threads, pairs per thread, halo slots per thread, waves/SIMD hint) of the run-time instantiations: the two shapes of the
+// built-in pair kernels.  "small": one pair per thread in 256-thread workgroups -- ~120 VGPRs are left for an arbitrary
+// Hamiltonian expression; "big": two pairs per thread in 512-thread workgroups + the parked halo ring, what the built-in
+// light stencils run from 6.5 M cells up -- taken for the light stencils on such grids IF the expression compiles into it
+// without scratch (hipFuncGetAttribute: a spilling kernel loses more than the shape gains), else the small shape.
+struct UShape { int nt, r, kh, occ; };
+constexpr UShape U_SMALL{256, 1, 2, 2}, U_BIG{512, 2, 2, 2};
 
 template <int ND>
 static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
@@ -175,25 +190,58 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     // MODE 1 / 2: the flag-free instantiations of plain RK stages (hj_inst.hip, launch_tiled); 0: every run-time flag
     const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0;
     const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
-    UserKernel& k = u.substep[s.scheme * 4 + mode];
-    if (!k.fn) {
-        std::ostringstream nm;
-        nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << s.scheme << ", " << U_NT << ", " << U_R << ", " << U_KH << ", "
-           << U_OCC << ", " << mode << ">";
-        int rc = rtc_build(u, s.ham, nm.str(), k);
-        if (rc) return rc;
+    const bool light = s.scheme == HJ_WENO5_ASSHIPPED || s.scheme == HJ_ENO2;
+    bool big = light && ND <= 3 && c->total >= 6500000 && c->pair != 0 && !u.big_spills[s.scheme * 4 + mode];
+    UserKernel* k = nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const UShape sh = big ? U_BIG : U_SMALL;
+        k = &u.substep[(s.scheme * 4 + mode) * 2 + (big ? 1 : 0)];
+        if (!k->fn) {
+            std::ostringstream nm;
+            nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << s.scheme << ", " << sh.nt << ", " << sh.r << ", " << sh.kh << ", "
+               << sh.occ << ", " << mode << ">";
+            int rc = rtc_build(u, s.ham, nm.str(), *k);
+            if (rc) return rc;
+            if (big) {
+                int scratch = 0;
+                if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn) != hipSuccess) scratch = 1;
+                if (scratch > 0) {                       // the expression does not fit two pairs per thread: small shape from now on
+                    u.big_spills[s.scheme * 4 + mode] = true;
+                    big = false;
+                    continue;
+                }
+            }
+        }
+        break;
     }
-    KernelCfg kc{U_NT, U_R, U_KH};
-    c->last_nbuf = 2;
-    Tiling t = make_tiling(c, kc, s.p0, s.p1, 2, 2);
+    const UShape sh = big ? U_BIG : U_SMALL;
+    KernelCfg kc{sh.nt, sh.r, sh.kh};
+    // halo ring parked in LDS with the big shape (as the built-in launches do, hj_inst.hip)
+    bool ring = big && !u.no_big_lds && (c->pair_ring == 1 || (c->pair_ring < 0 && c->total >= 6500000));
+    c->last_nbuf = ring ? 2 + c->pair_ah : 2;
+    Tiling t = make_tiling(c, kc, s.p0, s.p1, 2, c->last_nbuf);
+    if (t.ok && t.lds_bytes > 64 * 1024 && k->lds_granted < t.lds_bytes) {
+        // more than 64 KB of dynamic LDS has to be granted to the function; if this runtime refuses that for a module
+        // function, the ring (5 plane buffers) is given up and the double buffer (< 64 KB) stays
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes) == hipSuccess) {
+            k->lds_granted = t.lds_bytes;
+        } else {
+            (void)hipGetLastError();
+            u.no_big_lds = true;
+            ring = false;
+            c->last_nbuf = 2;
+            t = make_tiling(c, kc, s.p0, s.p1, 2, 2);
+        }
+    }
     if (!t.ok) return fail(HJ_EUNSUPPORTED, "no tiling of this grid for the run-time kernel");
-    if (!k.occ) {
+    if (t.lds_bytes > 64 * 1024 && k->lds_granted < t.lds_bytes) return fail(HJ_EUNSUPPORTED, "tile of the run-time kernel needs %zu bytes of LDS", t.lds_bytes);
+    if (!k->occ) {
         int nb = 0;
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, U_NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
-        k.occ = nb;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k->fn, sh.nt, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+        k->occ = nb;
     }
     EdgePlan ep;
-    int rc = plan_chunks(c, s, t, k.occ, ep);
+    int rc = plan_chunks(c, s, t, k->occ, ep);
     if (rc) return rc;
     PairKernArgs<T, ND> K;
     memset(&K, 0, sizeof(K));
@@ -205,11 +253,18 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     if (s.scheme == HJ_WENO5 && s.eps_nrows > 0) { K.A.eps_rows = s.eps_rows; K.A.eps_nrows = s.eps_nrows; }
     unsigned grid_blocks = 0;
     if ((rc = fill_fused_args<T, ND>(c, s, t, ep, s.scheme, true, K.A, grid_blocks))) return rc;
-    if (t.lds_bytes > 64 * 1024) return fail(HJ_EUNSUPPORTED, "tile of the run-time kernel needs %zu bytes of LDS", t.lds_bytes);
+    if (c->debug) {
+        int regs = 0, scr = 0;
+        (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn);
+        (void)hipFuncGetAttribute(&scr, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn);
+        fprintf(stderr, "[hj] run-time kernel '%s' scheme %d mode %d: shape (%d,%d,%d,%d)%s, %d VGPRs, %d B scratch, tile (%d,%d), chunk %d, %d blocks, lds %zu\n",
+                u.name.c_str(), s.scheme, mode, sh.nt, sh.r, sh.kh, sh.occ, ring ? " + ring" : "", regs, scr, t.E[1], t.E[2], t.chunk, t.nblocks, t.lds_bytes);
+        c->debug = 0;
+    }
     c->last_kernel = "fused_pair_kernel (hipRTC)";
     c->last_E[0] = t.chunk;
     for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < ND ? t.E[d] : 0;
-    return module_launch(k.fn, grid_blocks, U_NT, t.lds_bytes, call_stream(c, s), &K, sizeof(K));
+    return module_launch(k->fn, grid_blocks, sh.nt, t.lds_bytes, call_stream(c, s), &K, sizeof(K));
 }
 
 int launch_user(hj_ctx* c, const SubstepCall& s) {
@@ -253,19 +308,25 @@ using namespace hjh;
 
 extern "C" {
 
-int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* include_dir, const char* hiprtc_path,
-                    int* ham_id) {
+int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol,
+                    const char* include_dir, const char* hiprtc_path, int* ham_id) {
     if (!name || !body || !include_dir || !ham_id) return fail(HJ_EINVAL, "null argument");
+    if (ncol < 0 || ncol > 8) return fail(HJ_EINVAL, "0..8 column values, got %d", ncol);
+    if (ncol > 0 && !column_body) return fail(HJ_EINVAL, "ncol > 0 needs a column expression");
+    const std::string cb = (column_body && ncol > 0) ? column_body : "";
     if (ndim < 2 || ndim > 3) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: grid.dim must be 2 or 3, got %d", ndim);
     if (nparams < 0 || nparams > 4) return fail(HJ_EINVAL, "a Hamiltonian takes 0..4 parameters, got %d", nparams);
     for (size_t i = 0; i < g_user.size(); ++i)
-        if (g_user[i].name == name && g_user[i].ndim == ndim && g_user[i].nparams == nparams && g_user[i].body == body) {
+        if (g_user[i].name == name && g_user[i].ndim == ndim && g_user[i].nparams == nparams && g_user[i].body == body &&
+            g_user[i].column_body == cb && g_user[i].ncol == ncol) {
             *ham_id = HJ_HAM_USER_BASE + (int)i;        // registering the same expression again: the same id, nothing recompiled
             return HJ_OK;
         }
     UserHam u;
     u.name = name;
     u.body = body;
+    u.column_body = cb;
+    u.ncol = ncol;
     u.include_dir = include_dir;
     u.rtc_path = hiprtc_path ? hiprtc_path : "";
     u.ndim = ndim;
@@ -296,7 +357,8 @@ int hj_ham_compile_check(int ham_id, int scheme) {
     int rc = rtc_load(u->rtc_path.empty() ? nullptr : u->rtc_path.c_str());
     if (rc) return rc;
     std::ostringstream nm;
-    nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << scheme << ", " << U_NT << ", " << U_R << ", " << U_KH << ", " << U_OCC << ", 0>";
+    nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << scheme << ", " << U_SMALL.nt << ", " << U_SMALL.r << ", " << U_SMALL.kh << ", "
+       << U_SMALL.occ << ", 0>";
     const std::string src = user_source(*u, ham_id);
     rtcProgram prog = nullptr;
     int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);

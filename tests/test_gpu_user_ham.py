@@ -21,8 +21,9 @@ from oracle import hj_oracle as O  # noqa: E402
 
 from test_gpu_parity import mk, sdata, DERIV, SCHEMES, close, dubins  # noqa: E402
 
+DUBINS_REL_COL = "col[0] = cos(x[2]); col[1] = sin(x[2]);"      # once per grid column, outside the march
 DUBINS_REL_SRC = """
-    const T c3 = cos(x[2]), s3 = sin(x[2]);
+    const T c3 = col[0], s3 = col[1];
     H = p[0] * (par[0] - par[1] * c3) - p[1] * (par[1] * s3) - par[2] * fabs(p[0] * x[1] - p[1] * x[0] - p[2]) + par[2] * fabs(p[2]);
     alpha[0] = fabs(par[0] - par[1] * c3) + fabs(par[2] * x[1]);
     alpha[1] = fabs(par[1] * s3) + fabs(par[2] * x[0]);
@@ -73,7 +74,7 @@ def test_runtime_dubins_relative_equals_builtin_and_oracle(scheme):
     g, og = dubins([23, 21, 19])
     d0 = O.shape_cylinder(og, 2, None, .5) + 0.03 * np.random.default_rng(2).standard_normal(og.shape)
     y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
-    reg = L.register_native_hamiltonian("dubins_rel_rt", 3, DUBINS_REL_SRC, nparams=4)
+    reg = L.register_native_hamiltonian("dubins_rel_rt", 3, DUBINS_REL_SRC, nparams=4, column_src=DUBINS_REL_COL, ncol=2)
     user = reg(g, [1.0, 1.0, 1.0, 2.0])
     builtin = L.DubinsVehicleRel(g, 1, 1)
     yd_u, sb_u, _ = L.termLaxFriedrichs(0., y, sdata(g, user, DERIV[scheme]))
