@@ -7,7 +7,7 @@ on the Dubins-relative 3-D problem, fp64 (BASELINE.json).
 
 One "step" = one odeCFL3 time step = 3 RK substeps over the whole grid; inputs are resident in HBM
 before the timed region; a window of exactly K steps is timed between synchronisations, R times (--repeats,
-default 25), and `value` is the MEDIAN window (inter-quartile range and min/max in "repeats").
+default 51), and `value` is the MEDIAN window (inter-quartile range and min/max in "repeats").
 
 N = 1 (default): BASELINE C2, the 201^3 grid.  The same run also times, each with its own spin-up and
 reported under "also" with its own roofline fraction: the intended WENO5 arithmetic at 201^3, the
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=25,
+    ap.add_argument("--repeats", type=int, default=51,
                     help="the window of EXACTLY K timed steps (synchronised on both sides) is repeated this many times; "
                          "value = the median window, the inter-quartile range is reported beside it")
     ap.add_argument("--n", type=int, default=201, help="grid points per axis of the single-GPU / weak-scaling leg")
@@ -473,7 +473,8 @@ def summarize(r, steps):
             "repeats": {"n": len(r["walls"]), "value_min": per_s(max(r["walls"])), "value_max": per_s(min(r["walls"])),
                         "value_q1": per_s(quartiles(r["walls"])[2]), "value_q3": per_s(quartiles(r["walls"])[0]),
                         "spread": (max(r["walls"]) - min(r["walls"])) / med,
-                        "iqr_over_median": (quartiles(r["walls"])[2] - quartiles(r["walls"])[0]) / med},
+                        "iqr_over_median": (quartiles(r["walls"])[2] - quartiles(r["walls"])[0]) / med,
+                        "windows_ms": [round(1e3 * w, 4) for w in r["walls"]]},
             "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "dev_step_ms": dev_step_ms}
 
 
