@@ -389,8 +389,9 @@ def time_api(L, torch, n, kind, scheme, steps, warmup, repeats, spinup):
     yfin = st["y"]
     if kind == "numpy":
         kind_out = type(yfin).__name__
-        yfin = torch.as_tensor(np.asarray(yfin))
-    assert bool(torch.isfinite(yfin).all())
+        assert bool(np.isfinite(np.asarray(yfin)).all())
+    else:
+        assert bool(torch.isfinite(yfin).all())
     med = statistics.median(walls)
     q = quartiles(walls)
     bps = BYTES_PER_SUBSTEP["float64"]

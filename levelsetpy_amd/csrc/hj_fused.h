@@ -100,6 +100,9 @@ template <typename T, int ND> struct FusedArgs {
     // (profiles/r04_c5_tile_order.txt): fabric reads per launch 4.55 -> 4.11 GB (2.47x -> 2.22x the algorithmic bytes), time
     // -1.5 %: the launch is not bound by its traffic (VALU 55-63 % busy, 130 lane-operations per cell)
     int tb[ND];
+    // pair kernel, round 4: the first 2*npairs chunks of the main range march in opposite directions, pairwise
+    // (hj_fusedv.h, "PAIRED CHUNKS"); 0 = every chunk marches up
+    int npairs;
     int eplane[2][2];
     int echunk, nchunks_e1, nchunks_e;
     int edge_blocks, edge_count, edge_bpx;

@@ -82,14 +82,11 @@ __device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsr
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(W, v), r, off, soff, 0);
 }
 
-// prologue experiments of round 4 (A/B through tune builds): HJ_EARLY_ARGS batches the kernel-argument loads,
-// HJ_PROLOGUE_V2 issues every load of the setup before the first wait (the rings of the first AH planes were requested and
-// waited for one after the other: two serialised memory round trips in front of the plane loop)
+// round 4: every load of the setup is issued before the first wait (the rings of the first AH planes used to be requested and
+// waited for one after the other: two serialised memory round trips in front of the plane loop), and HJ_EARLY_ARGS batches
+// the kernel-argument loads (profiles/r04_headline_skeleton.txt)
 #ifndef HJ_EARLY_ARGS
 #define HJ_EARLY_ARGS 1
-#endif
-#ifndef HJ_PROLOGUE_V2
-#define HJ_PROLOGUE_V2 1
 #endif
 constexpr int HJ_VPAD = 4;      // left pad of an LDS row (cells): even, so that tile cell 0 of a row is 16-byte aligned
 
@@ -123,8 +120,26 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #endif
     const int L = logical_block(A);
     if (L < 0) return;
+    // PAIRED CHUNKS (round 4, A.npairs > 0): the main range's chunks 2k and 2k+1 share their boundary plane B; chunk 2k marches
+    // DOWN from B - 1, chunk 2k+1 UP from B, and the two workgroups of a pair are neighbours in the logical order (same XCD):
+    // both then request the six planes B-3 .. B+2 that fill their register queues in the same microsecond, and the second
+    // request of a line is served by L2 / merges with the miss in flight.  Every chunk start costs 6 planes of loads beyond
+    // the chunk (1.35x the stencil source at 201^3); an ablation in which 3 of them hit the cache runs the 201^3 launch
+    // 4 % faster (profiles/r04_shared_warmup_ablation.txt).  Same values: a cell's result does not depend on the direction.
     int chunk_id, rem;
-    fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);
+    bool down = false;
+    {
+        const int paired = 2 * A.npairs * A.ntiles;
+        if (L < paired) {
+            int pr, r2;
+            fdivmod(L, fdiv_make(2 * A.ntiles), pr, r2);
+            rem = r2 >> 1;
+            chunk_id = 2 * pr + (r2 & 1);
+            down = (r2 & 1) == 0;
+        } else {
+            fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);
+        }
+    }
     if (A.timing && threadIdx.x == 0) {         // HJ_TIMING_DUMP: start clock, XCC the hardware put us on, chunk, HW_ID
         A.timing[4 * L + 0] = wall_clock64();
         A.timing[4 * L + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);
@@ -141,6 +156,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     }
     int p_begin, p_end;
     chunk_planes(A, chunk_id, p_begin, p_end);
+    // march position m = 0, 1, ... <-> plane P(m) = p_begin + m (up) or p_end - 1 - m (down)
+    const int p_first = down ? p_end - 1 : p_begin, dirn = down ? -1 : 1;
+    auto plane_at = [&](int m) { return p_first + dirn * m; };
+    auto clamp_q = [&](int p) { return min(max(p, p_begin - HJ_STENCIL), p_end + HJ_STENCIL - 1); };   // planes a queue may hold
+    auto clamp_c = [&](int p) { return min(max(p, p_begin), p_end - 1); };                            // planes that are computed
 
     // ---- LDS geometry: rows of the last axis are A.lpitch (even) apart, cell j of a row sits at j + HJ_VPAD;
     // the other plane axes keep the 3-cell pad
@@ -230,37 +250,21 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             for (int r = 0; r < R; ++r) dst[r] = buf_load2<HJ_PAIR_AUX_Y0>(ry0, own_g[r], so, T());
         }
     };
-    const int p_last = p_end - 1;
 
-    // axis-0 queue q[r][c][j] <-> plane p-3+j of cell c of slot r
+    // axis-0 queue q[r][c][j] <-> plane P(m - 3 + j) of cell c of slot r; filled in ASCENDING plane order whatever the
+    // direction (the two workgroups of a pair then ask for their common planes at the same moment)
     T q[R][2][7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int jj = 0; jj < 7; ++jj) {
         V tmp[R];
-        load_own(p_begin - 3 + j, tmp);
+        load_own(p_begin - 3 + jj + (down ? (p_end - 1 - p_begin) : 0), tmp);      // up: P(jj - 3); down: P(3 - jj)
 #pragma unroll
-        for (int r = 0; r < R; ++r) { q[r][0][j] = tmp[r].x; q[r][1][j] = tmp[r].y; }
+        for (int r = 0; r < R; ++r) {
+            if (down) { q[r][0][6 - jj] = tmp[r].x; q[r][1][6 - jj] = tmp[r].y; }
+            else { q[r][0][jj] = tmp[r].x; q[r][1][jj] = tmp[r].y; }
+        }
     }
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 0] = wall_clock64();
-#if !HJ_PROLOGUE_V2
-    V own[PD][R], y0s[PD][R];
-    typename HAM::Plane pls[PD];
-#pragma unroll
-    for (int s = 0; s < PD; ++s) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { own[s][r].x = T(0); own[s][r].y = T(0); }
-        if (s < PD - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < PD; ++s) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { y0s[s][r].x = T(0); y0s[s][r].y = T(0); }
-        const int ps = min(p_begin + s, p_last);
-        load_y0(ps, y0s[s]);
-        pls[s] = HAM::plane(A.ham, ps, A.sc);
-    }
-
-#endif
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 1] = wall_clock64();
     // ---- halo slots (single cells): the cross around the tile, as in the scalar kernel.
     // 4-D (HP, round 3): the halo layers of the plane axes OTHER than the contiguous one are rows of the tile's own row structure,
@@ -512,7 +516,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < KP; ++k) { halp[s][k].x = T(0); halp[s][k].y = T(0); hinp[s][k].x = T(0); hinp[s][k].y = T(0); }
     }
-#if HJ_PROLOGUE_V2
     // every load of the setup goes out before anything waits: the rings of the first AH planes (parked in LDS below, after
     // the Hamiltonian constants: by then they have landed), the two rings the loop consumes from registers, then the
     // prefetched own plane and the y0 planes -- in the order the loop needs them (loads return in order)
@@ -525,44 +528,27 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         for (int k = 0; k < KS; ++k) { th[a][k] = T(0); ti[a][k] = T(0); }
 #pragma unroll
         for (int k = 0; k < KP; ++k) { tp[a][k].x = T(0); tp[a][k].y = T(0); tq[a][k].x = T(0); tq[a][k].y = T(0); }
-        if (a < AH) load_halo(min(p_begin + a, p_last), th[a], ti[a], tp[a], tq[a]);
+        if (a < AH) load_halo(clamp_c(plane_at(a)), th[a], ti[a], tp[a], tq[a]);
     }
 #pragma unroll
-    for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s], halp[s], hinp[s]);
+    for (int s = 0; s < PD; ++s) load_halo(clamp_c(plane_at(AH + s)), hal[s], hin[s], halp[s], hinp[s]);
     V own[PD][R], y0s[PD][R];
     typename HAM::Plane pls[PD];
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
 #pragma unroll
         for (int r = 0; r < R; ++r) { own[s][r].x = T(0); own[s][r].y = T(0); }
-        if (s < PD - 1) load_own(min(p_begin + 4 + s, p_end + 2), own[s]);
+        if (s < PD - 1) load_own(clamp_q(plane_at(4 + s)), own[s]);
     }
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
 #pragma unroll
         for (int r = 0; r < R; ++r) { y0s[s][r].x = T(0); y0s[s][r].y = T(0); }
-        const int ps = min(p_begin + s, p_last);
+        const int ps = clamp_c(plane_at(s));
         load_y0(ps, y0s[s]);
         pls[s] = HAM::plane(A.ham, ps, A.sc);
     }
 
-#else
-    if (AH > 0) {
-        // the rings of the first AH planes go straight to their LDS buffers (the first barrier of the loop orders them)
-        for (int a = 0; a < AH; ++a) {
-            T th[KS], ti[KS];
-            V tp[KP], tq[KP];
-#pragma unroll
-            for (int k = 0; k < KS; ++k) { th[k] = T(0); ti[k] = T(0); }
-#pragma unroll
-            for (int k = 0; k < KP; ++k) { tp[k].x = T(0); tp[k].y = T(0); tq[k].x = T(0); tq[k].y = T(0); }
-            load_halo(min(p_begin + a, p_last), th, ti, tp, tq);
-            park_halo(lds + a * lds_plane, th, ti, tp, tq);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < PD; ++s) load_halo(min(p_begin + AH + s, p_last), hal[s], hin[s], halp[s], hinp[s]);
-#endif
 
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 3] = wall_clock64();
     // the arithmetic on the Hamiltonian tables, now that every load of the setup is in flight
@@ -571,12 +557,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         hcell[r][0] = HAM::cell_fin(A.ham, hraw[r][0], A.sc);
         hcell[r][1] = HAM::cell_fin(A.ham, hraw[r][1], A.sc);
     }
-#if HJ_PROLOGUE_V2
     // the rings of the first AH planes -> their LDS buffers (the first barrier of the loop orders them)
 #pragma unroll
     for (int a = 0; a < AHM; ++a)
         if (a < AH) park_halo(lds + a * lds_plane, th[a], ti[a], tp[a], tq[a]);
-#endif
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
@@ -585,7 +569,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
     int ring_c = 0;                                            // LDS buffer of the plane the next iteration computes
-    auto body = [&](int p, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
+    auto body = [&](int m, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
+        const int p = plane_at(m);                              // the plane this iteration computes
 #ifdef HJ_STAMP
         const unsigned long long st0 = __builtin_readcyclecounter();
 #endif
@@ -594,7 +579,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (ring_h >= NB) ring_h -= NB;
         T* bufh = lds + ring_h * lds_plane;                     // plane p + AH: where hal_c goes
         ring_c = (ring_c + 1 == NB) ? 0 : ring_c + 1;
-        load_own(min(p + 3 + PD, p_end + 2), own_n);
+        load_own(clamp_q(plane_at(m + 3 + PD)), own_n);
         // stage the centre plane: one 16-byte LDS store per pair
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -614,8 +599,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #ifdef HJ_STAMP
         const unsigned long long st2 = __builtin_readcyclecounter();
 #endif
-        const int p2 = min(p + PD, p_last);
-        load_halo(min(p + PD + AH, p_last), hal_c, hin_c, halp_c, hinp_c);
+        const int p2 = clamp_c(plane_at(m + PD));
+        load_halo(clamp_c(plane_at(m + PD + AH)), hal_c, hin_c, halp_c, hinp_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
         pl_c = HAM::plane(A.ham, p2, A.sc);
@@ -623,7 +608,17 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         for (int r = 0; r < R; ++r) {
             T pc[2][ND], hd[2][ND];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) upwind_cd<SCHEME, T>(q[r][c], A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+            for (int c = 0; c < 2; ++c) {
+                if (down) {
+                    // the queue holds the planes in MARCH order: hand the stencil the same seven values in grid order
+                    T qg[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) qg[j] = q[r][c][6 - j];
+                    upwind_cd<SCHEME, T>(qg, A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+                } else {
+                    upwind_cd<SCHEME, T>(q[r][c], A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+                }
+            }
             const T* base = buf + own_lds[r];
             // plane axes other than the contiguous one: the pair's neighbours are pairs (16-byte LDS reads)
 #pragma unroll
@@ -728,10 +723,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     };
 
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 5] = wall_clock64();   // loop start
-    for (int p = p_begin; p < p_end; p += PD) {
-        body(p, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
-        if (p + 1 < p_end) body(p + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
-        if (A.timing && tid == 0 && p == p_begin) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 7] = wall_clock64();
+    const int nplanes = p_end - p_begin;
+    for (int m = 0; m < nplanes; m += PD) {
+        body(m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
+        if (m + 1 < nplanes) body(m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
+        if (A.timing && tid == 0 && m == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 7] = wall_clock64();
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
 

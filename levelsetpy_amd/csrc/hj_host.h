@@ -125,6 +125,7 @@ struct hj_ctx {
     std::map<long long, hjh::TuneState> tune;       // per launch shape (scheme, stage class, kernel configuration)
     hipEvent_t tune_ev[2] = {nullptr, nullptr};
     int tile_cells = 0;                             // HJ_TILE_CELLS: cap on the cells of a tile (0 = what the configuration holds)
+    int pair_dirs = 0;                              // HJ_PAIR_DIRS (resolved in hj_ctx_create): chunks of a tile column march pairwise in opposite directions
     int tile_block[2] = {4, 4};                     // HJ_TB1 / HJ_TB2: 4-D tile order in blocks of this many tiles along axes 1 and 2 (0: plain order)
     int f12_e1 = 0;                                 // tuning / tests: force the tile's row count (pair variant)
     int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail

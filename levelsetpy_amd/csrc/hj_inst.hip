@@ -72,6 +72,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
         const int rc_fill = fill_fused_args<T, ND>(c, s, t, ep, SCHEME, PAIR, A, grid_blocks);
         if (rc_fill) return rc_fill;
     }
+    if (produce) A.npairs = 0;        // the output reduction of the intended WENO5 pairs planes in ascending order
     auto kern = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
     c->last_kernel = PAIR ? "fused_pair_kernel" : "fused_substep_kernel";
     c->last_E[0] = t.chunk;

@@ -503,3 +503,51 @@ def test_gated_slab_schedule_self_ring_bitwise(n, scheme):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((37, 21, 19), 2), ((64, 40, 130), 2), ((45, 300), None)])
+def test_paired_chunk_directions_bitwise(scheme, n, pd, monkeypatch):
+    """HJ_PAIR_DIRS=1: the chunks of a tile column march pairwise in opposite directions (the axis-0 queue then holds the
+    planes in march order and the stencil is handed the reversed view).  A cell's value must not depend on the direction:
+    three RK3 steps bitwise equal to the all-upward march and to the direct kernel, every scheme, odd chunk counts, 2-D."""
+    nd = len(n)
+    if nd == 3:
+        g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+        ham, par = _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.]
+        data = O.shape_cylinder(og, 2, None, .5)
+    else:
+        g, og = mk([-1, -1], [1, 1], n, pd)
+        ham, par = _ffi.HAM_DOUBLE_INTEGRATOR, [1., 0., 0., 0.]
+        data = O.shape_sphere(og, None, .3)
+    y0 = torch.as_tensor(data + 0.02 * np.random.default_rng(17).standard_normal(og.shape), device="cuda")
+    sid = _ffi.SCHEME_IDS[scheme]
+    outs = {}
+    for tag, env in (("up", {"HJ_PAIR": "2", "HJ_PAIR_DIRS": "0", "HJ_MIN_CHUNK": "4"}), ("paired", {"HJ_PAIR": "2", "HJ_PAIR_DIRS": "1", "HJ_MIN_CHUNK": "4"}),
+                     ("direct", {"HJ_FORCE_DIRECT": "1"})):
+        for k in ("HJ_PAIR", "HJ_PAIR_DIRS", "HJ_FORCE_DIRECT", "HJ_MIN_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dg = DeviceGrid(g, "float64")
+        dg.bind_stream()
+        cur, nxt, w0, w1 = y0.clone(), torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)
+        tout, dtout = C.c_double(), C.c_double()
+        t = 0.
+        for _ in range(3):
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, sid, ham, _ffi.darr(par), t, 1e9, 0.8, 1e300, 0, dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0),
+                                         dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+            cur, nxt = nxt, cur
+            t = float(tout.value)
+        dg.sync()
+        if tag != "direct":
+            assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel"
+            ext = (C.c_int * 4)()
+            _ffi.check(dg.lib.hj_last_tile(dg.ctx, ext))
+            assert ext[0] < n[0]                       # several chunks per tile column: there ARE pairs
+        outs[tag] = cur.clone()
+    if scheme == "WENO5":
+        # (the intended WENO5's epsilon comes from a reduction whose order does not depend on the march either)
+        pass
+    assert torch.equal(outs["up"], outs["paired"]), float((outs["up"] - outs["paired"]).abs().max())
+    assert torch.equal(outs["paired"], outs["direct"]), float((outs["paired"] - outs["direct"]).abs().max())
