@@ -2,7 +2,8 @@
 """Randomised bitwise stress of the pair kernel (double buffer and LDS ring) against the one-cell-per-lane kernel:
 random 2-D / 3-D shapes, periodic axes, towardZero flags, schemes, RK orders.  Round 3: the intended WENO5 reduces its
 epsilon inside the producing launches at every size here (HJ_EPS_FUSE_MIN_CELLS=0) and a fourth variant runs the
-one-cell-per-lane kernel with the two-launch pre-pass in front of every stage (HJ_EPS_FUSE=0).
+one-cell-per-lane kernel with the two-launch pre-pass in front of every stage (HJ_EPS_FUSE=0).  Round 4: two more variants
+march the chunks of a tile column pairwise in opposite directions (HJ_PAIR_DIRS=1, with and without the ring).
 usage: stress_pair.py [cases] [seed]"""
 import ctypes as C, os, sys
 import numpy as np
@@ -28,9 +29,11 @@ for it in range(cases):
     res = {}
     ah = str(int(rng.integers(1, 4)))
     os.environ["HJ_EPS_FUSE_MIN_CELLS"] = "0"
-    for flag in ("0", "2", "2r", "0n"):
+    VARIANTS = ("0", "2", "2r", "0n", "2p", "2rp")
+    for flag in VARIANTS:
         os.environ["HJ_PAIR"] = flag[0]
-        os.environ["HJ_PAIR_RING"] = "1" if flag.endswith("r") else "0"
+        os.environ["HJ_PAIR_RING"] = "1" if "r" in flag else "0"
+        os.environ["HJ_PAIR_DIRS"] = "1" if "p" in flag else "0"
         os.environ["HJ_EPS_FUSE"] = "0" if flag.endswith("n") else "1"
         os.environ["HJ_PAIR_AH"] = ah
         dg = DeviceGrid(g, "float64"); dg.bind_stream()
@@ -44,9 +47,9 @@ for it in range(cases):
             cur, nxt = nxt, (dg.empty() if cur is y else cur)
         dg.sync()
         res[flag] = (cur.clone(), tout.value)
-    ok = all(torch.equal(res["0"][0], res[f][0]) and res["0"][1] == res[f][1] for f in ("2", "2r", "0n"))
+    ok = all(torch.equal(res["0"][0], res[f][0]) and res["0"][1] == res[f][1] for f in VARIANTS[1:])
     if not ok:
         bad += 1
-        print("MISMATCH", n, pd, scheme, order, [float((res["0"][0] - res[f][0]).abs().max()) for f in ("2", "2r", "0n")], flush=True)
+        print("MISMATCH", n, pd, scheme, order, [float((res["0"][0] - res[f][0]).abs().max()) for f in VARIANTS[1:]], flush=True)
 print("%d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
