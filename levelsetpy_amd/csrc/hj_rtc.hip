@@ -311,6 +311,9 @@ extern "C" {
 int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol,
                     const char* include_dir, const char* hiprtc_path, int* ham_id) {
     if (!name || !body || !include_dir || !ham_id) return fail(HJ_EINVAL, "null argument");
+    // the name goes into #line directives of the generated source (compiler messages then point into the caller's text)
+    for (const char* ch = name; *ch; ++ch)
+        if (*ch == '"' || *ch == '\\' || (unsigned char)*ch < 32) return fail(HJ_EINVAL, "the name of a Hamiltonian must not contain quotes, backslashes or control characters");
     if (ncol < 0 || ncol > 8) return fail(HJ_EINVAL, "0..8 column values, got %d", ncol);
     if (ncol > 0 && !column_body) return fail(HJ_EINVAL, "ncol > 0 needs a column expression");
     const std::string cb = (column_body && ncol > 0) ? column_body : "";

@@ -152,6 +152,8 @@ def test_runtime_hamiltonian_registration_and_compile_check():
         L.register_native_hamiltonian("cabi_4d", 4, "H = 0;", nparams=0)          # 2-D / 3-D only
     with pytest.raises(ValueError):
         _ffi.check(_ffi.lib().hj_ham_info(9999, None, None, None))
+    with pytest.raises(ValueError):
+        L.register_native_hamiltonian('quote"d', 2, "H = 0; alpha[0] = 1; alpha[1] = 1;")      # the name goes into #line directives
 
 
 def test_runtime_hamiltonian_is_selected_by_callable_identity():
