@@ -318,6 +318,11 @@ int hj_ham_register(const char* name, int ndim, int nparams, const char* body, c
 int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built);
 /* compile the substep kernel of `scheme` and the alpha-bound kernel WITHOUT launching (needs no GPU) */
 int hj_ham_compile_check(int ham_id, int scheme);
+/* Compiled code objects are kept on disk, keyed by the generated source, the kernel headers' text and the compile options
+ * ($HJ_RTC_CACHE, else $XDG_CACHE_HOME/levelsetpy_amd, else $HOME/.cache/levelsetpy_amd; HJ_RTC_CACHE=0 turns it off): a
+ * process that registers an expression seen before loads the kernel in milliseconds instead of compiling for 1-2 s.
+ * Counters of this process: kernels compiled with hipRTC, kernels loaded from the cache.  No reference counterpart. */
+int hj_ham_cache_stats(int* compiled, int* loaded_from_cache);
 
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);

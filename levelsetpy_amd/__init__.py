@@ -23,7 +23,7 @@ from .spatial import (upwindFirstENO2, upwindFirstENO3, upwindFirstENO3a, upwind
 from .dissipation import (artificialDissipationGLF, artificialDissipationLLF,      # noqa: F401
                           artificialDissipationLLLF)
 from .dynamics import DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D      # noqa: F401
-from .user_ham import register_native_hamiltonian, NativeRegistration, RegisteredSystem   # noqa: F401
+from .user_ham import register_native_hamiltonian, NativeRegistration, RegisteredSystem, kernel_cache_stats   # noqa: F401
 from .term import termLaxFriedrichs, termRestrictUpdate                         # noqa: F401
 from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      # noqa: F401
                           odeCFLmultipleSteps, odeCFLcallPostTimestep)

@@ -72,6 +72,7 @@ SIGNATURES = {
     "hj_ham_register": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _i, C.c_char_p, C.c_char_p, _pi]),
     "hj_ham_info": (_i, [_i, _pi, _pi, _pi]),
     "hj_ham_compile_check": (_i, [_i, _i]),
+    "hj_ham_cache_stats": (_i, [_pi, _pi]),
     "hj_sync": (_i, [_vp]),
     "hj_last_error": (C.c_char_p, []),
     "hj_last_kernel": (C.c_char_p, [C.c_void_p]),

@@ -16,6 +16,10 @@
 // dubins_absolute.py:150-170, double_integrator.py:84-89, bird.py:346): the CFL bound is then a property of the grid
 // (hj_static_step_bound) and a time step needs no host synchronisation.  fp64, 2-D and 3-D grids.
 #include <dlfcn.h>
+#include <errno.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 #include <sstream>
 #include "hj_launch.h"
 #include "hj_fusedv.h"
@@ -123,16 +127,97 @@ static std::string user_source(const UserHam& u, int id) {
     return o.str();
 }
 
+// ---- code-object cache on disk: a registered expression is compiled once per (source, kernel headers, options), not once per
+// process.  Directory: $HJ_RTC_CACHE ("0" / "off" disables), else $XDG_CACHE_HOME/levelsetpy_amd, else $HOME/.cache/levelsetpy_amd.
+// File <key>.hjco = "HJCO1\n" + lowered kernel name + "\n" + code object; key = FNV-1a of the generated source, the name
+// expression, the compile options, the TEXT of the kernel headers it includes and the HIP runtime version.  Written atomically (temporary + rename); a
+// file that does not load is ignored and replaced.
+static unsigned long long fnv1a(const void* data, size_t n, unsigned long long h = 1469598103934665603ull) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+static bool read_file(const std::string& path, std::string& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+static std::string cache_dir() {
+    const char* e = getenv("HJ_RTC_CACHE");
+    if (e && (!strcmp(e, "0") || !strcmp(e, "off"))) return "";
+    std::string d;
+    if (e && *e) d = e;
+    else if ((e = getenv("XDG_CACHE_HOME")) && *e) d = std::string(e) + "/levelsetpy_amd";
+    else if ((e = getenv("HOME")) && *e) d = std::string(e) + "/.cache/levelsetpy_amd";
+    else return "";
+    // mkdir -p of the last two components (the parents of a cache home exist)
+    const size_t cut = d.find_last_of('/');
+    if (cut != std::string::npos && cut > 0) (void)mkdir(d.substr(0, cut).c_str(), 0700);
+    if (mkdir(d.c_str(), 0700) != 0 && errno != EEXIST) return "";
+    return d;
+}
+static unsigned long long headers_hash(const std::string& include_dir) {
+    static std::map<std::string, unsigned long long> memo;
+    auto it = memo.find(include_dir);
+    if (it != memo.end()) return it->second;
+    unsigned long long h = 1469598103934665603ull;
+    const char* files[] = {"/hj_fusedv.h", "/hj_fused.h", "/hj_device.h", "/hj_split.h", "/../../include/hj_mi355x.h"};
+    std::string text;
+    for (const char* f : files)
+        if (read_file(include_dir + f, text)) h = fnv1a(text.data(), text.size(), h);
+    memo[include_dir] = h;
+    return h;
+}
+static int g_rtc_cache_hits = 0, g_rtc_compiles = 0;
+
 static int rtc_build(UserHam& u, int id, const std::string& name_expr, UserKernel& out) {
+    const std::string src = user_source(u, id);
+    const char* base_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-DHJ_RTC=1"};
+    std::string cache_file;
+    {
+        const std::string dir = cache_dir();
+        if (!dir.empty()) {
+            unsigned long long h = fnv1a(src.data(), src.size());
+            h = fnv1a(name_expr.data(), name_expr.size(), h);
+            for (const char* o : base_opts) h = fnv1a(o, strlen(o), h);
+            const unsigned long long hh = headers_hash(u.include_dir);
+            h = fnv1a(&hh, sizeof(hh), h);
+            int rtv = 0;                                   // a new ROCm release compiles again
+            (void)hipRuntimeGetVersion(&rtv);
+            h = fnv1a(&rtv, sizeof(rtv), h);
+            char nm[64];
+            snprintf(nm, sizeof(nm), "/%016llx.hjco", h);
+            cache_file = dir + nm;
+            std::string blob;
+            if (read_file(cache_file, blob) && blob.compare(0, 6, "HJCO1\n") == 0) {
+                const size_t nl = blob.find('\n', 6);
+                if (nl != std::string::npos && nl + 1 < blob.size()) {
+                    const std::string kname = blob.substr(6, nl - 6);
+                    if (hipModuleLoadData(&out.mod, blob.data() + nl + 1) == hipSuccess &&
+                        hipModuleGetFunction(&out.fn, out.mod, kname.c_str()) == hipSuccess) {
+                        ++g_rtc_cache_hits;
+                        return HJ_OK;
+                    }
+                    (void)hipGetLastError();
+                    out.mod = nullptr; out.fn = nullptr;
+                }
+            }
+        }
+    }
     int rc = rtc_load(u.rtc_path.empty() ? nullptr : u.rtc_path.c_str());
     if (rc) return rc;
-    const std::string src = user_source(u, id);
+    ++g_rtc_compiles;
     rtcProgram prog = nullptr;
     int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);
     if (e) return fail(HJ_EHIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(e));
     e = g_rtc.AddNameExpression(prog, name_expr.c_str());
     const std::string inc1 = "-I" + u.include_dir, inc2 = "-I" + u.include_dir + "/../../include";
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", inc1.c_str(), inc2.c_str(), "-DHJ_RTC=1"};
+    const char* opts[] = {base_opts[0], base_opts[1], base_opts[2], base_opts[3], inc1.c_str(), inc2.c_str(), base_opts[4]};
     if (!e) e = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
     if (e) {
         size_t n = 0;
@@ -153,6 +238,18 @@ static int rtc_build(UserHam& u, int id, const std::string& name_expr, UserKerne
     if (e) return fail(HJ_EHIP, "hipRTC: %s", g_rtc.GetErrorString(e));
     HIP_TRY(hipModuleLoadData(&out.mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&out.fn, out.mod, kname.c_str()));
+    if (!cache_file.empty()) {
+        char tmpn[64];
+        snprintf(tmpn, sizeof(tmpn), ".tmp%ld", (long)getpid());
+        const std::string tmp = cache_file + tmpn;
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (f) {
+            bool ok = fwrite("HJCO1\n", 1, 6, f) == 6 && fwrite(kname.data(), 1, kname.size(), f) == kname.size() && fputc('\n', f) != EOF &&
+                      fwrite(code.data(), 1, code.size(), f) == code.size();
+            ok = (fclose(f) == 0) && ok;
+            if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
+        }
+    }
     return HJ_OK;
 }
 
@@ -349,6 +446,12 @@ int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built) {
         for (const auto& kv : u->substep) n += kv.second.fn ? 1 : 0;
         *kernels_built = n;
     }
+    return HJ_OK;
+}
+
+int hj_ham_cache_stats(int* compiled, int* loaded_from_cache) {
+    if (compiled) *compiled = g_rtc_compiles;
+    if (loaded_from_cache) *loaded_from_cache = g_rtc_cache_hits;
     return HJ_OK;
 }
 

@@ -18,14 +18,15 @@ identity, exactly as the built-in systems are (dynamics.native_of).
 In the expression: x[d] node coordinates, p[d] costates (the reference's derivC), par[k] parameters; assign H and every
 alpha[d].  Values that depend on the in-plane coordinates only (cos / sin of x[2] above) can be hoisted out of the march:
 `column_src="col[0] = cos(x[2]); col[1] = sin(x[2]);", ncol=2` evaluates them once per grid column, `col[k]` is then
-readable in the expression (8 % faster for the Dubins systems).  fp64, 2-D and 3-D grids; the kernels are built with hipRTC on first use (1-2 s per scheme).
+readable in the expression (8 % faster for the Dubins systems).  fp64, 2-D and 3-D grids; the kernels are built with hipRTC on first
+use (1-2 s per scheme) and kept on disk (kernel_cache_stats): a later process loads them in milliseconds.
 """
 import ctypes as C
 import os
 
 from . import _ffi
 
-__all__ = ["register_native_hamiltonian", "NativeRegistration", "RegisteredSystem"]
+__all__ = ["register_native_hamiltonian", "NativeRegistration", "RegisteredSystem", "kernel_cache_stats"]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -115,6 +116,14 @@ class NativeRegistration(object):
         att.params(obj)                      # validates the count now
         obj._hj_native = att
         return obj
+
+
+def kernel_cache_stats():
+    """(kernels compiled with hipRTC, kernels loaded from the on-disk cache) in this process.  The cache lives in
+    $HJ_RTC_CACHE, else $XDG_CACHE_HOME/levelsetpy_amd, else ~/.cache/levelsetpy_amd; HJ_RTC_CACHE=0 turns it off."""
+    a, b = C.c_int(), C.c_int()
+    _ffi.check(_ffi.lib().hj_ham_cache_stats(C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def register_native_hamiltonian(name, dim, device_src, nparams=0, column_src=None, ncol=0):

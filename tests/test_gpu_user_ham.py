@@ -224,3 +224,50 @@ def test_runtime_hamiltonian_through_the_slab_stepper_virtual_ranks():
         got, ref = st.state(), cur[st.slab.begin:st.slab.end]
         assert torch.equal(got, ref), "rank %d differs by %g" % (st.slab.rank, float((got - ref).abs().max()))
         st.close()
+
+
+_CACHE_SCRIPT = r'''
+import sys, time, json, hashlib
+import numpy as np, torch
+import levelsetpy_amd as L
+reg = L.register_native_hamiltonian("cache_probe", 2, "H = -(p[0] * x[1]) + par[0] * fabs(p[1]); alpha[0] = fabs(x[1]); alpha[1] = par[0];", nparams=1)
+g = L.createGrid(-np.ones((2, 1)), np.ones((2, 1)), np.array([[70], [90]], dtype=np.int64), None)
+s = reg(g, [1.5])
+sd = L.Bundle(dict(grid=g, hamFunc=s.hamiltonian, partialFunc=s.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=L.upwindFirstENO3))
+y0 = torch.as_tensor(L.shapeSphere(g, np.zeros((2, 1)), .4), device="cuda").reshape(-1, 1)
+t0 = time.perf_counter()
+t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 0.05], y0, L.odeCFLset(L.Bundle(dict(factorCFL=.8))), sd)
+torch.cuda.synchronize()
+sec = time.perf_counter() - t0
+print(json.dumps({"stats": L.kernel_cache_stats(), "sec": sec, "t": t, "sha": hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()}))
+'''
+
+
+def test_compiled_kernels_are_cached_on_disk(tmp_path):
+    """A registered expression is compiled once per (source, headers, options), not once per process: the second process
+    loads every kernel from $HJ_RTC_CACHE (no hipRTC compile, the cache files untouched) and computes the same bits;
+    HJ_RTC_CACHE=0 compiles again and leaves the directory alone."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = tmp_path / "rtc"
+
+    def run(cache_env):
+        env = dict(os.environ, HJ_RTC_CACHE=cache_env, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        p = subprocess.run([sys.executable, "-c", _CACHE_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    first = run(str(cache))
+    assert first["stats"][0] >= 2 and first["stats"][1] == 0           # substep kernel(s) + the alpha-bound kernel, all compiled
+    files = sorted(cache.glob("*.hjco"))
+    assert len(files) == first["stats"][0]
+    stamp = [(f.name, f.stat().st_mtime_ns, f.stat().st_size) for f in files]
+    second = run(str(cache))
+    assert second["stats"] == [0, first["stats"][0]]                   # nothing compiled, everything loaded
+    assert second["sha"] == first["sha"] and second["t"] == first["t"]
+    assert [(f.name, f.stat().st_mtime_ns, f.stat().st_size) for f in sorted(cache.glob("*.hjco"))] == stamp
+    off = run("0")
+    assert off["stats"] == [first["stats"][0], 0] and off["sha"] == first["sha"]
+    assert [(f.name, f.stat().st_mtime_ns, f.stat().st_size) for f in sorted(cache.glob("*.hjco"))] == stamp
