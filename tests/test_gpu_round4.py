@@ -551,3 +551,17 @@ def test_paired_chunk_directions_bitwise(scheme, n, pd, monkeypatch):
         pass
     assert torch.equal(outs["up"], outs["paired"]), float((outs["up"] - outs["paired"]).abs().max())
     assert torch.equal(outs["paired"], outs["direct"]), float((outs["paired"] - outs["direct"]).abs().max())
+
+
+def test_grid_of_a_billion_cells_tiled_equals_direct():
+    """1025^3 fp64 (1.08e9 cells, 8.6 GB per array -- a grid for the 288 GB of this card): one odeCFL3 step through the tiled
+    kernels against the direct kernel, bitwise (tools/big_grid_check.py in its own process: ~55 GB peak)."""
+    import subprocess
+    import sys
+    free, _total = torch.cuda.mem_get_info()
+    if free < 80e9:
+        pytest.skip("needs 80 GB of free device memory")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "big_grid_check.py"), "1025"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+    assert "bitwise: True" in p.stdout
