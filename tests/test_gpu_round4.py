@@ -591,3 +591,25 @@ def test_sixty_rk3_steps_at_41_cubed_vs_oracle(scheme):
     else:
         assert abs(t - to) <= 1e-12
         close(got, yo, 1e-10, what=scheme)
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3"])
+def test_eighty_rk2_steps_double_integrator_restricted_vs_oracle_bitwise(scheme):
+    """The 2-D stencil path (C3's kernels at 97 x 143) over a long horizon through termRestrictUpdate and odeCFL2, as the air3D-style
+    drivers call it ((N,) vectors): 80 steps bit for bit the oracle's (= the reference's operation order)."""
+    n = (97, 143)
+    g, og = mk([-1., -1.5], [1., 1.5], n, None)
+    d0 = L.shapeSphere(g, np.zeros((2, 1)), .45)
+    sd = L.Bundle(dict(innerFunc=L.termLaxFriedrichs, innerData=sdata(g, L.DoubleIntegrator(g, 1.25), DERIV[scheme]), positive=0))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.7, singleStep='on')))
+    inner = lambda tt, yy: O.term_lax_friedrichs(og, O.DoubleIntegrator(og, 1.25), scheme, tt, yy)  # noqa: E731
+    term = O.term_restrict_update(inner, positive=False)
+    y, t = torch.as_tensor(d0.reshape(-1), device="cuda"), 0.
+    yo, to = d0.reshape(-1), 0.
+    for _ in range(80):
+        t, y, _ = L.odeCFL2(L.termRestrictUpdate, [t, 10.], y, op, sd)
+        to, yo = O.ode_cfl_2(term, [to, 10.], yo, 0.7, single_step=True)
+    got = y.cpu().numpy()
+    assert float(np.abs(yo - d0.reshape(-1)).max()) > 0.05
+    assert t == to
+    assert np.array_equal(got, yo.reshape(got.shape)), "%d cells differ, max %.3e" % (int((got != yo.reshape(got.shape)).sum()), float(np.abs(got - yo.reshape(got.shape)).max()))
