@@ -59,15 +59,46 @@ __global__ __launch_bounds__(256) void upwind_kernel(const T* __restrict__ phi, 
     double m[4] = {-1e300, -1e300, -1e300, -1e300};
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
-        const long long in_i = t % V.inner;
-        const long long r = t / V.inner;
-        const int i = (int)(r % V.n);
-        const long long o = r / V.n;
-        const T* line = phi + o * V.n * V.inner + in_i;
+        // position on the line (32-bit divisions when the grid allows: a 64-bit one costs ~4x as much) and the seven values,
+        // every load issued unconditionally (round 4; as gather_stencils below: the branches of line_value() in front of each
+        // load serialised them), ghost values fixed up afterwards by the waves that touch an extrapolated edge
+        int i;
+        if (total < (1ll << 31)) {
+            const unsigned r = (unsigned)t / (unsigned)V.inner;
+            i = (int)(r % (unsigned)V.n);
+        } else {
+            i = (int)((t / V.inner) % V.n);
+        }
+        const T* pc0 = phi + t;
+        const int n = V.n;
+        const bool per = V.bc == HJ_BC_PERIODIC;
+        bool ghost = false;
         T v[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
-            v[k] = line_value(line, V.inner, i + k - 3, V.n, V.bc, V.km, V.halo_lo, V.halo_hi);
+        for (int k = 0; k < 7; ++k) {
+            int j = i + k - 3;
+            if (j < 0 && !V.halo_lo) {
+                if (per) j += n; else { j = 0; ghost = true; }
+            } else if (j >= n && !V.halo_hi) {
+                if (per) j -= n; else { j = n - 1; ghost = true; }
+            }
+            v[k] = pc0[(long long)(j - i) * V.inner];
+        }
+        if (__any(ghost ? 1 : 0)) {
+            const T* line = pc0 - (long long)i * V.inner;
+            if (!per && i < HJ_STENCIL && !V.halo_lo) {
+                const T e = line[0], in = line[V.inner];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (i + k - 3 < 0) v[k] = ghost_value(e, in, T(3 - k - i) * V.km);
+            }
+            if (!per && i + HJ_STENCIL >= n && !V.halo_hi) {
+                const T e = line[(long long)(n - 1) * V.inner], in = line[(long long)(n - 2) * V.inner];
+#pragma unroll
+                for (int k = 4; k < 7; ++k)
+                    if (i + k - 3 >= n) v[k] = ghost_value(e, in, T(i + k - 3 - n + 1) * V.km);
+            }
+        }
         T L, R;
         upwind<SCHEME, T>(v, V.K, eps, L, R);
         dL[t] = L;
@@ -400,6 +431,55 @@ template <typename T, int ND> struct DirectArgs {
     HamTables<T> ham;
 };
 
+// The 7-point stencils of one cell along every dimension, straight from global memory, every load issued unconditionally
+// (round 3; shared by direct_substep_kernel and, from round 4, term_kernel -- which went through line_value(), whose boundary
+// branches sit in front of each of the 6*ND neighbour loads and serialise them: 223-325 us per term at 201^3).  The neighbour
+// offsets are formed with selects (periodic: the wrapped cell; extrapolated: the edge cell, fixed up afterwards), all loads
+// go out back to back, and only waves that touch an extrapolated edge run the ghost fix-up (two more loads per ghost value).
+template <typename T, int ND>
+__device__ __forceinline__ void gather_stencils(const GridArgs<T, ND>& G, const T* pc0, const int* idx, T centre, T (&v)[ND][7]) {
+    bool ghost = false;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int n = G.n[d], i = idx[d];
+        const bool per = G.bc[d] == HJ_BC_PERIODIC;
+        const bool hlo = d == 0 && G.halo_lo, hhi = d == 0 && G.halo_hi;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (k == 3) { v[d][k] = centre; continue; }
+            int j = i + k - 3;
+            if (j < 0 && !hlo) {
+                if (per) j += n; else { j = 0; ghost = true; }
+            } else if (j >= n && !hhi) {
+                if (per) j -= n; else { j = n - 1; ghost = true; }
+            }
+            v[d][k] = pc0[(long long)(j - i) * G.stride[d]];
+        }
+    }
+    if (__any(ghost ? 1 : 0)) {
+        // ghost cells of an extrapolated boundary: edge + k*slope from the edge cell and its inner neighbour
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int n = G.n[d], i = idx[d];
+            if (G.bc[d] == HJ_BC_PERIODIC) continue;
+            const bool hlo = d == 0 && G.halo_lo, hhi = d == 0 && G.halo_hi;
+            const T* line = pc0 - (long long)i * G.stride[d];
+            if (i < HJ_STENCIL && !hlo) {
+                const T e = line[0], in = line[G.stride[d]];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (i + k - 3 < 0) v[d][k] = ghost_value(e, in, T(3 - k - i) * G.km[d]);
+            }
+            if (i + HJ_STENCIL >= n && !hhi) {
+                const T e = line[(long long)(n - 1) * G.stride[d]], in = line[(long long)(n - 2) * G.stride[d]];
+#pragma unroll
+                for (int k = 4; k < 7; ++k)
+                    if (i + k - 3 >= n) v[d][k] = ghost_value(e, in, T(i + k - 3 - n + 1) * G.km[d]);
+            }
+        }
+    }
+}
+
 // Round 3: every stencil load is issued unconditionally.  The first version went through line_value(), whose boundary
 // branches sit in front of each of the 6*ND neighbour loads: the loads were serialised behind one another (a memory round
 // trip each) and the kernel took ~40 us on a 51^3 grid.  Now the neighbour offsets are formed with selects (periodic: the
@@ -434,50 +514,11 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
         decode<T, ND>(A.G, t, idx);
         const T* pc0 = A.y + t;
         T v[ND][7];
-        bool ghost = false;
         const T centre = pc0[0];
         const T y0v = use_y0 ? A.y0[t] : T(0);
         const typename HAM::Cell hc = HAM::cell(A.ham, idx, A.sc);
         const typename HAM::Plane hp = HAM::plane(A.ham, idx[0], A.sc);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int n = A.G.n[d], i = idx[d];
-            const bool per = A.G.bc[d] == HJ_BC_PERIODIC;
-            const bool hlo = d == 0 && A.G.halo_lo, hhi = d == 0 && A.G.halo_hi;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                if (k == 3) { v[d][k] = centre; continue; }
-                int j = i + k - 3;
-                if (j < 0 && !hlo) {
-                    if (per) j += n; else { j = 0; ghost = true; }
-                } else if (j >= n && !hhi) {
-                    if (per) j -= n; else { j = n - 1; ghost = true; }
-                }
-                v[d][k] = pc0[(long long)(j - i) * A.G.stride[d]];
-            }
-        }
-        if (__any(ghost ? 1 : 0)) {
-            // ghost cells of an extrapolated boundary: edge + k*slope from the edge cell and its inner neighbour
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const int n = A.G.n[d], i = idx[d];
-                if (A.G.bc[d] == HJ_BC_PERIODIC) continue;
-                const bool hlo = d == 0 && A.G.halo_lo, hhi = d == 0 && A.G.halo_hi;
-                const T* line = pc0 - (long long)i * A.G.stride[d];
-                if (i < HJ_STENCIL && !hlo) {
-                    const T e = line[0], in = line[A.G.stride[d]];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        if (i + k - 3 < 0) v[d][k] = ghost_value(e, in, T(3 - k - i) * A.G.km[d]);
-                }
-                if (i + HJ_STENCIL >= n && !hhi) {
-                    const T e = line[(long long)(n - 1) * A.G.stride[d]], in = line[(long long)(n - 2) * A.G.stride[d]];
-#pragma unroll
-                    for (int k = 4; k < 7; ++k)
-                        if (i + k - 3 >= n) v[d][k] = ghost_value(e, in, T(i + k - 3 - n + 1) * A.G.km[d]);
-                }
-            }
-        }
+        gather_stencils<T, ND>(A.G, pc0, idx, centre, v);
         T pc[ND], hd[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) upwind_cd<SCHEME, T>(v[d], A.G.K[d], eps[d], wk[d], pc[d], hd[d]);

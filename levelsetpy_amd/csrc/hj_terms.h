@@ -15,8 +15,8 @@
 // parity UNPINNED, checked against the oracle.  Contraction is off: the expressions are evaluated operation by
 // operation in the order of the host implementation they replace (levelsetpy_amd/normal_reinit.py, convection.py),
 // so the two agree to the last bit wherever the derivatives do.
-// One thread per cell, neighbours straight from global memory (the direct form of hj_split.h: L1/L2 absorb the
-// stencil reuse); these terms are not on the benchmark path, what counts is one launch and no temporaries.
+// One thread per cell, neighbours straight from global memory, every stencil load issued unconditionally (gather_stencils
+// of hj_split.h, as in direct_substep_kernel: L1/L2 absorb the stencil reuse).
 #pragma once
 #include "hj_split.h"
 
@@ -57,15 +57,13 @@ __global__ __launch_bounds__(256) void term_kernel(const TermArgs<T, ND> A) {
         int idx[ND];
         decode<T, ND>(A.G, t, idx);
         T dL[ND], dR[ND];
+        {
+            // every stencil load issued back to back (hj_split.h, gather_stencils), then the derivatives
+            const T* pc0 = A.y + t;
+            T v[ND][7];
+            gather_stencils<T, ND>(A.G, pc0, idx, pc0[0], v);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const T* line = A.y + (t - (long long)idx[d] * A.G.stride[d]);
-            T v[7];
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-                v[k] = line_value(line, A.G.stride[d], idx[d] + k - 3, A.G.n[d], A.G.bc[d], A.G.km[d],
-                                  d == 0 ? A.G.halo_lo : 0, d == 0 ? A.G.halo_hi : 0);
-            upwind<SCHEME, T>(v, A.G.K[d], eps[d], dL[d], dR[d]);
+            for (int d = 0; d < ND; ++d) upwind<SCHEME, T>(v[d], A.G.K[d], eps[d], dL[d], dR[d]);
         }
         T o;
         if constexpr (KIND == HJ_TERM_NORMAL) {
