@@ -197,6 +197,8 @@ extern template int launch_scheme<double, HamDoublePendulum<double>>(hj_ctx*, co
 extern template int launch_scheme<float, HamDubinsRel<float>>(hj_ctx*, const SubstepCall&);
 extern template int launch_scheme<float, HamDoubleIntegrator<float>>(hj_ctx*, const SubstepCall&);
 extern template int launch_scheme<float, HamDoublePendulum<float>>(hj_ctx*, const SubstepCall&);
+extern template int launch_term_tiled<double, 2>(hj_ctx*, int, const SubstepCall&);
+extern template int launch_term_tiled<double, 3>(hj_ctx*, int, const SubstepCall&);
 extern template int launch_stage12<double, HamDubinsRel<double>>(hj_ctx*, const Stage12Call&);
 extern template int launch_stage12<double, HamDoubleIntegrator<double>>(hj_ctx*, const Stage12Call&);
 extern template int launch_stage12<double, HamDoublePendulum<double>>(hj_ctx*, const Stage12Call&);
@@ -1006,6 +1008,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     // 0 never, 1 always
     c->pair_dirs = env_int("HJ_PAIR_DIRS", -1);
     if (c->pair_dirs < 0) c->pair_dirs = (ndim == 3 && total < 10000000) ? 1 : 0;
+    c->term_tiled_from = (long long)env_int("HJ_TERM_TILED_FROM", 1000000);     // cells; negative: never (the direct term_kernel everywhere)
     c->tile_block[0] = env_int("HJ_TB1", 4);      // 4 x 4 positions x the 4 axis-3 tiles = the 64 workgroups an XCD holds (C5)
     c->tile_block[1] = env_int("HJ_TB2", 4);
     // launch-time choice of the tile shape on grids of >= HJ_AUTOTUNE_MIN_CELLS cells (hj_inst.hip, tuned_tiling)
@@ -1249,6 +1252,23 @@ int hj_lf_split_end(hj_ctx* c, const void* const* dL, const void* const* dR, con
 // ---- termNormal / termReinit / termConvection: one launch each (hj_terms.h)
 extern "C++" {
 namespace {
+template <typename T>
+void fill_term_par(const hj_ctx* c, const void* const* arr, const double* scal, int order, TermPar<T>& P) {
+    double mdx = 0.0;
+    for (int d = 0; d < HJ_MAX_DIM; ++d) {
+        const bool in = d < c->ndim;
+        P.arr[d] = (in && arr) ? (const T*)arr[d] : nullptr;
+        P.scal[d] = (in && scal) ? (T)scal[d] : T(0);
+        P.dx_inv[d] = in ? (T)(1.0 / c->dx[d]) : T(0);
+        P.dx[d] = in ? (T)c->dx[d] : T(1);
+        if (in) mdx = std::max(mdx, c->dx[d]);
+    }
+    P.max_dx = (T)mdx;
+    P.subcell_order = order;
+    const double e = (double)std::numeric_limits<double>::epsilon();
+    P.small2 = (T)((1e6 * e) * (1e6 * e));     // robust_small_epsilon^2, term_reinit.py:128,274
+    P.tiny = (T)e;                             // term_reinit.py:206
+}
 template <typename T, int ND>
 int term_launch_nd(hj_ctx* c, int kind, int scheme, const void* y, const void* const* arr, const double* scal, int order,
                    void* out, unsigned long long* keys) {
@@ -1258,19 +1278,7 @@ int term_launch_nd(hj_ctx* c, int kind, int scheme, const void* y, const void* c
     A.out = (T*)out;
     hjh::fill_grid<T, ND>(c, A.G);
     A.max_d1sq = (const T*)(c->weno_src ? c->weno_src : c->weno_vals);
-    double mdx = 0.0;
-    for (int d = 0; d < ND; ++d) {
-        A.arr[d] = arr ? (const T*)arr[d] : nullptr;
-        A.scal[d] = scal ? (T)scal[d] : T(0);
-        A.dx_inv[d] = (T)(1.0 / c->dx[d]);
-        A.dx[d] = (T)c->dx[d];
-        mdx = std::max(mdx, c->dx[d]);
-    }
-    A.max_dx = (T)mdx;
-    A.subcell_order = order;
-    const double e = (double)std::numeric_limits<double>::epsilon();
-    A.small2 = (T)((1e6 * e) * (1e6 * e));     // robust_small_epsilon^2, term_reinit.py:128,274
-    A.tiny = (T)e;                             // term_reinit.py:206
+    fill_term_par<T>(c, arr, scal, order, A.P);
     A.keys = keys;
     const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 16);
 #define HJ_TK(S, K) hipLaunchKernelGGL((term_kernel<T, ND, S, K>), dim3(blocks), dim3(256), 0, c->stream, A)
@@ -1305,15 +1313,30 @@ int term_run(hj_ctx* c, int kind, int scheme, const void* y, const void* const* 
     }
     unsigned long long* keys = c->keys + 8;        // scratch keys of the split path: [8, 8 + HJ_MAX_DIM + 1)
     HIP_TRY(hipMemsetAsync(keys, 0, (HJ_MAX_DIM + 1) * sizeof(unsigned long long), c->stream));
+    // Round 4: on fp64 2-D / 3-D grids of HJ_TERM_TILED_FROM cells or more (default 1 M) the term runs through the tiled substep
+    // kernel (LDS-staged stencils, register queue along axis 0; TermOp of hj_termop.h) -- the same cell arithmetic as the direct
+    // term_kernel (term_cell), 3-5x its speed at 201^3.  Slabs, fp32, 4-D and small grids keep the direct kernel.
+    const bool tiled = c->dtype == HJ_F64 && (c->ndim == 2 || c->ndim == 3) && !c->halo_lo && !c->halo_hi && !c->force_direct &&
+                       c->term_tiled_from >= 0 && c->total >= c->term_tiled_from;
+    if (tiled) {
+        TermPar<double> P;
+        fill_term_par<double>(c, arr, scal, order, P);
+        SubstepCall s{scheme, 0, HJ_STAGE_YDOT, 0, nullptr, 0.0, y, arr ? arr[0] : nullptr, out, keys, 0, c->N[0]};
+        s.term = &P;
+        rc = c->ndim == 2 ? launch_term_tiled<double, 2>(c, kind, s) : launch_term_tiled<double, 3>(c, kind, s);
+    } else {
 #define HJ_TN(T_, ND_) rc = term_launch_nd<T_, ND_>(c, kind, scheme, y, arr, scal, order, out, keys)
-    if (c->dtype == HJ_F64) { if (c->ndim == 2) HJ_TN(double, 2); else if (c->ndim == 3) HJ_TN(double, 3); else HJ_TN(double, 4); }
-    else { if (c->ndim == 2) HJ_TN(float, 2); else if (c->ndim == 3) HJ_TN(float, 3); else HJ_TN(float, 4); }
+        if (c->dtype == HJ_F64) { if (c->ndim == 2) HJ_TN(double, 2); else if (c->ndim == 3) HJ_TN(double, 3); else HJ_TN(double, 4); }
+        else { if (c->ndim == 2) HJ_TN(float, 2); else if (c->ndim == 3) HJ_TN(float, 3); else HJ_TN(float, 4); }
 #undef HJ_TN
+        c->last_kernel = "term_kernel";
+    }
     if (rc) return rc;
     unsigned long long h[HJ_MAX_DIM + 1];
     HIP_TRY(hipMemcpyAsync(h, keys, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int d = 0; d <= c->ndim; ++d) k[d] = h[d] ? key_to_double(h[d]) : -1.0;
+    if (tiled && kind == HJ_TERM_NORMAL) { k[c->ndim] = k[0]; k[0] = -1.0; }     // the tiled kernel carries termNormal's maximum in slot 0
     return HJ_OK;
 }
 }  // namespace

@@ -23,6 +23,13 @@ template <typename T> struct Lim;
 template <> struct Lim<double> { static constexpr double tiny = 1e-99; };
 template <> struct Lim<float>  { static constexpr float  tiny = 1e-30f; };
 
+// epsilon of the intended WENO5 formed as a product, then a sum (no FMA): what the term kernels and the host-side array path use
+template <typename T> __device__ __forceinline__ T weno_eps_uncontracted(T max_d1sq) {
+#pragma clang fp contract(off)
+    const T a = T(1e-6) * max_d1sq;
+    return a + Lim<T>::tiny;
+}
+
 template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
 template <> __device__ __forceinline__ double t_abs<double>(double x) { return __builtin_fabs(x); }
 template <> __device__ __forceinline__ float  t_abs<float>(float x)   { return __builtin_fabsf(x); }

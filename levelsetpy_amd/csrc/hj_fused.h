@@ -29,6 +29,7 @@
 //     atomicMax per workgroup and dimension.
 #pragma once
 #include "hj_device.h"
+#include "hj_termop.h"
 
 // Surplus halo slots shadow slot 0 (same source, same LDS cell, same value).  In 4-D (10 slots per thread, 2-3 % of them
 // surplus) their LDS stores go out unpredicated -- a benign duplicate write instead of an exec save + branch per slot and
@@ -130,6 +131,7 @@ template <typename T, int ND> struct FusedArgs {
     T inv_dx[ND];
     // debug (HJ_TIMING_DUMP): per logical block {start, end} of the constant 100 MHz clock, {xcc id, chunk}
     unsigned long long* timing;
+    TermPar<T> term;              // TermOp launches (termNormal / termReinit / termConvection through the tiled kernel; hj_termop.h)
 };
 
 // Logical block of this workgroup, -1 for the padding blocks of the launch.  Blocks b, b + 8, b + 16 ... share an XCD
@@ -295,6 +297,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     constexpr int ND = HAM::ND;
     constexpr bool GEN = (MODE == 0);
     constexpr bool NP = np_order(SCHEME);       // ENO2 / ENO3: every operation rounded as NumPy rounds it (hj_device.h)
+    // TERM (round 4): HAM is a TermOp -- the launch evaluates termNormal / termReinit / termConvection instead of the
+    // Lax-Friedrichs term: the stencils yield derivL / derivR (upwind<SCHEME>), the cell arithmetic is term_cell, the
+    // coefficient array 0 (speed / initial / velocity 0) rides in the y0 stream, the output is ydot (MODE 0, A.ydot_only)
+    constexpr bool TERM = ham_traits<HAM>::is_term;
+    constexpr int TKIND = ham_traits<HAM>::kind;
+    static_assert(!TERM || MODE == 0, "terms run the general instantiation");
     const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
     extern __shared__ __align__(16) unsigned char hj_smem[];
     // dynamic LDS only (keeps the carve base 16-byte aligned): [0,512) reduction scratch, then planes
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     // only the last round of the deal can run past the tile: shadows compute but do not write
     const bool last_real = (tid + (R - 1) * NT) < tile_cells;
     unsigned nbv[R];              // bit d: the forward neighbour on plane axis d lies inside the tile (eps_part pairs)
+    unsigned e_lo[R], e_hi[R];    // TERM: bit d: the cell has a lower / upper neighbour INSIDE the grid on plane axis d
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int c = min(tid + r * NT, tile_cells - 1);
@@ -358,6 +367,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         int idx[ND];
         idx[0] = 0;
         nbv[r] = 0u;
+        e_lo[r] = 0u; e_hi[r] = 0u;
 #pragma unroll
         for (int d = ND - 1; d >= 1; --d) {
             int q, j;
@@ -368,6 +378,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             lo += (j + HJ_STENCIL) * ls[d];
             g += gi * A.pstride[d];
             if (j + 1 < A.E[d]) nbv[r] |= 1u << d;
+            if (TERM && gi > 0) e_lo[r] |= 1u << d;
+            if (TERM && gi + 1 < A.n[d]) e_hi[r] |= 1u << d;
         }
         own_lds[r] = lo;
         own_g[r] = (unsigned)g * (unsigned)sizeof(T);   // byte offset within a plane
@@ -391,6 +403,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
     const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
     const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
+    // TERM: velocity components 1 .. ND-1 of termConvection (component 0 is the y0 stream); a null array = its scalar
+    __amdgpu_buffer_rsrc_t rcf[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        rcf[d] = make_srd((TERM && d >= 1 && A.term.arr[d]) ? A.term.arr[d] + (long long)p_lo * A.stride0 : y, (TERM && d >= 1 && A.term.arr[d]) ? span : 0u);
     auto load_own = [&](int p, T* dst) {
         const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
         if (direct) {
@@ -546,6 +563,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             if (A.eps_nrows <= 0) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            if constexpr (TERM) eps[d] = weno_eps_uncontracted<T>(A.max_d1sq[d]);     // as term_kernel forms it (product, then sum)
             wk[d] = weno_consts<T>(eps[d], A.K[d]);
         }
     }
@@ -609,6 +627,35 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         HJ_ST(st0);
         T* buf = lds + ((p - p_begin) & 1) * lds_plane;
         load_own(min(p + 3 + PDO, p_end + 2), own_n);
+        // TERM: what term_cell needs besides the stencils, requested here and consumed behind the barrier and the stencil
+        // arithmetic: the further velocity components (termConvection), the six neighbours of the INITIAL array (sub-cell fix)
+        T tcf[R][ND], tlo[R][ND], thi[R][ND];
+        if constexpr (TERM) {
+            const unsigned so_t = (unsigned)(p - p_lo) * plane_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { tcf[r][d] = A.term.scal[d]; tlo[r][d] = T(0); thi[r][d] = T(0); }
+                if constexpr (TKIND == HJ_TERM_CONVECTION) {
+#pragma unroll
+                    for (int d = 1; d < ND; ++d)
+                        if (A.term.arr[d]) tcf[r][d] = buf_load(rcf[d], own_g[r], so_t, T());
+                }
+                if constexpr (TKIND == HJ_TERM_REINIT) {
+                    if (A.term.subcell_order == 1) {
+                        // a missing neighbour re-reads the cell itself (term_cell does not look at it)
+                        tlo[r][0] = buf_load(ry0, own_g[r], p > 0 ? so_t - plane_bytes : so_t, T());
+                        thi[r][0] = buf_load(ry0, own_g[r], p + 1 < A.n[0] ? so_t + plane_bytes : so_t, T());
+#pragma unroll
+                        for (int d = 1; d < ND; ++d) {
+                            const unsigned sb = (unsigned)A.pstride[d] * (unsigned)sizeof(T);
+                            tlo[r][d] = buf_load(ry0, ((e_lo[r] >> d) & 1u) ? own_g[r] - sb : own_g[r], so_t, T());
+                            thi[r][d] = buf_load(ry0, ((e_hi[r] >> d) & 1u) ? own_g[r] + sb : own_g[r], so_t, T());
+                        }
+                    }
+                }
+            }
+        }
         // stage the centre plane
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -640,7 +687,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
             for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(q[r][j]));
 #else
-            upwind_cd<SCHEME, T>(q[r], A.K[0], eps[0], wk[0], pc[0], hd[0]);
+            if constexpr (TERM) upwind<SCHEME, T>(q[r], A.K[0], eps[0], pc[0], hd[0]);          // pc = derivL, hd = derivR
+            else upwind_cd<SCHEME, T>(q[r], A.K[0], eps[0], wk[0], pc[0], hd[0]);
 #endif
 #pragma unroll
             for (int d = 1; d < ND; ++d) {
@@ -662,14 +710,31 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #pragma unroll
                 for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(v[j]));
 #else
-                upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pc[d], hd[d]);
+                if constexpr (TERM) upwind<SCHEME, T>(v, A.K[d], eps[d], pc[d], hd[d]);
+                else upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pc[d], hd[d]);
 #endif
             }
-            T alpha[ND];
-            T ydot = lf_ydot<NP, HAM>(A.ham, hcell[r], pl_use, A.sc, pc, hd, alpha);
+            T ydot;
+            if constexpr (TERM) {
+                tcf[r][0] = use_y0 ? y0_c[r] : A.term.scal[0];
+                double mm[ND + 1];
 #pragma unroll
-            for (int d = 0; d < ND; ++d)
-                if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
+                for (int d = 0; d <= ND; ++d) mm[d] = -1e300;
+                const unsigned hl = e_lo[r] | (p > 0 ? 1u : 0u), hh = e_hi[r] | (p + 1 < A.n[0] ? 1u : 0u);
+                ydot = term_cell<TKIND, T, ND>(A.term, pc, hd, tcf[r], q[r][3], tlo[r], thi[r], hl, hh, mm);
+                // termNormal's single maximum travels in slot 0 (the host reads key 0 for it)
+                if constexpr (TKIND == HJ_TERM_NORMAL) amax[0] = fmax(amax[0], mm[ND]);
+                else {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) amax[d] = fmax(amax[d], mm[d]);
+                }
+            } else {
+                T alpha[ND];
+                ydot = lf_ydot<NP, HAM>(A.ham, hcell[r], pl_use, A.sc, pc, hd, alpha);
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
+            }
             // termRestrictUpdate clamp; written so that a NaN stays a NaN
             if (GEN && A.do_clamp) {
                 ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
@@ -755,7 +820,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         }
     }
     if (A.bound) {   // a launch whose bound nobody reads (hj_rk_step: dt comes from the static bound) skips the reduction
-        {   // alphas that are constant along the march: one max per column, taken once (any plane does)
+        if constexpr (!TERM) {   // alphas that are constant along the march: one max per column, taken once (any plane does)
             T pz[ND], Hz, az[ND];
     #pragma unroll
             for (int d = 0; d < ND; ++d) pz[d] = T(0);

@@ -101,6 +101,7 @@ struct hj_ctx {
     hipEvent_t ev_int[3];              // interior of RK stage s done (deep-halo stepper)
     int slab_pending;
     int slab_overlap2 = 0;             // HJ_SLAB_SCHEDULE=overlap2 (experiment)
+    long long term_tiled_from = 1000000;   // HJ_TERM_TILED_FROM: grids of at least this many cells run the terms through the tiled kernel
     int slab_gated = 0;                // HJ_SLAB_SCHEDULE=gated (round 4): edges + interior in ONE launch, exchange gated on a counter
     unsigned long long* gate = nullptr;           // device counter the edge workgroups of gated launches add to
     unsigned long long gate_count = 0;            // its value once every gated launch issued so far has published
@@ -216,6 +217,7 @@ struct SubstepCall {
     // will (ctx->gate_posted); 0 = the launch could not gate (direct kernel): the caller orders the exchange with an event
     int64_t e0[2] = {0, 0}, e1[2] = {0, 0};
     bool gated = false;
+    const void* term = nullptr;   // TermPar<T> of a TermOp launch (hj_termop.h; the tiled term path of round 4), else null
     int post_op = 0;          // fused post-step min/max with the state the step started from
     bool on_aux = false;      // launch on the ctx's auxiliary (edge) stream instead of the ctx stream
     // intended WENO5 inside hj_rk_step / hj_rk_integrate: this launch's output is the next launch's input (reduce max(D1^2)
@@ -225,6 +227,9 @@ struct SubstepCall {
     int eps_nrows = 0;                  // reading weno_vals
 };
 constexpr int HJ_EPS_ROWS = 256;  // workgroups (= rows) of eps_seam_kernel
+
+// termNormal / termReinit / termConvection through the tiled substep kernel (hj_inst.hip compiled with -DHJ_INST_TERM_ND; fp64, 2-D / 3-D)
+template <typename T, int ND> int launch_term_tiled(hj_ctx* c, int kind, const SubstepCall& s);
 
 inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s.on_aux ? c->edge_stream : c->stream; }
 

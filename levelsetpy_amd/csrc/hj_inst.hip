@@ -719,7 +719,42 @@ int launch_stage12(hj_ctx* c, const Stage12Call& s) {
     return hjh::fail(HJ_EUNSUPPORTED, "no stage-fused kernel for scheme %d", s.scheme);
 }
 
+#ifdef HJ_INST_TERM_ND
+// ---- termNormal / termReinit / termConvection through the tiled one-cell-per-lane kernel (round 4): HAM = TermOp<T, ND, KIND>,
+// MODE 0 (ydot only).  256 threads x 2 cells (two to four workgroups per CU); the direct term_kernel stays for small grids,
+// 4-D, fp32 and slabs (hj_api.hip, term_run).
+template <typename T, int ND, int KIND, int SCHEME>
+int launch_term_cfg(hj_ctx* c, const SubstepCall& s) {
+    // two cells per thread; the intended WENO5 (the heaviest stencil) one: with two it spills 60-268 bytes per lane
+    constexpr int NT = 256, R = (SCHEME == HJ_WENO5) ? 1 : 2, KH = 2, OCC = 2, PD = 2;
+    const KernelCfg k{NT, R, KH};
+    const Tiling t = make_tiling(c, k, s.p0, s.p1, 1, 2);
+    if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "no tiling of this grid for the tiled term kernel");
+    return launch_tiled_mode<T, hj::TermOp<T, ND, KIND>, SCHEME, NT, R, KH, OCC, PD, 0, false>(c, s, t);
+}
+template <typename T, int ND, int KIND>
+int launch_term_kind(hj_ctx* c, const SubstepCall& s) {
+    switch (s.scheme) {
+        case HJ_ENO2: return launch_term_cfg<T, ND, KIND, HJ_ENO2>(c, s);
+        case HJ_ENO3: return launch_term_cfg<T, ND, KIND, HJ_ENO3>(c, s);
+        case HJ_WENO5: return launch_term_cfg<T, ND, KIND, HJ_WENO5>(c, s);
+        case HJ_WENO5_ASSHIPPED: return launch_term_cfg<T, ND, KIND, HJ_WENO5_ASSHIPPED>(c, s);
+    }
+    return hjh::fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
+}
+template <typename T, int ND>
+int launch_term_tiled(hj_ctx* c, int kind, const SubstepCall& s) {
+    switch (kind) {
+        case hj::HJ_TERM_NORMAL: return launch_term_kind<T, ND, hj::HJ_TERM_NORMAL>(c, s);
+        case hj::HJ_TERM_REINIT: return launch_term_kind<T, ND, hj::HJ_TERM_REINIT>(c, s);
+        case hj::HJ_TERM_CONVECTION: return launch_term_kind<T, ND, hj::HJ_TERM_CONVECTION>(c, s);
+    }
+    return hjh::fail(HJ_EINVAL, "unknown term %d", kind);
+}
+template int launch_term_tiled<HJ_INST_T, HJ_INST_TERM_ND>(hj_ctx*, int, const SubstepCall&);
+#else
 template int launch_scheme<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const SubstepCall&);
 template int launch_stage12<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const Stage12Call&);
+#endif
 
 }  // namespace hjh

@@ -49,7 +49,7 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
         A.ntile[d] = t.ntile[d];
     }
     for (int d = 0; d < ND; ++d) A.tb[d] = 0;
-    if (ND == 4 && c->tile_block[0] > 0 && c->tile_block[1] > 0) { A.tb[1] = c->tile_block[0]; A.tb[2] = c->tile_block[1]; }
+    if constexpr (ND == 4) { if (c->tile_block[0] > 0 && c->tile_block[1] > 0) { A.tb[1] = c->tile_block[0]; A.tb[2] = c->tile_block[1]; } }
     A.halo_lo = c->halo_lo;
     A.halo_hi = c->halo_hi;
     A.ntiles = t.ntiles;
@@ -93,6 +93,11 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
     A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
     fill_ham<T>(c, s.par, A.ham);
+    if (s.term) {            // a TermOp launch: coefficient array 0 rides in the y0 stream whatever the stage says
+        A.term = *static_cast<const hj::TermPar<T>*>(s.term);
+        A.use_y0 = A.term.arr[0] != nullptr;
+        for (int d = 0; d < ND; ++d) A.sc[d] = T(1);
+    }
     return HJ_OK;
 }
 

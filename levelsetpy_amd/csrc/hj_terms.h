@@ -19,26 +19,18 @@
 // of hj_split.h, as in direct_substep_kernel: L1/L2 absorb the stencil reuse).
 #pragma once
 #include "hj_split.h"
+#include "hj_termop.h"
 
 namespace hj {
-
-enum { HJ_TERM_NORMAL = 0, HJ_TERM_REINIT = 1, HJ_TERM_CONVECTION = 2 };
 
 template <typename T, int ND> struct TermArgs {
     const T* y;
     T* out;
     GridArgs<T, ND> G;
     const T* max_d1sq;            // HJ_WENO5 only
-    // termNormal: speed array or scalar;  termConvection: velocity arrays or scalars;  termReinit: initial
-    const T* arr[HJ_MAX_DIM];
-    T scal[HJ_MAX_DIM];
-    T dx_inv[ND], dx[ND], max_dx;
-    int subcell_order;            // termReinit
-    T small2, tiny;               // (1e6 eps)^2 and eps of termReinit
+    TermPar<T> P;                 // coefficient arrays / scalars, spacings, termReinit's constants (hj_termop.h)
     unsigned long long* keys;     // ND + 1 atomicMax keys: per-dimension maxima, then the scalar one
 };
-
-template <typename T> __device__ __forceinline__ T t_sign(T a) { return a > T(0) ? T(1) : (a < T(0) ? T(-1) : T(0)); }
 
 template <typename T, int ND, int SCHEME, int KIND>
 __global__ __launch_bounds__(256) void term_kernel(const TermArgs<T, ND> A) {
@@ -57,104 +49,36 @@ __global__ __launch_bounds__(256) void term_kernel(const TermArgs<T, ND> A) {
         int idx[ND];
         decode<T, ND>(A.G, t, idx);
         T dL[ND], dR[ND];
+        T pc0v;
         {
             // every stencil load issued back to back (hj_split.h, gather_stencils), then the derivatives
             const T* pc0 = A.y + t;
             T v[ND][7];
-            gather_stencils<T, ND>(A.G, pc0, idx, pc0[0], v);
+            pc0v = pc0[0];
+            gather_stencils<T, ND>(A.G, pc0, idx, pc0v, v);
 #pragma unroll
             for (int d = 0; d < ND; ++d) upwind<SCHEME, T>(v[d], A.G.K[d], eps[d], dL[d], dR[d]);
         }
-        T o;
-        if constexpr (KIND == HJ_TERM_NORMAL) {
-            const T speed = A.arr[0] ? A.arr[0][t] : A.scal[0];
-            T magnitude = T(0), sbi = T(0);
+        // the cell's arithmetic: term_cell (hj_termop.h), shared with the tiled kernel
+        T coef[ND];
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const T prodL = speed * dL[d], prodR = speed * dR[d];
-                const T magL = t_abs(prodL), magR = t_abs(prodR);
-                const bool conv = (prodL >= T(0)) && (prodR <= T(0));
-                const bool flowL = ((prodL >= T(0)) && (prodR >= T(0))) || (conv && (magL >= magR));
-                const bool flowR = ((prodL <= T(0)) && (prodR <= T(0))) || (conv && (magL < magR));
-                const T fl = flowL ? T(1) : T(0), fr = flowR ? T(1) : T(0);
-                magnitude = magnitude + ((dL[d] * dL[d]) * fl + (dR[d] * dR[d]) * fr);
-                const T vel = magL * fl + magR * fr;
-                sbi = sbi + vel / A.dx[d];
-            }
-            magnitude = sqrt(magnitude);
-            o = -(speed * magnitude);
-            if (magnitude > T(0)) m[ND] = fmax(m[ND], (double)(sbi / magnitude));
-        } else if constexpr (KIND == HJ_TERM_CONVECTION) {
-            T delta = T(0);
+        for (int d = 0; d < ND; ++d) coef[d] = A.P.arr[d] ? A.P.arr[d][t] : A.P.scal[d];
+        T nb_lo[ND], nb_hi[ND];
+        unsigned has_lo = 0u, has_hi = 0u;
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const T v = A.arr[d] ? A.arr[d][t] : A.scal[d];
-                const T deriv = dL[d] * (v > T(0) ? T(1) : T(0)) + dR[d] * (v < T(0) ? T(1) : T(0));
-                delta = delta + deriv * v;
-                m[d] = fmax(m[d], (double)t_abs(v));
-            }
-            o = -delta;
-        } else {
-            const T init = A.arr[0][t];
-            const T data = A.y[t];
-            T S;
-            if (A.subcell_order) S = t_sign(init);
-            else S = init / sqrt(init * init + A.max_dx * A.max_dx);
-            T deriv[ND];
-            T mag = T(0);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const T sL = S * dL[d], sR = S * dR[d];
-                bool flowL = (sR <= T(0)) && (sL <= T(0));
-                bool flowR = (sR >= T(0)) && (sL >= T(0));
-                const bool flows = (sR < T(0)) && (sL > T(0));
-                T den = dR[d] - dL[d];
-                den = den + (den == T(0) ? T(1) : T(0));
-                const T s = S * (t_abs(dR[d]) - t_abs(dL[d])) / den;
-                flowL = flowL || (flows && (s < T(0)));
-                flowR = flowR || (flows && (s >= T(0)));
-                deriv[d] = dL[d] * (flowR ? T(1) : T(0)) + dR[d] * (flowL ? T(1) : T(0));
-                mag = mag + deriv[d] * deriv[d];
-            }
-            mag = sqrt(mag);
-            mag = mag > A.tiny ? mag : A.tiny;
-            T delta = -S;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const T v = S * deriv[d] / mag;
-                delta = delta + v * deriv[d];
-                m[d] = fmax(m[d], (double)t_abs(v));
-            }
-            if (A.subcell_order == 1) {
-                // Russo & Smereka's sub-cell fix with the robust distance estimate (long differences, short ones
-                // where they are larger), applied at the nodes next to the interface
-                T denom = T(0);
-                bool near = (t_sign(init) == T(0));
+        for (int d = 0; d < ND; ++d) { nb_lo[d] = T(0); nb_hi[d] = T(0); }
+        if constexpr (KIND == HJ_TERM_REINIT) {
+            if (A.P.subcell_order == 1) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
-                    const int i = idx[d], n = A.G.n[d];
-                    const long long s = A.G.stride[d];
-                    const T* p = A.arr[0] + t;
-                    const T di = A.dx_inv[d];
-                    const T lo = i > 0 ? p[-s] : init, hi = i + 1 < n ? p[s] : init;
-                    T diff2;
-                    if (i > 0 && i + 1 < n) { const T c = (T(0.5) * di) * (hi - lo); diff2 = c * c; }
-                    else if (i == 0) { const T c = di * (hi - init); diff2 = c * c; }
-                    else { const T c = di * (init - lo); diff2 = c * c; }
-                    if (i + 1 < n) { const T c = di * (hi - init); const T s2 = c * c; diff2 = diff2 > s2 ? diff2 : s2; }
-                    if (i > 0) { const T c = di * (init - lo); const T s2 = c * c; diff2 = diff2 > s2 ? diff2 : s2; }
-                    diff2 = diff2 > A.small2 ? diff2 : A.small2;
-                    denom = denom + diff2;
-                    const T sg = t_sign(init);
-                    if (i > 0) near = near || (t_sign(lo) != sg);
-                    if (i + 1 < n) near = near || (t_sign(hi) != sg);
+                    const T* p = A.P.arr[0] + t;
+                    const long long st = A.G.stride[d];
+                    if (idx[d] > 0) { has_lo |= 1u << d; nb_lo[d] = p[-st]; }
+                    if (idx[d] + 1 < A.G.n[d]) { has_hi |= 1u << d; nb_hi[d] = p[st]; }
                 }
-                const T D = init / sqrt(denom);
-                const T nr = near ? T(1) : T(0), fr = near ? T(0) : T(1);
-                delta = delta * fr + (S * t_abs(data) - D) / A.max_dx * nr;
             }
-            o = -delta;
         }
+        const T o = term_cell<KIND, T, ND>(A.P, dL, dR, coef, pc0v, nb_lo, nb_hi, has_lo, has_hi, m);
         A.out[t] = o;
     }
     __shared__ double red[4][ND + 1];

@@ -613,3 +613,43 @@ def test_eighty_rk2_steps_double_integrator_restricted_vs_oracle_bitwise(scheme)
     assert float(np.abs(yo - d0.reshape(-1)).max()) > 0.05
     assert t == to
     assert np.array_equal(got, yo.reshape(got.shape)), "%d cells differ, max %.3e" % (int((got != yo.reshape(got.shape)).sum()), float(np.abs(got - yo.reshape(got.shape)).max()))
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((37, 21, 19), 2), ((20, 70, 45), (0, 2)), ((45, 300), None), ((64, 33), 1), ((9, 8, 7), None)])
+def test_terms_through_the_tiled_kernel_equal_the_direct_kernel_bitwise(scheme, n, pd, monkeypatch):
+    """Round 4: on large fp64 grids termNormal / termReinit / termConvection run through the tiled substep kernel (TermOp,
+    csrc/hj_termop.h: LDS-staged stencils, register queue along axis 0) instead of the one-thread-per-cell term_kernel.  Both
+    call the same cell function: ydot and the step bound must be equal to the last bit -- every scheme, both sub-cell orders,
+    scalar and array coefficients, periodic and extrapolated axes, extents below the tile, chunks of a few planes."""
+    nd = len(n)
+    lo, hi = [-1.0] * nd, [1.0] * nd
+    rng = np.random.default_rng(23)
+    res = {}
+    for tag, env in (("tiled", "0"), ("direct", "-1")):
+        monkeypatch.setenv("HJ_TERM_TILED_FROM", env)
+        monkeypatch.setenv("HJ_MIN_CHUNK", "4")
+        g, og = mk(lo, hi, n, pd)
+        if tag == "tiled":
+            phi = O.shape_sphere(og, None, .45) * (1.0 + 0.4 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[1])) + 0.02 * rng.standard_normal(n)
+            speed = 0.5 + 0.3 * np.cos(og.xs[0]) * np.ones(n)
+            vels = [0.7 * np.ones(n) * np.sin(2 * og.xs[nd - 1]), -0.4 + 0.5 * np.sin(3 * og.xs[1]) * np.ones(n), -0.2][:nd]
+        y = torch.as_tensor(phi.reshape(-1, 1), device="cuda")
+        tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+        cases = [("normal array", L.termNormal, dict(speed=tt(speed))), ("normal scalar", L.termNormal, dict(speed=-1.25)),
+                 ("reinit 0", L.termReinit, dict(initial=tt(phi), subcell_fix_order=0)), ("reinit 1", L.termReinit, dict(initial=tt(phi), subcell_fix_order=1)),
+                 ("convection arrays", L.termConvection, dict(velocity=[tt(v) if isinstance(v, np.ndarray) else v for v in vels])),
+                 ("convection scalars", L.termConvection, dict(velocity=[0.3, -0.6, 0.2][:nd]))]
+        out = {}
+        for name, fn, extra in cases:
+            a, sb, _ = fn(0., y, L.Bundle(dict(grid=g, derivFunc=DERIV[scheme], **extra)))
+            dg = device_grid(g, "float64")
+            out[name] = (a.clone(), sb, dg.lib.hj_last_kernel(dg.ctx))
+        res[tag] = out
+    for name in res["tiled"]:
+        a, sba, ka = res["tiled"][name]
+        b, sbb, kb = res["direct"][name]
+        assert ka == b"fused_substep_kernel" and kb == b"term_kernel", (ka, kb)
+        assert bool(torch.isfinite(a).all())
+        assert torch.equal(a, b), "%s: %d cells differ, max %.3e" % (name, int((a != b).sum()), float((a - b).abs().max()))
+        assert sba == sbb, (name, sba, sbb)

@@ -26,6 +26,12 @@ def classify(name):
         bound = "fp64 VALU" if scheme in ("WENO5", "ENO3") and T == "double" else ("HBM / fp32 VALU" if ham == "DoublePendulum" else "HBM")
         return ("fused_pair_kernel %s %s (%s,%s,%s) %s" % (ham, scheme, nt, r, kh, {"1": "stage 1", "2": "stages 2,3", "0": "general"}[mode]), units, words * es,
                 "read y%s, write out" % (" + y0" if words == 3 else ""), bound)
+    m = re.match(r"fused_substep_kernel<(\w+), TermOp<\w+, (\d), (\d)>, (\d), (\d+), (\d+)", s)
+    if m:
+        T, nd, kind, sch, nt, r = m.groups()
+        kindn = ["termNormal", "termReinit", "termConvection"][int(kind)]
+        scheme = ["ENO2", "ENO3", "WENO5", "WENO5 as shipped"][int(sch)]
+        return ("fused_substep_kernel %s %s (%s,%s) tiled, TermOp" % (kindn, scheme, nt, r), N3, 24, "read y + one coefficient array, write ydot", "fp64 VALU (uncontracted, sqrt / divisions)")
     m = re.match(r"fused_substep_kernel<(\w+), Ham(\w+)<\w+>, (\d)", s)
     if m:
         T, ham, sch = m.groups()
