@@ -290,7 +290,9 @@ int hj_slab_rk_step_deep(hj_ctx* ctx, int order, int scheme, int ham_id, const d
  *   hj_term_convection  termConvection  ExplicitIntegration/Term/term_convection.py:7 (:154-180)
  *                       ydot = -V . grad phi; velocity[d] = array of the grid or null (velocity_scalar[d])
  * y, ydot (must differ) and the arrays are device pointers of the ctx dtype; *step_bound as the reference returns it
- * (inf when nothing moves).  One host synchronisation per call (the step bound). */
+ * (inf when nothing moves).  One host synchronisation per call (the step bound).  fp64 2-D / 3-D grids of at least
+ * HJ_TERM_TILED_FROM cells (environment, default 1 000 000; negative: never) run the tiled substep kernel with the term in
+ * the Hamiltonian's place, everything else the one-thread-per-cell kernel: same cell function, same bits. */
 int hj_term_normal(hj_ctx* ctx, int scheme, const void* y, const void* speed, double speed_scalar, void* ydot,
                    double* step_bound);
 int hj_term_reinit(hj_ctx* ctx, int scheme, const void* y, const void* initial, int subcell_order, void* ydot,
@@ -327,8 +329,9 @@ int hj_ham_cache_stats(int* compiled, int* loaded_from_cache);
 int hj_sync(hj_ctx* ctx);
 const char* hj_last_error(void);
 /* Name of the substep kernel the last hj_rk_substep / hj_rk_step / hj_lf_term on this ctx launched:
- * "fused_pair_kernel", "fused_substep_kernel", "fused12_kernel" or "direct_substep_kernel" (bench.py names the
- * kernel its roofline is about; no reference counterpart). */
+ * "fused_pair_kernel", "fused_substep_kernel", "fused12_kernel" or "direct_substep_kernel"; after hj_term_*:
+ * "fused_substep_kernel" (tiled) or "term_kernel" (bench.py names the kernel its roofline is about; no reference
+ * counterpart). */
 const char* hj_last_kernel(hj_ctx* ctx);
 /* LDS schedule of that launch: plane buffers in the ring (2 = double buffer) and how many planes ahead of its use the halo
  * ring of a plane is parked in LDS (0 = staged in the iteration that consumes it); tests assert the variant that ran. */
