@@ -726,7 +726,13 @@ int launch_stage12(hj_ctx* c, const Stage12Call& s) {
 template <typename T, int ND, int KIND, int SCHEME>
 int launch_term_cfg(hj_ctx* c, const SubstepCall& s) {
     // two cells per thread; the intended WENO5 (the heaviest stencil) one: with two it spills 60-268 bytes per lane
-    constexpr int NT = 256, R = (SCHEME == HJ_WENO5) ? 1 : 2, KH = 2, OCC = 2, PD = 2;
+#ifndef HJ_TERM_R
+#define HJ_TERM_R 2
+#endif
+#ifndef HJ_TERM_OCC
+#define HJ_TERM_OCC 2
+#endif
+    constexpr int NT = 256, R = (SCHEME == HJ_WENO5) ? 1 : HJ_TERM_R, KH = 2, OCC = HJ_TERM_OCC, PD = 2;
     const KernelCfg k{NT, R, KH};
     const Tiling t = make_tiling(c, k, s.p0, s.p1, 1, 2);
     if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "no tiling of this grid for the tiled term kernel");
