@@ -580,6 +580,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+TRACE_STEPS = 400      # steps of the kernel-trace child pass that are looked at (after its spin-up)
 STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel",
                 "max_d1sq_kernel", "partials_to_values_kernel", "keys_to_values_kernel", "eps_seam_kernel")
 
@@ -608,7 +609,9 @@ def live_traffic(a, n=None, scheme=None):
         # run the settled shape: ADVICE r03)
         # (the duration pass spins up 4x longer than the timed leg's fixed part: it cannot use the leg's settle loop -- its rows
         # are dealt to steps by position -- and has to reach the same clocks)
-        spin, warm, steps = (60, 1, 4) if ctr else (4 * SPINUP_STEPS, 2, 20)
+        # (and it reports the MEDIAN step of its last 400: the mean of a 2 ms tail was hit by a transient once -- 42.4 us per
+        # launch where the timed leg and a whole-run trace of the same box both read 38.6-39.0)
+        spin, warm, steps = (60, 1, 4) if ctr else (4 * SPINUP_STEPS, 2, TRACE_STEPS)
         nstep = spin + warm + steps
         d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin), HJ_BENCH_SETTLE_BLOCKS="0")   # (fixed step count: the rows are dealt to steps by position)
@@ -649,9 +652,13 @@ def live_traffic(a, n=None, scheme=None):
                 per_step = len(rows) // nstep if rows else 0
                 if per_step:
                     tail = rows[-per_step * steps:]
-                    sub = [e - b for b, e, is_sub in tail if is_sub]
-                    dur = {"kernel_ms": 1e-6 * sum(sub) / len(sub),                      # mean substep-kernel dispatch
-                           "step_kernels_ms": 1e-6 * sum(e - b for b, e, _ in tail) / steps,   # all kernels of a step
+                    # per step: all its kernels, and its substep kernels alone; the median step speaks for the pass
+                    by_step = [tail[i * per_step:(i + 1) * per_step] for i in range(steps)]
+                    all_ms = sorted(1e-6 * sum(e - b for b, e, _ in st) for st in by_step)
+                    sub_ms = sorted(1e-6 * sum(e - b for b, e, is_sub in st if is_sub) / max(1, sum(1 for _, _, is_sub in st if is_sub)) for st in by_step)
+                    dur = {"kernel_ms": sub_ms[len(sub_ms) // 2],                        # substep-kernel dispatch, median step
+                           "step_kernels_ms": all_ms[len(all_ms) // 2],                  # all kernels of a step, median step
+                           "step_kernels_ms_q1_q3": [all_ms[len(all_ms) // 4], all_ms[(3 * len(all_ms)) // 4]],
                            "dispatches_per_step": per_step}
         except Exception:  # noqa: BLE001
             if ctr:
@@ -664,7 +671,7 @@ def live_traffic(a, n=None, scheme=None):
             "fetch_kib_per_step": vals["FETCH_SIZE"][0], "write_kib_per_step": vals["WRITE_SIZE"][0],
             "rocprof": dur,
             "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 65 RK3 steps, --kernel-trace: "
-                      "the last 20 of %d; every kernel of the step counted; %.0f s)" % (4 * SPINUP_STEPS + 22, time.perf_counter() - t0)}
+                      "the median step of the last %d of %d; every kernel of the step counted; %.0f s)" % (TRACE_STEPS, 4 * SPINUP_STEPS + 2 + TRACE_STEPS, time.perf_counter() - t0)}
 
 
 def achievable_rates():
