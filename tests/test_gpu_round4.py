@@ -653,3 +653,30 @@ def test_terms_through_the_tiled_kernel_equal_the_direct_kernel_bitwise(scheme, 
         assert bool(torch.isfinite(a).all())
         assert torch.equal(a, b), "%s: %d cells differ, max %.3e" % (name, int((a != b).sum()), float((a - b).abs().max()))
         assert sba == sbb, (name, sba, sbb)
+
+
+def test_bench_line_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver reads: metric / value / unit /
+    n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config{workload} + roofline
+    {bound, achieved, peak, unit, frac, traffic} + cpu_baseline{value, unit, cores, kind, sample} + parity (ok).  (The extra
+    workloads and the rocprofv3 child passes are switched off here: they are exercised by every default bench run.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--repeats", "5",
+                        "--no-also", "--no-live-traffic"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("grid-cell RK-substep updates/sec, Dubins-3D HJI 201^3 fp64") and d["unit"] == "cell-substeps/s"
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["higher_is_better"], d["scaling"], d["dtype"], d["data"]) == (1, 5, 2, True, "weak", "f64", "synthetic")
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 5e10 and abs(d["value"] - 8120601 * 3 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "infinity-cache/fabric") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "cell-substeps/s" and c["value"] > 1e5 and c["sample"]
+    assert d["parity"]["ok"] is True and d["parity"]["max_abs_diff"] <= d["parity"]["tol"] == 1e-11
