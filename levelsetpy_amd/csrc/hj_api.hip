@@ -1318,13 +1318,16 @@ int term_run(hj_ctx* c, int kind, int scheme, const void* y, const void* const* 
     // term_kernel (term_cell), 3-5x its speed at 201^3.  Slabs, fp32, 4-D and small grids keep the direct kernel.
     const bool tiled = c->dtype == HJ_F64 && (c->ndim == 2 || c->ndim == 3) && !c->halo_lo && !c->halo_hi && !c->force_direct &&
                        c->term_tiled_from >= 0 && c->total >= c->term_tiled_from;
+    bool tiled_ran = false;
     if (tiled) {
         TermPar<double> P;
         fill_term_par<double>(c, arr, scal, order, P);
         SubstepCall s{scheme, 0, HJ_STAGE_YDOT, 0, nullptr, 0.0, y, arr ? arr[0] : nullptr, out, keys, 0, c->N[0]};
         s.term = &P;
         rc = c->ndim == 2 ? launch_term_tiled<double, 2>(c, kind, s) : launch_term_tiled<double, 3>(c, kind, s);
-    } else {
+        tiled_ran = rc != HJ_EUNSUPPORTED;         // a grid the tiled kernel has no tiling for: the direct kernel below
+    }
+    if (!tiled_ran) {
 #define HJ_TN(T_, ND_) rc = term_launch_nd<T_, ND_>(c, kind, scheme, y, arr, scal, order, out, keys)
         if (c->dtype == HJ_F64) { if (c->ndim == 2) HJ_TN(double, 2); else if (c->ndim == 3) HJ_TN(double, 3); else HJ_TN(double, 4); }
         else { if (c->ndim == 2) HJ_TN(float, 2); else if (c->ndim == 3) HJ_TN(float, 3); else HJ_TN(float, 4); }
@@ -1336,7 +1339,7 @@ int term_run(hj_ctx* c, int kind, int scheme, const void* y, const void* const* 
     HIP_TRY(hipMemcpyAsync(h, keys, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int d = 0; d <= c->ndim; ++d) k[d] = h[d] ? key_to_double(h[d]) : -1.0;
-    if (tiled && kind == HJ_TERM_NORMAL) { k[c->ndim] = k[0]; k[0] = -1.0; }     // the tiled kernel carries termNormal's maximum in slot 0
+    if (tiled_ran && kind == HJ_TERM_NORMAL) { k[c->ndim] = k[0]; k[0] = -1.0; }     // the tiled kernel carries termNormal's maximum in slot 0
     return HJ_OK;
 }
 }  // namespace
