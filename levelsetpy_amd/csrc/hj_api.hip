@@ -569,6 +569,34 @@ template <typename T> static int upwind_launch(hj_ctx* c, int scheme, int dim, c
     return HJ_OK;
 }
 
+template <typename T, int ND>
+static int upwind_all_launch(hj_ctx* c, int scheme, const void* y, void* const* dL, void* const* dR, unsigned long long* keys, const T* epsv) {
+    UpwindAllArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    hjh::fill_grid<T, ND>(c, A.G);
+    for (int d = 0; d < ND; ++d) { A.dL[d] = (T*)dL[d]; A.dR[d] = (T*)dR[d]; }
+    A.max_d1sq = epsv;
+    A.keys = keys;
+    const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 16);
+#define HJ_UPA(S) hipLaunchKernelGGL((upwind_all_kernel<T, ND, S>), dim3(blocks), dim3(256), 0, c->stream, (const T*)y, A)
+    switch (scheme) {
+        case HJ_ENO2: HJ_UPA(HJ_ENO2); break;
+        case HJ_ENO3: HJ_UPA(HJ_ENO3); break;
+        case HJ_WENO5: HJ_UPA(HJ_WENO5); break;
+        case HJ_WENO5_ASSHIPPED: HJ_UPA(HJ_WENO5_ASSHIPPED); break;
+        default: return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    }
+#undef HJ_UPA
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+template <typename T>
+static int upwind_all_dispatch(hj_ctx* c, int scheme, const void* y, void* const* dL, void* const* dR, unsigned long long* keys, const T* epsv) {
+    if (c->ndim == 2) return upwind_all_launch<T, 2>(c, scheme, y, dL, dR, keys, epsv);
+    if (c->ndim == 3) return upwind_all_launch<T, 3>(c, scheme, y, dL, dR, keys, epsv);
+    return upwind_all_launch<T, 4>(c, scheme, y, dL, dR, keys, epsv);
+}
+
 // ------------------------------------------------------------------------------------ RCCL (dlopen)
 struct Rccl {
     void* handle = nullptr;
@@ -1190,9 +1218,16 @@ int hj_lf_split_begin(hj_ctx* c, int scheme, const void* y, void* const* dL, voi
         if ((rc = weno_eps_pass(c, y))) return rc;
         if ((rc = keys_to_vals(c, c->weno_vals))) return rc;
     }
-    // all dimensions are launched back to back; ONE host synchronisation fetches the 4*ndim reductions
+    // Round 4: ONE launch for all dimensions (upwind_all_kernel: the stencils of a cell gathered once); ONE host synchronisation
+    // fetches the 4*ndim reductions.  HJ_UPWIND_ALL=0: one launch per dimension (rounds 1-3; A/B)
     unsigned long long* keys = c->keys + 8;        // [8, 8 + 4*HJ_MAX_DIM)
     if (mm) HIP_TRY(hipMemsetAsync(keys, 0, 4 * HJ_MAX_DIM * sizeof(unsigned long long), c->stream));
+    static const int one_launch = env_int("HJ_UPWIND_ALL", 1);
+    if (one_launch) {
+        rc = c->dtype == HJ_F64 ? upwind_all_dispatch<double>(c, scheme, y, dL, dR, mm ? keys : nullptr, (const double*)epsv)
+                                : upwind_all_dispatch<float>(c, scheme, y, dL, dR, mm ? keys : nullptr, (const float*)epsv);
+        if (rc) return rc;
+    } else
     for (int d = 0; d < c->ndim; ++d) {
         unsigned long long* k = mm ? keys + 4 * d : nullptr;
         rc = c->dtype == HJ_F64 ? upwind_launch<double>(c, scheme, d, y, dL[d], dR[d], k, (const double*)epsv)

@@ -480,6 +480,62 @@ __device__ __forceinline__ void gather_stencils(const GridArgs<T, ND>& G, const 
     }
 }
 
+// ---- derivL[d], derivR[d] for EVERY dimension in one launch (round 4; hj_lf_split_begin: the split path of termLaxFriedrichs,
+// computeGradients): the stencils of a cell are gathered once (19 loads in 3-D instead of 3 x 7 in three launches that each
+// stream the whole array), 2*ND arrays are written, and the 4*ND reductions {-min L, max L, -min R, max R} per dimension go to
+// keys[4*d + k] as upwind_kernel leaves them.  The intended WENO5's epsilon is formed on the device (product, then sum, as the
+// host formed it for upwind_kernel: no per-dimension host synchronisation any more).  Same upwind<SCHEME>, same bits.
+template <typename T, int ND> struct UpwindAllArgs {
+    GridArgs<T, ND> G;
+    T* dL[ND];
+    T* dR[ND];
+    const T* max_d1sq;            // HJ_WENO5 only
+    unsigned long long* keys;     // 4*ND atomicMax keys, or null
+};
+template <typename T, int ND, int SCHEME>
+__global__ __launch_bounds__(256) void upwind_all_kernel(const T* __restrict__ y, const UpwindAllArgs<T, ND> A) {
+    T eps[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        eps[d] = T(0);
+        if constexpr (SCHEME == HJ_WENO5) eps[d] = weno_eps_uncontracted<T>(A.max_d1sq[d]);
+    }
+    double m[4 * ND];
+#pragma unroll
+    for (int k = 0; k < 4 * ND; ++k) m[k] = -1e300;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < A.G.total; t += (long long)gridDim.x * blockDim.x) {
+        int idx[ND];
+        decode<T, ND>(A.G, t, idx);
+        const T* pc0 = y + t;
+        T v[ND][7];
+        gather_stencils<T, ND>(A.G, pc0, idx, pc0[0], v);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            T L, R;
+            upwind<SCHEME, T>(v[d], A.G.K[d], eps[d], L, R);
+            A.dL[d][t] = L;
+            A.dR[d][t] = R;
+            m[4 * d + 0] = fmax(m[4 * d + 0], -(double)L); m[4 * d + 1] = fmax(m[4 * d + 1], (double)L);
+            m[4 * d + 2] = fmax(m[4 * d + 2], -(double)R); m[4 * d + 3] = fmax(m[4 * d + 3], (double)R);
+        }
+    }
+    if (A.keys) {
+        __shared__ double red[4][4 * ND];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 4 * ND; ++k) {
+            const double w = wave_max(m[k]);
+            if (lane == 0) red[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 * ND) {
+            const int k = threadIdx.x;
+            const double w = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
+            if (w > -1e299) atomicMax(A.keys + k, max_key(w));
+        }
+    }
+}
+
 // Round 3: every stencil load is issued unconditionally.  The first version went through line_value(), whose boundary
 // branches sit in front of each of the 6*ND neighbour loads: the loads were serialised behind one another (a memory round
 // trip each) and the kernel took ~40 us on a 51^3 grid.  Now the neighbour offsets are formed with selects (periodic: the

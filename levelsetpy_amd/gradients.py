@@ -15,7 +15,7 @@ caller's array is not modified), and derivL/derivR are lists over dimensions lik
 import numpy as np
 
 from .context import is_tensor
-from .spatial import upwindFirstWENO5
+from .spatial import upwindFirstWENO5, upwind_all_dims
 from .utilities import cell, error
 
 __all__ = ["computeGradients"]
@@ -48,18 +48,26 @@ def computeGradients(g, data, dims=None, derivFunc=None):
         nanInds, infInds = np.isnan(data), np.isinf(data)
         work = np.where(nanInds | infInds, numInfty, data)
     derivC, derivL, derivR = cell(g.dim), cell(g.dim), cell(g.dim)
+    # a device tensor, every dimension, one of this package's derivative functions: ONE launch for all dimensions
+    # (hj_lf_split_begin, round 4) instead of one per dimension
+    both = upwind_all_dims(derivFunc, g, work) if (is_tensor(work) and nd == g.dim and dims.all()) else None
+    # the masks are only applied where there is something to restore (one reduction instead of six masked assignments)
+    masked = bool((nanInds | infInds).any())
     for i in range(g.dim):
         if not dims[i]:
             continue
-        if tau_length == 1 and nd == g.dim:
+        if both is not None:
+            L, R = both[0][i], both[1][i]
+        elif tau_length == 1 and nd == g.dim:
             L, R = derivFunc(g, work, i)                         # :63
         else:
             pairs = [derivFunc(g, work[t], i) for t in range(tau_length)]      # :69-71
             stack = (lambda xs: __import__("torch").stack(xs)) if is_tensor(pairs[0][0]) else np.stack
             L, R = stack([p[0] for p in pairs]), stack([p[1] for p in pairs])
         C = 0.5 * (L + R)                                        # :66
-        for arr in (C, L, R):
-            arr[nanInds] = float('nan')
-            arr[infInds] = float('inf')
+        if masked:
+            for arr in (C, L, R):
+                arr[nanInds] = float('nan')
+                arr[infInds] = float('inf')
         derivC[i], derivL[i], derivR[i] = C, L, R
     return derivC, derivL, derivR

@@ -680,3 +680,26 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "cell-substeps/s" and c["value"] > 1e5 and c["sample"]
     assert d["parity"]["ok"] is True and d["parity"]["max_abs_diff"] <= d["parity"]["tol"] == 1e-11
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd,dtype", [((23, 18, 31), 2, "float64"), ((40, 77), None, "float64"), ((9, 8, 10, 11), (0, 3), "float32"),
+                                        ((33, 20, 17), (0, 2), "float32")])
+def test_all_dimension_derivatives_in_one_launch_equal_the_per_dimension_kernel(scheme, n, pd, dtype):
+    """hj_lf_split_begin (round 4: ONE launch for every dimension, the stencils of a cell gathered once) against hj_upwind
+    (one launch per dimension): derivL / derivR bitwise equal, and the min / max the launch reduces equal to the arrays' own."""
+    from levelsetpy_amd.spatial import upwind_all_dims, cached_minmax
+    nd = len(n)
+    g, og = mk([-1.0] * nd, [1.0] * nd, n, pd)
+    rng = np.random.default_rng(31)
+    data = (O.shape_sphere(og, None, .4) + 0.05 * rng.standard_normal(n)).astype(dtype)
+    y = torch.as_tensor(data, device="cuda")
+    both = upwind_all_dims(DERIV[scheme], g, y)
+    assert both is not None
+    dL, dR = both
+    for d in range(nd):
+        l1, r1 = DERIV[scheme](g, y, d)
+        assert torch.equal(dL[d], l1) and torch.equal(dR[d], r1), "dim %d: %g / %g" % (d, float((dL[d] - l1).abs().max()), float((dR[d] - r1).abs().max()))
+        mm = cached_minmax(dL[d], dR[d])
+        assert mm is not None
+        assert mm[0] == min(float(dL[d].min()), float(dR[d].min())) and mm[1] == max(float(dL[d].max()), float(dR[d].max()))
