@@ -261,8 +261,11 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
         // second differences shared by both sides
         const T t0 = (u0 + u2) - T(2) * u1, t1 = (u1 + u3) - T(2) * u2;
         const T t2 = (u2 + u4) - T(2) * u3, t3 = (u3 + u5) - T(2) * u4;
-        const T bl1 = u0 + (T(3) * u2 - T(4) * u1), bl2 = u1 - u3, bl3 = u4 + (T(3) * u2 - T(4) * u3);
-        const T br1 = u5 + (T(3) * u3 - T(4) * u4), br2 = u4 - u2, br3 = u1 + (T(3) * u3 - T(4) * u2);
+        // the first-difference parts of the smoothness measures through the second differences (round 4: one FMA each instead
+        // of three operations):  u0 - 4u1 + 3u2 = t0 + 2(u2 - u1),  3u2 - 4u3 + u4 = t2 - 2(u3 - u2), and mirrored
+        const T s1 = u2 - u1, s2 = u3 - u2, s3 = u4 - u3;
+        const T bl1 = t0 + T(2) * s1, bl2 = u1 - u3, bl3 = t2 - T(2) * s2;
+        const T br1 = t3 - T(2) * s3, br2 = u4 - u2, br3 = t1 + T(2) * s2;
         // q = (S + eps)/eps = c13*t^2 + c4*b^2 + 1   with c13 = (13/12)/eps', c4 = (1/4)/eps'
         const T c13 = wk.c13, c4 = wk.c4;
         T l1 = c13 * (t0 * t0) + (c4 * (bl1 * bl1) + T(1));
