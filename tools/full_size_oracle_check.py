@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""BASELINE C4 (513^3 Dubins, fp64) and C5 (129^4 pendulum, fp32) against the CPU oracle at FULL size, once (minutes of one host core:
+too slow for the suite, which checks these sizes through size-independent properties).  C4: one odeCFL3 step through the drop-in
+API against oracle.ode_cfl_3; C5: one termLaxFriedrichs evaluation against oracle.term_lax_friedrichs (fp32 product, fp64 oracle).
+Test infrastructure: imports oracle/.  usage: full_size_oracle_check.py [c4|c5|both]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import levelsetpy_amd as L
+from oracle import hj_oracle as O
+
+what = sys.argv[1] if len(sys.argv) > 1 else "both"
+
+
+def mem_available_gb():
+    for ln in open("/proc/meminfo"):
+        if ln.startswith("MemAvailable:"):
+            return int(ln.split()[1]) / 1e6
+    return 0.0
+
+
+# the NumPy oracle keeps a few dozen whole-grid temporaries alive: refuse to start on a host that could run out of memory
+need = {"c4": 80.0, "c5": 160.0}
+for leg in ("c4", "c5"):
+    if what in (leg, "both") and mem_available_gb() < need[leg]:
+        print("%s: %.0f GB of host memory available, %.0f wanted: leg skipped" % (leg, mem_available_gb(), need[leg]))
+        what = {"both": "c5" if leg == "c4" else "c4", leg: "none"}.get(what, what)
+if what in ("c4", "both"):
+    n = int(os.environ.get("N", "513"))
+    lo, hi = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n)]
+    g = L.createGrid(np.array([lo]).T, np.array([hi]).T, n * np.ones((3, 1), dtype=np.int64), 2)
+    og = O.Grid(lo, hi, [n, n, n], [2])
+    d0 = O.shape_cylinder(og, 2, None, .5)
+    sysn = L.DubinsVehicleRel(g, 1, 1)
+    sd = L.Bundle(dict(grid=g, hamFunc=sysn.hamiltonian, partialFunc=sysn.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=L.upwindFirstWENO5))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], torch.as_tensor(d0.reshape(-1, 1), device="cuda"), op, sd)
+    got = y.cpu().numpy()
+    print("C4 %d^3: product step done (t = %.6e); oracle running on one core ..." % (n, t), flush=True)
+    osys = O.DubinsRel(og, 1, 1)
+    calls = [0]
+    def term(tt, yy):
+        calls[0] += 1
+        t0 = time.time()
+        r = O.term_lax_friedrichs(og, osys, "WENO5_ASSHIPPED", tt, yy)
+        print("   oracle stage %d: %.0f s" % (calls[0], time.time() - t0), flush=True)
+        return r
+    t0 = time.time()
+    to, yo = O.ode_cfl_3(term, [0., 10.], d0.reshape(-1, 1), 0.8, single_step=True)
+    diff = float(np.abs(got - yo).max())
+    print("C4 %d^3 one odeCFL3 step vs oracle: max |diff| = %.3e (max |y| %.3f), t %r / %r, oracle %.0f s" % (n, diff, float(np.abs(yo).max()), t, to, time.time() - t0), flush=True)
+    assert diff <= 1e-11 and abs(t - to) <= 1e-14
+    del got, yo, y, d0
+if what in ("c5", "both"):
+    q = int(os.environ.get("Q", "129"))
+    lo, hi = [-np.pi] * 4, [np.pi * (1 - 2 / q)] * 4
+    g = L.createGrid(np.array([lo]).T, np.array([hi]).T, q * np.ones((4, 1), dtype=np.int64), [0, 1, 2, 3], low_mem=True)
+    og = O.Grid(lo, hi, [q] * 4, [0, 1, 2, 3])
+    d0 = O.shape_sphere(og, None, .5)
+    s4 = L.DoublePendulum4D(g, 1.0)
+    sd = L.Bundle(dict(grid=g, hamFunc=s4.hamiltonian, partialFunc=s4.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=L.upwindFirstWENO5))
+    yd, sb, _ = L.termLaxFriedrichs(0., torch.as_tensor(d0.astype(np.float32).reshape(-1, 1), device="cuda"), sd)
+    got = yd.cpu().numpy().astype(np.float64)
+    print("C5 %d^4 fp32: product term done (stepBound %.6e); oracle (fp64) running on one core ..." % (q, sb), flush=True)
+    t0 = time.time()
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), "WENO5_ASSHIPPED", 0., d0.astype(np.float32).astype(np.float64).reshape(-1, 1))
+    scale = float(np.abs(yo).max())
+    diff = float(np.abs(got - yo).max())
+    print("C5 %d^4 termLaxFriedrichs (fp32) vs oracle (fp64): max |diff| = %.3e = %.2e of max |ydot| %.3f; stepBound rel. diff %.2e; oracle %.0f s" %
+          (q, diff, diff / scale, scale, abs(sb - sbo) / sbo, time.time() - t0), flush=True)
+    assert diff <= 1e-4 * scale and abs(sb - sbo) <= 1e-5 * sbo
+print("full-size oracle check: ok")
