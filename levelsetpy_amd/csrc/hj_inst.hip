@@ -349,7 +349,8 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // halo ring parked in LDS (5 plane buffers, hj_fusedv.h): pays for the two-pairs-per-thread configuration
                 // from 201^3 up (A/B tools/experiments/r02_run32.sh, r02_run33.sh: +1 % at 201^3, +3.6 % at 513^3 with
                 // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
-                const bool ring = c->pair_ring == 1 || (c->pair_ring < 0 && HAM::ND <= 3 && kp.NT == 512 && kp.R == 2 && c->total >= 6500000);
+                // (2-D / 3-D only: the 4-D instantiations are built without the parked ring -- hj_fusedv.h, AHM -- whatever HJ_PAIR_RING says)
+                const bool ring = HAM::ND <= 3 && (c->pair_ring == 1 || (c->pair_ring < 0 && kp.NT == 512 && kp.R == 2 && c->total >= 6500000));
                 c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
                 const long long key = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (1ll << 35) |
                                       ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0) |
