@@ -1029,11 +1029,9 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_warm = env_int("HJ_F12_WARM", 9);
     c->f12_e2 = env_int("HJ_F12_E2", 0);
     c->tile_cells = env_int("HJ_TILE_CELLS", 0);
-    // chunks of a tile column marching pairwise in opposite directions (hj_fusedv.h, "PAIRED CHUNKS"): -1 (default) on 3-D grids
-    // below 10 M cells, where a launch is a single round of short chunks and their starts are 12 % of its traffic (201^3: +0.8 %,
-    // 38.8 -> 38.5 us per launch, four alternations on one box; 221^3 +-0; 301^3 -1.8 %, 513^3 -3.7 %: there the pair order halves
-    // the number of neighbouring tiles an XCD holds and the halo ring misses L2 more often -- profiles/r04_paired_chunks.txt);
-    // 0 never, 1 always
+    // chunks of a tile column marching pairwise in opposite directions (hj_fusedv.h, "PAIRED CHUNKS"): only in -DHJ_MAYDOWN=1 builds
+    // (hj_fused.h: measured in round 4 and compiled out -- the support costs every launch more than pairing gains); there -1 (default)
+    // = on for 3-D grids below 10 M cells, 0 never, 1 always.  Ignored by the default build.
     c->pair_dirs = env_int("HJ_PAIR_DIRS", -1);
     if (c->pair_dirs < 0) c->pair_dirs = (ndim == 3 && total < 10000000) ? 1 : 0;
     c->term_tiled_from = (long long)env_int("HJ_TERM_TILED_FROM", 1000000);     // cells; negative: never (the direct term_kernel everywhere)

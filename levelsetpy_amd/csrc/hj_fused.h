@@ -31,6 +31,16 @@
 #include "hj_device.h"
 #include "hj_termop.h"
 
+// PAIRED CHUNKS (hj_fusedv.h): chunks of a tile column marching pairwise in opposite directions so that the two workgroups of a
+// pair request their six common planes at the same moment.  Built and measured in round 4: -4 % fabric traffic at 201^3, but the
+// down-marching support costs the plane loop ~90 instructions per two planes (8 more uniform branches, 30 more SGPR-spill moves,
+// a second copy of the axis-0 stencil code) in EVERY launch -- and a build without it is faster than pairing everywhere:
+// 201^3 36.3-38.5 us per launch against 38.4-38.7 paired, 513^3 +0.5 % (profiles/r04_paired_chunks.txt, last section).
+// 0 (default): compiled out, HJ_PAIR_DIRS is ignored; 1: the round-4 experiment.
+#ifndef HJ_MAYDOWN
+#define HJ_MAYDOWN 0
+#endif
+
 // Surplus halo slots shadow slot 0 (same source, same LDS cell, same value).  In 4-D (10 slots per thread, 2-3 % of them
 // surplus) their LDS stores go out unpredicated -- a benign duplicate write instead of an exec save + branch per slot and
 // plane: C5 +3 % (tools/experiments/r03_run54.sh).  In 2-D / 3-D most slots of the last round are surplus (2-D: 506 of 512)

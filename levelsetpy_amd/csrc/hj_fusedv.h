@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     int chunk_id, rem;
     bool down = false;
     {
-        const int paired = 2 * A.npairs * A.ntiles;
+        const int paired = HJ_MAYDOWN ? 2 * A.npairs * A.ntiles : 0;      // (0: `down` is provably false and the loop is the lean one)
         if (L < paired) {
             int pr, r2;
             fdivmod(L, fdiv_make(2 * A.ntiles), pr, r2);

@@ -64,8 +64,9 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
     A.nblocks = t.nblocks;
     if (t.nblocks >= (1 << 22)) return hjh::fail(HJ_EUNSUPPORTED, "more than 4 M workgroups in one launch (index arithmetic of the kernels)");
     A.blocks_per_xcd = t.bpx;
-    // chunks marching pairwise in opposite directions (pair kernel): not with edge ranges or a second range in the launch
-    A.npairs = (pair && c->pair_dirs && !s.gated && s.q1 <= s.q0 && ep.edge_count == 0) ? t.nchunks1 / 2 : 0;
+    // chunks marching pairwise in opposite directions (pair kernel; only in -DHJ_MAYDOWN=1 builds, hj_fused.h): not with edge ranges or a
+    // second range in the launch
+    A.npairs = (HJ_MAYDOWN && pair && c->pair_dirs && !s.gated && s.q1 <= s.q0 && ep.edge_count == 0) ? t.nchunks1 / 2 : 0;
     A.echunk = ep.echunk;
     A.nchunks_e1 = ep.ne[0];
     A.nchunks_e = ep.ne[0] + ep.ne[1];

@@ -3,7 +3,7 @@
 random 2-D / 3-D shapes, periodic axes, towardZero flags, schemes, RK orders.  Round 3: the intended WENO5 reduces its
 epsilon inside the producing launches at every size here (HJ_EPS_FUSE_MIN_CELLS=0) and a fourth variant runs the
 one-cell-per-lane kernel with the two-launch pre-pass in front of every stage (HJ_EPS_FUSE=0).  Round 4: two more variants
-march the chunks of a tile column pairwise in opposite directions (HJ_PAIR_DIRS=1, with and without the ring).
+march the chunks of a tile column pairwise in opposite directions (HJ_PAIR_DIRS=1, with and without the ring; only -DHJ_MAYDOWN=1 builds honour it).
 usage: stress_pair.py [cases] [seed]"""
 import ctypes as C, os, sys
 import numpy as np
