@@ -88,6 +88,7 @@ __device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsr
 #ifndef HJ_EARLY_ARGS
 #define HJ_EARLY_ARGS 1
 #endif
+template <int K> struct IntTag { static constexpr int value = K; };
 constexpr int HJ_VPAD = 4;      // left pad of an LDS row (cells): even, so that tile cell 0 of a row is 16-byte aligned
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int MODE = 0>
@@ -253,7 +254,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 
     // axis-0 queue q[r][c][j] <-> plane P(m - 3 + j) of cell c of slot r; filled in ASCENDING plane order whatever the
     // direction (the two workgroups of a pair then ask for their common planes at the same moment)
-    T q[R][2][7];
+    // (8 deep: the two plane iterations of a loop pass read windows [0, 7) and [1, 8) of it and the queue is shifted by TWO places
+    //  once per pass -- 6 register moves per cell and pass instead of 12; round 4, late: the 201^3 launch is bound by instruction issue)
+    T q[R][2][8];
 #pragma unroll
     for (int jj = 0; jj < 7; ++jj) {
         V tmp[R];
@@ -569,7 +572,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
     int ring_c = 0;                                            // LDS buffer of the plane the next iteration computes
-    auto body = [&](int m, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
+    auto body = [&](auto off_tag, int m, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
+        constexpr int OFF = decltype(off_tag)::value;          // window [OFF, OFF + 7) of the queue is planes P(m - 3) .. P(m + 3)
         const int p = plane_at(m);                              // the plane this iteration computes
 #ifdef HJ_STAMP
         const unsigned long long st0 = __builtin_readcyclecounter();
@@ -585,8 +589,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         for (int r = 0; r < R; ++r)
             if (r < R - 1 || last_real) {
                 V c2;
-                c2.x = q[r][0][3];
-                c2.y = q[r][1][3];
+                c2.x = q[r][0][3 + OFF];
+                c2.y = q[r][1][3 + OFF];
                 *reinterpret_cast<V*>(buf + own_lds[r]) = c2;
             }
         park_halo(bufh, hal_c, hin_c, halp_c, hinp_c);
@@ -613,10 +617,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                     // the queue holds the planes in MARCH order: hand the stencil the same seven values in grid order
                     T qg[7];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) qg[j] = q[r][c][6 - j];
+                    for (int j = 0; j < 7; ++j) qg[j] = q[r][c][6 - j + OFF];
                     upwind_cd<SCHEME, T>(qg, A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
                 } else {
-                    upwind_cd<SCHEME, T>(q[r][c], A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+                    upwind_cd<SCHEME, T>(q[r][c] + OFF, A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
                 }
             }
             const T* base = buf + own_lds[r];
@@ -626,9 +630,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 T va[7], vb[7];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
-                    if (j == 3) { va[j] = q[r][0][3]; vb[j] = q[r][1][3]; continue; }
+                    if (j == 3) { va[j] = q[r][0][3 + OFF]; vb[j] = q[r][1][3 + OFF]; continue; }
 #if defined(HJ_ABLATE) && (HJ_ABLATE & 2)
-                    va[j] = q[r][0][j]; vb[j] = q[r][1][j];
+                    va[j] = q[r][0][j + OFF]; vb[j] = q[r][1][j + OFF];
 #else
                     const V n2 = *reinterpret_cast<const V*>(base + (j - 3) * ls[d]);
                     va[j] = n2.x;
@@ -641,13 +645,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             {   // the contiguous axis: cells j-3 .. j+4 = [b64][b128][own pair][b128][b64]
                 T w[8];
 #if defined(HJ_ABLATE) && (HJ_ABLATE & 2)
-                w[0] = q[r][0][0]; w[1] = q[r][0][1]; w[2] = q[r][0][2]; w[5] = q[r][1][4]; w[6] = q[r][1][5]; w[7] = q[r][1][6];
-                w[3] = q[r][0][3]; w[4] = q[r][1][3];
+                w[0] = q[r][0][0 + OFF]; w[1] = q[r][0][1 + OFF]; w[2] = q[r][0][2 + OFF]; w[5] = q[r][1][4 + OFF]; w[6] = q[r][1][5 + OFF]; w[7] = q[r][1][6 + OFF];
+                w[3] = q[r][0][3 + OFF]; w[4] = q[r][1][3 + OFF];
 #else
                 w[0] = base[-3];
                 const V l2 = *reinterpret_cast<const V*>(base - 2);
                 w[1] = l2.x; w[2] = l2.y;
-                w[3] = q[r][0][3]; w[4] = q[r][1][3];
+                w[3] = q[r][0][3 + OFF]; w[4] = q[r][1][3 + OFF];
                 const V r2 = *reinterpret_cast<const V*>(base + 2);
                 w[5] = r2.x; w[6] = r2.y;
                 w[7] = base[4];
@@ -677,8 +681,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 T o;
                 if (GEN && A.ydot_only) o = ydot;
                 else {
-                    o = rk_stage_out<NP>(A.stage, A.ca, A.cb, A.dt, y0v, q[r][c][3], ydot);
-                    if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0v : q[r][c][3]);
+                    o = rk_stage_out<NP>(A.stage, A.ca, A.cb, A.dt, y0v, q[r][c][3 + OFF], ydot);
+                    if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0v : q[r][c][3 + OFF]);
                 }
                 if (c == 0) o2.x = o; else o2.y = o;
             }
@@ -709,10 +713,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         load_y0(p2, y0_c);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            if constexpr (OFF == 0) {            // the pass's first plane: the new plane joins behind the window, nothing moves
+                q[r][0][7] = own_c[r].x;
+                q[r][1][7] = own_c[r].y;
+            } else {                              // its second plane: two places down, ready for the next pass
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { q[r][0][j] = q[r][0][j + 1]; q[r][1][j] = q[r][1][j + 1]; }
-            q[r][0][6] = own_c[r].x;
-            q[r][1][6] = own_c[r].y;
+                for (int j = 0; j < 6; ++j) { q[r][0][j] = q[r][0][j + 2]; q[r][1][j] = q[r][1][j + 2]; }
+                q[r][0][6] = own_c[r].x;
+                q[r][1][6] = own_c[r].y;
+            }
         }
 #ifdef HJ_STAMP
         {   // diagnostic build: shader-clock time of the phases of a plane iteration, summed per wave
@@ -725,8 +734,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 5] = wall_clock64();   // loop start
     const int nplanes = p_end - p_begin;
     for (int m = 0; m < nplanes; m += PD) {
-        body(m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
-        if (m + 1 < nplanes) body(m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
+        body(IntTag<0>(), m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
+        if (m + 1 < nplanes) body(IntTag<1>(), m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
         if (A.timing && tid == 0 && m == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 7] = wall_clock64();
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
