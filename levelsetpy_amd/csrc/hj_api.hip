@@ -155,12 +155,13 @@ static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t 
 // Axis-0 chunking: blocks = ntiles * nchunks should fill the GPU in whole "rounds" of resident
 // workgroups (capacity = CUs * workgroups per CU for this kernel), and every chunk pays 6 warm-up
 // planes of loads.  Pick the chunk count that minimises  rounds * (chunk + warm-up cost).
-void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu) {
+void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu, int64_t chunk_max) {
     const int64_t planes = p1 - p0;
     const int64_t capacity = (int64_t)c->num_cus * std::max(1, blocks_per_cu);
     // one buffer descriptor spans a chunk plus 3 planes either side: keep it below 4 GiB
     const double plane_bytes = (double)(c->total / c->N[0]) * (double)c->esz;
     int64_t chunk_cap = (int64_t)(4294967295.0 / plane_bytes) - 2 * HJ_STENCIL;
+    if (chunk_max > 0) chunk_cap = std::min(chunk_cap, chunk_max);
     if (chunk_cap < 1) { t.ok = false; return; }
     int64_t best_nch = 1;
     double best_cost = 1e300;
@@ -1045,6 +1046,8 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->f12_pair = env_int("HJ_F12_PAIR", 1);
     c->f12_e1 = env_int("HJ_F12_E1", 0);
     c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on grids of >= 6.5 M cells (light stencils) / 2.5 M (heavy stencils, fp32 4-D) (0: scalar kernel everywhere, 2: pair kernel whatever the size)
+    c->tile4_sel = env_int("HJ_TILE4_SEL", -1);
+    c->pair4 = env_int("HJ_PAIR4", 1);        // 4-D fp32 light stencils: the compile-time-tile kernel (hj_fused4v.h); 0: the generic pair kernel
     c->pair_nt = env_int("HJ_PAIR_NT", 0);
     c->pair_r = env_int("HJ_PAIR_R", 0);
     c->pair_kh = env_int("HJ_PAIR_KH", 0);

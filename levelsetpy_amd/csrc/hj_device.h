@@ -20,8 +20,8 @@
 namespace hj {
 
 template <typename T> struct Lim;
-template <> struct Lim<double> { static constexpr double tiny = 1e-99; };
-template <> struct Lim<float>  { static constexpr float  tiny = 1e-30f; };
+template <> struct Lim<double> { static constexpr double tiny = 1e-99; static constexpr double lowest = -1.0e300; };
+template <> struct Lim<float>  { static constexpr float  tiny = 1e-30f; static constexpr float lowest = -3.0e38f; };
 
 // epsilon of the intended WENO5 formed as a product, then a sum (no FMA): what the term kernels and the host-side array path use
 template <typename T> __device__ __forceinline__ T weno_eps_uncontracted(T max_d1sq) {
@@ -44,6 +44,11 @@ template <> __device__ __forceinline__ float  t_abs<float>(float x)   { return _
 __device__ __forceinline__ double max_acc(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_acc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 struct FDiv { int d; float r; };
@@ -503,10 +508,54 @@ template <typename T> struct HamDoublePendulum {
     // state (th1, w1, th2, w2); drift f of the frictionless double pendulum with unit masses and
     // lengths, g = 9.8 (dynamics as in the reference's Tests/double_pendulum.py:29-51);
     // H = sum p_i f_i + u(|p2|+|p4|), alpha_i = |f_i| + u*[i in {1,3}].  aux = sin/cos tables.
+    //
+    // Round 5: the drift FACTORED by what it depends on.  With sd = sin(th2-th1), cd = cos(th2-th1), den = 2 - cd^2:
+    //     f1 =  a*w1^2 + b1 + c*w2^2        a  = sd*cd/den,  c = sd/den,  b1 = g*(s2*cd - 2 s1)/den
+    //     f3 = -a*w2^2 + b3 - 2c*w1^2                                     b3 = 2g*(s1*cd - s2)/den
+    // a, b1, c, b3 depend on (th1, th2) only -- one ROW of the table below per (axis-0 plane, axis-2 index) -- and a cell is
+    // left with four FMAs.  Until round 4 every cell of every plane recomputed sd, cd, den, a division and two ten-term
+    // polynomials (a fifth of the C5 loop's vector instructions).  row() + eval_row() is the one arithmetic of the system:
+    // eval() composes them per cell (direct / one-cell-per-lane / generic pair kernels), the 4-D pair kernel (hj_fused4v.h)
+    // evaluates row() once per (plane, tile row) into LDS.  The costate scales sc[1], sc[3] are folded into the row.
     static constexpr unsigned PLANE_DEP = 0xA;
     struct Cell { T w1, w2, s2, c2; };
     struct Plane { T s1, c1; };
     using Raw = Cell;
+    struct Row { T a1, b1, c1, a3, b3, c3; };          // f1s = sc1*f1 = a1*w1^2 + b1 + c1*w2^2;  f3s = sc3*f3 = a3*w2^2 + b3 + c3*w1^2
+    struct TCell { T w1s, w1q, w2s, w2q; };            // sc0*w1, w1^2, sc2*w2, w2^2
+    static constexpr int ROW_AXIS = 2;                 // the plane axis a Row varies along (besides axis 0)
+    __device__ static __forceinline__ Row row(T s1, T c1, T s2, T c2, const T* sc) {
+        const T G = T(9.8);
+        const T sd = s2 * c1 - c2 * s1;  // sin(th2-th1)
+        const T cd = c2 * c1 + s2 * s1;  // cos(th2-th1)
+        const T den = T(2) - cd * cd;
+        const T rden = T(1) / den;
+        const T a = (sd * cd) * rden, c = sd * rden;
+        const T b1 = (G * (s2 * cd - T(2) * s1)) * rden;
+        const T b3 = (T(2) * G * (s1 * cd - s2)) * rden;
+        Row r;
+        r.a1 = sc[1] * a; r.b1 = sc[1] * b1; r.c1 = sc[1] * c;
+        r.a3 = -(sc[3] * a); r.b3 = sc[3] * b3; r.c3 = T(-2) * (sc[3] * c);
+        return r;
+    }
+    // the row of axis-0 plane i0 and axis-ROW_AXIS index irow
+    __device__ static __forceinline__ Row row_at(const HamTables<T>& P, int i0, int irow, const T* sc) {
+        return row(P.aux[0][i0], P.aux[1][i0], P.aux[2][irow], P.aux[3][irow], sc);
+    }
+    __device__ static __forceinline__ TCell tcell(const Cell& c, const T* sc) {
+        return TCell{sc[0] * c.w1, c.w1 * c.w1, sc[2] * c.w2, c.w2 * c.w2};
+    }
+    // q: unscaled costates (p_d = sc[d] q_d); alpha comes back in the stencil's scale (sc[d]*alpha_d)
+    __device__ static __forceinline__ void eval_row(const HamTables<T>& P, const TCell& c, const Row& r, const T* sc, const T* q, T& H, T* alpha) {
+        const T us1 = sc[1] * P.par[0], us3 = sc[3] * P.par[0];
+        const T f1s = r.a1 * c.w1q + (r.c1 * c.w2q + r.b1);
+        const T f3s = r.a3 * c.w2q + (r.c3 * c.w1q + r.b3);
+        H = q[0] * c.w1s + (q[1] * f1s + (q[2] * c.w2s + (q[3] * f3s + (us1 * t_abs(q[1]) + us3 * t_abs(q[3])))));
+        alpha[0] = t_abs(c.w1s);
+        alpha[1] = t_abs(f1s) + us1;
+        alpha[2] = t_abs(c.w2s);
+        alpha[3] = t_abs(f3s) + us3;
+    }
     __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {
         Cell c;
         c.w1 = P.coord[1][idx[1]];
@@ -515,8 +564,8 @@ template <typename T> struct HamDoublePendulum {
         c.c2 = P.aux[3][idx[2]];
         return c;
     }
-    // next cell along axis 3: only w2 changes -- sin/cos of the angle difference, the denominator and its reciprocal are then
-    // computed once per PAIR in eval() (common subexpressions of the two inlined calls)
+    // next cell along axis 3: only w2 changes -- the row is then computed once per PAIR in eval() (common subexpressions of
+    // the two inlined calls)
     __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw& first) {
         Cell c = first;
         c.w2 = P.coord[3][idx[3]];
@@ -535,38 +584,13 @@ template <typename T> struct HamDoublePendulum {
     template <bool NP = false>      // (build-defined system: there is no reference expression order to follow)
     __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& pl,
                                                 const T* sc, const T* q, T& H, T* alpha) {
-        // the generic (unfolded) form: scale the costates first
-        T p[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) p[d] = sc[d] * q[d];
-        const T G = T(9.8), L1 = T(1), L2 = T(1), M1 = T(1), M2 = T(1);
-        const T u = P.par[0];
-        const T w1 = c.w1, w2 = c.w2, s1 = pl.s1, c1 = pl.c1, s2 = c.s2, c2 = c.c2;
-        const T sd = s2 * c1 - c2 * s1;  // sin(th2-th1)
-        const T cd = c2 * c1 + s2 * s1;  // cos(th2-th1)
-        const T den1 = (M1 + M2) * L1 - M2 * L1 * cd * cd;
-        // ONE division for both accelerations (den2 = (L2/L1)*den1 = den1 here): an IEEE fp32 division is ~10 VALU
-        // instructions, two of them were a fifth of the C5 loop's arithmetic (round 3)
-#ifdef HJ_PENDULUM_TWO_DIV
-        const T f1 = (M2 * L1 * w1 * w1 * sd * cd + M2 * G * s2 * cd + M2 * L2 * w2 * w2 * sd
-                      - (M1 + M2) * G * s1) / den1;
-        const T den2 = (L2 / L1) * den1;
-        const T f3 = (-M2 * L2 * w2 * w2 * sd * cd + (M1 + M2) * G * s1 * cd
-                      - (M1 + M2) * L1 * w1 * w1 * sd - (M1 + M2) * G * s2) / den2;
-#else
-        const T rden = T(1) / den1;
-        const T f1 = (M2 * L1 * w1 * w1 * sd * cd + M2 * G * s2 * cd + M2 * L2 * w2 * w2 * sd
-                      - (M1 + M2) * G * s1) * rden;
-        const T f3 = (-M2 * L2 * w2 * w2 * sd * cd + (M1 + M2) * G * s1 * cd
-                      - (M1 + M2) * L1 * w1 * w1 * sd - (M1 + M2) * G * s2) * ((L1 / L2) * rden);
-#endif
-        H = p[0] * w1 + p[1] * f1 + p[2] * w2 + p[3] * f3 + u * (t_abs(p[1]) + t_abs(p[3]));
-        alpha[0] = sc[0] * t_abs(w1);
-        alpha[1] = sc[1] * (t_abs(f1) + u);
-        alpha[2] = sc[2] * t_abs(w2);
-        alpha[3] = sc[3] * (t_abs(f3) + u);
+        eval_row(P, tcell(c, sc), row(pl.s1, pl.c1, c.s2, c.c2, sc), sc, q, H, alpha);
     }
 };
+// does a Hamiltonian type factor its coefficients into rows (Row / row() / tcell() / eval_row(), as HamDoublePendulum does)?
+template <typename...> struct hj_void { typedef void type; };
+template <typename H, typename = void> struct ham_has_rows { static constexpr bool value = false; };
+template <typename H> struct ham_has_rows<H, typename hj_void<typename H::Row>::type> { static constexpr bool value = true; };
 
 // ---- the tail of one cell's substep, shared by every kernel (fused, pair, stage-fused, direct)
 // ydot = -(H - sum_d hd_d alpha_d): termLaxFriedrichs / artificialDissipationGLF (term_lax_friedrich.py:111-128,
@@ -576,6 +600,25 @@ __device__ __forceinline__ T lf_ydot(const HamTables<T>& P, const typename HAM::
                                      const T* sc, const T* pc, const T* hd, T* alpha) {
     T H;
     HAM::template eval<NP>(P, c, u, sc, pc, H, alpha);
+    if constexpr (NP) {
+#pragma clang fp contract(off)
+        T diss = T(0);
+#pragma unroll
+        for (int d = 0; d < HAM::ND; ++d) diss = diss + hd[d] * alpha[d];
+        return -(H - diss);
+    } else {
+        T diss = T(0);
+#pragma unroll
+        for (int d = 0; d < HAM::ND; ++d) diss += hd[d] * alpha[d];
+        return -(H - diss);
+    }
+}
+// the same with the Hamiltonian's coefficients handed over as a row (Hamiltonians that factor them: ham_has_rows)
+template <bool NP, typename HAM, typename T>
+__device__ __forceinline__ T lf_ydot_row(const HamTables<T>& P, const typename HAM::TCell& c, const typename HAM::Row& r,
+                                         const T* sc, const T* pc, const T* hd, T* alpha) {
+    T H;
+    HAM::eval_row(P, c, r, sc, pc, H, alpha);
     if constexpr (NP) {
 #pragma clang fp contract(off)
         T diss = T(0);

@@ -130,6 +130,8 @@ struct hj_ctx {
     int tile_block[2] = {4, 4};                     // HJ_TB1 / HJ_TB2: 4-D tile order in blocks of this many tiles along axes 1 and 2 (0: plain order)
     int f12_e1 = 0;                                 // tuning / tests: force the tile's row count (pair variant)
     int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail
+    int tile4_sel = -1;                             // HJ_TILE4_SEL: which tile of HJ_TILE4 (hj_inst.hip) to take (-1: the first that fits)
+    int pair4 = 1;                                  // HJ_PAIR4: 4-D fp32 light stencils through the compile-time-tile kernel (hj_fused4v.h)
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
     int last_nbuf = 2;
@@ -163,7 +165,7 @@ using namespace hj;
 
 int env_int(const char* name, int dflt);
 Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1, int nbuf = 2, std::vector<Tiling>* all = nullptr);
-void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu);
+void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu, int64_t chunk_max = 0);
 int cfg_kh(int nd, int nt, int r);
 int eps_rows_to_vals(hj_ctx* c, const double* rows, int nrows, hipStream_t stream);   // rows -> ctx->weno_vals (kernels that do not fold)
 

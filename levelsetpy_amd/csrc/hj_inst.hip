@@ -7,6 +7,7 @@
 #include "hj_fused12.h"
 #include "hj_fusedv.h"
 #include "hj_fused12v.h"
+#include "hj_fused4v.h"
 #include "hj_launch.h"
 
 namespace hjh {
@@ -149,6 +150,113 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
     if (plain && s.stage == HJ_STAGE_EULER) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 1, PAIR>(c, s, t);
     if (plain) return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 2, PAIR>(c, s, t);
     return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 0, PAIR>(c, s, t);
+}
+
+// ---- the 4-D pair kernel with a compile-time tile (hj_fused4v.h; round 5): (threads, pairs per thread, E1, E2, E3, waves/SIMD hint).
+// 256 threads x 2 pairs on a 5 x 6 x 34 tile (1020 cells, two workgroups per CU) is the shape the round-3 sweeps of C5 settled on
+#ifndef HJ_TILE4
+#define HJ_TILE4(X) X(256, 2, 3, 5, 66, 2) X(512, 2, 5, 6, 66, 2) X(256, 2, 5, 6, 34, 2)
+#endif
+// does the fixed tile fit this grid?  A tile never exceeds an axis (the last one is shifted back inside), and no tile may begin
+// or end 1 or 3 cells from an end of the contiguous axis: its halo columns are pairs (hj_fused4v.h), which must lie wholly inside
+// or wholly outside the grid
+inline bool tile4_fits(const hj_ctx* c, int e1, int e2, int e3) {
+    if (!(c->ndim == 4 && c->N[1] >= e1 && c->N[2] >= e2 && c->N[3] >= e3 && c->total < (1ll << 31))) return false;
+    const int n3 = (int)c->N[3], nt = (n3 + e3 - 1) / e3;
+    for (int t = 0; t < nt; ++t) {
+        const int org = std::min(t * e3, n3 - e3), rest = n3 - org - e3;
+        if (org == 1 || org == 3 || rest == 1 || rest == 3) return false;
+    }
+    return true;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int E1, int E2, int E3, int OCC, bool PG, int MODE>
+int launch_pair4_mode(hj_ctx* c, const SubstepCall& s) {
+    using G = hj::Tile4<E1, E2, E3>;
+    constexpr bool ROWS = hj::ham_has_rows<HAM>::value;
+    constexpr int ER = hj::RowAxis<HAM, ROWS>::value == 1 ? E1 : E2;
+    auto kern = fused_pair4_kernel<T, HAM, SCHEME, NT, R, E1, E2, E3, OCC, PG, MODE>;
+    Tiling t;
+    memset(&t, 0, sizeof(t));
+    t.ok = true;
+    const int Ed[4] = {1, E1, E2, E3};
+    t.ntiles = 1;
+    for (int d = 0; d < HJ_MAX_DIM; ++d) { t.E[d] = 1; t.ntile[d] = 1; }
+    for (int d = 1; d < 4; ++d) {
+        t.E[d] = Ed[d];
+        t.ntile[d] = (int)((c->N[d] + Ed[d] - 1) / Ed[d]);
+        t.ntiles *= t.ntile[d];
+    }
+    t.lpitch = G::PITCH;
+    const size_t base_lds = 512 + 2 * (size_t)G::PLANE * sizeof(T);
+    // two workgroups per CU (OCC waves per SIMD of NT threads): each may take half the CU's LDS; the row table of a chunk
+    // (ER rows x ROWF values per plane) has to fit in what the plane buffers leave
+    const int wg_per_cu = std::max(1, OCC * 256 / NT);
+    const size_t lds_cap = (size_t)(160 * 1024) / wg_per_cu - 256;
+    int64_t chunk_max = 0;
+    if (ROWS) {
+        if (base_lds + (size_t)ER * G::ROWF * sizeof(T) * 8 > lds_cap) return hjh::fail(HJ_EUNSUPPORTED, "4-D tile leaves no LDS for the row table");
+        chunk_max = (int64_t)((lds_cap - base_lds) / ((size_t)ER * G::ROWF * sizeof(T)));
+    }
+    EdgePlan ep;
+    {
+        const int rc_plan = plan_chunks(c, s, t, wg_per_cu, ep, chunk_max);
+        if (rc_plan) return rc_plan;
+    }
+    t.lds_bytes = base_lds + (ROWS ? (size_t)t.chunk * ER * G::ROWF * sizeof(T) : 0);
+    if (c->debug) {
+        fprintf(stderr, "[hj] pair4 tiling NT=%d R=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d lds=%zu PG=%d MODE=%d\n",
+                NT, R, OCC, E1, E2, E3, G::PITCH, t.ntiles, t.chunk, t.nchunks, t.nblocks, t.lds_bytes, (int)PG, MODE);
+        c->debug = 0;
+    }
+    FusedArgs<T, 4> A;
+    memset(&A, 0, sizeof(A));
+    A.bound = s.bound;
+    unsigned grid_blocks = 0;
+    {
+        const int rc_fill = fill_fused_args<T, 4>(c, s, t, ep, SCHEME, true, A, grid_blocks);
+        if (rc_fill) return rc_fill;
+    }
+    A.lds_nbuf = 2;
+    A.halo_ahead = 0;
+    A.npairs = 0;
+    c->last_nbuf = 2;
+    c->last_kernel = "fused_pair4_kernel";
+    c->last_E[0] = t.chunk;
+    for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = t.E[d];
+    if (t.lds_bytes > 64 * 1024) {
+        static std::mutex mu;
+        static std::map<std::pair<int, const void*>, size_t> granted_by_kernel;
+        std::lock_guard<std::mutex> lock(mu);
+        size_t& granted = granted_by_kernel[std::make_pair(c->device, reinterpret_cast<const void*>(kern))];
+        if (granted < t.lds_bytes) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+            granted = t.lds_bytes;
+        }
+    }
+    if (c->launch_stop) {
+        hipExtLaunchKernelGGL(kern, dim3(grid_blocks), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
+                              (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
+        c->launch_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid_blocks), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
+    }
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int E1, int E2, int E3, int OCC>
+int launch_pair4(hj_ctx* c, const SubstepCall& s) {
+    // PG: can a halo cell of a plane axis be a ghost (an extrapolated axis among 1..3)?  All-periodic grids take the lean instantiation
+    const bool pg = c->bc[1] != HJ_BC_PERIODIC || c->bc[2] != HJ_BC_PERIODIC || c->bc[3] != HJ_BC_PERIODIC;
+    const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0 && !c->no_plain;
+    const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
+#define HJ_P4(PG_, MODE_) return launch_pair4_mode<T, HAM, SCHEME, NT, R, E1, E2, E3, OCC, PG_, MODE_>(c, s)
+    if (pg) { if (mode == 1) HJ_P4(true, 1); if (mode == 2) HJ_P4(true, 2); HJ_P4(true, 0); }
+    if (mode == 1) HJ_P4(false, 1);
+    if (mode == 2) HJ_P4(false, 2);
+    HJ_P4(false, 0);
+#undef HJ_P4
 }
 
 // (threads, PAIRS per thread, halo slots per thread, waves/SIMD hint) of the pair kernel
@@ -334,6 +442,16 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             // light stencils on 2-D / 3-D grids: from 6.5 M cells (191^3 up the (512,2) shape + ring wins; 141^3 ... 181^3 run 3-10 % faster as
             // three 256-thread workgroups per CU of the one-cell-per-lane kernel, tools/experiments/r03_run50.sh, r03_run51.sh)
             const long long pair_from = (HAM::ND <= 3 && light_scheme(SCHEME)) ? 6500000 : 2500000;
+            // 4-D, fp32, light stencil: the compile-time-tile kernel (hj_fused4v.h) when its tile fits the grid (HJ_PAIR4=0: the generic pair kernel)
+            if constexpr (HAM::ND == 4 && sizeof(T) == 4 && light_scheme(SCHEME)) {
+                if (c->pair != 0 && c->pair4 != 0 && c->pair_nt <= 0 && (c->total >= pair_from || c->pair == 2)) {
+                    // the first tile of the list that fits (HJ_TILE4_SEL = k: only the k-th, for A/B runs)
+                    int k4 = 0;
+#define X(NT_, R_, E1_, E2_, E3_, OCC_) if ((c->tile4_sel < 0 || c->tile4_sel == k4) && tile4_fits(c, E1_, E2_, E3_)) return launch_pair4<T, HAM, SCHEME, NT_, R_, E1_, E2_, E3_, OCC_>(c, s); ++k4;
+                    HJ_TILE4(X)
+#undef X
+                }
+            }
             if (c->pair != 0 && pair_dim && (c->total >= pair_from || c->pair_nt > 0 || c->pair == 2)) {
                 // two cells per lane (hj_fusedv.h), round-2 A/B at 151^3 ... 513^3: the light stencils
                 // run 2 pairs per thread in 512-thread workgroups (220-232 VGPRs against 246-256 for four single

@@ -9,8 +9,9 @@ namespace hjh {
 
 struct EdgePlan { int echunk = 0, ne[2] = {0, 0}, edge_count = 0; };
 
-inline int plan_chunks(hj_ctx* c, const SubstepCall& s, Tiling& t, int occ_blocks, EdgePlan& ep) {
-        choose_chunks(c, t, s.p0, s.p1, occ_blocks);
+// chunk_max > 0: no chunk longer than this many planes (kernels whose LDS use grows with the chunk: hj_fused4v.h)
+inline int plan_chunks(hj_ctx* c, const SubstepCall& s, Tiling& t, int occ_blocks, EdgePlan& ep, int64_t chunk_max = 0) {
+        choose_chunks(c, t, s.p0, s.p1, occ_blocks, chunk_max);
         if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
         t.nchunks1 = t.nchunks;
         if (s.q1 > s.q0) {     // second range: same chunk length

@@ -179,7 +179,7 @@ def _pendulum_alpha_max(g, u):
 
 def test_c5_129_to_the_4_fp32_all_periodic_properties(monkeypatch):
     """BASELINE C5 at full size and precision (129^4 = 277 M cells, fp32, every axis periodic): the kernel the
-    library picks (round 3: two cells per lane, 256 threads x 2 pairs, three tiled plane axes), the one-cell-per-lane
+    library picks (round 5: the compile-time-tile pair kernel, hj_fused4v.h), the one-cell-per-lane
     kernel (1024,1,3,2,2) and the independent direct kernel on an RK3 step -- bit for bit the same state; the last
     substep split into plane ranges bitwise, the CFL bound against the definition."""
     n = 129
@@ -192,7 +192,7 @@ def test_c5_129_to_the_4_fp32_all_periodic_properties(monkeypatch):
     par = [1.0, 0., 0., 0.]
     dt = 2e-4
     outs = {}
-    for name, force, pair, kern in (("default", "0", None, b"fused_pair_kernel"), ("single", "0", "0", b"fused_substep_kernel"),
+    for name, force, pair, kern in (("default", "0", None, b"fused_pair4_kernel"), ("single", "0", "0", b"fused_substep_kernel"),
                                     ("direct", "1", None, b"direct_substep_kernel")):
         monkeypatch.setenv("HJ_FORCE_DIRECT", force)
         if pair is None:

@@ -1,0 +1,162 @@
+"""Round-5 GPU tests.
+
+* the 4-D compile-time-tile kernel (csrc/hj_fused4v.h: `fused_pair4_kernel`, the kernel BASELINE C5 runs from round 5):
+  against the fp64 oracle at the tolerance SURVEY 8(c) states for fp32 (1e-4 relative), bit for bit against the independent
+  direct kernel and the one-cell-per-lane kernel, on grids just above its 5 x 6 x 34 tile (shifted last tiles, all-periodic
+  and mixed boundary conditions: the PG instantiation), through plane ranges, the termRestrictUpdate clamp and the CFL bound.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import levelsetpy_amd as L  # noqa: E402
+from levelsetpy_amd import _ffi  # noqa: E402
+from levelsetpy_amd.context import DeviceGrid  # noqa: E402
+from oracle import hj_oracle as O  # noqa: E402
+
+from test_gpu_parity import sdata, DERIV, _substep  # noqa: E402
+from test_gpu_configs import pendulum_grid  # noqa: E402
+
+
+def _substep_rs(dg, scheme, ham, par, stage, dt, y, y0, out, restrict_sign):
+    _ffi.check(dg.lib.hj_rk_substep(dg.ctx, _ffi.SCHEME_IDS[scheme], ham, _ffi.darr(par), 0., stage, dt, restrict_sign,
+                                    dg.ptr(y), dg.ptr(y0) if y0 is not None else None, dg.ptr(out), 3, 0, dg.shape[0]))
+
+
+def _last_kernel(g):
+    dg = g.__dict__["_hj_device"]
+    dg = dg[next(iter(dg))] if isinstance(dg, dict) else dg
+    return dg.lib.hj_last_kernel(dg.ctx)
+
+
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO2"])
+@pytest.mark.parametrize("n,pd", [((8, 7, 9, 40), (0, 1, 2, 3)),        # all periodic: the lean instantiation; every axis has a shifted last tile
+                                  ((7, 11, 6, 36), (0, 2)),             # axes 1 and 3 extrapolated: ghosts of the plane axes (PG)
+                                  ((9, 5, 13, 34), None),               # nothing periodic; axis 1 and axis 3 exactly one tile
+                                  ((6, 12, 8, 70), (1, 3))])            # axis 0 extrapolated (ghost planes), axis 2 extrapolated
+def test_pair4_kernel_vs_fp64_oracle_and_direct(scheme, n, pd, monkeypatch):
+    g, og = pendulum_grid(n, pd)
+    rng = np.random.default_rng(5)
+    data = O.shape_sphere(og, None, 1.5) + 0.05 * np.sin(2 * og.xs[0]) * np.cos(og.xs[2]) + 0.02 * rng.standard_normal(n)
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), scheme, 0., data.reshape(-1, 1))
+    scale = float(np.max(np.abs(yo)))
+    y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
+    got = {}
+    want = {"pair4": b"fused_pair4_kernel", "pair": b"fused_pair_kernel", "single": b"fused_substep_kernel", "direct": b"direct_substep_kernel"}
+    for name in ("pair4", "pair", "single", "direct"):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if name == "direct" else "0")
+        monkeypatch.setenv("HJ_PAIR", "0" if name == "single" else "2")
+        monkeypatch.setenv("HJ_PAIR4", "1" if name == "pair4" else "0")
+        g.__dict__.pop("_hj_device", None)
+        yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
+        assert _last_kernel(g) == want[name], (name, _last_kernel(g))
+        assert abs(sb - sbo) <= 1e-5 * sbo, (name, sb, sbo)
+        got[name] = yd.cpu().numpy().astype(np.float64)
+    g.__dict__.pop("_hj_device", None)
+    rel = np.abs(got["pair4"] - yo) / scale
+    if scheme.startswith("WENO"):
+        assert rel.max() <= 1e-4, rel.max()
+    else:       # fp32 ENO2: a selector whose margin is below fp32 rounding may go the other way (masked comparison)
+        assert np.mean(rel > 1e-4) <= 2e-3 and rel.max() <= 0.2, (float(np.mean(rel > 1e-4)), rel.max())
+    for name in ("pair", "single", "direct"):
+        assert np.array_equal(got["pair4"], got[name]), (name, float(np.max(np.abs(got["pair4"] - got[name]))))
+
+
+@pytest.mark.parametrize("sel", [0, 1, 2])
+@pytest.mark.parametrize("pd", [(0, 1, 2, 3), (2,), None])
+def test_pair4_every_built_tile_bitwise_vs_direct(sel, pd, monkeypatch):
+    """Each compile-time tile of HJ_TILE4 (hj_inst.hip: 3x5x66 in 256 threads, 5x6x66 in 512, 5x6x34 in 256) on a grid all of them
+    fit, periodic / mixed / extrapolated axes: the term equals the direct kernel's bit for bit and the oracle's to 1e-4."""
+    n = (6, 7, 9, 72)
+    g, og = pendulum_grid(n, pd)
+    rng = np.random.default_rng(11)
+    data = O.shape_sphere(og, None, 1.5) + 0.05 * np.sin(2 * og.xs[0]) * np.cos(og.xs[2]) + 0.02 * rng.standard_normal(n)
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), "WENO5_ASSHIPPED", 0., data.reshape(-1, 1))
+    y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
+    got = {}
+    for name in ("pair4", "direct"):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if name == "direct" else "0")
+        monkeypatch.setenv("HJ_PAIR", "2")
+        monkeypatch.setenv("HJ_TILE4_SEL", str(sel))
+        g.__dict__.pop("_hj_device", None)
+        yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV["WENO5_ASSHIPPED"]))
+        assert _last_kernel(g) == (b"fused_pair4_kernel" if name == "pair4" else b"direct_substep_kernel")
+        if name == "pair4":
+            dg = g.__dict__["_hj_device"]
+            dg = dg[next(iter(dg))] if isinstance(dg, dict) else dg
+            e = (C.c_int * 4)()
+            _ffi.check(dg.lib.hj_last_tile(dg.ctx, e))
+            assert tuple(e)[1:] == {0: (3, 5, 66), 1: (5, 6, 66), 2: (5, 6, 34)}[sel], tuple(e)
+        assert abs(sb - sbo) <= 1e-5 * sbo
+        got[name] = yd.cpu().numpy().astype(np.float64)
+    g.__dict__.pop("_hj_device", None)
+    assert np.array_equal(got["pair4"], got["direct"]), float(np.max(np.abs(got["pair4"] - got["direct"])))
+    assert (np.abs(got["pair4"] - yo) / float(np.max(np.abs(yo)))).max() <= 1e-4
+
+
+def test_pair4_rk3_steps_clamp_ranges_and_bound(monkeypatch):
+    """One RK3 step through hj_rk_substep with the new kernel: the three stage instantiations (Euler / with y0 / general with
+    the termRestrictUpdate clamp) equal the direct kernel bit for bit; a stage computed as three plane ranges equals one launch;
+    the in-kernel CFL maxima equal the definition."""
+    n = (37, 10, 12, 68)
+    g, og = pendulum_grid(n)
+    rng = np.random.default_rng(7)
+    d0 = torch.as_tensor(O.shape_sphere(og, None, 1.5) + 0.05 * np.sin(2 * og.xs[0]) * np.cos(og.xs[2]) + 0.02 * rng.standard_normal(n),
+                         device="cuda", dtype=torch.float32).contiguous()
+    par = [1.0, 0., 0., 0.]
+    dt = 2e-3
+    outs = {}
+    for name, force in (("pair4", "0"), ("direct", "1")):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+        monkeypatch.setenv("HJ_PAIR", "2")
+        dg = DeviceGrid(g, "float32")
+        dg.bind_stream()
+        a, b, c, r = dg.empty(), dg.empty(), dg.empty(), dg.empty()
+        _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_EULER, dt, d0, None, a)
+        _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_HALF, dt, a, d0, b)
+        _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_FULL, dt, b, d0, c)
+        assert dg.lib.hj_last_kernel(dg.ctx) == (b"fused_pair4_kernel" if force == "0" else b"direct_substep_kernel")
+        _substep_rs(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_FULL, dt, b, d0, r, -1)
+        if force == "0":
+            c2 = torch.zeros_like(c)
+            for k, (p0, p1) in enumerate([(0, 5), (5, 30), (30, n[0])]):
+                _substep(dg, "WENO5_ASSHIPPED", _ffi.HAM_DOUBLE_PENDULUM, par, _ffi.STAGE_RK3_FULL, dt, b, d0, c2, p0, p1, slot=4 + k)
+            dg.sync()
+            assert torch.equal(c, c2), float((c - c2).abs().max())
+            sb, am = C.c_double(), (C.c_double * 4)()
+            _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 3, C.byref(sb), am))
+            f = O.DoublePendulum4D(og, 1.0).drift()
+            ref = [float(np.max(np.abs(f[0]))), float(np.max(np.abs(f[1]))) + 1.0, float(np.max(np.abs(f[2]))), float(np.max(np.abs(f[3]))) + 1.0]
+            for d in range(4):
+                assert abs(am[d] - ref[d]) <= 3e-6 * ref[d], (d, am[d], ref[d])
+        dg.sync()
+        outs[name] = (a, b, c, r)
+    for k in range(4):
+        assert torch.equal(outs["pair4"][k], outs["direct"][k]), (k, float((outs["pair4"][k] - outs["direct"][k]).abs().max()))
+    assert float((outs["pair4"][2] - outs["pair4"][3]).abs().max()) > 0      # the clamp did something
+
+
+def test_pair4_long_axis0_chunks_the_row_table():
+    """An axis 0 longer than one LDS row table holds: several chunks per tile column, each with its own table."""
+    n = (300, 5, 6, 34)
+    g, og = pendulum_grid(n)
+    data = O.shape_sphere(og, None, 1.5) + 0.05 * np.sin(2 * og.xs[0]) * np.cos(og.xs[2])
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), "WENO5_ASSHIPPED", 0., data.reshape(-1, 1))
+    import os
+    os.environ["HJ_PAIR"] = "2"
+    try:
+        g.__dict__.pop("_hj_device", None)
+        y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
+        yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV["WENO5_ASSHIPPED"]))
+        assert _last_kernel(g) == b"fused_pair4_kernel"
+    finally:
+        os.environ.pop("HJ_PAIR", None)
+        g.__dict__.pop("_hj_device", None)
+    rel = np.abs(yd.cpu().numpy().astype(np.float64) - yo) / float(np.max(np.abs(yo)))
+    assert rel.max() <= 1e-4, rel.max()
+    assert abs(sb - sbo) <= 1e-5 * sbo

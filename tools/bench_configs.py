@@ -49,4 +49,4 @@ if "c5" in which:
     g = L.createGrid(gmin, gmax, n * np.ones((4, 1), dtype=np.int64), [0, 1, 2, 3], low_mem=True)
     d0 = L.shapeSphere(g, np.zeros((4, 1)), .5).astype(np.float32)
     run("C5 double pendulum %d^4 (one GPU)" % n, g, _ffi.HAM_DOUBLE_PENDULUM, [1.0], "WENO5_ASSHIPPED",
-        "float32", torch.as_tensor(d0), steps=3, warmup=1)
+        "float32", torch.as_tensor(d0), steps=int(os.environ.get("C5_STEPS", "3")), warmup=int(os.environ.get("C5_WARMUP", "1")))
