@@ -22,7 +22,44 @@
 #pragma once
 #include "hj_fusedv.h"
 
+// HJ_ABLATE4 (tuning builds only; the results are WRONG): bits 1 no stencil / Hamiltonian arithmetic, 2 no LDS stencil reads, 8 no halo
+// loads, 16 no halo LDS stores, 32 no barrier, 64 no y0 loads -- what each part of the plane loop costs (profiles/r05_c5_ablation.txt)
+#if defined(HJ_ABLATE4) && !defined(HJ_TUNE_BUILD)
+#error "HJ_ABLATE4 gives wrong results: tuning builds (-DHJ_TUNE_BUILD) only"
+#endif
+#ifndef HJ_ABLATE4
+#define HJ_ABLATE4 0
+#endif
+// planes the own cells / the RK operand y0 are requested ahead of their use (register sets; the loop is unrolled by their common multiple)
+// cache policy of the streams (gfx940+ aux encoding: 1 = sc0, 2 = nt, 16 = sc1): own cells, y0, output
+#ifndef HJ_P4_AUX_OWN
+#define HJ_P4_AUX_OWN 0
+#endif
+#ifndef HJ_P4_AUX_Y0
+#define HJ_P4_AUX_Y0 0
+#endif
+#ifndef HJ_P4_AUX_OUT
+#define HJ_P4_AUX_OUT 0
+#endif
+#ifndef HJ_P4_AUX_HALO
+#define HJ_P4_AUX_HALO 0
+#endif
+#ifndef HJ_P4_DO
+#define HJ_P4_DO 2
+#endif
+#ifndef HJ_P4_DY
+#define HJ_P4_DY 2
+#endif
+
 namespace hj {
+
+template <int AUX>
+__device__ __forceinline__ void buf_store2_aux(Pair<float>::V v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    using W2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(W2, v), r, off, soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store2_aux(Pair<double>::V v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) { buf_store2(v, r, off, soff); }
 
 // geometry of an (E1, E2, E3) tile, in cells of T
 template <int E1, int E2, int E3> struct Tile4 {
@@ -91,7 +128,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
     constexpr int LS1 = G::LS1, LS2 = G::LS2, PLANE = G::PLANE, HALF = G::HALF;
     constexpr int KP = (G::NPS + NT - 1) / NT;
     static_assert(G::SLOTS <= NT * R, "tile does not fit the slots");
-    static_assert((PLANE + 2 * W * LS1 + 8) * (int)sizeof(T) < 65536, "the LDS offsets of a stencil read should fit the 16-bit immediate");
     constexpr bool GEN = (MODE == 0);
     constexpr bool NP = np_order(SCHEME);
     constexpr bool ROWS = ham_has_rows<HAM>::value;
@@ -160,7 +196,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         if (direct) {
             const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load2(ry, own_g[r], so, T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load2<HJ_P4_AUX_OWN>(ry, own_g[r], so, T());
         } else {
             const PlaneSrc<T> s = plane_src<T, ND>(A, p);
             const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
@@ -181,10 +217,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         }
     };
     auto load_y0 = [&](int p, V* dst) {
-        if (use_y0) {
+        if (use_y0 && !(HJ_ABLATE4 & 64)) {
             const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = buf_load2(ry0, own_g[r], so, T());
+            for (int r = 0; r < R; ++r) dst[r] = buf_load2<HJ_P4_AUX_Y0>(ry0, own_g[r], so, T());
         }
     };
 
@@ -284,8 +320,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
     struct Halo { V p[KP]; V pi[KP]; };
     auto load_halo = [&](int p, Halo& h) {
         const unsigned so = (unsigned)(p - p_lo) * plane_bytes;
+        if (HJ_ABLATE4 & 8) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) h.p[k] = buf_load2(ry, hp_src[k], so, T());
+        for (int k = 0; k < KP; ++k) h.p[k] = buf_load2<HJ_P4_AUX_HALO>(ry, hp_src[k], so, T());
         if constexpr (PG) {
             if (tile_ghost) {
 #pragma unroll
@@ -297,6 +334,11 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         }
     };
     auto park_halo = [&](T* buf, const Halo& h) {
+        if (HJ_ABLATE4 & 16) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) asm volatile("" ::"v"(h.p[k]));
+            return;
+        }
         if (PG && tile_ghost) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
@@ -322,20 +364,26 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         for (int k = 0; k < KP; ++k) { hal[s].pi[k].x = T(0); hal[s].pi[k].y = T(0); }
         load_halo(clamp_c(p_begin + s), hal[s]);
     }
-    V own[PD][R], y0s[PD][R];
+    constexpr int DO = HJ_P4_DO, DY = HJ_P4_DY;
+    constexpr int UNR = (DO == 4 || DY == 4) ? 4 : ((DO == 3 || DY == 3) ? 6 : 2);
+    static_assert(UNR % DO == 0 && UNR % DY == 0 && UNR % PD == 0, "prefetch depths 2, 3 or 4");
+    V own[DO][R], y0s[DY][R];
     typename HAM::Plane pls[PD];
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
+    for (int s = 0; s < DO; ++s) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) { own[s][r].x = T(0); own[s][r].y = T(0); y0s[s][r].x = T(0); y0s[s][r].y = T(0); }
-        if (s < PD - 1) load_own(clamp_q(p_begin + 4 + s), own[s]);
+        for (int r = 0; r < R; ++r) { own[s][r].x = T(0); own[s][r].y = T(0); }
+        if (s < DO - 1) load_own(clamp_q(p_begin + 4 + s), own[s]);
     }
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
-        const int ps = clamp_c(p_begin + s);
-        load_y0(ps, y0s[s]);
-        if constexpr (!ROWS) pls[s] = HAM::plane(A.ham, ps, A.sc);
+    for (int s = 0; s < DY; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { y0s[s][r].x = T(0); y0s[s][r].y = T(0); }
+        load_y0(clamp_c(p_begin + s), y0s[s]);
     }
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if constexpr (!ROWS) pls[s] = HAM::plane(A.ham, clamp_c(p_begin + s), A.sc);
 
     // ---- ROWS: the Hamiltonian's rows of every plane of the chunk -> LDS (the loop's first barrier orders them)
     if constexpr (ROWS) {
@@ -356,10 +404,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
 #pragma unroll
     for (int d = 0; d < ND; ++d) { amax[d][0] = Lim<T>::lowest; amax[d][1] = Lim<T>::lowest; }
 
+    auto stencil = [&](const T* v, const T* K, T& pcv, T& hdv) {
+        if (HJ_ABLATE4 & 1) {
+            pcv = v[0]; hdv = v[6];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) asm volatile("" ::"v"(v[j]));
+        } else {
+            upwind_cd<SCHEME, T>(v, K, T(0), WenoK<T>{T(0), T(0)}, pcv, hdv);
+        }
+    };
     auto body = [&](auto off_tag, int p, V* own_c, V* own_n, Halo& hal_c, V* y0_c, typename HAM::Plane& pl_c) {
         constexpr int OFF = decltype(off_tag)::value;          // window [OFF, OFF + 7) of the queue; LDS buffer OFF
         T* const buf = lds + OFF * PLANE;
-        load_own(clamp_q(p + 3 + PD), own_n);
+        load_own(clamp_q(p + 3 + DO), own_n);
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (r < R - 1 || last_real) {
@@ -369,7 +426,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
                 *reinterpret_cast<V*>(buf + W * LS1 + own_lds[r]) = c2;
             }
         park_halo(buf, hal_c);
-        __syncthreads();
+        if (!(HJ_ABLATE4 & 32)) __syncthreads();
         const int p2 = clamp_c(p + PD);
         load_halo(p2, hal_c);
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
@@ -380,7 +437,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         for (int r = 0; r < R; ++r) {
             T pc[2][ND], hd[2][ND];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) upwind_cd<SCHEME, T>(q[r][c] + OFF, A.K[0], T(0), WenoK<T>{T(0), T(0)}, pc[c][0], hd[c][0]);
+            for (int c = 0; c < 2; ++c) stencil(q[r][c] + OFF, A.K[0], pc[c][0], hd[c][0]);
             const T* base = buf + own_lds[r];           // = the pair's cell - W*LS1
 #pragma unroll
             for (int d = 1; d < LA; ++d) {
@@ -389,16 +446,21 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
                     if (j == 3) { va[j] = q[r][0][3 + OFF]; vb[j] = q[r][1][3 + OFF]; continue; }
+                    if (HJ_ABLATE4 & 2) { va[j] = q[r][0][j + OFF]; vb[j] = q[r][1][j + OFF]; continue; }
                     const V n2 = *reinterpret_cast<const V*>(base + W * LS1 + (j - 3) * LSD[d]);
                     va[j] = n2.x;
                     vb[j] = n2.y;
                 }
-                upwind_cd<SCHEME, T>(va, A.K[d], T(0), WenoK<T>{T(0), T(0)}, pc[0][d], hd[0][d]);
-                upwind_cd<SCHEME, T>(vb, A.K[d], T(0), WenoK<T>{T(0), T(0)}, pc[1][d], hd[1][d]);
+                stencil(va, A.K[d], pc[0][d], hd[0][d]);
+                stencil(vb, A.K[d], pc[1][d], hd[1][d]);
             }
             {
                 T w[8];
                 const T* ctr = base + W * LS1;
+                if (HJ_ABLATE4 & 2) {
+                    w[0] = q[r][0][0 + OFF]; w[1] = q[r][0][1 + OFF]; w[2] = q[r][0][2 + OFF]; w[5] = q[r][1][4 + OFF]; w[6] = q[r][1][5 + OFF]; w[7] = q[r][1][6 + OFF];
+                    w[3] = q[r][0][3 + OFF]; w[4] = q[r][1][3 + OFF];
+                } else {
                 w[0] = ctr[-3];
                 const V l2 = *reinterpret_cast<const V*>(ctr - 2);
                 w[1] = l2.x; w[2] = l2.y;
@@ -406,13 +468,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
                 const V r2 = *reinterpret_cast<const V*>(ctr + 2);
                 w[5] = r2.x; w[6] = r2.y;
                 w[7] = ctr[4];
-                upwind_cd<SCHEME, T>(w, A.K[LA], T(0), WenoK<T>{T(0), T(0)}, pc[0][LA], hd[0][LA]);
-                upwind_cd<SCHEME, T>(w + 1, A.K[LA], T(0), WenoK<T>{T(0), T(0)}, pc[1][LA], hd[1][LA]);
+                }
+                stencil(w, A.K[LA], pc[0][LA], hd[0][LA]);
+                stencil(w + 1, A.K[LA], pc[1][LA], hd[1][LA]);
             }
             V o2;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 T alpha[ND], ydot;
+                if (HJ_ABLATE4 & 1) {
+                    ydot = pc[c][0] + hd[c][ND - 1];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) { alpha[d] = pc[c][d]; ydot += hd[c][d]; }
+                } else
                 if constexpr (ROWS) {
                     typedef T V4 __attribute__((ext_vector_type(4)));
                     const T* rp = rowtab + row_plane + rowoff[r];
@@ -440,9 +508,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
                 }
                 if (c == 0) o2.x = o; else o2.y = o;
             }
-            if (r < R - 1 || last_real) buf_store2(o2, rout, own_g[r], so_out);
+            if (r < R - 1 || last_real) buf_store2_aux<HJ_P4_AUX_OUT>(o2, rout, own_g[r], so_out);
         }
-        load_y0(p2, y0_c);
+        load_y0(clamp_c(p + DY), y0_c);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if constexpr (OFF == 0) {
@@ -457,10 +525,15 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         }
     };
 
-    for (int p = p_begin; p < p_end; p += PD) {
-        body(IntTag<0>(), p, own[0], own[1], hal[0], y0s[0], pls[0]);
-        if (p + 1 < p_end) body(IntTag<1>(), p + 1, own[1], own[0], hal[1], y0s[1], pls[1]);
+#define HJ_BODY4(u)                                                                                                     \
+    if constexpr (UNR > (u)) {                                                                                          \
+        if (p + (u) < p_end)                                                                                            \
+            body(IntTag<(u) & 1>(), p + (u), own[(u) % DO], own[((u) + DO - 1) % DO], hal[(u) % PD], y0s[(u) % DY], pls[(u) % PD]); \
     }
+    for (int p = p_begin; p < p_end; p += UNR) {
+        HJ_BODY4(0) HJ_BODY4(1) HJ_BODY4(2) HJ_BODY4(3) HJ_BODY4(4) HJ_BODY4(5)
+    }
+#undef HJ_BODY4
 
     if (A.bound) {
         {   // alpha of the dimensions that do not vary along the march: column constants, taken once

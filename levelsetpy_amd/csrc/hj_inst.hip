@@ -152,10 +152,14 @@ int launch_tiled(hj_ctx* c, const SubstepCall& s, const Tiling& t) {
     return launch_tiled_mode<T, HAM, SCHEME, NT, R, KH, OCC, PD, 0, PAIR>(c, s, t);
 }
 
-// ---- the 4-D pair kernel with a compile-time tile (hj_fused4v.h; round 5): (threads, pairs per thread, E1, E2, E3, waves/SIMD hint).
-// 256 threads x 2 pairs on a 5 x 6 x 34 tile (1020 cells, two workgroups per CU) is the shape the round-3 sweeps of C5 settled on
+// ---- the 4-D pair kernel with a compile-time tile (hj_fused4v.h; round 5): (threads, pairs per thread, E1, E2, E3, waves/SIMD hint), in
+// order of preference; the first whose tile fits the grid is taken.  C5 (129^4 fp32; profiles/r05_c5_tiles.txt): rows of 66 cells (264 B)
+// instead of 34 cost the CU's texture-address path a third less per byte (profiles/r05_l1_rate.txt) and halve the partial cache lines:
+// 5x6x66 in 512 threads (one workgroup per CU) 0.335-0.35 of 8 TB/s with fabric traffic 1.42x algorithmic, 3x5x66 in 256 threads (two
+// per CU) 0.34, 5x6x34 in 256 threads 0.30 (= the generic pair kernel on the same tile: the round-4 default, traffic 1.86x).
+// Shapes with 3 and 4 waves per SIMD (768 x 2 pairs, 1024 x 1 pair at 122 VGPRs) run at the same 0.335-0.35.
 #ifndef HJ_TILE4
-#define HJ_TILE4(X) X(256, 2, 3, 5, 66, 2) X(512, 2, 5, 6, 66, 2) X(256, 2, 5, 6, 34, 2)
+#define HJ_TILE4(X) X(512, 2, 5, 6, 66, 2) X(256, 2, 3, 5, 66, 2) X(256, 2, 5, 6, 34, 2)
 #endif
 // does the fixed tile fit this grid?  A tile never exceeds an axis (the last one is shifted back inside), and no tile may begin
 // or end 1 or 3 cells from an end of the contiguous axis: its halo columns are pairs (hj_fused4v.h), which must lie wholly inside
