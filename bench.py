@@ -71,9 +71,10 @@ def parse():
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported under 'also'")
-    ap.add_argument("--also", default="WENO5,513,C3,C5,CFL,API,RTC", help="comma list of the extra workloads to time (API = the 201^3 / "
+    ap.add_argument("--also", default="WENO5,513,C3,C5,CFL,API,RTC,RANGE", help="comma list of the extra workloads to time (API = the 201^3 / "
                     "51^3 workloads through odeCFL3 / HJIPDE_solve, the reference's own call protocol; RTC = the same system as a "
-                    "Hamiltonian compiled at run time with hipRTC, and as Python callbacks on the split path)")
+                    "Hamiltonian compiled at run time with hipRTC, and as Python callbacks on the split path; RANGE = a Hamiltonian whose alpha depends "
+                    "on the costate range, fused in two launches per stage against the split path)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -460,6 +461,82 @@ def time_runtime_ham(L, torch, _ffi, DeviceGrid, a, s_head):
         "value": cells * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k,
         "vs_run_time_hamiltonian": (cells * 3 * k / med) / s["value"]}
     return out
+
+
+RANGE_SRC = """
+    H = par[0] * x[0] * p[1] + 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    alpha[0] = fmax(fabs(dmin[0]), fabs(dmax[0]));
+    alpha[1] = fmax(fabs(dmin[1]), fabs(dmax[1])) + fabs(par[0] * x[0]);
+    alpha[2] = fmax(fabs(dmin[2]), fabs(dmax[2]));
+"""
+
+
+class _RangeSystem(object):
+    """H = |p|^2 / 2 + c x_0 p_1 with the partials bounded over the costate RANGE the reference hands to partialFunc
+    (artificial_diss_glf.py:80-99) -- a system whose alpha depends on derivMin / derivMax: the general protocol."""
+
+    def __init__(self, grid, c, torch):
+        self.grid, self.c, self.torch = grid, c, torch
+        self._x0 = None
+
+    def _x0t(self, like):
+        if self._x0 is None:
+            v = np.asarray(self.grid.vs[0]).ravel()
+            self._x0 = self.torch.as_tensor(v, device=like.device, dtype=like.dtype).reshape(-1, 1, 1)
+        return self._x0
+
+    def hamiltonian(self, t, data, p, sd=None):
+        return self.c * self._x0t(p[0]) * p[1] + 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2])
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        a = max(abs(float(dmin[dim])), abs(float(dmax[dim])))
+        if dim != 1:
+            return a
+        return (a + (self.c * self._x0t(data)).abs()).expand(data.shape).contiguous()
+
+
+def time_range_ham(L, torch, a):
+    """A Hamiltonian whose alpha depends on the costate range, through odeCFL3 single-step calls (device tensors): as Python
+    callbacks on the split path (before registration), then registered as a device expression: range pass + fused substep per
+    stage, deltaT from the first stage's reduced bound (one host read per step)."""
+    g = dubins_grid(L, a.n, a.n)
+    calc = {"WENO5_ASSHIPPED": L.upwindFirstWENO5, "ENO3": L.upwindFirstENO3, "ENO2": L.upwindFirstENO2, "WENO5": L.upwindFirstWENO5Intended}[a.scheme]
+    sysd = _RangeSystem(g, 0.7, torch)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    res = {}
+    ys = {}
+    for kind in ("split", "fused"):
+        if kind == "fused":
+            L.register_native_hamiltonian("bench_range", 3, RANGE_SRC, nparams=1).attach(sysd, params=lambda o: [o.c])
+        sd = L.Bundle(dict(grid=g, hamFunc=sysd.hamiltonian, partialFunc=sysd.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
+        y, t = device_sdf(torch, g, 0.5, ignore=(2,)).reshape(-1, 1), 0.0
+        for _ in range(3):
+            t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+        ys[kind] = (t, y.clone())
+        k = max(3, min(10, a.steps)) if kind == "split" else a.steps
+        walls = []
+        for _ in range(3 if kind == "split" else min(9, a.repeats)):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t1)
+        assert bool(torch.isfinite(y).all())
+        med = statistics.median(walls)
+        res[kind] = {"value": y.numel() * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k}
+    # the two paths computed the same three steps (1e-11: different operation order in the range reduction and the callbacks)
+    dmax = float((ys["fused"][1] - ys["split"][1]).abs().max())
+    assert abs(ys["fused"][0] - ys["split"][0]) <= 1e-12 and dmax <= 1e-10, (ys["fused"][0], ys["split"][0], dmax)
+    bps = BYTES_PER_SUBSTEP["float64"]
+    return {"%d^3 data-dependent alpha (range pass + fused substep)" % a.n: {
+        "workload": "H = |p|^2/2 + c x0 p1, alpha_d = max(|derivMin_d|, |derivMax_d|) (+ |c x0|), %s + GLF: a Hamiltonian registered at run time "
+                    "whose alpha reads the costate range (artificial_diss_glf.py:80-99), odeCFL3 singleStep calls on device tensors; "
+                    "two launches per stage + one elementwise launch and one host read of the bound per step" % a.scheme,
+        "value": res["fused"]["value"], "ms_per_step": res["fused"]["ms_per_step"], "steps": res["fused"]["steps"],
+        "roofline_frac": res["fused"]["value"] * bps / 1e9 / HBM_PEAK_GBS,
+        "split_path_ms_per_step": res["split"]["ms_per_step"], "vs_split_path": res["fused"]["value"] / res["split"]["value"],
+        "fused_vs_split_max_abs_diff_after_3_steps": dmax}}
 
 
 def summarize(r, steps):
@@ -1042,6 +1119,9 @@ def run(a, rank, world, local, slab_leg, cpu):
                     continue
                 if name == "RTC":
                     also.update(time_runtime_ham(L, torch, _ffi, DeviceGrid, a, s))
+                    continue
+                if name == "RANGE":
+                    also.update(time_range_ham(L, torch, a))
                     continue
                 if name == "API":
                     rep = min(15, a.repeats)

@@ -318,6 +318,25 @@ int hj_term_convection(hj_ctx* ctx, int scheme, const void* y, const void* const
 int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol,
                     const char* include_dir, const char* hiprtc_path, int* ham_id);
 int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built);
+/* Round 5: the same with flags.  HJ_HAM_RANGE: the expression also reads dmin[d] / dmax[d], the costate range the reference's
+ * artificialDissipationGLF hands to partialFunc (Dissipation/artificial_diss_glf.py:80-99: derivMin[i] = min over the grid of derivL[i]
+ * and derivR[i], derivMax likewise) -- alpha then depends on the data, and max(alpha) (:101-107) is reduced in the launch.  A substep of
+ * such a Hamiltonian is two launches (range pass, then the fused substep); hj_rk_step reads the first stage's bound once per step
+ * (ode_cfl_3.py:142) and keeps the later stages' bounds for the reference's CFL warning (hj_rk_last_bounds); hj_static_step_bound
+ * fails with HJ_EUNSUPPORTED (the bound is a property of the data).  fp64 and fp32 grids, 2-D / 3-D / 4-D. */
+#define HJ_HAM_RANGE 1
+int hj_ham_register2(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol, int flags,
+                     const char* include_dir, const char* hiprtc_path, int* ham_id);
+int hj_ham_flags(int ham_id, int* flags_host);
+/* stepBound of the stages of the last hj_rk_step on this ctx with an HJ_HAM_RANGE Hamiltonian (sb_host[0..*n_host), n <= 3):
+ * ode_cfl_3.py:173-175,215-217 warn when deltaT > min(1, 1.2 factorCFL) * stepBound at the later stages. */
+int hj_rk_last_bounds(hj_ctx* ctx, double* sb_host /* 3 */, int* n_host);
+/* Decomposed grids: the range of ONE slab is not the grid's.  hj_range_pass reduces derivL / derivR of the ctx's planes (pads read
+ * where the slab has neighbours) into 2*HJ_MAX_DIM order-preserving 64-bit keys at keys_dev ([d] max, [HJ_MAX_DIM-independent ndim + d]
+ * -min; an element-wise MAX over ranks of the keys is the reduction); hj_ctx_set_range_source makes later launches read the
+ * range from such keys instead of running their own pass (NULL: back to per-launch passes).  No reference counterpart. */
+int hj_range_pass(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, const void* y, void* keys_dev);
+int hj_ctx_set_range_source(hj_ctx* ctx, const void* keys_dev);
 /* compile the substep kernel of `scheme` and the alpha-bound kernel WITHOUT launching (needs no GPU) */
 int hj_ham_compile_check(int ham_id, int scheme);
 /* Compiled code objects are kept on disk, keyed by the generated source, the kernel headers' text and the compile options

@@ -70,6 +70,11 @@ SIGNATURES = {
     "hj_term_reinit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _pd]),
     "hj_term_convection": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _pd]),
     "hj_ham_register": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _i, C.c_char_p, C.c_char_p, _pi]),
+    "hj_ham_register2": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _pi]),
+    "hj_ham_flags": (_i, [_i, _pi]),
+    "hj_rk_last_bounds": (_i, [_vp, _pd, _pi]),
+    "hj_range_pass": (_i, [_vp, _i, _i, _pd, _vp, _vp]),
+    "hj_ctx_set_range_source": (_i, [_vp, _vp]),
     "hj_ham_info": (_i, [_i, _pi, _pi, _pi]),
     "hj_ham_compile_check": (_i, [_i, _i]),
     "hj_ham_cache_stats": (_i, [_pi, _pi]),
@@ -80,6 +85,8 @@ SIGNATURES = {
     "hj_last_tile": (_i, [_vp, _pi]),
     "hj_version": (C.c_char_p, []),
 }
+
+HAM_RANGE = 1          # hj_ham_register2 flag: alpha reads the costate range (dmin / dmax)
 
 _lib = None
 
@@ -108,11 +115,16 @@ def lib():
     return _lib
 
 
+class Unsupported(ValueError):
+    """HJ_EUNSUPPORTED: the library has no kernel for this combination (callers with another path may take it)."""
+
+
 def check(rc):
     """Non-zero return code -> ValueError, as the reference's error() (matlab_utils.py:134-137)."""
     if rc != 0:
         msg = lib().hj_last_error()
-        raise ValueError((msg or b"hj_mi355x error").decode("utf-8", "replace") + " (code %d)" % rc)
+        text = (msg or b"hj_mi355x error").decode("utf-8", "replace") + " (code %d)" % rc
+        raise (Unsupported if rc == -3 else ValueError)(text)
 
 
 def darr(values):

@@ -21,6 +21,27 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
+// a zeroed entry of the range-key ring becomes ctx->range_keys (as next_ring() does for the CFL bounds: a memset launch per pass
+// costs 4 us of launch time, the ring is zeroed once per RANGE_RING passes)
+int next_range_keys(hj_ctx* c) {
+    const size_t entry = 2 * HJ_MAX_DIM;
+    if (!c->range_ring) {
+        HIP_TRY(hipMalloc((void**)&c->range_ring, sizeof(unsigned long long) * entry * RANGE_RING));
+        HIP_TRY(hipMemsetAsync(c->range_ring, 0, sizeof(unsigned long long) * entry * RANGE_RING, c->stream));
+        c->range_pos = 0;
+    }
+    if (c->range_pos >= RANGE_RING) {
+        // every launch that reads or writes an entry is stream-ordered on the ctx streams: drain them, zero, go round again
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->edge_stream) HIP_TRY(hipStreamSynchronize(c->edge_stream));
+        HIP_TRY(hipMemsetAsync(c->range_ring, 0, sizeof(unsigned long long) * entry * RANGE_RING, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->range_pos = 0;
+    }
+    c->range_keys = c->range_ring + entry * (size_t)c->range_pos++;
+    return HJ_OK;
+}
+
 // ------------------------------------------------------------------------------------ tiling
 // Pick tile extents E[1..nd-1] (cells <= NT*R, halo slots <= KH*NT, LDS <= limit) minimising
 // (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
@@ -683,6 +704,8 @@ int post_halo(hj_ctx* c, void* buf, hipStream_t st, int depth = HJ_STENCIL) {
 int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, double dt, int rs,
                  const void* y, const void* y0, void* out) {
     int rc;
+    if (user_ham_dynamic(ham))
+        return fail(HJ_EUNSUPPORTED, "a range-dependent alpha needs the costate range of ALL ranks before a substep: use dist.SlabIntegrator (dynamic=True), not the native stepper");
     const int64_t n = c->N[0];
     hipStream_t main = c->stream;
     const bool talk = (c->lo_rank >= 0 || c->hi_rank >= 0);
@@ -1114,6 +1137,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
 }
 
 void hj_ctx_destroy(hj_ctx* c) {
+    if (c && c->range_ring) (void)hipFree(c->range_ring);
     if (!c) return;
     (void)hj_comm_destroy(c);
     for (int d = 0; d < HJ_MAX_DIM; ++d) if (c->coord[d]) (void)hipFree(c->coord[d]);
@@ -1547,6 +1571,121 @@ int hj_ctx_set_dissipation(hj_ctx* c, int kind) {
     return HJ_OK;
 }
 
+// One odeCFLn step for a Hamiltonian whose alpha depends on the data (the costate range; hj_rtc.hip, HJ_HAM_RANGE).  The reference's
+// first schemeFunc call yields ydot AND the stepBound that fixes deltaT (ode_cfl_3.py:129-151).  alpha(x, range) does not depend on a
+// node's own costate, so the bound of the first stage follows from the range alone: range pass of y, max(alpha) over the grid (the
+// kernel of hj_static_step_bound, a few microseconds), ONE host read, and the first stage is an ordinary fused Euler launch with
+// deltaT known -- no ydot array, no separate y + deltaT*ydot pass.  The later stages are range pass + fused substep with the
+// in-kernel max(alpha) kept; their bounds are read once at the end of the step for the reference's CFL warning (hj_rk_last_bounds).
+static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf, double factor_cfl,
+                           double max_step, int restrict_sign, const void* y_in, void* y_out, void* work0, void* work1,
+                           double* t_out, double* dt_out) {
+    if (c->diss_local) return fail(HJ_EUNSUPPORTED, "range-dependent alpha with the local Lax-Friedrichs variants runs on the split path");
+    if (c->range_src) return fail(HJ_ESTATE, "hj_rk_step with an external range source: step the slab through hj_rk_substep (dist.SlabIntegrator)");
+    const int64_t n0 = c->N[0];
+    int rc;
+    const int slot2 = HJ_BOUND_SLOTS - 2, slot3 = HJ_BOUND_SLOTS - 3;
+    {   // the range of y_in -> ctx->range_keys (a fresh entry of the ring)
+        SubstepCall r{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y_in, nullptr, y_out, nullptr, 0, n0};
+        r.range_only = true;
+        if ((rc = do_substep(c, r, -1))) return rc;
+    }
+    double sb1 = 0;
+    {   // stepBound = 1 / sum_d max_x alpha_d(x, range) / dx_d   (artificial_diss_glf.py:101-109)
+        HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
+        if ((rc = user_alpha_bound(c, ham, par, c->keys, true))) return rc;
+        unsigned long long k[HJ_MAX_DIM];
+        HIP_TRY(hipMemcpyAsync(k, c->keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        double inv = 0.0;
+        for (int d = 0; d < c->ndim; ++d) inv += key_to_double(k[d]) / c->dx[d];
+        sb1 = 1.0 / inv;
+    }
+    const double dt = std::min(std::min(factor_cfl * sb1, tf - t0), max_step);       // ode_cfl_3.py:142
+    c->last_bounds[0] = sb1;
+    c->last_bounds_n = 1;
+    void* first = order == 1 ? y_out : work0;
+    {
+        SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, first, nullptr, 0, n0};
+        a.range_ready = true;
+        if (order == 1) a.post_op = c->post_step_op;
+        if ((rc = do_substep(c, a, -1))) return rc;
+    }
+    double t = t0 + dt;
+    if (order >= 2) {
+        const int stage2 = order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF;
+        void* out2 = order == 2 ? y_out : work1;
+        SubstepCall b{scheme, ham, stage2, restrict_sign, par, dt, first, y_in, out2, nullptr, 0, n0};
+        if (order == 2) b.post_op = c->post_step_op;
+        if ((rc = do_substep(c, b, slot2))) return rc;
+        const double t1 = t0 + dt, t2 = t1 + dt;
+        t = 0.5 * (t0 + t2);
+        if (order == 3) {
+            SubstepCall d{scheme, ham, HJ_STAGE_RK3_FULL, restrict_sign, par, dt, work1, y_in, y_out, nullptr, 0, n0};
+            d.post_op = c->post_step_op;
+            if ((rc = do_substep(c, d, slot3))) return rc;
+            const double tHalf = 0.25 * (3 * t0 + t2);
+            t = (1.0 / 3.0) * (t0 + 2 * (tHalf + dt));
+        }
+        // the later stages' bounds: one more host read at the end of the step (the reference warns when deltaT exceeds them)
+        const int pos2 = c->slot_ring[slot2], pos3 = order == 3 ? c->slot_ring[slot3] : pos2;
+        if (order == 3 && pos3 == pos2 + 1) {            // consecutive ring entries: one copy, one synchronisation
+            unsigned long long k[2 * HJ_MAX_DIM];
+            HIP_TRY(hipMemcpyAsync(k, c->ring + (size_t)pos2 * HJ_MAX_DIM, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (int st = 0; st < 2; ++st) {
+                double inv = 0.0;
+                for (int d = 0; d < c->ndim; ++d) {
+                    if (k[st * HJ_MAX_DIM + d] == 0) return fail(HJ_ESTATE, "bound slot holds no reduction for dim %d", d);
+                    inv += key_to_double(k[st * HJ_MAX_DIM + d]) / c->dx[d];
+                }
+                c->last_bounds[1 + st] = 1.0 / inv;
+            }
+            c->last_bounds_n = 3;
+        } else {
+            double sb2 = 0, sb3 = 0;
+            if ((rc = read_ring(c, pos2, &sb2, nullptr))) return rc;
+            c->last_bounds[1] = sb2;
+            c->last_bounds_n = 2;
+            if (order == 3) {
+                if ((rc = read_ring(c, pos3, &sb3, nullptr))) return rc;
+                c->last_bounds[2] = sb3;
+                c->last_bounds_n = 3;
+            }
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!c->post_arr[k]) continue;
+        const int op = c->post_arr_op[k] == 1 ? HJ_OP_MIN : (c->post_arr_op[k] == 2 ? HJ_OP_MAX : HJ_OP_MAX_NEG);
+        if ((rc = hj_minmax_with(c, op, y_out, c->post_arr[k], c->total))) return rc;
+    }
+    if (t_out) *t_out = t;
+    if (dt_out) *dt_out = dt;
+    return HJ_OK;
+}
+
+int hj_rk_last_bounds(hj_ctx* c, double* sb, int* n) {
+    if (!c || !sb || !n) return fail(HJ_EINVAL, "null argument");
+    *n = c->last_bounds_n;
+    for (int k = 0; k < c->last_bounds_n; ++k) sb[k] = c->last_bounds[k];
+    return HJ_OK;
+}
+
+int hj_ctx_set_range_source(hj_ctx* c, const void* keys_dev) {
+    if (!c) return fail(HJ_EINVAL, "null ctx");
+    c->range_src = (const unsigned long long*)keys_dev;
+    return HJ_OK;
+}
+
+int hj_range_pass(hj_ctx* c, int scheme, int ham, const double* par, const void* y, void* keys_dev) {
+    if (!c || !y || !keys_dev) return fail(HJ_EINVAL, "null argument");
+    if (!user_ham_dynamic(ham)) return fail(HJ_EINVAL, "Hamiltonian %d does not read the costate range", ham);
+    SubstepCall s{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y, nullptr, keys_dev /* unused as an array */, nullptr, 0, c->N[0]};
+    s.range_only = true;
+    s.range_out = (unsigned long long*)keys_dev;
+    return do_substep(c, s, -1);
+}
+
 int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf,
                double factor_cfl, double max_step, int restrict_sign, const void* y_in, void* y_out,
                void* work0, void* work1, double* t_out, double* dt_out) {
@@ -1555,6 +1694,7 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     if (order >= 2 && !work0) return fail(HJ_EINVAL, "work0 required for order >= 2");
     if (order == 3 && !work1) return fail(HJ_EINVAL, "work1 required for order 3");
     if (y_out == y_in) return fail(HJ_EINVAL, "y_out must not alias y_in");
+    if (user_ham_dynamic(ham)) return rk_step_dynamic(c, order, scheme, ham, par, t0, tf, factor_cfl, max_step, restrict_sign, y_in, y_out, work0, work1, t_out, dt_out);
     double sb;
     int rc = hj_static_step_bound(c, ham, par, &sb, nullptr);
     if (rc) return rc;

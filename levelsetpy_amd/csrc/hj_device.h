@@ -51,6 +51,22 @@ __device__ __forceinline__ float max_acc(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// lo = a - |b|, hi = a + |b| folded into running min / max: one instruction each (v_min / v_max with source modifiers) -- the range
+// pass of a substep (derivL = pc - hd, derivR = pc + hd: min(derivL, derivR) = pc - |hd|, max = pc + |hd|)
+__device__ __forceinline__ void range_acc(double& mn, double& mx, double a, double b) {
+    double lo, hi;
+    asm("v_add_f64 %0, %1, -|%2|" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_add_f64 %0, %1, |%2|" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(lo));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(hi));
+}
+__device__ __forceinline__ void range_acc(float& mn, float& mx, float a, float b) {
+    float lo, hi;
+    asm("v_sub_f32 %0, %1, |%2|" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_add_f32 %0, %1, |%2|" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(lo));
+    asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(hi));
+}
 struct FDiv { int d; float r; };
 __device__ __forceinline__ FDiv fdiv_make(int d) { return FDiv{d, __builtin_amdgcn_rcpf((float)d)}; }
 __device__ __forceinline__ void fdivmod(int a, const FDiv& f, int& q, int& rem) {
@@ -391,7 +407,16 @@ template <typename T> struct HamTables {
     const T* coord[HJ_MAX_DIM];  // grid.vs[d]
     const T* aux[4];             // Hamiltonian-specific 1-D tables
     T par[4];
+    // Hamiltonians whose alpha depends on the costate RANGE (round 5; artificial_diss_glf.py:80-99 hands partialFunc derivMin / derivMax):
+    // 2*ND order-preserving keys written by the range pass of the substep (MODE 3 of the tiled kernels): [d] = key(max(derivL_d, derivR_d)
+    // over the grid), [ND + d] = key(-min(...)); null for everybody else
+    const unsigned long long* range;
 };
+// value of an order-preserving key (max_key below)
+__device__ __forceinline__ double key_value(unsigned long long k) {
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
 
 // Interface (all three systems):
 //   Cell  cell(P, idx, sc)  -- constants of a grid column (depend on idx[1..] only); the fused kernel

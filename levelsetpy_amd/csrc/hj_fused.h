@@ -142,7 +142,31 @@ template <typename T, int ND> struct FusedArgs {
     // debug (HJ_TIMING_DUMP): per logical block {start, end} of the constant 100 MHz clock, {xcc id, chunk}
     unsigned long long* timing;
     TermPar<T> term;              // TermOp launches (termNormal / termReinit / termConvection through the tiled kernel; hj_termop.h)
+    // MODE 3 (the RANGE PASS of a substep, round 5): nothing is written but 2*ND keys -- [d] max, [ND + d] -min of derivL_d / derivR_d
+    // over the launch's cells (artificial_diss_glf.py:80-88: derivMin / derivMax), for Hamiltonians whose alpha reads them
+    unsigned long long* range_keys;
 };
+
+// end of a range pass: the per-thread minima / maxima -> 2*ND atomicMax on order-preserving keys (one per workgroup and value)
+template <int ND, int NT, typename T>
+__device__ __forceinline__ void publish_range(unsigned long long* keys, double (*red)[ND], const T* rmn, const T* rmx, const T* sc) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const double m = wave_max(half == 0 ? (double)(sc[d] * rmx[d]) : -(double)(sc[d] * rmn[d]));
+            if (lane == 0) red[wv][d] = m;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ND) {
+            double m = red[0][threadIdx.x];
+            for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][threadIdx.x]);
+            atomicMax(keys + half * ND + threadIdx.x, max_key(m));
+        }
+    }
+}
 
 // Logical block of this workgroup, -1 for the padding blocks of the launch.  Blocks b, b + 8, b + 16 ... share an XCD
 // (round-robin dispatch): every XCD gets a contiguous run of logical blocks.  In a gated slab launch the first edge_blocks
@@ -313,6 +337,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     constexpr bool TERM = ham_traits<HAM>::is_term;
     constexpr int TKIND = ham_traits<HAM>::kind;
     static_assert(!TERM || MODE == 0, "terms run the general instantiation");
+    constexpr bool RNG = (MODE == 3);           // range pass: derivL / derivR of every cell reduced to their minima / maxima, nothing stored
     const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
     extern __shared__ __align__(16) unsigned char hj_smem[];
     // dynamic LDS only (keeps the carve base 16-byte aligned): [0,512) reduction scratch, then planes
@@ -622,6 +647,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
+    T rmn[ND], rmx[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { rmn[d] = -Lim<T>::lowest; rmx[d] = Lim<T>::lowest; }
 
     // one plane.  own_c holds plane p+4 (joins the queue at the end); own_n is refilled with plane
     // p+3+PD; hal_c / y0_c / pl_c hold plane p's halo ring, RK operand and Hamiltonian scalars and
@@ -724,6 +752,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
                 else upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pc[d], hd[d]);
 #endif
             }
+            if constexpr (RNG) {
+                if (r < R - 1 || last_real) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) range_acc(rmn[d], rmx[d], pc[d], hd[d]);      // derivL = sc (pc - hd), derivR = sc (pc + hd); scaled in publish_range
+                }
+                continue;
+            }
             T ydot;
             if constexpr (TERM) {
                 tcf[r][0] = use_y0 ? y0_c[r] : A.term.scal[0];
@@ -814,6 +849,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const unsigned long long st_loop1 = wall_clock64(), st_cyc1 = __builtin_readcyclecounter();
 #endif
 
+    if constexpr (RNG) {
+        publish_range<ND, NT>(A.range_keys, red, rmn, rmx, A.sc);
+        return;
+    }
     if constexpr (SCHEME == HJ_WENO5) {
         if (eps_prod) {
             __syncthreads();

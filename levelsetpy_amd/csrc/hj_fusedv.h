@@ -98,6 +98,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     constexpr int LA = ND - 1;                  // the contiguous axis
     constexpr int PD = 2;
     constexpr bool GEN = (MODE == 0);
+    constexpr bool RNG = (MODE == 3);           // range pass (FusedArgs::range_keys): derivL / derivR reduced to minima / maxima, nothing stored
     constexpr bool NP = np_order(SCHEME);       // ENO2 / ENO3: every operation rounded as NumPy rounds it (hj_device.h)
     using V = typename Pair<T>::V;
     const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
@@ -567,6 +568,21 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
+    T rmn[ND], rmx[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { rmn[d] = -Lim<T>::lowest; rmx[d] = Lim<T>::lowest; }
+    // one stencil: centred costate + half jump of the substep, or (range pass) derivL / derivR themselves, reduced
+    auto sten = [&](auto dim_tag, const T* v, T& pcv, T& hdv, bool real) {
+        constexpr int d = decltype(dim_tag)::value;
+        if constexpr (RNG) {
+            // derivL = sc (pc - hd), derivR = sc (pc + hd) with the centred costate and half jump the substep forms anyway (sc > 0:
+            // the minima / maxima are taken unscaled and scaled once, in publish_range)
+            upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pcv, hdv);
+            if (real) range_acc(rmn[d], rmx[d], pcv, hdv);
+        } else {
+            upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pcv, hdv);
+        }
+    };
 
 #ifdef HJ_STAMP
     unsigned long long st_acc[4] = {0, 0, 0, 0};
@@ -611,6 +627,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             T pc[2][ND], hd[2][ND];
+            const bool slot_real = r < R - 1 || last_real;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (down) {
@@ -618,9 +635,9 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                     T qg[7];
 #pragma unroll
                     for (int j = 0; j < 7; ++j) qg[j] = q[r][c][6 - j + OFF];
-                    upwind_cd<SCHEME, T>(qg, A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+                    sten(IntTag<0>(), qg, pc[c][0], hd[c][0], slot_real);
                 } else {
-                    upwind_cd<SCHEME, T>(q[r][c] + OFF, A.K[0], eps[0], wk[0], pc[c][0], hd[c][0]);
+                    sten(IntTag<0>(), q[r][c] + OFF, pc[c][0], hd[c][0], slot_real);
                 }
             }
             const T* base = buf + own_lds[r];
@@ -639,8 +656,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                     vb[j] = n2.y;
 #endif
                 }
-                upwind_cd<SCHEME, T>(va, A.K[d], eps[d], wk[d], pc[0][d], hd[0][d]);
-                upwind_cd<SCHEME, T>(vb, A.K[d], eps[d], wk[d], pc[1][d], hd[1][d]);
+                if (d == 1) { sten(IntTag<1>(), va, pc[0][1], hd[0][1], slot_real); sten(IntTag<1>(), vb, pc[1][1], hd[1][1], slot_real); }
+                else { sten(IntTag<(ND > 3 ? 2 : 1)>(), va, pc[0][d], hd[0][d], slot_real); sten(IntTag<(ND > 3 ? 2 : 1)>(), vb, pc[1][d], hd[1][d], slot_real); }
             }
             {   // the contiguous axis: cells j-3 .. j+4 = [b64][b128][own pair][b128][b64]
                 T w[8];
@@ -656,9 +673,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 w[5] = r2.x; w[6] = r2.y;
                 w[7] = base[4];
 #endif
-                upwind_cd<SCHEME, T>(w, A.K[LA], eps[LA], wk[LA], pc[0][LA], hd[0][LA]);
-                upwind_cd<SCHEME, T>(w + 1, A.K[LA], eps[LA], wk[LA], pc[1][LA], hd[1][LA]);
+                sten(IntTag<LA>(), w, pc[0][LA], hd[0][LA], slot_real);
+                sten(IntTag<LA>(), w + 1, pc[1][LA], hd[1][LA], slot_real);
             }
+            if constexpr (RNG) continue;
             V o2;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -740,6 +758,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
 
+    if constexpr (RNG) {
+        publish_range<ND, NT>(A.range_keys, red, rmn, rmx, A.sc);
+        return;
+    }
     if constexpr (SCHEME == HJ_WENO5) {
         if (eps_prod) {
             __syncthreads();

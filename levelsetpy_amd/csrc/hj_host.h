@@ -37,6 +37,7 @@ int fail(int code, const char* fmt, ...);     // records the message for hj_last
     } while (0)
 
 constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys)
+constexpr int RANGE_RING = 1024;  // range-key ring (each entry: 2*HJ_MAX_DIM keys)
 
 struct Tiling {
     int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
@@ -130,6 +131,13 @@ struct hj_ctx {
     int tile_block[2] = {4, 4};                     // HJ_TB1 / HJ_TB2: 4-D tile order in blocks of this many tiles along axes 1 and 2 (0: plain order)
     int f12_e1 = 0;                                 // tuning / tests: force the tile's row count (pair variant)
     int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail
+    // Hamiltonians whose alpha reads the costate range (hj_rtc.hip, HJ_HAM_RANGE): 2*HJ_MAX_DIM keys the range pass of a substep writes
+    unsigned long long* range_keys = nullptr;       // the entry of range_ring the last range pass wrote (what fill_ham hands to the kernels)
+    unsigned long long* range_ring = nullptr;       // RANGE_RING entries of 2*HJ_MAX_DIM keys, zeroed in bulk (no memset launch per pass)
+    int range_pos = 0;
+    const unsigned long long* range_src = nullptr;  // hj_ctx_set_range_source: keys reduced by the caller (over all ranks); the launches then skip their own range pass
+    double last_bounds[3] = {0, 0, 0};              // stepBound of the stages of the last hj_rk_step with such a Hamiltonian (hj_rk_last_bounds)
+    int last_bounds_n = 0;
     int tile4_sel = -1;                             // HJ_TILE4_SEL: which tile of HJ_TILE4 (hj_inst.hip) to take (-1: the first that fits)
     int pair4 = 1;                                  // HJ_PAIR4: 4-D fp32 light stencils through the compile-time-tile kernel (hj_fused4v.h)
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
@@ -176,6 +184,7 @@ template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTable
     for (int s = 0; s < 2; ++s)
         if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
     for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
+    H.range = c->range_src ? c->range_src : c->range_keys;
 }
 
 template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G) {
@@ -227,6 +236,10 @@ struct SubstepCall {
     bool want_eps = false, eps_from_prev = false;
     const double* eps_rows = nullptr;   // set by do_substep: fold these rows of max D1^2 (HJ_MAX_DIM doubles each) instead of
     int eps_nrows = 0;                  // reading weno_vals
+    // range-dependent alpha (hj_rtc.hip): run ONLY the range pass of [p0, p1) into range_out (2*HJ_MAX_DIM keys, zeroed by the launch code)
+    bool range_only = false;
+    unsigned long long* range_out = nullptr;
+    bool range_ready = false;           // ctx->range_keys already hold the range of this launch's input: no pass of its own
 };
 constexpr int HJ_EPS_ROWS = 256;  // workgroups (= rows) of eps_seam_kernel
 
@@ -274,11 +287,13 @@ constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz =
 }
 
 // Hamiltonians compiled at run time (hj_rtc.hip)
+int next_range_keys(hj_ctx* c);           // advance ctx->range_keys to a zeroed entry of the range ring
 bool user_ham_valid(int ham);
+bool user_ham_dynamic(int ham);           // alpha depends on the data (the costate range): no static step bound, dt from the first stage's reduction
 int user_ham_ndim(int ham);
 int user_ham_npar(int ham);
 int launch_user(hj_ctx* c, const SubstepCall& s);
-int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys);
+int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, bool with_range = false);
 
 // the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
 // instantiated in hj_inst.hip

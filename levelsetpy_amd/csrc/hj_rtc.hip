@@ -12,9 +12,13 @@
 //
 // What the expression may use:  x[d] (node coordinates, d = 0 .. ND-1), p[d] (costates), par[k] (the ham_params of the
 // call), t-independent device math (sin, cos, fabs, sqrt, fmin, fmax ...); what it must set:  H  and  alpha[d] for every d.
-// alpha must not depend on p (true of every system the reference ships: dubins_relative.py:106-111,
-// dubins_absolute.py:150-170, double_integrator.py:84-89, bird.py:346): the CFL bound is then a property of the grid
-// (hj_static_step_bound) and a time step needs no host synchronisation.  fp64, 2-D and 3-D grids.
+// alpha may not depend on p itself -- but (round 5, flag HJ_HAM_RANGE) it may depend on the costate RANGE the reference hands to
+// partialFunc: dmin[d] / dmax[d] = derivMin / derivMax of artificial_diss_glf.py:80-88.  Without the flag (every system the reference
+// ships: dubins_relative.py:106-111, dubins_absolute.py:150-170, double_integrator.py:84-89, bird.py:346) the CFL bound is a
+// property of the grid (hj_static_step_bound) and a time step needs no host synchronisation; with it a substep is TWO launches
+// (the range pass -- MODE 3 of the tiled kernel: derivL / derivR of every cell reduced to 2*ND minima / maxima, nothing written --
+// then the substep with the range visible to the expression and the in-kernel max(alpha) reduction kept) and hj_rk_step takes
+// dt from the first stage's reduced bound, as ode_cfl_3.py:142 does.  fp64 and fp32; 2-D, 3-D and 4-D grids.
 #include <dlfcn.h>
 #include <errno.h>
 #include <sys/stat.h>
@@ -70,14 +74,22 @@ static int rtc_load(const char* path) {
     return HJ_OK;
 }
 
-struct UserKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; int occ = 0; size_t lds_granted = 0; };
+// a module is loaded on ONE device (hipModuleLoadData binds it to the device that is current): kernels are kept per device
+// (ADVICE r04), their occupancy per dynamic-LDS size
+struct UserKernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    std::map<size_t, int> occ;              // dynamic LDS bytes -> resident workgroups per CU
+    size_t lds_granted = 0;
+};
 struct UserHam {
     std::string name, body, column_body, include_dir, rtc_path;
-    int ndim = 0, nparams = 0, ncol = 0;
-    std::map<int, UserKernel> substep;      // key: (scheme * 4 + MODE) * 2 + (big shape ? 1 : 0)
-    std::map<int, bool> big_spills;         // key: scheme * 4 + MODE -- the big shape needed scratch for this expression
+    int ndim = 0, nparams = 0, ncol = 0, flags = 0;
+    // key: ((((device * 2 + fp32) * 4 + scheme) * 4 + MODE) * 4 + shape)    shape: 0 small pair, 1 big pair, 2 one cell per lane (4-D fp64)
+    std::map<long long, UserKernel> substep;
+    std::map<int, bool> big_spills;         // key: (fp32 * 4 + scheme) * 4 + MODE -- the big shape needed scratch for this expression
     bool no_big_lds = false;                // the runtime refused > 64 KB of dynamic LDS for a module function
-    UserKernel alpha;
+    std::map<int, UserKernel> alpha;        // key: device * 2 + fp32
 };
 static std::vector<UserHam> g_user;
 
@@ -86,19 +98,23 @@ static UserHam* user_of(int ham) {
     return (i >= 0 && i < (int)g_user.size()) ? &g_user[(size_t)i] : nullptr;
 }
 bool user_ham_valid(int ham) { return user_of(ham) != nullptr; }
+bool user_ham_dynamic(int ham) { const UserHam* u = user_of(ham); return u && (u->flags & HJ_HAM_RANGE); }
 int user_ham_ndim(int ham) { const UserHam* u = user_of(ham); return u ? u->ndim : -1; }
 int user_ham_npar(int ham) { const UserHam* u = user_of(ham); return u ? u->nparams : 0; }
 
 // the translation unit hipRTC compiles: the kernel headers + the Hamiltonian type around the caller's expression
 static std::string user_source(const UserHam& u, int id) {
+    const bool rng = (u.flags & HJ_HAM_RANGE) != 0;
     std::ostringstream o;
-    o << "#include \"hj_fusedv.h\"\n#include \"hj_split.h\"\nnamespace hj {\n"
+    o << "#include \"hj_fusedv.h\"\n#include \"hj_fused4v.h\"\n#include \"hj_split.h\"\nnamespace hj {\n"
          "template <typename T> struct HamUser {\n"
          "    static constexpr int ND = " << u.ndim << ";\n"
          "    static constexpr int ID = " << id << ";\n"
          "    static constexpr unsigned PLANE_DEP = 0xFu;     // any alpha may vary along the march\n"
          "    static constexpr int NCOL = " << (u.ncol > 0 ? u.ncol : 1) << ";\n"
-         "    struct Cell { T x[ND]; T col[NCOL]; };\n    struct Plane { T x0; };\n    using Raw = Cell;\n"
+         "    static constexpr bool RANGE = " << (rng ? "true" : "false") << ";\n"
+         "    struct Cell { T x[ND]; T col[NCOL]; };\n"
+         "    struct Plane { T x0; T dmin[RANGE ? ND : 1], dmax[RANGE ? ND : 1]; };\n    using Raw = Cell;\n"
          "    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {\n"
          "        Cell c; c.x[0] = T(0);\n"
          "        for (int d = 1; d < ND; ++d) c.x[d] = P.coord[d][idx[d]];\n"
@@ -114,13 +130,20 @@ static std::string user_source(const UserHam& u, int id) {
          "        {\n#line 1 \"" << u.name << " (column)\"\n" << u.column_body << "\n        }\n"
          "        for (int k = 0; k < NCOL; ++k) c.col[k] = col[k];\n        return c;\n    }\n"
          "    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) { return cell_fin(P, cell_raw(P, idx), sc); }\n"
-         "    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T*) { Plane u; u.x0 = P.coord[0][i0]; return u; }\n"
+         "    // per axis-0 plane: its coordinate and (RANGE) the costate range the range pass left in P.range (wave-uniform)\n"
+         "    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int i0, const T*) {\n"
+         "        Plane u; u.x0 = P.coord[0][i0];\n"
+         "        u.dmin[0] = T(0); u.dmax[0] = T(0);\n"
+         "        if constexpr (RANGE) {\n"
+         "            for (int d = 0; d < ND; ++d) { u.dmax[d] = (T)key_value(P.range[d]); u.dmin[d] = (T)(-key_value(P.range[ND + d])); }\n"
+         "        }\n        return u;\n    }\n"
          "    template <bool NP = false>\n"
          "    __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& pl, const T* sc, const T* q, T& H, T* alpha) {\n"
          "        T x[ND], p[ND];\n        x[0] = pl.x0;\n"
          "        for (int d = 1; d < ND; ++d) x[d] = c.x[d];\n"
          "        for (int d = 0; d < ND; ++d) { p[d] = sc[d] * q[d]; alpha[d] = T(0); }\n"
-         "        const T* par = P.par;\n        const T* col = c.col;\n        (void)col; (void)par;\n        H = T(0);\n"
+         "        const T* par = P.par;\n        const T* col = c.col;\n        const T* dmin = pl.dmin;\n        const T* dmax = pl.dmax;\n"
+         "        (void)col; (void)par; (void)dmin; (void)dmax;\n        H = T(0);\n"
          "        {\n#line 1 \"" << u.name << "\"\n" << u.body << "\n        }\n"
          "        for (int d = 0; d < ND; ++d) alpha[d] = sc[d] * alpha[d];     // the kernels carry alpha in the stencil's scale\n"
          "    }\n};\n}\n";
@@ -128,10 +151,13 @@ static std::string user_source(const UserHam& u, int id) {
 }
 
 // ---- code-object cache on disk: a registered expression is compiled once per (source, kernel headers, options), not once per
-// process.  Directory: $HJ_RTC_CACHE ("0" / "off" disables), else $XDG_CACHE_HOME/levelsetpy_amd, else $HOME/.cache/levelsetpy_amd.
-// File <key>.hjco = "HJCO1\n" + lowered kernel name + "\n" + code object; key = FNV-1a of the generated source, the name
-// expression, the compile options, the TEXT of the kernel headers it includes and the HIP runtime version.  Written atomically (temporary + rename); a
-// file that does not load is ignored and replaced.
+// process.  Directory: $HJ_RTC_CACHE ("0" / "off" disables), else $XDG_CACHE_HOME/levelsetpy_amd, else $HOME/.cache/levelsetpy_amd;
+// it must belong to the user and not be writable by group or others (a planted file would be code run on the GPU), else the cache
+// is off.  File <key>.hjco = "HJCO2\n" + lowered kernel name + "\n" + 16 hex digits: size of the code object + "\n" + 16 hex digits:
+// FNV-1a of (key material, code object) + "\n" + code object; key = two FNV-1a hashes (128 bits) of the generated source, the name
+// expression, the compile options, the TEXT of every kernel header the source includes, sizeof(FusedArgs) (the kernel-argument ABI)
+// and the HIP runtime version.  A header that cannot be read turns the cache off (the key would not cover it).  Written atomically
+// (temporary + rename); a file whose size or checksum does not match is ignored and replaced.
 static unsigned long long fnv1a(const void* data, size_t n, unsigned long long h = 1469598103934665603ull) {
     const unsigned char* p = (const unsigned char*)data;
     for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
@@ -159,18 +185,25 @@ static std::string cache_dir() {
     const size_t cut = d.find_last_of('/');
     if (cut != std::string::npos && cut > 0) (void)mkdir(d.substr(0, cut).c_str(), 0700);
     if (mkdir(d.c_str(), 0700) != 0 && errno != EEXIST) return "";
+    struct stat st;
+    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return "";
     return d;
 }
-static unsigned long long headers_hash(const std::string& include_dir) {
-    static std::map<std::string, unsigned long long> memo;
-    auto it = memo.find(include_dir);
-    if (it != memo.end()) return it->second;
-    unsigned long long h = 1469598103934665603ull;
-    const char* files[] = {"/hj_fusedv.h", "/hj_fused.h", "/hj_device.h", "/hj_split.h", "/../../include/hj_mi355x.h"};
+// hash of the text of every header the generated source can include; ok = false if one of them cannot be read
+static unsigned long long headers_hash(const std::string& include_dir, unsigned long long seed, bool& ok) {
+    static std::map<std::string, std::pair<unsigned long long, bool>> memo;
+    const std::string key = include_dir + "#" + std::to_string(seed);
+    auto it = memo.find(key);
+    if (it != memo.end()) { ok = it->second.second; return it->second.first; }
+    unsigned long long h = seed;
+    ok = true;
+    const char* files[] = {"/hj_fusedv.h", "/hj_fused4v.h", "/hj_fused.h", "/hj_termop.h", "/hj_device.h", "/hj_split.h", "/../../include/hj_mi355x.h"};
     std::string text;
-    for (const char* f : files)
+    for (const char* f : files) {
         if (read_file(include_dir + f, text)) h = fnv1a(text.data(), text.size(), h);
-    memo[include_dir] = h;
+        else ok = false;
+    }
+    memo[key] = std::make_pair(h, ok);
     return h;
 }
 static int g_rtc_cache_hits = 0, g_rtc_compiles = 0;
@@ -179,32 +212,51 @@ static int rtc_build(UserHam& u, int id, const std::string& name_expr, UserKerne
     const std::string src = user_source(u, id);
     const char* base_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-DHJ_RTC=1"};
     std::string cache_file;
+    unsigned long long key_lo = 0;
     {
         const std::string dir = cache_dir();
         if (!dir.empty()) {
-            unsigned long long h = fnv1a(src.data(), src.size());
-            h = fnv1a(name_expr.data(), name_expr.size(), h);
-            for (const char* o : base_opts) h = fnv1a(o, strlen(o), h);
-            const unsigned long long hh = headers_hash(u.include_dir);
-            h = fnv1a(&hh, sizeof(hh), h);
-            int rtv = 0;                                   // a new ROCm release compiles again
-            (void)hipRuntimeGetVersion(&rtv);
-            h = fnv1a(&rtv, sizeof(rtv), h);
-            char nm[64];
-            snprintf(nm, sizeof(nm), "/%016llx.hjco", h);
-            cache_file = dir + nm;
-            std::string blob;
-            if (read_file(cache_file, blob) && blob.compare(0, 6, "HJCO1\n") == 0) {
-                const size_t nl = blob.find('\n', 6);
-                if (nl != std::string::npos && nl + 1 < blob.size()) {
-                    const std::string kname = blob.substr(6, nl - 6);
-                    if (hipModuleLoadData(&out.mod, blob.data() + nl + 1) == hipSuccess &&
-                        hipModuleGetFunction(&out.fn, out.mod, kname.c_str()) == hipSuccess) {
-                        ++g_rtc_cache_hits;
-                        return HJ_OK;
+            unsigned long long h[2];
+            bool ok = true;
+            for (int w = 0; w < 2; ++w) {
+                const unsigned long long seed = w == 0 ? 1469598103934665603ull : 0x9e3779b97f4a7c15ull;
+                unsigned long long x = fnv1a(src.data(), src.size(), seed);
+                x = fnv1a(name_expr.data(), name_expr.size(), x);
+                for (const char* o : base_opts) x = fnv1a(o, strlen(o), x);
+                bool okh = true;
+                const unsigned long long hh = headers_hash(u.include_dir, seed, okh);
+                ok = ok && okh;
+                x = fnv1a(&hh, sizeof(hh), x);
+                const unsigned long long abi[3] = {sizeof(FusedArgs<double, 3>), sizeof(FusedArgs<float, 4>), sizeof(HamTables<double>)};
+                x = fnv1a(abi, sizeof(abi), x);
+                int rtv = 0;                                   // a new ROCm release compiles again
+                (void)hipRuntimeGetVersion(&rtv);
+                x = fnv1a(&rtv, sizeof(rtv), x);
+                h[w] = x;
+            }
+            if (ok) {
+                key_lo = h[0];
+                char nm[64];
+                snprintf(nm, sizeof(nm), "/%016llx%016llx.hjco", h[0], h[1]);
+                cache_file = dir + nm;
+                std::string blob;
+                if (read_file(cache_file, blob) && blob.compare(0, 6, "HJCO2\n") == 0) {
+                    const size_t n1 = blob.find('\n', 6);
+                    if (n1 != std::string::npos && blob.size() >= n1 + 1 + 17 + 17) {
+                        const std::string kname = blob.substr(6, n1 - 6);
+                        const unsigned long long want_size = strtoull(blob.substr(n1 + 1, 16).c_str(), nullptr, 16);
+                        const unsigned long long want_sum = strtoull(blob.substr(n1 + 18, 16).c_str(), nullptr, 16);
+                        const size_t off = n1 + 1 + 17 + 17;
+                        if (blob[n1 + 17] == '\n' && blob[n1 + 34] == '\n' && blob.size() - off == want_size &&
+                            fnv1a(blob.data() + off, blob.size() - off, key_lo) == want_sum &&
+                            hipModuleLoadData(&out.mod, blob.data() + off) == hipSuccess &&
+                            hipModuleGetFunction(&out.fn, out.mod, kname.c_str()) == hipSuccess) {
+                            ++g_rtc_cache_hits;
+                            return HJ_OK;
+                        }
+                        (void)hipGetLastError();
+                        out.mod = nullptr; out.fn = nullptr;
                     }
-                    (void)hipGetLastError();
-                    out.mod = nullptr; out.fn = nullptr;
                 }
             }
         }
@@ -244,8 +296,10 @@ static int rtc_build(UserHam& u, int id, const std::string& name_expr, UserKerne
         const std::string tmp = cache_file + tmpn;
         FILE* f = fopen(tmp.c_str(), "wb");
         if (f) {
-            bool ok = fwrite("HJCO1\n", 1, 6, f) == 6 && fwrite(kname.data(), 1, kname.size(), f) == kname.size() && fputc('\n', f) != EOF &&
-                      fwrite(code.data(), 1, code.size(), f) == code.size();
+            char meta[64];
+            snprintf(meta, sizeof(meta), "%016llx\n%016llx\n", (unsigned long long)code.size(), fnv1a(code.data(), code.size(), key_lo));
+            bool ok = fwrite("HJCO2\n", 1, 6, f) == 6 && fwrite(kname.data(), 1, kname.size(), f) == kname.size() && fputc('\n', f) != EOF &&
+                      fwrite(meta, 1, 34, f) == 34 && fwrite(code.data(), 1, code.size(), f) == code.size();
             ok = (fclose(f) == 0) && ok;
             if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
         }
@@ -253,7 +307,7 @@ static int rtc_build(UserHam& u, int id, const std::string& name_expr, UserKerne
     return HJ_OK;
 }
 
-// kernel-argument block of fused_pair_kernel(const T* y, const T* y0, T* out, const FusedArgs<T, ND> A)
+// kernel-argument block of the tiled kernels: (const T* y, const T* y0, T* out, const FusedArgs<T, ND> A)
 template <typename T, int ND> struct PairKernArgs {
     const T* y;
     const T* y0;
@@ -273,72 +327,112 @@ static int module_launch(hipFunction_t fn, unsigned grid, unsigned block, size_t
     return HJ_OK;
 }
 
-// (threads, pairs per thread, halo slots per thread, waves/SIMD hint) of the run-time instantiations: the two shapes of the
-// built-in pair kernels.  "small": one pair per thread in 256-thread workgroups -- ~120 VGPRs are left for an arbitrary
-// Hamiltonian expression; "big": two pairs per thread in 512-thread workgroups + the parked halo ring, what the built-in
-// light stencils run from 6.5 M cells up -- taken for the light stencils on such grids IF the expression compiles into it
-// without scratch (hipFuncGetAttribute: a spilling kernel loses more than the shape gains), else the small shape.
-struct UShape { int nt, r, kh, occ; };
-constexpr UShape U_SMALL{256, 1, 2, 2}, U_BIG{512, 2, 2, 2};
+// Kernel shapes of the run-time instantiations -- those of the built-in systems (hj_inst.hip):
+//   0 "small": pair kernel, one pair per thread in 256-thread workgroups -- ~120 VGPRs are left for an arbitrary expression
+//   1 "big":   pair kernel, two pairs per thread in 512-thread workgroups + the parked halo ring, what the built-in light stencils run
+//              from 6.5 M cells up -- taken for the light stencils on such 2-D / 3-D grids IF the expression compiles into it without
+//              scratch (hipFuncGetAttribute: a spilling kernel loses more than the shape gains), else the small shape
+//   2 "single": one cell per lane (fused_substep_kernel) -- 4-D grids: 512 threads in fp64, 1024 in fp32 (heavy stencils)
+//   3 "pair4d": pair kernel on 4-D fp32 grids with a light stencil (256 threads x 2 pairs, 5 pair + 1 single halo slots)
+struct UShape { int nt, r, kh, occ, pd; bool pair; };
+static UShape shape_of(int shape, bool fp32) {
+    switch (shape) {
+        case 1: return UShape{512, 2, 2, 2, 2, true};
+        case 2: return fp32 ? UShape{1024, 1, 3, 2, 2, false} : UShape{512, 1, 4, 2, 2, false};
+        case 3: return UShape{256, 2, 6, 2, 2, true};
+    }
+    return UShape{256, 1, 2, 2, 2, true};
+}
+static std::string kernel_name(const UShape& sh, const char* tname, int scheme, int mode) {
+    std::ostringstream nm;
+    if (sh.pair)
+        nm << "hj::fused_pair_kernel<" << tname << ", hj::HamUser<" << tname << ">, " << scheme << ", " << sh.nt << ", " << sh.r << ", " << sh.kh << ", "
+           << sh.occ << ", " << mode << ">";
+    else
+        nm << "hj::fused_substep_kernel<" << tname << ", hj::HamUser<" << tname << ">, " << scheme << ", " << sh.nt << ", " << sh.r << ", " << sh.kh << ", "
+           << sh.occ << ", " << sh.pd << ", " << mode << ">";
+    return nm.str();
+}
 
-template <int ND>
+template <typename T, int ND>
 static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
-    using T = double;
-    // MODE 1 / 2: the flag-free instantiations of plain RK stages (hj_inst.hip, launch_tiled); 0: every run-time flag
+    constexpr bool F32 = sizeof(T) == 4;
+    const char* tname = F32 ? "float" : "double";
+    HIP_TRY(hipSetDevice(c->device));        // the modules below belong to this device
+    // MODE 1 / 2: the flag-free instantiations of plain RK stages (hj_inst.hip, launch_tiled); 0: every run-time flag; 3: the range pass
     const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0;
     const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
     const bool light = s.scheme == HJ_WENO5_ASSHIPPED || s.scheme == HJ_ENO2;
-    bool big = light && ND <= 3 && c->total >= 6500000 && c->pair != 0 && !u.big_spills[s.scheme * 4 + mode];
+    const bool dynamic = (u.flags & HJ_HAM_RANGE) != 0;
+    const int spill_key = ((F32 ? 1 : 0) * 4 + s.scheme) * 4 + mode;
+    int shape = 0;
+    if (ND == 4) shape = (F32 && light) ? 3 : 2;
+    else if (light && c->total >= 6500000 && c->pair != 0 && !u.big_spills[spill_key]) shape = 1;
+    auto kernel_of = [&](int shp, int md) -> UserKernel& {
+        return u.substep[((((long long)c->device * 2 + (F32 ? 1 : 0)) * 4 + s.scheme) * 4 + md) * 4 + shp];
+    };
     UserKernel* k = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const UShape sh = big ? U_BIG : U_SMALL;
-        k = &u.substep[(s.scheme * 4 + mode) * 2 + (big ? 1 : 0)];
+        k = &kernel_of(shape, mode);
         if (!k->fn) {
-            std::ostringstream nm;
-            nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << s.scheme << ", " << sh.nt << ", " << sh.r << ", " << sh.kh << ", "
-               << sh.occ << ", " << mode << ">";
-            int rc = rtc_build(u, s.ham, nm.str(), *k);
+            int rc = rtc_build(u, s.ham, kernel_name(shape_of(shape, F32), tname, s.scheme, mode), *k);
             if (rc) return rc;
-            if (big) {
+            if (shape == 1) {
                 int scratch = 0;
                 if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn) != hipSuccess) scratch = 1;
                 if (scratch > 0) {                       // the expression does not fit two pairs per thread: small shape from now on
-                    u.big_spills[s.scheme * 4 + mode] = true;
-                    big = false;
+                    u.big_spills[spill_key] = true;
+                    shape = 0;
                     continue;
                 }
             }
         }
         break;
     }
-    const UShape sh = big ? U_BIG : U_SMALL;
+    UserKernel* kr = nullptr;                            // the range pass of the same shape
+    if (dynamic) {
+        kr = &kernel_of(shape, 3);
+        if (!kr->fn) {
+            int rc = rtc_build(u, s.ham, kernel_name(shape_of(shape, F32), tname, s.scheme, 3), *kr);
+            if (rc) return rc;
+        }
+    }
+    const UShape sh = shape_of(shape, F32);
     KernelCfg kc{sh.nt, sh.r, sh.kh};
     // halo ring parked in LDS with the big shape (as the built-in launches do, hj_inst.hip)
-    bool ring = big && !u.no_big_lds && (c->pair_ring == 1 || (c->pair_ring < 0 && c->total >= 6500000));
+    bool ring = shape == 1 && !u.no_big_lds && (c->pair_ring == 1 || (c->pair_ring < 0 && c->total >= 6500000));
     c->last_nbuf = ring ? 2 + c->pair_ah : 2;
-    Tiling t = make_tiling(c, kc, s.p0, s.p1, 2, c->last_nbuf);
-    if (t.ok && t.lds_bytes > 64 * 1024 && k->lds_granted < t.lds_bytes) {
+    Tiling t = make_tiling(c, kc, s.p0, s.p1, sh.pair ? 2 : 1, c->last_nbuf);
+    auto grant = [&](UserKernel* kk) -> bool {
+        if (!(t.ok && t.lds_bytes > 64 * 1024 && kk->lds_granted < t.lds_bytes)) return true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kk->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes) == hipSuccess) {
+            kk->lds_granted = t.lds_bytes;
+            return true;
+        }
+        (void)hipGetLastError();
+        return false;
+    };
+    if (!grant(k) || (kr && !grant(kr))) {
         // more than 64 KB of dynamic LDS has to be granted to the function; if this runtime refuses that for a module
         // function, the ring (5 plane buffers) is given up and the double buffer (< 64 KB) stays
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes) == hipSuccess) {
-            k->lds_granted = t.lds_bytes;
-        } else {
-            (void)hipGetLastError();
-            u.no_big_lds = true;
-            ring = false;
-            c->last_nbuf = 2;
-            t = make_tiling(c, kc, s.p0, s.p1, 2, 2);
-        }
+        u.no_big_lds = true;
+        ring = false;
+        c->last_nbuf = 2;
+        t = make_tiling(c, kc, s.p0, s.p1, sh.pair ? 2 : 1, 2);
     }
     if (!t.ok) return fail(HJ_EUNSUPPORTED, "no tiling of this grid for the run-time kernel");
     if (t.lds_bytes > 64 * 1024 && k->lds_granted < t.lds_bytes) return fail(HJ_EUNSUPPORTED, "tile of the run-time kernel needs %zu bytes of LDS", t.lds_bytes);
-    if (!k->occ) {
-        int nb = 0;
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k->fn, sh.nt, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
-        k->occ = nb;
-    }
+    auto occ_of = [&](UserKernel* kk) {
+        auto it = kk->occ.find(t.lds_bytes);
+        if (it == kk->occ.end()) {
+            int nb = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kk->fn, sh.nt, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+            it = kk->occ.emplace(t.lds_bytes, nb).first;
+        }
+        return it->second;
+    };
     EdgePlan ep;
-    int rc = plan_chunks(c, s, t, k->occ, ep);
+    int rc = plan_chunks(c, s, t, occ_of(k), ep);
     if (rc) return rc;
     PairKernArgs<T, ND> K;
     memset(&K, 0, sizeof(K));
@@ -349,35 +443,69 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     K.A.bound = s.bound;
     if (s.scheme == HJ_WENO5 && s.eps_nrows > 0) { K.A.eps_rows = s.eps_rows; K.A.eps_nrows = s.eps_nrows; }
     unsigned grid_blocks = 0;
-    if ((rc = fill_fused_args<T, ND>(c, s, t, ep, s.scheme, true, K.A, grid_blocks))) return rc;
+    if ((rc = fill_fused_args<T, ND>(c, s, t, ep, s.scheme, sh.pair, K.A, grid_blocks))) return rc;
+    if (!sh.pair) { K.A.lds_nbuf = 2; K.A.halo_ahead = 0; }
     if (c->debug) {
         int regs = 0, scr = 0;
         (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn);
         (void)hipFuncGetAttribute(&scr, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn);
-        fprintf(stderr, "[hj] run-time kernel '%s' scheme %d mode %d: shape (%d,%d,%d,%d)%s, %d VGPRs, %d B scratch, tile (%d,%d), chunk %d, %d blocks, lds %zu\n",
-                u.name.c_str(), s.scheme, mode, sh.nt, sh.r, sh.kh, sh.occ, ring ? " + ring" : "", regs, scr, t.E[1], t.E[2], t.chunk, t.nblocks, t.lds_bytes);
+        fprintf(stderr, "[hj] run-time kernel '%s' %s scheme %d mode %d: shape %d (%d,%d,%d,%d)%s%s, %d VGPRs, %d B scratch, tile (%d,%d,%d), chunk %d, %d blocks, lds %zu\n",
+                u.name.c_str(), tname, s.scheme, mode, shape, sh.nt, sh.r, sh.kh, sh.occ, ring ? " + ring" : "", dynamic ? " + range pass" : "", regs, scr,
+                t.E[1], ND > 2 ? t.E[2] : 0, ND > 3 ? t.E[3] : 0, t.chunk, t.nblocks, t.lds_bytes);
         c->debug = 0;
     }
-    c->last_kernel = "fused_pair_kernel (hipRTC)";
+    c->last_kernel = sh.pair ? "fused_pair_kernel (hipRTC)" : "fused_substep_kernel (hipRTC)";
     c->last_E[0] = t.chunk;
     for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < ND ? t.E[d] : 0;
+    if (s.range_only && !dynamic) return fail(HJ_EINVAL, "'%s' does not read the costate range", u.name.c_str());
+    if (dynamic && (s.range_only || !(c->range_src || s.range_ready))) {
+        // the range pass: same tiling, same arguments, MODE 3 -- derivL / derivR of every cell of [p0, p1) reduced into 2*ND keys.
+        // Skipped when the caller supplies the range itself (hj_ctx_set_range_source: a slab of a decomposed grid, whose range is
+        // the reduction over all ranks).
+        if (s.gated) return fail(HJ_EUNSUPPORTED, "Hamiltonians with a range-dependent alpha do not run in gated slab launches");
+        if (!(s.range_only && s.range_out)) {
+            if ((rc = next_range_keys(c))) return rc;           // a zeroed entry of the ring: no memset launch
+            K.A.ham.range = c->range_keys;                      // (fill_ham ran before the ring advanced)
+        }
+        unsigned long long* keys = (s.range_only && s.range_out) ? s.range_out : c->range_keys;
+        PairKernArgs<T, ND> R3 = K;
+        R3.out = nullptr;
+        R3.A.bound = nullptr;
+        R3.A.range_keys = keys;
+        R3.A.gate = nullptr;
+        R3.A.use_y0 = 0; R3.A.ydot_only = 0; R3.A.post_op = 0; R3.A.do_clamp = 0;
+        R3.A.eps_part = nullptr;
+        if (s.range_only && s.range_out) HIP_TRY(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * 2 * HJ_MAX_DIM, call_stream(c, s)));
+        if ((rc = module_launch(kr->fn, grid_blocks, sh.nt, t.lds_bytes, call_stream(c, s), &R3, sizeof(R3)))) return rc;
+        if (s.range_only) return HJ_OK;
+    }
     return module_launch(k->fn, grid_blocks, sh.nt, t.lds_bytes, call_stream(c, s), &K, sizeof(K));
 }
 
 int launch_user(hj_ctx* c, const SubstepCall& s) {
     UserHam* u = user_of(s.ham);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", s.ham);
-    if (c->dtype != HJ_F64) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians are compiled for fp64 grids");
-    if (c->ndim == 2) return launch_user_nd<2>(c, s, *u);
-    if (c->ndim == 3) return launch_user_nd<3>(c, s, *u);
-    return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D and 3-D grids");
+    if (c->ndim != u->ndim) return fail(HJ_EINVAL, "Hamiltonian '%s' is %d-dimensional, the grid has dim %d", u->name.c_str(), u->ndim, c->ndim);
+    if (c->dtype == HJ_F64) {
+        if (c->ndim == 2) return launch_user_nd<double, 2>(c, s, *u);
+        if (c->ndim == 3) return launch_user_nd<double, 3>(c, s, *u);
+        if (c->ndim == 4) return launch_user_nd<double, 4>(c, s, *u);
+    } else {
+        if (c->ndim == 2) return launch_user_nd<float, 2>(c, s, *u);
+        if (c->ndim == 3) return launch_user_nd<float, 3>(c, s, *u);
+        if (c->ndim == 4) return launch_user_nd<float, 4>(c, s, *u);
+    }
+    return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D, 3-D and 4-D grids");
 }
 
-template <int ND>
+template <typename T, int ND>
 static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long long* keys, UserHam& u) {
-    using T = double;
-    if (!u.alpha.fn) {
-        int rc = rtc_build(u, ham, "hj::alpha_bound_kernel<double, hj::HamUser<double>>", u.alpha);
+    constexpr bool F32 = sizeof(T) == 4;
+    HIP_TRY(hipSetDevice(c->device));
+    UserKernel& ak = u.alpha[c->device * 2 + (F32 ? 1 : 0)];
+    if (!ak.fn) {
+        const std::string tn = F32 ? "float" : "double";
+        int rc = rtc_build(u, ham, "hj::alpha_bound_kernel<" + tn + ", hj::HamUser<" + tn + ">>", ak);
         if (rc) return rc;
     }
     AlphaKernArgs<T, ND> K;
@@ -387,16 +515,26 @@ static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long lo
     K.keys = keys;
     for (int d = 0; d < HJ_MAX_DIM; ++d) K.DX.dx[d] = c->dx[d];
     const unsigned blocks = (unsigned)std::min<int64_t>((c->total + 255) / 256, 256 * 2);
-    return module_launch(u.alpha.fn, blocks, 256, 0, c->stream, &K, sizeof(K));
+    return module_launch(ak.fn, blocks, 256, 0, c->stream, &K, sizeof(K));
 }
 
-int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys) {
+// with_range: the caller has just run the range pass of the state in question (ctx->range_keys / range_src): max(alpha) over the grid is
+// then well defined for an HJ_HAM_RANGE Hamiltonian too (alpha never depends on the node's own costate)
+int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, bool with_range) {
     UserHam* u = user_of(ham);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham);
-    if (c->dtype != HJ_F64) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians are compiled for fp64 grids");
-    if (c->ndim == 2) return alpha_user_nd<2>(c, ham, par, keys, *u);
-    if (c->ndim == 3) return alpha_user_nd<3>(c, ham, par, keys, *u);
-    return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D and 3-D grids");
+    if ((u->flags & HJ_HAM_RANGE) && !with_range)
+        return fail(HJ_EUNSUPPORTED, "the alpha of '%s' depends on the costate range: its step bound is a property of the data, not of the grid", u->name.c_str());
+    if (c->dtype == HJ_F64) {
+        if (c->ndim == 2) return alpha_user_nd<double, 2>(c, ham, par, keys, *u);
+        if (c->ndim == 3) return alpha_user_nd<double, 3>(c, ham, par, keys, *u);
+        if (c->ndim == 4) return alpha_user_nd<double, 4>(c, ham, par, keys, *u);
+    } else {
+        if (c->ndim == 2) return alpha_user_nd<float, 2>(c, ham, par, keys, *u);
+        if (c->ndim == 3) return alpha_user_nd<float, 3>(c, ham, par, keys, *u);
+        if (c->ndim == 4) return alpha_user_nd<float, 4>(c, ham, par, keys, *u);
+    }
+    return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D, 3-D and 4-D grids");
 }
 
 }  // namespace hjh
@@ -405,20 +543,21 @@ using namespace hjh;
 
 extern "C" {
 
-int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol,
-                    const char* include_dir, const char* hiprtc_path, int* ham_id) {
+int hj_ham_register2(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol, int flags,
+                     const char* include_dir, const char* hiprtc_path, int* ham_id) {
     if (!name || !body || !include_dir || !ham_id) return fail(HJ_EINVAL, "null argument");
     // the name goes into #line directives of the generated source (compiler messages then point into the caller's text)
     for (const char* ch = name; *ch; ++ch)
         if (*ch == '"' || *ch == '\\' || (unsigned char)*ch < 32) return fail(HJ_EINVAL, "the name of a Hamiltonian must not contain quotes, backslashes or control characters");
     if (ncol < 0 || ncol > 8) return fail(HJ_EINVAL, "0..8 column values, got %d", ncol);
     if (ncol > 0 && !column_body) return fail(HJ_EINVAL, "ncol > 0 needs a column expression");
+    if (flags & ~HJ_HAM_RANGE) return fail(HJ_EINVAL, "unknown flags 0x%x", flags);
     const std::string cb = (column_body && ncol > 0) ? column_body : "";
-    if (ndim < 2 || ndim > 3) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: grid.dim must be 2 or 3, got %d", ndim);
+    if (ndim < 2 || ndim > 4) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: grid.dim must be 2, 3 or 4, got %d", ndim);
     if (nparams < 0 || nparams > 4) return fail(HJ_EINVAL, "a Hamiltonian takes 0..4 parameters, got %d", nparams);
     for (size_t i = 0; i < g_user.size(); ++i)
         if (g_user[i].name == name && g_user[i].ndim == ndim && g_user[i].nparams == nparams && g_user[i].body == body &&
-            g_user[i].column_body == cb && g_user[i].ncol == ncol) {
+            g_user[i].column_body == cb && g_user[i].ncol == ncol && g_user[i].flags == flags) {
             *ham_id = HJ_HAM_USER_BASE + (int)i;        // registering the same expression again: the same id, nothing recompiled
             return HJ_OK;
         }
@@ -427,6 +566,7 @@ int hj_ham_register(const char* name, int ndim, int nparams, const char* body, c
     u.body = body;
     u.column_body = cb;
     u.ncol = ncol;
+    u.flags = flags;
     u.include_dir = include_dir;
     u.rtc_path = hiprtc_path ? hiprtc_path : "";
     u.ndim = ndim;
@@ -436,16 +576,29 @@ int hj_ham_register(const char* name, int ndim, int nparams, const char* body, c
     return HJ_OK;
 }
 
+int hj_ham_register(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol,
+                    const char* include_dir, const char* hiprtc_path, int* ham_id) {
+    return hj_ham_register2(name, ndim, nparams, body, column_body, ncol, 0, include_dir, hiprtc_path, ham_id);
+}
+
 int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built) {
     const UserHam* u = user_of(ham_id);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
     if (ndim) *ndim = u->ndim;
     if (nparams) *nparams = u->nparams;
     if (kernels_built) {
-        int n = u->alpha.fn ? 1 : 0;
+        int n = 0;
+        for (const auto& kv : u->alpha) n += kv.second.fn ? 1 : 0;
         for (const auto& kv : u->substep) n += kv.second.fn ? 1 : 0;
         *kernels_built = n;
     }
+    return HJ_OK;
+}
+
+int hj_ham_flags(int ham_id, int* flags) {
+    const UserHam* u = user_of(ham_id);
+    if (!u || !flags) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
+    *flags = u->flags;
     return HJ_OK;
 }
 
@@ -462,15 +615,15 @@ int hj_ham_compile_check(int ham_id, int scheme) {
     if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
     int rc = rtc_load(u->rtc_path.empty() ? nullptr : u->rtc_path.c_str());
     if (rc) return rc;
-    std::ostringstream nm;
-    nm << "hj::fused_pair_kernel<double, hj::HamUser<double>, " << scheme << ", " << U_SMALL.nt << ", " << U_SMALL.r << ", " << U_SMALL.kh << ", "
-       << U_SMALL.occ << ", 0>";
+    const bool dynamic = (u->flags & HJ_HAM_RANGE) != 0;
+    const UShape sh = shape_of(u->ndim == 4 ? 2 : 0, false);
     const std::string src = user_source(*u, ham_id);
     rtcProgram prog = nullptr;
     int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);
     if (e) return fail(HJ_EHIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(e));
-    e = g_rtc.AddNameExpression(prog, nm.str().c_str());
-    if (!e) e = g_rtc.AddNameExpression(prog, "hj::alpha_bound_kernel<double, hj::HamUser<double>>");
+    e = g_rtc.AddNameExpression(prog, kernel_name(sh, "double", scheme, 0).c_str());
+    if (!e && dynamic) e = g_rtc.AddNameExpression(prog, kernel_name(sh, "double", scheme, 3).c_str());
+    if (!e && !dynamic) e = g_rtc.AddNameExpression(prog, "hj::alpha_bound_kernel<double, hj::HamUser<double>>");
     const std::string inc1 = "-I" + u->include_dir, inc2 = "-I" + u->include_dir + "/../../include";
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", inc1.c_str(), inc2.c_str(), "-DHJ_RTC=1"};
     if (!e) e = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);

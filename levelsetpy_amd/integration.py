@@ -189,6 +189,7 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     spare = None
     # RK3: the first stage buffer doubles as the output (stage 3 reads w1 and y_in only); RK2's second
     # stage reads the first stage buffer as its stencil input, so it needs its own
+    dynamic = getattr(plan, 'dynamic', False)       # alpha depends on the data: deltaT from the first stage's reduced bound, per step
     w0_own = dg.work('rk_w0') if order == 2 else None
     w1 = dg.work('rk_w1') if order == 3 else None
     parv = plan.parv
@@ -209,7 +210,9 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     sb_static = plan.static_step_bound(dg)
     # no per-step callbacks and nothing to warn about: the whole span is one native call
     # (hj_rk_integrate runs the same loop in C; no Python and no host synchronisation per step)
-    if (not post and not terminal and not single and factorCFL <= safetyFactorCFL and tf - t >= small * abs(tf)):
+    # (a data-dependent alpha can violate the bound at a later stage whatever factorCFL is: those plans step one call at a time below,
+    # where the reference's warning is raised from the stages' bounds)
+    if (not post and not terminal and not single and not dynamic and factorCFL <= safetyFactorCFL and tf - t >= small * abs(tf)):
         buf_b = dg.empty()
         work = dg.work('rk_w1')
         nsteps, where = C.c_int64(), C.c_int()
@@ -229,7 +232,14 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
         cur = nxt
         t = float(tout.value)
         steps += 1
-        if order > 1 and dtout.value > safetyFactorCFL * sb_static:
+        if dynamic:
+            if order > 1:
+                sbs, nsb = (C.c_double * 3)(), C.c_int()
+                _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
+                for k, which in enumerate(('Second', 'Third')[:order - 1]):
+                    if k + 1 < nsb.value and dtout.value > safetyFactorCFL * sbs[k + 1]:      # ode_cfl_3.py:173-175,215-217
+                        warn('%s substep violated CFL effective number %s' % (which, dtout.value / sbs[k + 1]))
+        elif order > 1 and dtout.value > safetyFactorCFL * sb_static:
             for which in ('Second', 'Third')[:order - 1]:
                 warn('%s substep violated CFL effective number %s' % (which, dtout.value / sb_static))
         if single and not post:

@@ -38,10 +38,13 @@ class _Plan(tuple):
     """(grid, scheme_id, ham_id, params) plus .diss, the hj_ctx_set_dissipation kind; .parv = params as a C array;
     .system = the object whose bound methods hamFunc / partialFunc are."""
 
-    def __new__(cls, items, diss, system=None):
+    def __new__(cls, items, diss, system=None, dynamic=False):
         self = super(_Plan, cls).__new__(cls, items)
         self.diss = diss
         self.system = system
+        # alpha depends on the data (a run-time Hamiltonian that reads the costate range, user_ham.py): no static stepBound --
+        # the integrators take deltaT from the first stage's reduced bound (hj_rk_step does, ode_cfl_3.py:142)
+        self.dynamic = dynamic
         self.parv = _ffi.darr(items[3])
         return self
 
@@ -61,6 +64,8 @@ class _Plan(tuple):
 
     def static_step_bound(self, dg):
         """stepBound of this (grid, system, dissipation kind): data independent for the native systems, one C call per ctx."""
+        if self.dynamic:
+            return None
         # kept ON the DeviceGrid (an id(dg) key could be reused by a later object once this one is collected)
         cache = dg.__dict__.setdefault("_sb_cache", {})
         key = (self[2], tuple(self[3]), self.diss)
@@ -122,8 +127,12 @@ def _classify(sd, fn):
         grid_bc(sd.grid)
     except ValueError:
         return None
+    att = getattr(nat[0], "_hj_native", None)
+    dynamic = bool(att is not None and getattr(att.reg, "uses_range", False))
+    if dynamic and sd.dissFunc is not artificialDissipationGLF:
+        return None          # per-node ranges of the local variants: the split path (dissipation.py)
     return _Plan((sd.grid, sid, nat[1], nat[2]),
-                 _ffi.DISS_GLF if sd.dissFunc is artificialDissipationGLF else _ffi.DISS_LOCAL, nat[0])
+                 _ffi.DISS_GLF if sd.dissFunc is artificialDissipationGLF else _ffi.DISS_LOCAL, nat[0], dynamic)
 
 
 def _fused_term(plan, t, y, restrict_sign):
@@ -153,8 +162,14 @@ def termLaxFriedrichs(t, y, schemeData):
     y0 = y[0] if iscell(y) else y
     plan = native_plan(sd0)          # looked up on the caller's own Bundle (the plan cache is keyed by it)
     if plan is not None:
-        out, stepBound, dg = _fused_term(plan, t, y0, 0)
-        return dg.like(out, y0, (dg.numel, 1), lazy=True), stepBound, schemeData
+        try:
+            out, stepBound, dg = _fused_term(plan, t, y0, 0)
+            return dg.like(out, y0, (dg.numel, 1), lazy=True), stepBound, schemeData
+        except _ffi.Unsupported:
+            # a run-time Hamiltonian the library has no kernel for on this grid (no tiling, ...): the callbacks still work --
+            # the split path, as before the registration (the built-in systems fall back inside the library)
+            if plan[2] < _ffi.HAM_USER_BASE:
+                raise
     thisSchemeData = copy.copy(sd0)      # the reference's shallow copy (term_lax_friedrich.py:80-83)
     # ---- split path (term_lax_friedrich.py:94-130)
     grid = thisSchemeData.grid

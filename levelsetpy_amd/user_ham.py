@@ -3,10 +3,13 @@
 The reference's termLaxFriedrichs calls arbitrary Python callables on whole arrays
 (ExplicitIntegration/Term/term_lax_friedrich.py:111, Dissipation/artificial_diss_glf.py:98); this package fuses the
 systems of dynamics.py and sends everything else down the split path (derivative kernels -> the callbacks -> a
-dissipation kernel: 25x the fused step at 201^3).  `register_native_hamiltonian` closes that gap for any system whose
-alpha does not depend on the costate (every system the reference ships): write H and alpha ONCE more, as a device
-expression, and the schemeData that carries the system's own bound methods runs fused -- selected by callable
-identity, exactly as the built-in systems are (dynamics.native_of).
+dissipation kernel: 25x the fused step at 201^3).  `register_native_hamiltonian` closes that gap: write H and alpha ONCE
+more, as a device expression, and the schemeData that carries the system's own bound methods runs fused -- selected by
+callable identity, exactly as the built-in systems are (dynamics.native_of).  alpha may depend on x and the parameters
+(every system the reference ships) and -- round 5 -- on the costate RANGE the reference's artificialDissipationGLF hands
+to partialFunc: `dmin[d]`, `dmax[d]` = derivMin[d], derivMax[d] (artificial_diss_glf.py:80-99).  Such an expression is
+detected (or declared: uses_range=True); each substep is then two launches (range pass + fused substep with the in-kernel
+max(alpha)), and the integrators take deltaT from the first stage's reduced stepBound as ode_cfl_3.py:142 does.
 
     DubinsAbs = register_native_hamiltonian("dubins_abs", 3, '''
         H = p[0] * par[0] * cos(x[2]) + p[1] * par[0] * sin(x[2]) + par[1] * fabs(p[2]);
@@ -18,11 +21,12 @@ identity, exactly as the built-in systems are (dynamics.native_of).
 In the expression: x[d] node coordinates, p[d] costates (the reference's derivC), par[k] parameters; assign H and every
 alpha[d].  Values that depend on the in-plane coordinates only (cos / sin of x[2] above) can be hoisted out of the march:
 `column_src="col[0] = cos(x[2]); col[1] = sin(x[2]);", ncol=2` evaluates them once per grid column, `col[k]` is then
-readable in the expression (8 % faster for the Dubins systems).  fp64, 2-D and 3-D grids; the kernels are built with hipRTC on first
+readable in the expression (8 % faster for the Dubins systems).  fp64 and fp32, 2-D / 3-D / 4-D grids; the kernels are built with hipRTC on first
 use (1-2 s per scheme) and kept on disk (kernel_cache_stats): a later process loads them in milliseconds.
 """
 import ctypes as C
 import os
+import re
 
 from . import _ffi
 
@@ -84,14 +88,19 @@ class RegisteredSystem(object):
 
 
 class NativeRegistration(object):
-    def __init__(self, name, dim, device_src, nparams=0, column_src=None, ncol=0):
+    def __init__(self, name, dim, device_src, nparams=0, column_src=None, ncol=0, uses_range=None):
         self.name, self.dim, self.nparams, self.device_src = str(name), int(dim), int(nparams), str(device_src)
         self.column_src, self.ncol = (str(column_src) if column_src else None), int(ncol)
+        # alpha reads the costate range (partialFunc's derivMin / derivMax, artificial_diss_glf.py:80-99): detected from the text
+        if uses_range is None:
+            uses_range = bool(re.search(r"\bd(min|max)\s*\[", self.device_src))
+        self.uses_range = bool(uses_range)
         ham = C.c_int()
         rtc = _hiprtc_path()
-        _ffi.check(_ffi.lib().hj_ham_register(self.name.encode(), self.dim, self.nparams, self.device_src.encode(),
-                                              self.column_src.encode() if self.column_src else None, self.ncol,
-                                              os.path.join(HERE, "csrc").encode(), rtc.encode() if rtc else None, C.byref(ham)))
+        _ffi.check(_ffi.lib().hj_ham_register2(self.name.encode(), self.dim, self.nparams, self.device_src.encode(),
+                                               self.column_src.encode() if self.column_src else None, self.ncol,
+                                               _ffi.HAM_RANGE if self.uses_range else 0,
+                                               os.path.join(HERE, "csrc").encode(), rtc.encode() if rtc else None, C.byref(ham)))
         self.ham_id = int(ham.value)
 
     def check(self, scheme="WENO5_ASSHIPPED"):
@@ -126,9 +135,11 @@ def kernel_cache_stats():
     return int(a.value), int(b.value)
 
 
-def register_native_hamiltonian(name, dim, device_src, nparams=0, column_src=None, ncol=0):
+def register_native_hamiltonian(name, dim, device_src, nparams=0, column_src=None, ncol=0, uses_range=None):
     """Register H / alpha as a device expression (module docstring); returns a NativeRegistration: call it to make a
     system object, or .attach() it to an existing one.
     column_src / ncol: statements assigning col[0..ncol-1] from x[1..] and par, evaluated once per grid column outside the
-    march along axis 0 and readable in device_src -- the place for cos / sin of in-plane coordinates."""
-    return NativeRegistration(name, dim, device_src, nparams, column_src, ncol)
+    march along axis 0 and readable in device_src -- the place for cos / sin of in-plane coordinates.
+    uses_range: the expression reads dmin[d] / dmax[d] (default: detected from the text) -- the general Lax-Friedrichs
+    protocol, alpha a function of the costate range; every substep then runs a range pass first (two launches)."""
+    return NativeRegistration(name, dim, device_src, nparams, column_src, ncol, uses_range)

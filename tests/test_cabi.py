@@ -149,7 +149,21 @@ def test_runtime_hamiltonian_registration_and_compile_check():
         bad.check()
     assert "no_such_symbol" in str(e.value) and "cabi_bad:1" in str(e.value)
     with pytest.raises(ValueError):
-        L.register_native_hamiltonian("cabi_4d", 4, "H = 0;", nparams=0)          # 2-D / 3-D only
+        L.register_native_hamiltonian("cabi_5d", 5, "H = 0;", nparams=0)          # 2-D / 3-D / 4-D
+    # round 5: 4-D grids, and an alpha that reads the costate range (dmin / dmax: artificial_diss_glf.py:80-99) -- detected from the text,
+    # flagged in the registration, compiled with its range pass
+    r4 = L.register_native_hamiltonian("cabi_4d", 4, "H = p[0] + x[1] * p[2]; alpha[0] = 1; alpha[1] = 0; alpha[2] = fabs(x[1]); alpha[3] = 0;")
+    assert not r4.uses_range
+    r4.check("WENO5_ASSHIPPED")
+    rr = L.register_native_hamiltonian("cabi_burgers", 2, "H = 0.5 * (p[0] * p[0] + p[1] * p[1]);\n"
+                                       "alpha[0] = fmax(fabs(dmin[0]), fabs(dmax[0])); alpha[1] = fmax(fabs(dmin[1]), fabs(dmax[1]));")
+    assert rr.uses_range
+    fl = C.c_int()
+    _ffi.check(_ffi.lib().hj_ham_flags(rr.ham_id, C.byref(fl)))
+    assert fl.value == _ffi.HAM_RANGE
+    _ffi.check(_ffi.lib().hj_ham_flags(reg.ham_id, C.byref(fl)))
+    assert fl.value == 0
+    rr.check("ENO2")
     with pytest.raises(ValueError):
         _ffi.check(_ffi.lib().hj_ham_info(9999, None, None, None))
     with pytest.raises(ValueError):

@@ -160,3 +160,146 @@ def test_pair4_long_axis0_chunks_the_row_table():
     rel = np.abs(yd.cpu().numpy().astype(np.float64) - yo) / float(np.max(np.abs(yo)))
     assert rel.max() <= 1e-4, rel.max()
     assert abs(sb - sbo) <= 1e-5 * sbo
+
+
+# ------------------------------------------------------------------------------ alpha depending on the costate range (general GLF)
+from test_gpu_parity import mk, close, SCHEMES  # noqa: E402
+
+
+def _is_t(a):
+    return type(a).__module__.startswith("torch")
+
+
+class BurgersDrift(object):
+    """H = sum_d p_d^2 / 2 + c x_0 p_1; alpha_d = max(|derivMin_d|, |derivMax_d|) (+ |c x_0| for d = 1): the partial of a convex H
+    bounded over the costate RANGE, which is what the reference's protocol hands to partialFunc (artificial_diss_glf.py:80-99).
+    Array callbacks as the reference would write them (NumPy or torch)."""
+
+    def __init__(self, grid, c):
+        self.grid, self.c = grid, c
+
+    def hamiltonian(self, t, data, p, sd=None):
+        x0 = np.asarray(self.grid.xs[0])
+        if _is_t(p[0]):
+            x0 = torch.as_tensor(x0, device=p[0].device)
+        h = 0
+        for d in range(len(p)):
+            h = h + 0.5 * p[d] * p[d]
+        return h + self.c * x0 * p[1]
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        a = max(abs(float(dmin[dim])), abs(float(dmax[dim])))
+        if dim != 1:
+            return a
+        x0 = np.asarray(self.grid.xs[0])
+        arr = a + np.abs(self.c * x0)
+        return torch.as_tensor(np.ascontiguousarray(arr), device=data.device) if _is_t(data) else arr
+
+
+def _burgers_src(dim):
+    s = "H = par[0] * x[0] * p[1];\n"
+    for d in range(dim):
+        s += "H += 0.5 * p[%d] * p[%d];  alpha[%d] = fmax(fabs(dmin[%d]), fabs(dmax[%d]));\n" % (d, d, d, d, d)
+    return s + "alpha[1] += fabs(par[0] * x[0]);\n"
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((40, 38), 1), ((23, 21, 26), 2), ((19, 24, 22), None)])
+def test_range_dependent_alpha_term_vs_oracle_and_split(scheme, n, pd):
+    """termLaxFriedrichs with a partialFunc that uses derivMin / derivMax: the fused two-launch path (range pass + substep with
+    the in-kernel max(alpha)) against the oracle's artificial_dissipation_glf semantics and against the split path (the same
+    object's Python callbacks between the library's derivative and dissipation kernels)."""
+    dim = len(n)
+    g, og = mk([-1.0] * dim, [1.0 - (2.0 / n[d] if pd == d else 0) for d in range(dim)], n, pd)
+    rng = np.random.default_rng(3)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[dim - 1]) + 0.02 * rng.standard_normal(n)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    sys_ = BurgersDrift(g, 0.7)
+    split, sb_s, _ = L.termLaxFriedrichs(0., y, sdata(g, sys_, DERIV[scheme]))            # not registered yet: the split path
+    reg = L.register_native_hamiltonian("burgers_drift_%dd" % dim, dim, _burgers_src(dim), nparams=1)
+    assert reg.uses_range
+    reg.attach(sys_, params=lambda o: [o.c])
+    fused, sb_f, _ = L.termLaxFriedrichs(0., y, sdata(g, sys_, DERIV[scheme]))
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    yo, sbo = O.term_lax_friedrichs(og, BurgersDrift(og, 0.7), scheme, 0., d0.reshape(-1, 1))
+    close(fused.cpu().numpy(), yo, 1e-11, what="fused vs oracle")
+    close(fused.cpu().numpy(), split.cpu().numpy(), 1e-11, what="fused vs split")
+    assert abs(sb_f - sbo) <= 1e-12 * sbo and abs(sb_s - sbo) <= 1e-12 * sbo, (sb_f, sb_s, sbo)
+
+
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "WENO5", "ENO3"])
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_range_dependent_alpha_through_odecfl_vs_oracle(scheme, order):
+    """odeCFL1/2/3 with a data-dependent alpha: deltaT comes from the FIRST stage's reduced stepBound (ode_cfl_3.py:142), the later
+    stages reduce their own ranges; four steps against the oracle's integrators within 1e-11, t to 1e-13."""
+    n = (26, 22, 24)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    sys_ = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)(
+        g, [0.7], hamiltonian=lambda s, t, data, p, sd: BurgersDrift(g, 0.7).hamiltonian(t, data, p, sd),
+        dissipation=lambda s, t, data, dmin, dmax, sd, dim: BurgersDrift(g, 0.7).dissipation(t, data, dmin, dmax, sd, dim))
+    sd = sdata(g, sys_, DERIV[scheme])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    ode = {1: L.odeCFL1, 2: L.odeCFL2, 3: L.odeCFL3}[order]
+    oode = {1: O.ode_cfl_1, 2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
+    term = lambda tt, yy: O.term_lax_friedrichs(og, BurgersDrift(og, 0.7), scheme, tt, yy)  # noqa: E731
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    yo, t, to = d0.reshape(-1, 1), 0., 0.
+    for _ in range(4):
+        t, y, _ = ode(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+        to, yo = oode(term, [to, 10.], yo, 0.8, single_step=True)
+    assert _last_kernel(g).endswith(b"(hipRTC)")
+    assert abs(t - to) <= 1e-13 * to, (t, to)
+    if scheme == "ENO3":
+        diff = np.abs(y.cpu().numpy() - yo)
+        assert np.mean(diff > 1e-11) <= 2e-3 and diff.max() <= 1e-3, (float(np.mean(diff > 1e-11)), diff.max())
+    else:
+        close(y.cpu().numpy(), yo, 1e-11, what="4 steps, order %d" % order)
+    # a whole span in one call (several steps inside odeCFLn's loop) lands on the same state as stepping it
+    t2, y2, _ = ode(L.termLaxFriedrichs, [0., float(t)], torch.as_tensor(d0.reshape(-1, 1), device="cuda"),
+                    L.odeCFLset(L.Bundle(dict(factorCFL=.8))), sd)
+    assert abs(t2 - t) <= 1e-13
+    if scheme != "ENO3":
+        close(y2.cpu().numpy(), y.cpu().numpy(), 1e-11, what="span vs single steps")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO3"])
+def test_runtime_hamiltonian_4d_and_fp32_vs_oracle(scheme, dtype):
+    """Run-time Hamiltonians beyond fp64 3-D (round 5): the double pendulum of BASELINE C5 written as a device expression on a 4-D
+    grid, fp64 (one-cell-per-lane kernel) and fp32 (pair kernel for the light stencil), against the fp64 oracle."""
+    n = (9, 11, 13, 12)
+    g, og = pendulum_grid(n)
+    src = """
+        const T s1 = sin(x[0]), c1 = cos(x[0]), s2 = sin(x[2]), c2 = cos(x[2]);
+        const T sd = s2 * c1 - c2 * s1, cd = c2 * c1 + s2 * s1, den = T(2) - cd * cd;
+        const T f1 = (x[1] * x[1] * sd * cd + T(9.8) * s2 * cd + x[3] * x[3] * sd - T(19.6) * s1) / den;
+        const T f3 = (-x[3] * x[3] * sd * cd + T(19.6) * s1 * cd - T(2) * x[1] * x[1] * sd - T(19.6) * s2) / den;
+        H = p[0] * x[1] + p[1] * f1 + p[2] * x[3] + p[3] * f3 + par[0] * (fabs(p[1]) + fabs(p[3]));
+        alpha[0] = fabs(x[1]); alpha[1] = fabs(f1) + par[0]; alpha[2] = fabs(x[3]); alpha[3] = fabs(f3) + par[0];
+    """
+    user = L.register_native_hamiltonian("pendulum_rt", 4, src, nparams=1)(g, [1.0])
+    rng = np.random.default_rng(2)
+    data = O.shape_sphere(og, None, 1.5) + 0.05 * np.sin(2 * og.xs[0]) * np.cos(og.xs[2]) + 0.02 * rng.standard_normal(n)
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), scheme, 0., data.reshape(-1, 1))
+    y = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=getattr(torch, dtype))
+    yd, sb, _ = L.termLaxFriedrichs(0., y, sdata(g, user, DERIV[scheme]))
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    assert yd.dtype == y.dtype
+    rel = np.abs(yd.cpu().numpy().astype(np.float64) - yo) / float(np.max(np.abs(yo)))
+    if dtype == "float64":
+        assert rel.max() <= 1e-11 and abs(sb - sbo) <= 1e-12 * sbo, (rel.max(), sb, sbo)
+    else:
+        assert abs(sb - sbo) <= 1e-5 * sbo
+        if scheme.startswith("WENO"):
+            assert rel.max() <= 1e-4, rel.max()
+        else:
+            assert np.mean(rel > 1e-4) <= 2e-3 and rel.max() <= 0.2
+    # and through an integrator step
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t1, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sdata(g, user, DERIV[scheme]))
+    term = lambda tt, yy: O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), scheme, tt, yy)  # noqa: E731
+    to, y1o = O.ode_cfl_3(term, [0., 10.], data.reshape(-1, 1), 0.8, single_step=True)
+    assert abs(t1 - to) <= (1e-12 if dtype == "float64" else 1e-5) * to
+    rel = np.abs(y1.cpu().numpy().astype(np.float64) - y1o) / float(np.max(np.abs(y1o)))
+    assert (rel.max() <= 1e-11) if dtype == "float64" else (np.mean(rel > 1e-4) <= 2e-3)
