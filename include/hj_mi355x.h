@@ -337,6 +337,9 @@ int hj_rk_last_bounds(hj_ctx* ctx, double* sb_host /* 3 */, int* n_host);
  * range from such keys instead of running their own pass (NULL: back to per-launch passes).  No reference counterpart. */
 int hj_range_pass(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, const void* y, void* keys_dev);
 int hj_ctx_set_range_source(hj_ctx* ctx, const void* keys_dev);
+/* max over this ctx's nodes of alpha_d(x, range) for the range currently in force (the source set above, else the last pass):
+ * amax_host[0..ndim); artificial_diss_glf.py:101-107 -- what the ranks all-reduce for deltaT.  One host synchronisation. */
+int hj_range_alpha_max(hj_ctx* ctx, int ham_id, const double* ham_params, double* amax_host);
 /* compile the substep kernel of `scheme` and the alpha-bound kernel WITHOUT launching (needs no GPU) */
 int hj_ham_compile_check(int ham_id, int scheme);
 /* Compiled code objects are kept on disk, keyed by the generated source, the kernel headers' text and the compile options

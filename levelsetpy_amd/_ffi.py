@@ -75,6 +75,7 @@ SIGNATURES = {
     "hj_rk_last_bounds": (_i, [_vp, _pd, _pi]),
     "hj_range_pass": (_i, [_vp, _i, _i, _pd, _vp, _vp]),
     "hj_ctx_set_range_source": (_i, [_vp, _vp]),
+    "hj_range_alpha_max": (_i, [_vp, _i, _pd, _pd]),
     "hj_ham_info": (_i, [_i, _pi, _pi, _pi]),
     "hj_ham_compile_check": (_i, [_i, _i]),
     "hj_ham_cache_stats": (_i, [_pi, _pi]),

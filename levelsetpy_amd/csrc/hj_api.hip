@@ -1677,6 +1677,21 @@ int hj_ctx_set_range_source(hj_ctx* c, const void* keys_dev) {
     return HJ_OK;
 }
 
+int hj_range_alpha_max(hj_ctx* c, int ham, const double* par, double* amax) {
+    if (!c || !amax) return fail(HJ_EINVAL, "null argument");
+    if (!user_ham_dynamic(ham)) return fail(HJ_EINVAL, "Hamiltonian %d does not read the costate range", ham);
+    if (!c->range_src && !c->range_keys) return fail(HJ_ESTATE, "no range yet: hj_range_pass + hj_ctx_set_range_source first");
+    int rc = check_ham(c, ham, par);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
+    if ((rc = user_alpha_bound(c, ham, par, c->keys, true))) return rc;
+    unsigned long long k[HJ_MAX_DIM];
+    HIP_TRY(hipMemcpyAsync(k, c->keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < c->ndim; ++d) amax[d] = key_to_double(k[d]);
+    return HJ_OK;
+}
+
 int hj_range_pass(hj_ctx* c, int scheme, int ham, const double* par, const void* y, void* keys_dev) {
     if (!c || !y || !keys_dev) return fail(HJ_EINVAL, "null argument");
     if (!user_ham_dynamic(ham)) return fail(HJ_EINVAL, "Hamiltonian %d does not read the costate range", ham);

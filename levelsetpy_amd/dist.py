@@ -128,9 +128,13 @@ class SlabIntegrator(object):
     }
 
     def __init__(self, slab, backend, dx, order=3, factor_cfl=0.8, group=None, needs_eps=False,
-                 exchanger=None, allreduce_max=None):
+                 exchanger=None, allreduce_max=None, dynamic=False):
         """exchanger / allreduce_max: transport overrides (tests run several ranks inside one
-        process); default is torch.distributed (RCCL on GPUs, gloo on CPU)."""
+        process); default is torch.distributed (RCCL on GPUs, gloo on CPU).
+        dynamic: the Hamiltonian's alpha depends on the costate range (user_ham.register_native_hamiltonian with dmin / dmax:
+        artificial_diss_glf.py:80-99).  The range is a property of the WHOLE grid: before every substep each rank reduces
+        derivL / derivR of its slab (backend.range_pass, pads in place), the ranks all-reduce (MAX) and every launch of the substep
+        reads the reduced range (backend.set_range); deltaT comes from the all-reduced max(alpha) of the first stage's range."""
         import torch
         self.torch = torch
         self.slab, self.be, self.order, self.factor_cfl = slab, backend, order, factor_cfl
@@ -143,6 +147,10 @@ class SlabIntegrator(object):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         self._allreduce_max = allreduce_max
         self.buf = {k: backend.alloc() for k in ("cur", "w0", "w1", "nxt")}
+        self.dynamic, self.dx = bool(dynamic), [float(v) for v in dx]
+        if self.dynamic:
+            self.alpha_max, self.step_bound = None, None       # per step (step())
+            return
         # stepBound = 1 / sum_d max_grid(alpha_d)/dx_d with the max over ALL ranks
         # (artificial_diss_glf.py:101-109); alpha is data-independent for the native systems
         amax = torch.tensor(backend.local_alpha_max(), dtype=torch.float64, device=backend.device)
@@ -174,11 +182,24 @@ class SlabIntegrator(object):
         """One odeCFLn step: dt = min(factorCFL*stepBound, tf - t, maxStep) (ode_cfl_3.py:142)."""
         be, s = self.be, self.slab
         n = s.n_local
-        dt = min(self.factor_cfl * self.step_bound, tf - t, max_step)
-        for (stage, ysrc, y0src, dst) in self.PLANS[self.order]:
+        dt = None if self.dynamic else min(self.factor_cfl * self.step_bound, tf - t, max_step)
+        for k, (stage, ysrc, y0src, dst) in enumerate(self.PLANS[self.order]):
             y, y0, out = self.buf[ysrc], (self.buf[y0src] if y0src else None), self.buf[dst]
             if self.needs_eps:
                 self._eps(y)
+            if self.dynamic:
+                # the costate range of the stage's input over the whole grid, then (first stage) deltaT from max(alpha) of that range
+                rng = be.range_pass(y)
+                if s.world > 1:
+                    self._allreduce_max(rng)
+                be.set_range(rng)
+                if k == 0:
+                    amax = self.torch.tensor(be.alpha_max_now(), dtype=self.torch.float64, device=be.device)
+                    if s.world > 1:
+                        self._allreduce_max(amax)
+                    self.alpha_max = [float(v) for v in amax.cpu()]
+                    self.step_bound = 1.0 / sum(a / d for a, d in zip(self.alpha_max, self.dx))
+                    dt = min(self.factor_cfl * self.step_bound, tf - t, max_step)      # ode_cfl_3.py:142
             # (1) edge planes first: they are what the neighbours wait for
             lo_e = min(HALO, n) if s.halo_lo else 0
             hi_b = max(n - HALO, lo_e) if s.halo_hi else n
@@ -241,6 +262,27 @@ class HipSlabBackend(object):
         sb = C.c_double()
         am = (C.c_double * 4)()
         _ffi.check(dg.lib.hj_static_step_bound(dg.ctx, self.ham, self.par, C.byref(sb), am))
+        return [am[d] for d in range(dg.dim)]
+
+    # ---- Hamiltonians whose alpha reads the costate range (SlabIntegrator(dynamic=True))
+    def range_pass(self, y):
+        """derivL / derivR of this slab (pads read where it has neighbours) reduced to 2*ndim order-preserving keys, returned as
+        an int64 tensor whose element-wise MAX over ranks is the reduction (the keys are unsigned: the sign bit is flipped so that
+        signed MAX orders them; set_range flips it back)."""
+        dg, torch = self.dg, self.torch
+        keys = torch.zeros(8, dtype=torch.int64, device=self.device)
+        _ffi.check(dg.lib.hj_range_pass(dg.ctx, self.sid, self.ham, self.par, self._interior_ptr(y), C.c_void_p(keys.data_ptr())))
+        return keys.bitwise_xor_(torch.tensor(-2 ** 63, dtype=torch.int64, device=self.device))
+
+    def set_range(self, keys_signed):
+        torch = self.torch
+        self._range = keys_signed.bitwise_xor(torch.tensor(-2 ** 63, dtype=torch.int64, device=self.device))   # keep alive
+        _ffi.check(self.dg.lib.hj_ctx_set_range_source(self.dg.ctx, C.c_void_p(self._range.data_ptr())))
+
+    def alpha_max_now(self):
+        dg = self.dg
+        am = (C.c_double * 4)()
+        _ffi.check(dg.lib.hj_range_alpha_max(dg.ctx, self.ham, self.par, am))
         return [am[d] for d in range(dg.dim)]
 
     def max_d1sq(self, y):

@@ -48,7 +48,7 @@ class OracleSlabBackend(object):
     def substep(self, stage, dt, y, y0, out, p0, p1):
         yi = y[HALO:HALO + self.n].numpy()
         ydot, _ = O.term_lax_friedrichs(self.g, self.sys, self.scheme, 0., yi.reshape(-1), self._halo(y),
-                                        self.eps)
+                                        self.eps, deriv_range=getattr(self, "deriv_range", None))
         ye = yi + dt * ydot.reshape(yi.shape)
         if stage == _ffi.STAGE_EULER:
             o = ye
@@ -64,6 +64,21 @@ class OracleSlabBackend(object):
 
     def local_alpha_max(self):
         return [float(np.max(self.sys.dissipation(0, None, None, None, None, d))) for d in range(self.g.dim)]
+
+    # ---- alpha depending on the costate range (SlabIntegrator(dynamic=True)): [max_d ..., -min_d ...] as float64, MAX-reducible
+    def range_pass(self, y):
+        yi = y[HALO:HALO + self.n].numpy()
+        lo, hi = O.costate_range(self.g, self.scheme, yi.reshape(-1), self._halo(y), self.eps)
+        return torch.tensor([float(v) for v in hi] + [-float(v) for v in lo], dtype=torch.float64)
+
+    def set_range(self, v):
+        D = self.g.dim
+        v = [float(x) for x in v]
+        self.deriv_range = ([-x for x in v[D:]], v[:D])
+
+    def alpha_max_now(self):
+        lo, hi = self.deriv_range
+        return [float(np.max(self.sys.dissipation(0, None, lo, hi, None, d))) for d in range(self.g.dim)]
 
     def max_d1sq(self, y):
         yi = y[HALO:HALO + self.n].numpy()
@@ -261,6 +276,81 @@ def test_c5_four_d_all_periodic_ring_of_slabs_equals_single_domain(world):
             assert abs(t - t_ref) <= 1e-14
             assert abs(sb - sb_ref) <= 1e-14 * sb_ref
         assert np.max(np.abs(got - y.reshape(N4))) <= 1e-11, (scheme, order, world)
+
+
+# ---------------------------------------------------------------- alpha depending on the costate range, decomposed
+class BurgersDriftOracle(object):
+    """H = |p|^2/2 + c x0 p1, alpha_d = max(|derivMin_d|, |derivMax_d|) (+ |c x0| for d = 1): artificial_diss_glf.py:80-99's protocol."""
+
+    def __init__(self, grid, c):
+        self.grid, self.c = grid, c
+
+    def hamiltonian(self, t, data, p, sd=None):
+        return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * self.grid.xs[0] * p[1]
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        a = max(abs(float(dmin[dim])), abs(float(dmax[dim])))
+        return a + np.abs(self.c * self.grid.xs[0]) if dim == 1 else a
+
+
+CASES_DYN = [("WENO5_ASSHIPPED", False, 3), ("ENO3", True, 2), ("WENO5", False, 3)]
+
+
+def _worker_dyn(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for ci, (scheme, periodic0, order) in enumerate(CASES_DYN):
+            pd = [0, 2] if periodic0 else [2]
+            og = O.Grid([-1., -1., -1.], [1. - (2. / N[0] if periodic0 else 0.), 1., 1. - 2. / N[2]], N, pd)
+            data = O.shape_sphere(og, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+            slab = SlabDecomposition(N[0], world, rank, periodic0)
+            be = OracleSlabBackend(og, slab, scheme, make_sys=lambda g: BurgersDriftOracle(g, 0.7))
+            integ = SlabIntegrator(slab, be, [float(v) for v in og.dx.ravel()], order, 0.8, needs_eps=(scheme == "WENO5"), dynamic=True)
+            integ.set_state(torch.from_numpy(np.ascontiguousarray(data[slab.begin:slab.end])))
+            t = 0.0
+            for _ in range(NSTEPS):
+                t, _dt = integ.step(t)
+            q.put((ci, rank, slab.begin, slab.end, t, integ.step_bound, integ.state().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
+    """A Hamiltonian whose alpha reads derivMin / derivMax, slab-decomposed: every substep all-reduces the 2*D range values of the
+    slabs, the first stage of a step all-reduces max(alpha) for deltaT; the decomposed run equals the undivided oracle run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dyn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world * len(CASES_DYN))]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for ci, (scheme, periodic0, order) in enumerate(CASES_DYN):
+        pd = [0, 2] if periodic0 else [2]
+        og = O.Grid([-1., -1., -1.], [1. - (2. / N[0] if periodic0 else 0.), 1., 1. - 2. / N[2]], N, pd)
+        data = O.shape_sphere(og, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+        sys_ = BurgersDriftOracle(og, 0.7)
+        term = lambda t, y: O.term_lax_friedrichs(og, sys_, scheme, t, y)  # noqa: E731
+        ode = {2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
+        y, t_ref, sb_last = data.reshape(-1, 1), 0.0, None
+        for _ in range(NSTEPS):
+            sb_last = term(t_ref, y)[1]                  # the bound of the step's first stage: what fixed its deltaT
+            t_ref, y = ode(term, [t_ref, 10.], y, 0.8, single_step=True)
+        got = np.full(N, np.nan)
+        parts = [r for r in res if r[0] == ci]
+        assert len(parts) == world
+        for (_ci, _rank, b, e, t, sb, ys) in parts:
+            got[b:e] = ys
+            assert abs(t - t_ref) <= 1e-13 * t_ref, (t, t_ref)
+            assert abs(sb - sb_last) <= 1e-13 * sb_last
+        assert np.max(np.abs(got - y.reshape(N))) <= 1e-11, (scheme, periodic0, order, world)
 
 
 def test_slab_decomposition_bookkeeping():

@@ -303,3 +303,57 @@ def test_runtime_hamiltonian_4d_and_fp32_vs_oracle(scheme, dtype):
     assert abs(t1 - to) <= (1e-12 if dtype == "float64" else 1e-5) * to
     rel = np.abs(y1.cpu().numpy().astype(np.float64) - y1o) / float(np.max(np.abs(y1o)))
     assert (rel.max() <= 1e-11) if dtype == "float64" else (np.mean(rel > 1e-4) <= 2e-3)
+
+
+@pytest.mark.parametrize("world,periodic0", [(2, True), (3, False)])
+def test_range_dependent_alpha_virtual_ranks_equal_undivided(world, periodic0):
+    """dist.SlabIntegrator(dynamic=True) + HipSlabBackend on one card (threads as ranks): before every substep the slabs' costate
+    ranges are reduced (hj_range_pass) and all-reduced, the launches read the reduced range (hj_ctx_set_range_source), deltaT comes
+    from the all-reduced max(alpha) (hj_range_alpha_max).  Two RK3 steps equal the undivided grid through odeCFL3."""
+    import threading
+    from test_gpu_round4 import ThreadRing
+    from levelsetpy_amd.dist import SlabDecomposition, SlabIntegrator, HipSlabBackend
+    n = (30, 22, 24)
+    pd = [0, 2] if periodic0 else 2
+    g, og = mk([-1.0] * 3, [1.0 - (2.0 / n[0] if periodic0 else 0.0), 1.0, 1.0 - 2.0 / n[2]], n, pd)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+    sys_ = reg(g, [0.7])
+    full = torch.as_tensor(d0, device="cuda")
+    sd = sdata(g, sys_, DERIV["WENO5_ASSHIPPED"])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y, t_ref = full.reshape(-1, 1), 0.
+    for _ in range(2):
+        t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
+    ref = y.reshape(n)
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    tr = ThreadRing(world)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                slab = SlabDecomposition(n[0], world, rank, periodic0, self_exchange=periodic0)
+                be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, [0.7], "float64")
+                integ = SlabIntegrator(slab, be, dxs, 3, 0.8, exchanger=tr.exchanger(slab), allreduce_max=tr.allreduce_max(rank), dynamic=True)
+                integ.set_state(full[slab.begin:slab.end])
+                t = 0.
+                for _ in range(2):
+                    t, dt = integ.step(t)
+                be.sync()
+                out[rank] = (slab.begin, slab.end, t, integ.state().clone())
+                be.sync()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            tr.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errs, errs
+    for r in range(world):
+        b, e, t, ys = out[r]
+        assert abs(t - t_ref) <= 1e-14 * t_ref, (t, t_ref)
+        assert float((ys - ref[b:e]).abs().max()) <= 1e-13, (r, float((ys - ref[b:e]).abs().max()))
