@@ -48,7 +48,14 @@ enum {
     HJ_ENO2 = 0,            /* SpatialDerivative/upwind_first_eno2.py:12  */
     HJ_ENO3 = 1,            /* SpatialDerivative/upwind_first_eno3a.py:14 */
     HJ_WENO5 = 2,           /* intended O&F WENO5 (upwind_first_weno5a.py:13, ENO3bHelper.py:135-160) */
-    HJ_WENO5_ASSHIPPED = 3  /* what upwind_first_weno5a.py computes as shipped: linear weights */
+    HJ_WENO5_ASSHIPPED = 3, /* what upwind_first_weno5a.py computes as shipped: linear weights */
+    /* Round 5, opt-in: ENO2 / ENO3 in the LEAN arithmetic (undivided differences, contracted FMAs, select-then-form) instead of
+     * the reference's operation order.  Same scheme, same stencil choices except where two |D2| / |D3| moduli lie within rounding
+     * of each other (masked comparison, margin < 1e-12); everything else agrees with the reference to 1e-11.  Accepted
+     * by the substep entry points (hj_lf_term, hj_rk_substep, hj_rk_step, hj_rk_integrate, the slab steppers); the array-level
+     * derivative / term entry points treat them as HJ_ENO2 / HJ_ENO3. */
+    HJ_ENO2_FAST = 4,
+    HJ_ENO3_FAST = 5
 };
 
 /* schemeData.hamFunc / partialFunc pairs with a native implementation */

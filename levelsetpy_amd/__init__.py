@@ -19,7 +19,7 @@ from .grids import createGrid, processGrid                                      
 from .init_conds import shapeCylinder, shapeSphere                              # noqa: F401
 from .spatial import (upwindFirstENO2, upwindFirstENO3, upwindFirstENO3a, upwindFirstWENO5,   # noqa: F401
                       upwindFirstWENO5a, upwindFirstWENO5Intended, upwindFirstENO3aHelper,
-                      set_weno5_mode, get_weno5_mode)
+                      set_weno5_mode, get_weno5_mode, set_eno_mode, get_eno_mode)
 from .dissipation import (artificialDissipationGLF, artificialDissipationLLF,      # noqa: F401
                           artificialDissipationLLLF)
 from .dynamics import DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D      # noqa: F401

@@ -22,7 +22,7 @@ OP_MIN, OP_MAX, OP_MAX_NEG = 0, 1, 2
 STENCIL = 3
 BOUND_SLOTS = 64
 
-SCHEME_IDS = {"ENO2": ENO2, "ENO3": ENO3, "WENO5": WENO5, "WENO5_ASSHIPPED": WENO5_ASSHIPPED}
+SCHEME_IDS = {"ENO2": ENO2, "ENO3": ENO3, "WENO5": WENO5, "WENO5_ASSHIPPED": WENO5_ASSHIPPED, "ENO2_FAST": 4, "ENO3_FAST": 5}
 
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _pd, _pi, _pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)

@@ -425,7 +425,7 @@ int keys_to_vals(hj_ctx* c, void* out) {
 int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
     int rc = check_ham(c, s.ham, s.par);
     if (rc) return rc;
-    if (s.scheme < 0 || s.scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
+    if (s.scheme < 0 || s.scheme > HJ_ENO3_FAST) return fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
     {   // pad planes may be computed too when the tables cover them (deep-halo stepper)
         const int64_t lo = c->halo_lo ? -(int64_t)c->pad0 : 0, hi = c->N[0] + (c->halo_hi ? c->pad0 : 0);
         if (s.p0 < lo || s.p1 > hi || s.p0 > s.p1 || (s.q1 > s.q0 && (s.q0 < lo || s.q1 > hi)))
@@ -502,7 +502,7 @@ int do_stage12(hj_ctx* c, Stage12Call& s, int user_slot) {
 
 // does hj_rk_step fuse the first two stages on this ctx?  (cached per scheme / Hamiltonian)
 bool use_stage12(hj_ctx* c, int order, int scheme, int ham, const double* par, int restrict_sign) {
-    if (order < 2 || c->fuse12 == 0 || restrict_sign != 0 || ham >= HJ_HAM_USER_BASE) return false;
+    if (order < 2 || c->fuse12 == 0 || restrict_sign != 0 || ham >= HJ_HAM_USER_BASE || scheme > HJ_WENO5_ASSHIPPED) return false;
     if (order == 2 && c->post_step_op != 0) return false;     // the fused post-step operator rides on the LAST stage
     if (c->fuse12 < 0) {
         // auto: the fusion trades HBM traffic for redundant ring / warm-up work; it pays once the arrays are
@@ -1204,6 +1204,7 @@ int hj_ghost(hj_ctx* c, int dim, int width, const void* in, void* out) {
 int hj_upwind(hj_ctx* c, int scheme, int dim, const void* phi, void* dL, void* dR, double* mm) {
     if (!c || !phi || !dL || !dR) return fail(HJ_EINVAL, "null argument");
     if (dim < 0 || dim >= c->ndim) return fail(HJ_EINVAL, "Illegal dim parameter");
+    scheme = base_scheme(scheme);          // (the fast ENO variants exist for the substep kernels only)
     if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
     if (c->N[dim] < HJ_STENCIL) return fail(HJ_EINVAL, "grid too small along dim %d (N=%lld)", dim, (long long)c->N[dim]);
     int rc;
@@ -1232,6 +1233,7 @@ int hj_upwind(hj_ctx* c, int scheme, int dim, const void* phi, void* dL, void* d
 
 int hj_lf_split_begin(hj_ctx* c, int scheme, const void* y, void* const* dL, void* const* dR, double* mm) {
     if (!c || !y || !dL || !dR) return fail(HJ_EINVAL, "null argument");
+    scheme = base_scheme(scheme);          // (the fast ENO variants exist for the substep kernels only)
     if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
     for (int d = 0; d < c->ndim; ++d) {
         if (!dL[d] || !dR[d]) return fail(HJ_EINVAL, "null derivative array for dim %d", d);
@@ -1362,6 +1364,7 @@ int term_launch_nd(hj_ctx* c, int kind, int scheme, const void* y, const void* c
 int term_run(hj_ctx* c, int kind, int scheme, const void* y, const void* const* arr, const double* scal, int order,
              void* out, double* k) {
     if (!c || !y || !out) return fail(HJ_EINVAL, "null argument");
+    scheme = base_scheme(scheme);          // (the fast ENO variants exist for the substep kernels only)
     if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
     if (y == out) return fail(HJ_EINVAL, "out must not alias the stencil input y");
     for (int d = 0; d < c->ndim; ++d)

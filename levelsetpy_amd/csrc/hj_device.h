@@ -133,6 +133,9 @@ constexpr int HJ_NK = 12;
 // reference's bit for bit and so is every later choice.  The WENO5 arithmetics keep their contracted forms (linear /
 // smooth in the data: no discrete choices to flip).
 constexpr bool np_order(int scheme) { return HJ_ENO_EXACT && (scheme == HJ_ENO2 || scheme == HJ_ENO3); }
+// the scheme an opt-in fast variant stands for (HJ_ENO2_FAST / HJ_ENO3_FAST: the lean arithmetic of upwind_cd, include/hj_mi355x.h)
+constexpr int base_scheme(int scheme) { return scheme == HJ_ENO2_FAST ? HJ_ENO2 : (scheme == HJ_ENO3_FAST ? HJ_ENO3 : scheme); }
+constexpr bool lean_eno(int scheme) { return scheme == HJ_ENO2_FAST || scheme == HJ_ENO3_FAST || (!HJ_ENO_EXACT && (scheme == HJ_ENO2 || scheme == HJ_ENO3)); }
 template <typename T> inline void fill_stencil_constants(double dx, T* K) {
     const double inv = 1.0 / dx;
     K[0] = (T)inv;
@@ -196,8 +199,9 @@ __device__ __forceinline__ void weno_smooth(T v1, T v2, T v3, T v4, T v5, T& s1,
 }
 
 // eps: only used by HJ_WENO5 (= 1e-6*max(D1^2)+tiny for this dim)
-template <int SCHEME, typename T>
+template <int SCHEME_IN, typename T>
 __device__ __forceinline__ void upwind(const T* v, const T* K, T eps, T& L, T& R) {
+    constexpr int SCHEME = base_scheme(SCHEME_IN);
     DD<T> t;
     dd_tables(v, K, t);
     const T dx = K[3];
@@ -255,6 +259,95 @@ __device__ __forceinline__ WenoK<T> weno_consts(T eps, const T* K) {
     return w;
 }
 
+// ---- the intended WENO5 in pieces (round 5).  u_j = v[j+1] - v[j] (undivided), candidates x6, smoothness x dx^2 (so is epsilon:
+// WenoK), weights x10, the two quotients L' = N_L/D_L, R' = N_R/D_R over one reciprocal; pc' = L'+R', hd' = R'-L' with p = pc'/(12dx).
+// The smoothness values enter as q_k = ((S_k + eps)/eps)^2 = (c13 t^2 + c4 b^2 + 1)^2 with t a second difference and b the
+// first-difference part.  The RIGHT-biased q's of cell i are the LEFT-biased q's of cell i+1 in reverse order -- term by term the same
+// expressions on the same operands (r3(i) = l1(i+1): second difference t1, first-difference part t1 + 2(u3 - u2); r2(i) = l2(i+1):
+// t2 and +-(u4 - u2), squared; r1(i) = l3(i+1): t3 and t3 - 2(u4 - u3)) -- so a kernel that walks a line forms three q's per cell
+// instead of six and the results equal the cell-by-cell form bit for bit (upwind_cd<HJ_WENO5>, which the direct kernels call).
+template <typename T> struct WenoLine { T u[6], t[4]; };
+template <typename T>
+__device__ __forceinline__ WenoLine<T> weno5_line(const T* v) {
+    WenoLine<T> ln;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ln.u[j] = v[j + 1] - v[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ln.t[j] = (ln.u[j] + ln.u[j + 2]) - T(2) * ln.u[j + 1];
+    return ln;
+}
+template <typename T>
+__device__ __forceinline__ T weno5_q(T t, T b, const WenoK<T>& wk) {
+    T q = wk.c13 * (t * t) + (wk.c4 * (b * b) + T(1));
+    return q * q;
+}
+// left-biased q's of the cell in the middle of the line (v[3]): l1, l2, l3
+template <typename T>
+__device__ __forceinline__ void weno5_left_q(const WenoLine<T>& ln, const WenoK<T>& wk, T* lq) {
+    const T s1 = ln.u[2] - ln.u[1], s2 = ln.u[3] - ln.u[2];
+    lq[0] = weno5_q(ln.t[0], ln.t[0] + T(2) * s1, wk);
+    lq[1] = weno5_q(ln.t[1], ln.u[1] - ln.u[3], wk);
+    lq[2] = weno5_q(ln.t[2], ln.t[2] - T(2) * s2, wk);
+}
+// right-biased q's: r1, r2, r3  ( = l3, l2, l1 of the next cell of the line)
+template <typename T>
+__device__ __forceinline__ void weno5_right_q(const WenoLine<T>& ln, const WenoK<T>& wk, T* rq) {
+    const T s2 = ln.u[3] - ln.u[2], s3 = ln.u[4] - ln.u[3];
+    rq[0] = weno5_q(ln.t[3], ln.t[3] - T(2) * s3, wk);
+    rq[1] = weno5_q(ln.t[2], ln.u[4] - ln.u[2], wk);
+    rq[2] = weno5_q(ln.t[1], ln.t[1] + T(2) * s2, wk);
+}
+template <typename T>
+__device__ __forceinline__ void weno5_combine(const WenoLine<T>& ln, const T* lq, const T* rq, T& pc, T& hd) {
+    const T* u = ln.u;
+    // candidates (x6): left phi1..3 = F1,F2,F3; right psi1 = G1, psi2 = F3, psi3 = F2
+    const T F1 = T(2) * u[0] + (T(-7) * u[1] + T(11) * u[2]);
+    const T F2 = T(5) * u[2] + (T(2) * u[3] - u[1]);
+    const T F3 = T(2) * u[2] + (T(5) * u[3] - u[4]);
+    const T G1 = T(2) * u[5] + (T(-7) * u[4] + T(11) * u[3]);
+    // weights x10: (.1,.6,.3)/q_k^2 multiplied through by q1^2 q2^2 q3^2
+    const T A1 = lq[1] * lq[2], A2 = T(6) * (lq[0] * lq[2]), A3 = T(3) * (lq[0] * lq[1]);
+    const T B1 = rq[1] * rq[2], B2 = T(6) * (rq[0] * rq[2]), B3 = T(3) * (rq[0] * rq[1]);
+    const T NL = A1 * F1 + (A2 * F2 + A3 * F3), DL = A1 + (A2 + A3);
+    const T NR = B1 * G1 + (B2 * F3 + B3 * F2), DR = B1 + (B2 + B3);
+    if constexpr (sizeof(T) == 8) {
+        // one reciprocal for both quotients (products stay < 1e62 in fp64): v_rcp_f64 (relative error 4.6e-8 on gfx950) + ONE Newton step
+        // = 2.2e-15 (tools/probes/rcp_probe.hip, profiles/r04_weno5_smoothness_terms.txt); the scheme is checked at 1e-11
+        const T den = DL * DR;
+        T rc = __builtin_amdgcn_rcp(den);
+        rc = rc + rc * (T(1) - den * rc);
+        const T a = NL * DR, b = NR * DL;
+        pc = (a + b) * rc;
+        hd = (b - a) * rc;
+    } else {
+        const T Lq = NL / DL, Rq = NR / DR;
+        pc = Lq + Rq;
+        hd = Rq - Lq;
+    }
+}
+// a cell of a line that is walked cell by cell (the axis-0 march): carry[] holds its left-biased q's on entry and those of the NEXT cell
+// on return (its own right-biased ones, reversed)
+template <typename T>
+__device__ __forceinline__ void weno5_cd_carry(const T* v, const WenoK<T>& wk, T* carry, T& pc, T& hd) {
+    const WenoLine<T> ln = weno5_line(v);
+    T rq[3];
+    weno5_right_q(ln, wk, rq);
+    weno5_combine(ln, carry, rq, pc, hd);
+    carry[0] = rq[2]; carry[1] = rq[1]; carry[2] = rq[0];
+}
+// two adjacent cells of a line (w[0..7], the cells at w[3] and w[4]): nine q's instead of twelve
+template <typename T>
+__device__ __forceinline__ void weno5_cd_pair(const T* w, const WenoK<T>& wk, T& pc0, T& hd0, T& pc1, T& hd1) {
+    const WenoLine<T> l0 = weno5_line(w), l1 = weno5_line(w + 1);
+    T lq0[3], m[3], rq1[3];
+    weno5_left_q(l0, wk, lq0);
+    weno5_right_q(l0, wk, m);              // right of the first cell = left of the second, reversed
+    weno5_right_q(l1, wk, rq1);
+    weno5_combine(l0, lq0, m, pc0, hd0);
+    const T lq1[3] = {m[2], m[1], m[0]};
+    weno5_combine(l1, lq1, rq1, pc1, hd1);
+}
+
 template <int SCHEME, typename T>
 __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const WenoK<T>& wk, T& pc, T& hd) {
     if constexpr (SCHEME == HJ_WENO5_ASSHIPPED) {
@@ -268,53 +361,13 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
         pc = T(45) * D1 + (T(-9) * D2 + D3);
         hd = T(15) * S1 + (T(-6) * S2 + (S3 + T(-20) * v[3]));
     } else if constexpr (SCHEME == HJ_WENO5) {
-        // Intended WENO5 (O&F 3.32-3.41; ENO3bHelper.py:135-160) on UNDIVIDED differences
-        // u_j = v[j+1]-v[j]: candidates x6, smoothness x dx^2 (so is epsilon: wk.e2), weights x10,
-        // the two quotients L' = N_L/D_L, R' = N_R/D_R brought over one reciprocal.  Returns
-        // pc' = L'+R', hd' = R'-L' with p = pc'/(12dx), (R-L)/2 = hd'/(12dx)  (sc[d] = 1/(12dx)).
-        const T u0 = v[1] - v[0], u1 = v[2] - v[1], u2 = v[3] - v[2];
-        const T u3 = v[4] - v[3], u4 = v[5] - v[4], u5 = v[6] - v[5];
-        // candidates (x6): left phi1..3 = F1,F2,F3; right psi1 = G1, psi2 = F3, psi3 = F2
-        const T F1 = T(2) * u0 + (T(-7) * u1 + T(11) * u2);
-        const T F2 = T(5) * u2 + (T(2) * u3 - u1);
-        const T F3 = T(2) * u2 + (T(5) * u3 - u4);
-        const T G1 = T(2) * u5 + (T(-7) * u4 + T(11) * u3);
-        // second differences shared by both sides
-        const T t0 = (u0 + u2) - T(2) * u1, t1 = (u1 + u3) - T(2) * u2;
-        const T t2 = (u2 + u4) - T(2) * u3, t3 = (u3 + u5) - T(2) * u4;
-        // the first-difference parts of the smoothness measures through the second differences (round 4: one FMA each instead
-        // of three operations):  u0 - 4u1 + 3u2 = t0 + 2(u2 - u1),  3u2 - 4u3 + u4 = t2 - 2(u3 - u2), and mirrored
-        const T s1 = u2 - u1, s2 = u3 - u2, s3 = u4 - u3;
-        const T bl1 = t0 + T(2) * s1, bl2 = u1 - u3, bl3 = t2 - T(2) * s2;
-        const T br1 = t3 - T(2) * s3, br2 = u4 - u2, br3 = t1 + T(2) * s2;
-        // q = (S + eps)/eps = c13*t^2 + c4*b^2 + 1   with c13 = (13/12)/eps', c4 = (1/4)/eps'
-        const T c13 = wk.c13, c4 = wk.c4;
-        T l1 = c13 * (t0 * t0) + (c4 * (bl1 * bl1) + T(1));
-        T l2 = c13 * (t1 * t1) + (c4 * (bl2 * bl2) + T(1));
-        T l3 = c13 * (t2 * t2) + (c4 * (bl3 * bl3) + T(1));
-        T r1 = c13 * (t3 * t3) + (c4 * (br1 * br1) + T(1));
-        T r2 = c13 * (t2 * t2) + (c4 * (br2 * br2) + T(1));
-        T r3 = c13 * (t1 * t1) + (c4 * (br3 * br3) + T(1));
-        l1 *= l1; l2 *= l2; l3 *= l3; r1 *= r1; r2 *= r2; r3 *= r3;
-        // weights x10: (.1,.6,.3)/q_k^2 multiplied through by q1^2 q2^2 q3^2
-        const T A1 = l2 * l3, A2 = T(6) * (l1 * l3), A3 = T(3) * (l1 * l2);
-        const T B1 = r2 * r3, B2 = T(6) * (r1 * r3), B3 = T(3) * (r1 * r2);
-        const T NL = A1 * F1 + (A2 * F2 + A3 * F3), DL = A1 + (A2 + A3);
-        const T NR = B1 * G1 + (B2 * F3 + B3 * F2), DR = B1 + (B2 + B3);
-        if constexpr (sizeof(T) == 8) {
-            // one reciprocal for both quotients (products stay < 1e62 in fp64): rcp + 2 Newton steps
-            const T den = DL * DR;
-            T rc = __builtin_amdgcn_rcp(den);
-            rc = rc + rc * (T(1) - den * rc);
-            rc = rc + rc * (T(1) - den * rc);
-            const T a = NL * DR, b = NR * DL;
-            pc = (a + b) * rc;
-            hd = (b - a) * rc;
-        } else {
-            const T Lq = NL / DL, Rq = NR / DR;
-            pc = Lq + Rq;
-            hd = Rq - Lq;
-        }
+        // Intended WENO5 (O&F 3.32-3.41; ENO3bHelper.py:135-160) on UNDIVIDED differences: weno5_* above (the six smoothness
+        // values of a cell formed here; the tiled kernels share them between neighbouring cells of a line)
+        const WenoLine<T> ln = weno5_line(v);
+        T lq[3], rq[3];
+        weno5_left_q(ln, wk, lq);
+        weno5_right_q(ln, wk, rq);
+        weno5_combine(ln, lq, rq, pc, hd);
     } else if constexpr ((SCHEME == HJ_ENO3 || SCHEME == HJ_ENO2) && HJ_ENO_EXACT) {
         // Bit-faithful ENO (round 3; the drop-in default).  The reference chooses its stencil by comparing
         // |D2| / |D3| of the DIVIDED-difference tables D1 = dxInv*(g[j+1]-g[j]), D2 = (0.5*dxInv)*(dD1),
@@ -359,8 +412,8 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
         }
         pc = T(0.5) * (L + R);
         hd = T(0.5) * (R - L);
-    } else if constexpr (SCHEME == HJ_ENO3) {
-        // lean ENO3 (-DHJ_ENO_EXACT=0; rounds 1-2): selectors on the undivided differences
+    } else if constexpr (base_scheme(SCHEME) == HJ_ENO3) {
+        // lean ENO3 (HJ_ENO3_FAST, or -DHJ_ENO_EXACT=0; rounds 1-2): selectors on the undivided differences
         // ENO3 (upwind_first_eno3a.py:105-141, ENO3aHelper.py:116-189) on UNDIVIDED differences
         // u_j = v[j+1]-v[j], s_j = u_{j+1}-u_j, t_j = s_{j+1}-s_j  (D1 = u/dx, D2 = s/(2dx^2), D3 = t/(6dx^3);
         // the |D2| / |D3| comparisons are comparisons of |s| / |t|), select FIRST, then form the one
@@ -384,8 +437,8 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
         const T Rq = u3 + (sL1 ? (sT1 ? qR0 : qR1) : (sT2 ? qR1 : qR2));
         pc = Lq + Rq;
         hd = Rq - Lq;
-    } else if constexpr (SCHEME == HJ_ENO2) {
-        // ENO2 (upwind_first_eno2.py:97-148): dx*L = u2 + sel(|s1|<|s2|, s1, s2)/2, dx*R = u3 - sel(|s2|<|s3|, s2, s3)/2
+    } else if constexpr (base_scheme(SCHEME) == HJ_ENO2) {
+        // lean ENO2 (upwind_first_eno2.py:97-148): dx*L = u2 + sel(|s1|<|s2|, s1, s2)/2, dx*R = u3 - sel(|s2|<|s3|, s2, s3)/2
         const T u1 = v[2] - v[1], u2 = v[3] - v[2], u3 = v[4] - v[3], u4 = v[5] - v[4];
         const T s1 = u2 - u1, s2 = u3 - u2, s3 = u4 - u3;
         const T Lq = u2 + T(0.5) * ((t_abs(s1) < t_abs(s2)) ? s1 : s2);

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
                                                               T* __restrict__ out, const FusedArgs<T, 4> A) {
     constexpr int ND = 4, LA = 3, PD = 2, W = HJ_STENCIL, VP = HJ_VPAD;
     static_assert(HAM::ND == 4, "4-D Hamiltonians");
-    static_assert(SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2, "light stencils");
+    static_assert(SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2 || SCHEME == HJ_ENO2_FAST, "light stencils");
     using G = Tile4<E1, E2, E3>;
     constexpr int LS1 = G::LS1, LS2 = G::LS2, PLANE = G::PLANE, HALF = G::HALF;
     constexpr int KP = (G::NPS + NT - 1) / NT;

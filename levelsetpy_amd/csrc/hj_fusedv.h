@@ -432,6 +432,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             wk[d] = weno_consts<T>(eps[d], A.K[d]);
         }
     }
+    // intended WENO5 (round 5): the left-biased smoothness values of every own cell along axis 0 travel with the march -- a cell's
+    // right-biased ones are the next plane's left-biased ones (hj_device.h, weno5_cd_carry): three per cell and plane instead of six
+    constexpr bool WCARRY = SCHEME == HJ_WENO5 && (MODE == 1 || MODE == 2);      // (the general instantiation would spill: it forms all six per cell)
+    T wl[R][2][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            wl[r][c][0] = T(0); wl[r][c][1] = T(0); wl[r][c][2] = T(0);
+            if constexpr (WCARRY) {
+                if (!down) weno5_left_q(weno5_line(q[r][c]), wk[0], wl[r][c]);      // the queue holds planes P(-3) .. P(3): the cell of plane P(0)
+            }
+        }
     // max(D1^2) of the output (eps_part, hj_fused.h): two more LDS planes behind the ring park the outputs of a plane
     // until the next iteration's barrier
     const bool eps_prod = SCHEME == HJ_WENO5 && A.eps_part != nullptr;
@@ -636,6 +649,8 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
                     for (int j = 0; j < 7; ++j) qg[j] = q[r][c][6 - j + OFF];
                     sten(IntTag<0>(), qg, pc[c][0], hd[c][0], slot_real);
+                } else if constexpr (WCARRY) {
+                    weno5_cd_carry(q[r][c] + OFF, wk[0], wl[r][c], pc[c][0], hd[c][0]);
                 } else {
                     sten(IntTag<0>(), q[r][c] + OFF, pc[c][0], hd[c][0], slot_real);
                 }
@@ -673,8 +688,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 w[5] = r2.x; w[6] = r2.y;
                 w[7] = base[4];
 #endif
-                sten(IntTag<LA>(), w, pc[0][LA], hd[0][LA], slot_real);
-                sten(IntTag<LA>(), w + 1, pc[1][LA], hd[1][LA], slot_real);
+                if constexpr (WCARRY) {
+                    weno5_cd_pair(w, wk[LA], pc[0][LA], hd[0][LA], pc[1][LA], hd[1][LA]);      // the pair shares three of its twelve smoothness values
+                } else {
+                    sten(IntTag<LA>(), w, pc[0][LA], hd[0][LA], slot_real);
+                    sten(IntTag<LA>(), w + 1, pc[1][LA], hd[1][LA], slot_real);
+                }
             }
             if constexpr (RNG) continue;
             V o2;

@@ -207,11 +207,8 @@ template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G
 template <typename T> T scheme_scale(int scheme, double dx) {
     if (scheme == HJ_WENO5_ASSHIPPED) return (T)((1.0 / dx) * (1.0 / 60.0));
     if (scheme == HJ_WENO5) return (T)((1.0 / dx) * (1.0 / 12.0));
-#if HJ_ENO_EXACT
+    if (lean_eno(scheme)) return (T)((1.0 / dx) * 0.5);     // lean ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
     return T(1);                      // ENO2 / ENO3 on the reference's divided-difference tables: true costates
-#else
-    return (T)((1.0 / dx) * 0.5);     // lean ENO2 / ENO3: costates on undivided differences, p = q/(2dx)
-#endif
 }
 
 struct SubstepCall {
@@ -271,7 +268,7 @@ inline hipStream_t call_stream(const hj_ctx* c, const SubstepCall& s) { return s
 #endif
 
 // light stencils: few enough live values that 4 cells (2 pairs) per thread fit in 256 VGPRs without scratch
-constexpr bool light_scheme(int scheme) { return scheme == HJ_WENO5_ASSHIPPED || scheme == HJ_ENO2; }
+constexpr bool light_scheme(int scheme) { return scheme == HJ_WENO5_ASSHIPPED || scheme == HJ_ENO2 || scheme == HJ_ENO2_FAST; }
 // is configuration (NT, R) of the one-cell-per-lane / pair kernel compiled for this scheme?
 constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz = 8) {
 #ifdef HJ_ALL_CONFIGS

@@ -431,10 +431,10 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // the light stencils keep 4 cells per thread in registers on large grids; below ~12 M cells
                 // (201^3 = 8.1 M: 32 k cells per CU) three small independent workgroups per CU with longer
                 // chunks win (sweeps at 101^3 ... 401^3 after the deferred-ghost fix)
-                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total >= 12000000) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
+                else if (light_scheme(SCHEME) && c->total >= 12000000) { k.NT = 512; k.R = 4; pd = 2; occ = 2; }
                 // tiny grids (<= ~135^3) run one wave per SIMD and a launch is a chain of ~10 plane
                 // iterations: one cell per thread shortens every iteration (7-10 % at 51^3 ... 129^3)
-                else if ((SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2) && c->total < 2500000) { k.NT = 512; k.R = 1; pd = 2; occ = 4; }
+                else if (light_scheme(SCHEME) && c->total < 2500000) { k.NT = 512; k.R = 1; pd = 2; occ = 4; }
                 // (the flag-free stage-2/3 instantiation of the as-shipped WENO5 lands on 170 VGPRs: two workgroups
                 // per CU with 34-plane chunks instead of three with 23.  Forcing 168 through the launch bound --
                 // config (256,2,2,3,2) -- was measured at 151^3 ... 251^3: within +-2 % of this, not kept)
@@ -462,7 +462,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // cells), the heavy ones 1 pair in 256-thread workgroups
                 KernelCfg kp{512, 2, 2};
                 int occp = 2;
-                if (!(SCHEME == HJ_WENO5_ASSHIPPED || SCHEME == HJ_ENO2)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
+                if (!light_scheme(SCHEME)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
                 if (HAM::ND == 4) { kp.NT = 256; kp.R = 2; kp.KH = 6; }      // 5 pair slots + 1 single slot per thread (hj_fusedv.h, HP)
                 if (c->pair_nt > 0) kp.NT = c->pair_nt;
                 if (c->pair_r > 0) kp.R = c->pair_r;
@@ -518,6 +518,8 @@ int launch_scheme(hj_ctx* c, const SubstepCall& s) {
         case HJ_ENO3: return launch_cfg<T, HAM, HJ_ENO3>(c, s);
         case HJ_WENO5: return launch_cfg<T, HAM, HJ_WENO5>(c, s);
         case HJ_WENO5_ASSHIPPED: return launch_cfg<T, HAM, HJ_WENO5_ASSHIPPED>(c, s);
+        case HJ_ENO2_FAST: return launch_cfg<T, HAM, HJ_ENO2_FAST>(c, s);
+        case HJ_ENO3_FAST: return launch_cfg<T, HAM, HJ_ENO3_FAST>(c, s);
     }
     return hjh::fail(HJ_EINVAL, "unknown scheme %d", s.scheme);
 }

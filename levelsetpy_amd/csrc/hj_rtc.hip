@@ -362,7 +362,7 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     // MODE 1 / 2: the flag-free instantiations of plain RK stages (hj_inst.hip, launch_tiled); 0: every run-time flag; 3: the range pass
     const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0;
     const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
-    const bool light = s.scheme == HJ_WENO5_ASSHIPPED || s.scheme == HJ_ENO2;
+    const bool light = light_scheme(s.scheme);
     const bool dynamic = (u.flags & HJ_HAM_RANGE) != 0;
     const int spill_key = ((F32 ? 1 : 0) * 4 + s.scheme) * 4 + mode;
     int shape = 0;
@@ -612,7 +612,7 @@ int hj_ham_cache_stats(int* compiled, int* loaded_from_cache) {
 int hj_ham_compile_check(int ham_id, int scheme) {
     UserHam* u = user_of(ham_id);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
-    if (scheme < 0 || scheme > 3) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    if (scheme < 0 || scheme > HJ_ENO3_FAST) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
     int rc = rtc_load(u->rtc_path.empty() ? nullptr : u->rtc_path.c_str());
     if (rc) return rc;
     const bool dynamic = (u->flags & HJ_HAM_RANGE) != 0;

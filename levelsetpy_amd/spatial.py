@@ -19,9 +19,26 @@ from .utilities import Bundle, error
 
 __all__ = ["upwindFirstENO2", "upwindFirstENO3", "upwindFirstENO3a", "upwindFirstWENO5",
            "upwindFirstWENO5a", "upwindFirstWENO5Intended", "upwindFirstENO3aHelper",
-           "set_weno5_mode", "get_weno5_mode"]
+           "set_weno5_mode", "get_weno5_mode", "set_eno_mode", "get_eno_mode"]
 
 _WENO5_MODE = "asshipped"
+_ENO_MODE = "exact"
+
+
+def set_eno_mode(mode):
+    """'exact' (default): upwindFirstENO2 / ENO3 in fused substeps evaluate the reference's array expressions operation by operation --
+    states, t and stepBound equal the reference's bit for bit.  'fast' (opt-in, round 5): the same schemes in a lean arithmetic
+    (undivided differences, contracted FMAs, the chosen candidate formed after the selection): 1e-11 from the reference everywhere
+    except in cells where two stencil-selector moduli lie within rounding of each other, which may take the other (equally valid)
+    stencil (masked comparison).  Only the fused substep path changes; the array-level derivative functions do not."""
+    global _ENO_MODE
+    if mode not in ("exact", "fast"):
+        error("ENO mode must be 'exact' or 'fast'")
+    _ENO_MODE = mode
+
+
+def get_eno_mode():
+    return _ENO_MODE
 
 
 def set_weno5_mode(mode):
@@ -42,6 +59,8 @@ def scheme_id_of(fn):
         return None
     if name == "WENO5_DEFAULT":
         name = "WENO5" if _WENO5_MODE == "weno5" else "WENO5_ASSHIPPED"
+    if _ENO_MODE == "fast" and name in ("ENO2", "ENO3"):
+        name += "_FAST"
     return _ffi.SCHEME_IDS[name]
 
 
