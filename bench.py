@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads reported under 'also'")
-    ap.add_argument("--also", default="WENO5,513,C3,C5,CFL,API,RTC,RANGE", help="comma list of the extra workloads to time (API = the 201^3 / "
+    ap.add_argument("--also", default="WENO5,513,C3,C3 fast,C5,CFL,API,RTC,RANGE", help="comma list of the extra workloads to time (API = the 201^3 / "
                     "51^3 workloads through odeCFL3 / HJIPDE_solve, the reference's own call protocol; RTC = the same system as a "
                     "Hamiltonian compiled at run time with hipRTC, and as Python callbacks on the split path; RANGE = a Hamiltonian whose alpha depends "
                     "on the costate range, fused in two launches per stage against the split path)")
@@ -249,6 +249,12 @@ def workload(L, _ffi, torch, name, scheme, dtype, n):
         g = L.createGrid(-np.ones((2, 1)), np.ones((2, 1)), n * np.ones((2, 1), dtype=np.int64), None, low_mem=True)
         return ("double integrator 2-D, 4096 x 4096 grid, ENO3 + GLF, odeCFL3 (factorCFL 0.8), sphere r=0.25 (BASELINE C3)",
                 g, _ffi.HAM_DOUBLE_INTEGRATOR, [1.0, 0, 0, 0], "ENO3", "float64", device_sdf(torch, g, 0.25))
+    if name == "C3 fast":
+        w = list(workload(L, _ffi, torch, "C3", scheme, dtype, n))
+        w[0] = w[0].replace("ENO3 + GLF", "ENO3 in the opt-in lean arithmetic (set_eno_mode('fast'): 1e-11 from the reference outside cells whose stencil "
+                            "selectors tie within rounding; the default is bit for bit) + GLF")
+        w[4] = "ENO3_FAST"
+        return tuple(w)
     if name == "C5":
         n = int(os.environ.get("HJ_BENCH_C5_N", "129"))
         gmin = np.array([[-np.pi, -8, -np.pi, -8]]).T

@@ -445,7 +445,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             const bool pair_dim = HAM::ND <= 3 || (sizeof(T) == 4 && light_scheme(SCHEME)) || c->pair_nt > 0;
             // light stencils on 2-D / 3-D grids: from 6.5 M cells (191^3 up the (512,2) shape + ring wins; 141^3 ... 181^3 run 3-10 % faster as
             // three 256-thread workgroups per CU of the one-cell-per-lane kernel, tools/experiments/r03_run50.sh, r03_run51.sh)
-            const long long pair_from = (HAM::ND <= 3 && light_scheme(SCHEME)) ? 6500000 : 2500000;
+            const long long pair_from = (HAM::ND <= 3 && light_cfg(SCHEME, HAM::ND)) ? 6500000 : 2500000;
             // 4-D, fp32, light stencil: the compile-time-tile kernel (hj_fused4v.h) when its tile fits the grid (HJ_PAIR4=0: the generic pair kernel)
             if constexpr (HAM::ND == 4 && sizeof(T) == 4 && light_scheme(SCHEME)) {
                 if (c->pair != 0 && c->pair4 != 0 && c->pair_nt <= 0 && (c->total >= pair_from || c->pair == 2)) {
@@ -462,7 +462,7 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // cells), the heavy ones 1 pair in 256-thread workgroups
                 KernelCfg kp{512, 2, 2};
                 int occp = 2;
-                if (!light_scheme(SCHEME)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
+                if (!light_cfg(SCHEME, HAM::ND)) { kp.NT = 256; kp.R = 1; kp.KH = 2; }
                 if (HAM::ND == 4) { kp.NT = 256; kp.R = 2; kp.KH = 6; }      // 5 pair slots + 1 single slot per thread (hj_fusedv.h, HP)
                 if (c->pair_nt > 0) kp.NT = c->pair_nt;
                 if (c->pair_r > 0) kp.R = c->pair_r;

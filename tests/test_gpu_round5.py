@@ -357,3 +357,86 @@ def test_range_dependent_alpha_virtual_ranks_equal_undivided(world, periodic0):
         b, e, t, ys = out[r]
         assert abs(t - t_ref) <= 1e-14 * t_ref, (t, t_ref)
         assert float((ys - ref[b:e]).abs().max()) <= 1e-13, (r, float((ys - ref[b:e]).abs().max()))
+
+
+# ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
+def _dilate(mask, r):
+    """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
+    out = mask.copy()
+    for ax in range(mask.ndim):
+        acc = out.copy()
+        for k in range(1, r + 1):
+            acc |= np.roll(out, k, axis=ax) | np.roll(out, -k, axis=ax)
+        out = acc
+    return out
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3"])
+def test_fast_eno_mode_masked_parity_with_the_reference_golden(scheme, golden):
+    """set_eno_mode('fast'): ENO2 / ENO3 substeps in the lean arithmetic against the goldens of the UNMODIFIED reference on noisy data,
+    by the rule of SURVEY 8(c): cells whose stencil selectors have a margin below 1e-12 (in any dimension, at any of the 15 substeps,
+    together with everything their values can have reached since) are excluded -- at most 1e-4 of the grid -- and every other cell
+    agrees within 1e-11 after five RK3 steps; t within 1e-13.  The default ('exact') stays bit for bit (test_eno_paths_bitwise...)."""
+    from test_gpu_parity import dubins
+    G = golden("ode.npz")
+    g, og = dubins(G["dubn_data"].shape)
+    sys_ = L.DubinsVehicleRel(g, 1, 1)
+    sd = sdata(g, sys_, DERIV[scheme])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    # the oracle's own run (pinned to the goldens elsewhere), recording the selector margins of every substep
+    taint = np.zeros(og.shape, dtype=bool)
+    osys = O.DubinsRel(og, 1, 1)
+
+    def term(tt, yy):
+        nonlocal taint
+        taint = _dilate(taint, 3)
+        data = yy.reshape(og.shape)
+        for d in range(3):
+            taint |= O.eno_selector_margin(og, data, d, scheme) < 1e-12
+        return O.term_lax_friedrichs(og, osys, scheme, tt, yy)
+    yo, to = G["dubn_data"].reshape(-1, 1), 0.
+    for _ in range(5):
+        to, yo = O.ode_cfl_3(term, [to, 10.], yo, 0.8, single_step=True)
+    assert np.max(np.abs(yo - G["rk3n_%s_y5" % scheme])) <= 1e-12      # the oracle is the reference here
+    L.set_eno_mode('fast')
+    try:
+        y, t = torch.as_tensor(G["dubn_data"].reshape(-1, 1), device="cuda"), 0.
+        for _ in range(5):
+            t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+    finally:
+        L.set_eno_mode('exact')
+    assert abs(t - float(G["rk3n_%s_t5" % scheme])) <= 1e-13
+    diff = np.abs(y.cpu().numpy().reshape(og.shape) - G["rk3n_%s_y5" % scheme].reshape(og.shape))
+    excluded = float(np.mean(taint))
+    assert excluded <= 1e-4, excluded
+    assert float(diff[~taint].max()) <= 1e-11, float(diff[~taint].max())
+    assert float(diff.max()) > 0                      # it IS another arithmetic (the exact mode gives 0)
+
+
+def test_fast_eno3_double_integrator_c3_shape_masked_parity(golden):
+    """The C3 system (double integrator, ENO3) in fast mode on the reference's noisy 2-D golden: same rule."""
+    G = golden("ode.npz")
+    g2, og2 = mk([-1, -1], [1, 1], [32, 32], None)
+    sd2 = sdata(g2, L.DoubleIntegrator(g2, 1), L.upwindFirstENO3)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    taint = np.zeros(og2.shape, dtype=bool)
+    osys = O.DoubleIntegrator(og2, 1)
+
+    def term(tt, yy):
+        nonlocal taint
+        taint = _dilate(taint, 3)
+        for d in range(2):
+            taint |= O.eno_selector_margin(og2, yy.reshape(og2.shape), d, "ENO3") < 1e-12
+        return O.term_lax_friedrichs(og2, osys, "ENO3", tt, yy)
+    yo, to = G["din_data"].reshape(-1, 1), 0.
+    for _ in range(5):
+        to, yo = O.ode_cfl_3(term, [to, 10.], yo, 0.8, single_step=True)
+    L.set_eno_mode('fast')
+    try:
+        y, t = torch.as_tensor(G["din_data"].reshape(-1, 1), device="cuda"), 0.
+        for _ in range(5):
+            t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd2)
+    finally:
+        L.set_eno_mode('exact')
+    diff = np.abs(y.cpu().numpy().reshape(og2.shape) - G["din_rk3_ENO3_y5"].reshape(og2.shape))
+    assert float(np.mean(taint)) <= 1e-4 and float(diff[~taint].max()) <= 1e-11, (float(np.mean(taint)), float(diff.max()))
