@@ -77,6 +77,9 @@ def parse():
                     "on the costate range, fused in two launches per stage against the split path)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="with --gpus N: print (one JSON line; a table on stderr) what every rank of the N-rank slab leg will do -- slab, "
+                         "stepper and schedule, the launches of a substep, halo bytes per step, predicted ms/step -- WITHOUT touching a GPU")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -869,10 +872,47 @@ def launch_ranks(a, argv, script=None, visible_devices=None):
     return min(rc, 255)
 
 
+def plan_only(a):
+    """--gpus N --plan-only: the N-rank slab leg on paper (levelsetpy_amd.dist.plan_slab_run); no GPU, no process group."""
+    from levelsetpy_amd import dist as hjdist
+    wname = a.workload or "C4"
+    gn = (513 if wname == "C4" else 129) if a.global_n is None else a.global_n
+    plan = hjdist.plan_slab_run(a, a.gpus, global_n=gn, workload=wname)
+    w = sys.stderr.write
+    w("%s %s, %s %s on %d ranks (planes per rank: %s)\n" % (plan["workload"], plan["grid"], plan["scheme"], plan["dtype"], a.gpus,
+                                                          "/".join(str(c) for c in plan["planes_per_rank"])))
+    for e in plan["ranks"]:
+        w("rank %d: planes [%d, %d) = %d, neighbours lo %s hi %s, %.1f MB per array; %s\n" % (
+            e["rank"], e["planes"][0], e["planes"][1], e["n_local"], e["lo"], e["hi"], e["slab_bytes_per_array"] / 1e6, e["stepper"]))
+
+        def line(tag, pl):
+            if pl:
+                w("    %-9s %s: %d workgroups x %d threads = %d tiles (%s) x %d chunks of %d planes, %d per CU -> %d round(s), LDS %d B\n" % (
+                    tag, pl["kernel"], pl["workgroups"], pl["threads"], pl["tiles"], "x".join(str(v) for v in pl["tile"]), pl["chunks"],
+                    pl["chunk_planes"], pl["workgroups_per_cu"], pl["rounds"], pl["lds_bytes"]))
+        if "launches_per_substep" in e:
+            line("interior", e["launches_per_substep"]["interior"])
+            line("edges", e["launches_per_substep"]["edges"])
+        else:
+            for st in e["launches_per_step"]:
+                line("stage %d in" % st["stage"], st["interior"])
+                line("stage %d ed" % st["stage"], st["edges"])
+        w("    halo bytes sent per step %.2f MB (%.3f ms per neighbour at the xGMI peak); self-ring prediction %s ms/step\n" % (
+            e["halo_bytes_sent_per_step"] / 1e6, e["link_ms_per_step_at_peak"], e["self_ring_ms_per_step"]))
+    pr = plan["predicted"]
+    w("predicted: compute %s ms/step (slowest rank, self ring), link %.3f ms/step at peak -> %s cell-substeps/s\n" % (
+        pr["ms_per_step_compute_self_ring"], pr["ms_per_step_link_at_peak"],
+        ("%.3e" % pr["value_cell_substeps_per_s"]) if pr["value_cell_substeps_per_s"] else "n/a"))
+    print(json.dumps(plan))
+
+
 def main():
     a = parse()
     if a.cpu_worker:
         cpu_worker(a.cpu_worker)
+        return
+    if a.plan_only:
+        plan_only(a)
         return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU

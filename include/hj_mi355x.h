@@ -368,6 +368,17 @@ int hj_last_launch(hj_ctx* ctx, int* lds_nbuf_host, int* halo_ahead_host);
 /* Tile extents of the last tiled launch on the plane axes (extents_host[0] = planes per chunk, [d] = cells on axis d, 0 beyond
  * the grid's dimension; all 0 after a direct launch): tests assert that the launch-time tuner rotates through tile shapes. */
 int hj_last_tile(hj_ctx* ctx, int* extents_host /* HJ_MAX_DIM */);
+/* The launch plan of one substep over planes [p0, p1) of axis 0, made WITHOUT a device or a context: what a rank of a slab run will
+ * launch (bench.py --gpus N --plan-only prints it for every rank before the node exists).  It runs the launch code of hj_rk_substep up to
+ * the point where the kernel would be enqueued -- configuration choice by scheme / grid size, tile search, chunking against num_cus
+ * compute units (0: 256, MI355X) -- with the occupancy taken from the kernel's launch bound instead of the runtime's query.
+ * halo_lo / halo_hi: the grid is a slab with pad planes on that side (hj_ctx_set_slab).  Built-in Hamiltonians only.
+ * out_host[12] = {threads per workgroup, workgroups, tiles per plane, chunks, planes per chunk, tile extents on axes 1..3 (0 beyond the
+ * dimension), LDS bytes per workgroup, workgroups per CU, slab flag, 0}; kernel_name_host receives the kernel's name (as hj_last_kernel).
+ * (The reference has no launch geometry: its term evaluates whole NumPy arrays, term_lax_friedrich.py:79-133.) */
+int hj_plan_substep(int ndim, const int64_t* N_host, const int* bc_host, int dtype, int scheme, int ham, int stage,
+                    int64_t p0, int64_t p1, int halo_lo, int halo_hi, int num_cus,
+                    int64_t* out_host /* 12 */, char* kernel_name_host, int name_cap);
 const char* hj_version(void);
 
 #ifdef __cplusplus

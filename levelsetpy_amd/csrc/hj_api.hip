@@ -985,8 +985,9 @@ int hj_last_tile(hj_ctx* c, int* e) {
 }
 const char* hj_version(void) { return "hj_mi355x 0.1 (gfx950)"; }
 
-int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,
-                  const int* bc, const int* toward_zero, int dtype, int device) {
+// dry_cus > 0: a host-only context for hj_plan_substep (no HIP call at all; the GPU is taken to have dry_cus compute units)
+static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,
+                           const int* bc, const int* toward_zero, int dtype, int device, int dry_cus) {
     if (!out || !N || !xmin || !dx || !bc) return fail(HJ_EINVAL, "null argument");
     if (ndim < 2 || ndim > HJ_MAX_DIM) return fail(HJ_EUNSUPPORTED, "grid.dim must be 2..4, got %d", ndim);
     if (dtype != HJ_F64 && dtype != HJ_F32) return fail(HJ_EINVAL, "unknown dtype %d", dtype);
@@ -998,9 +999,10 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         total *= N[d];
     }
     if (total / N[0] >= (1ll << 31)) return fail(HJ_EUNSUPPORTED, "axis-0 plane exceeds 2^31 cells");
-    HIP_TRY(hipSetDevice(device));
+    if (!dry_cus) HIP_TRY(hipSetDevice(device));
     hj_ctx* c = new hj_ctx();
     c->ndim = ndim; c->dtype = dtype; c->device = device;
+    c->dry = dry_cus > 0;
     c->esz = dtype == HJ_F64 ? 8 : 4;
     c->total = total;
     c->halo_lo = c->halo_hi = 0;
@@ -1034,8 +1036,8 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->lds_pad = env_int("HJ_LDS_PAD", -1);
     c->target_blocks = env_int("HJ_TARGET_BLOCKS", 0);   // 0 = choose from the GPU's capacity
     {
-        int ncu = 0;
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu < 1) ncu = 256;
+        int ncu = dry_cus;
+        if (!dry_cus && (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu < 1)) ncu = 256;
         c->num_cus = ncu;
     }
     // shortest chunk a workgroup may get.  A launch never lasts less than ~9 us (kernel-argument, table and queue
@@ -1117,6 +1119,7 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
         return fail(HJ_EINVAL, "unsupported HJ_NT/HJ_R combination %d/%d", nt, r);
     }
     *out = c;
+    if (c->dry) return HJ_OK;
     int rc = HJ_OK;
     auto bail = [&](int code) { hj_ctx_destroy(c); *out = nullptr; return code; };
     for (int d = 0; d < ndim; ++d) {
@@ -1134,6 +1137,40 @@ int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, 
     c->ring_pos = RING_SLOTS;  // forces the first use to zero the ring
     for (int i = 0; i < HJ_BOUND_SLOTS; ++i) c->slot_ring[i] = -1;
     return HJ_OK;
+}
+
+int hj_ctx_create(hj_ctx** out, int ndim, const int64_t* N, const double* xmin, const double* dx,
+                  const int* bc, const int* toward_zero, int dtype, int device) {
+    return ctx_create_impl(out, ndim, N, xmin, dx, bc, toward_zero, dtype, device, 0);
+}
+
+// The launch plan of one substep over planes [p0, p1) of an N-cell grid, made WITHOUT a device (bench.py --plan-only: what every rank of
+// an N-GPU run will launch, before the node is there).  Same code as the real launch up to the point where the kernel would be enqueued.
+// out[12] = {threads per workgroup, workgroups, tiles, chunks, chunk length (planes), tile extents E1..E3, LDS bytes, workgroups per CU,
+// slab pads honoured (1/0), 0}; kernel_name (cap bytes) receives the kernel's name.  Built-in Hamiltonians only.
+int hj_plan_substep(int ndim, const int64_t* N, const int* bc, int dtype, int scheme, int ham, int stage, int64_t p0, int64_t p1,
+                    int halo_lo, int halo_hi, int num_cus, int64_t* out, char* kernel_name, int cap) {
+    if (!N || !bc || !out) return fail(HJ_EINVAL, "null argument");
+    if (ham_ndim(ham) != ndim || user_ham_valid(ham)) return fail(HJ_EUNSUPPORTED, "hj_plan_substep plans the built-in Hamiltonians (id %d, dim %d)", ham, ndim);
+    if (scheme < HJ_ENO2 || scheme > HJ_ENO3_FAST) return fail(HJ_EINVAL, "unknown scheme %d", scheme);
+    double xmin[HJ_MAX_DIM] = {0, 0, 0, 0}, dx[HJ_MAX_DIM] = {1, 1, 1, 1};
+    hj_ctx* c = nullptr;
+    int rc = ctx_create_impl(&c, ndim, N, xmin, dx, bc, nullptr, dtype, -1, num_cus > 0 ? num_cus : 256);
+    if (rc) return rc;
+    c->halo_lo = halo_lo != 0; c->halo_hi = halo_hi != 0;
+    const double par[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    SubstepCall s{};
+    s.scheme = scheme; s.ham = ham; s.stage = stage; s.restrict_sign = 0; s.par = par; s.dt = 0.0;
+    s.y = s.y0 = nullptr; s.out = nullptr; s.bound = nullptr; s.p0 = p0; s.p1 = p1;
+    rc = c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
+    if (rc == HJ_OK) {
+        out[0] = c->last_plan.threads; out[1] = c->last_plan.nblocks; out[2] = c->last_plan.ntiles; out[3] = c->last_plan.nchunks;
+        out[4] = c->last_E[0]; out[5] = c->last_E[1]; out[6] = c->last_E[2]; out[7] = c->last_E[3];
+        out[8] = (int64_t)c->last_plan.lds_bytes; out[9] = c->last_plan.wg_per_cu; out[10] = (c->halo_lo || c->halo_hi) ? 1 : 0; out[11] = 0;
+        if (kernel_name && cap > 0) { strncpy(kernel_name, c->last_kernel, (size_t)cap - 1); kernel_name[cap - 1] = 0; }
+    }
+    delete c;
+    return rc;
 }
 
 void hj_ctx_destroy(hj_ctx* c) {

@@ -157,6 +157,9 @@ struct hj_ctx {
     int keep_bounds = 0;                            // HJ_KEEP_BOUNDS: reduce the CFL bound in launches whose bound nobody reads
     int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
+    // hj_plan_substep: a host-only context (no device, no allocation) whose launches stop after the tile / chunk plan is made
+    int dry = 0;
+    struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)
     size_t lds_limit;
     // resident workgroups per CU of (kernel instantiation, dynamic LDS bytes) on THIS ctx's device

@@ -37,13 +37,23 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
         auto it = c->occ_cache.find(key);
         if (it == c->occ_cache.end()) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
+            // (planning without a device: the launch bound's waves per SIMD, and the CU's 160 KB of LDS)
+            if (c->dry) nb = std::max(1, std::min(OCC * 256 / NT, (int)((size_t)(160 * 1024) / std::max<size_t>(1, t.lds_bytes))));
+            else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
             it = c->occ_cache.emplace(key, nb).first;
         }
         const int occ_blocks = it->second;
         {
             const int rc_plan = plan_chunks(c, s, t, occ_blocks, ep);
             if (rc_plan) return rc_plan;
+        }
+        c->last_plan.ntiles = t.ntiles; c->last_plan.nchunks = t.nchunks; c->last_plan.nblocks = t.nblocks; c->last_plan.threads = NT;
+        c->last_plan.wg_per_cu = occ_blocks; c->last_plan.lds_bytes = t.lds_bytes;
+        if (c->dry) {
+            c->last_kernel = PAIR ? "fused_pair_kernel" : "fused_substep_kernel";
+            c->last_E[0] = t.chunk;
+            for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < ND ? t.E[d] : 0;
+            return HJ_OK;
         }
         if (c->debug) {
             fprintf(stderr, "[hj] %stiling NT=%d R=%d KH=%d PD=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu score=%.3f\n",
@@ -208,6 +218,14 @@ int launch_pair4_mode(hj_ctx* c, const SubstepCall& s) {
         if (rc_plan) return rc_plan;
     }
     t.lds_bytes = base_lds + (ROWS ? (size_t)t.chunk * ER * G::ROWF * sizeof(T) : 0);
+    c->last_plan.ntiles = t.ntiles; c->last_plan.nchunks = t.nchunks; c->last_plan.nblocks = t.nblocks; c->last_plan.threads = NT;
+    c->last_plan.wg_per_cu = wg_per_cu; c->last_plan.lds_bytes = t.lds_bytes;
+    if (c->dry) {
+        c->last_kernel = "fused_pair4_kernel";
+        c->last_E[0] = t.chunk;
+        for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = t.E[d];
+        return HJ_OK;
+    }
     if (c->debug) {
         fprintf(stderr, "[hj] pair4 tiling NT=%d R=%d OCC=%d E=(%d,%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d lds=%zu PG=%d MODE=%d\n",
                 NT, R, OCC, E1, E2, E3, G::PITCH, t.ntiles, t.chunk, t.nchunks, t.nblocks, t.lds_bytes, (int)PG, MODE);
@@ -282,7 +300,7 @@ struct TuneTrial { TuneState* ts = nullptr; int cand = -1; };
 // HJ_AUTOTUNE_MIN_MCELLS cells -- the next candidate of the tuning rotation / the shape the rotation settled on.
 template <int ND>
 Tiling tune_begin(hj_ctx* c, const SubstepCall& s, const KernelCfg& k, int vec, int nbuf, long long key, TuneTrial& tr) {
-    bool tunable = c->autotune && c->total >= c->autotune_min_cells && !c->full_rows && !c->tile_cells && !s.on_aux &&
+    bool tunable = !c->dry && c->autotune && c->total >= c->autotune_min_cells && !c->full_rows && !c->tile_cells && !s.on_aux &&
                    !c->launch_stop && !c->halo_lo && !c->halo_hi && s.p0 == 0 && s.p1 == c->N[0] && s.q1 <= s.q0 &&
                    !c->timing_dump;
     if (!tunable) return make_tiling(c, k, s.p0, s.p1, vec, nbuf);
@@ -352,6 +370,14 @@ int tune_end(hj_ctx* c, const SubstepCall& s, TuneTrial& tr, int rc, int scheme)
 template <typename T, typename HAM, int SCHEME>
 int launch_direct(hj_ctx* c, const SubstepCall& s) {
     constexpr int ND = HAM::ND;
+    if (c->dry) {
+        const long long cells = (s.p1 - s.p0) * (c->total / c->N[0]);
+        c->last_plan.ntiles = 0; c->last_plan.nchunks = 1; c->last_plan.threads = 256; c->last_plan.wg_per_cu = 8; c->last_plan.lds_bytes = 0;
+        c->last_plan.nblocks = (int)std::min<long long>((cells + 255) / 256, 256 * 16);
+        c->last_kernel = "direct_substep_kernel";
+        for (int d = 0; d < HJ_MAX_DIM; ++d) c->last_E[d] = 0;
+        return HJ_OK;
+    }
     DirectArgs<T, ND> A;
     memset(&A, 0, sizeof(A));
     A.y = (const T*)s.y;

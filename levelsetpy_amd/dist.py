@@ -552,6 +552,109 @@ def slab_workload(L, name, world, args, global_n):
     raise ValueError("unknown slab workload %r (C4, C5)" % (name,))
 
 
+# measured on ONE MI355X with the ring closed through a real RCCL self send/recv (tools/thin_slab_ring.py, slabs of the 513^3 Dubins
+# grid, WENO5_ASSHIPPED, fp64; profiles/r04_thin_slab_gated.txt, profiles/r05_thin_slab.txt): planes -> ms per RK3 step of the schedule
+# bench_slab picks for that thickness.  Everything but the link is in these numbers.
+SELF_RING_MS_C4 = [(64, 0.357), (65, 0.362), (129, 0.616), (257, 1.099), (513, 1.745)]
+XGMI_LINK_GBS = 153.0        # per link and neighbour, peak (the pool's figure for MI355X: 7 links x ~153 GB/s per GPU)
+
+
+def plan_substep(N, bc, dtype, scheme, ham, stage, p0, p1, halo_lo=False, halo_hi=False, num_cus=256):
+    """The launch plan of one substep over planes [p0, p1) -- kernel, workgroups, tiles, chunks -- from the C library's own launch
+    code run WITHOUT a device (hj_plan_substep).  Returns a dict."""
+    import ctypes as C
+    out = (C.c_int64 * 12)()
+    name = C.create_string_buffer(64)
+    nd = len(N)
+    _ffi.check(_ffi.lib().hj_plan_substep(nd, (C.c_int64 * nd)(*[int(v) for v in N]), (C.c_int * nd)(*[int(v) for v in bc]),
+                                          _ffi.F64 if str(dtype) in ("float64", "f64") else _ffi.F32, int(scheme), int(ham), int(stage),
+                                          int(p0), int(p1), int(bool(halo_lo)), int(bool(halo_hi)), int(num_cus), out, name, 64))
+    v = [int(x) for x in out]
+    return {"kernel": name.value.decode(), "threads": v[0], "workgroups": v[1], "tiles": v[2], "chunks": v[3], "chunk_planes": v[4],
+            "tile": [e for e in v[5:8] if e > 0], "lds_bytes": v[8], "workgroups_per_cu": v[9],
+            "rounds": (v[1] + num_cus * max(1, v[9]) - 1) // (num_cus * max(1, v[9]))}
+
+
+def plan_slab_run(args, world, global_n=513, workload="C4", num_cus=256):
+    """bench.py --gpus N --plan-only: what every rank of the N-rank slab leg will do -- its slab, the stepper and schedule bench_slab
+    picks, the launches of one substep (from the library's launch code, no device), the halo bytes it exchanges per step, and a
+    predicted ms/step from the single-GPU self-ring measurements (C4) with the link time at the xGMI peak beside it.  No GPU, no
+    process group: the first real N-GPU run can be checked against this line by line."""
+    import levelsetpy_amd as L
+    wl = slab_workload(L, workload, world, args, global_n)
+    g, n0, plane = wl["grid"], wl["n0"], wl["plane"]
+    esz = 8 if wl["dtype"] == "float64" else 4
+    sid = _ffi.SCHEME_IDS[wl["scheme"]]
+    nd = int(g.dim)
+    Ng = [int(v) for v in np.asarray(g.N).ravel()]
+    bc = [0, 0, 1] if wl["name"] == "C4" else [1] * nd       # (slab_grid / slab_workload: heading periodic; the 4-D grid all periodic)
+    counts = SlabDecomposition(n0, world, 0, wl["periodic0"], self_exchange=wl["periodic0"]).counts
+    thick = min(counts) >= 128 and wl["name"] == "C4"
+    ranks = []
+    for r in range(world):
+        sl = SlabDecomposition(n0, world, r, wl["periodic0"], self_exchange=wl["periodic0"])
+        n = sl.n_local
+        lo, hi = sl.halo_lo, sl.halo_hi
+        Nl = [n] + Ng[1:]
+        deep = thick and n >= 18 and (lo or hi)
+        ent = {"rank": r, "planes": [sl.begin, sl.end], "n_local": n, "lo": sl.lo, "hi": sl.hi,
+               "cells": n * plane, "slab_bytes_per_array": n * plane * esz}
+        nb = int(lo) + int(hi)
+        if deep:
+            ent["stepper"] = "native deep-halo (hj_slab_rk_step_deep): ONE 9-plane exchange per RK3 step"
+            ent["halo_bytes_sent_per_step"] = nb * 9 * plane * esz
+            ent["launches_per_step"] = []
+            for st in (1, 2, 3):
+                ext = 3 * (3 - st)
+                ent["launches_per_step"].append({
+                    "stage": st,
+                    "interior": plan_substep(Nl, bc, wl["dtype"], sid, wl["ham"], _ffi.STAGE_EULER if st == 1 else _ffi.STAGE_RK3_FULL,
+                                             3 * st, n - 3 * st, lo, hi, num_cus),
+                    "edges": plan_substep(Nl, bc, wl["dtype"], sid, wl["ham"], _ffi.STAGE_EULER if st == 1 else _ffi.STAGE_RK3_FULL,
+                                          -ext if lo else 0, 3 * st, lo, hi, num_cus) if nb else None,
+                    "edge_planes_each_side": 3 * st + ext})
+        else:
+            sched = "serial (edges, then interior, on one stream; exchange beside the interior)" if n >= 192 else \
+                    "overlap (edges on the high-priority stream beside the interior)"
+            ent["stepper"] = "native per-substep (hj_slab_rk_step): a 3-plane exchange per substep, %s" % sched if nb else \
+                             "single slab, no exchange"
+            ent["halo_bytes_sent_per_step"] = nb * 3 * 3 * plane * esz
+            lo_e, hi_b = (3 if lo else 0), (n - 3 if hi else n)
+            edges = plan_substep(Nl, bc, wl["dtype"], sid, wl["ham"], _ffi.STAGE_EULER, 0 if lo else hi_b, 3 if lo else n, lo, hi, num_cus) if nb else None
+            if edges and nb == 2:      # both edge ranges ride in ONE launch (hj_api.hip, slab_substep): twice the chunks
+                edges["chunks"] *= 2
+                edges["workgroups"] *= 2
+                edges["rounds"] = (edges["workgroups"] + num_cus * max(1, edges["workgroups_per_cu"]) - 1) // (num_cus * max(1, edges["workgroups_per_cu"]))
+            ent["launches_per_substep"] = {
+                "interior": plan_substep(Nl, bc, wl["dtype"], sid, wl["ham"], _ffi.STAGE_EULER, lo_e, hi_b, lo, hi, num_cus),
+                "edges": edges, "edge_ranges": [[0, lo_e]] * int(lo) + [[hi_b, n]] * int(hi)}
+        # prediction: the self-ring table (C4's 513^2-cell planes), scaled by plane size for other grids
+        if wl["name"] == "C4" and wl["scheme"] == "WENO5_ASSHIPPED" and wl["dtype"] == "float64":
+            xs = [a for a, _ in SELF_RING_MS_C4]
+            ys = [b for _, b in SELF_RING_MS_C4]
+            ms = float(np.interp(n, xs, ys)) * (plane / float(513 * 513))
+            ent["self_ring_ms_per_step"] = round(ms, 4)
+        else:
+            ent["self_ring_ms_per_step"] = None
+        per_dir = ent["halo_bytes_sent_per_step"] / max(1, nb)
+        ent["link_ms_per_step_at_peak"] = round(per_dir / (XGMI_LINK_GBS * 1e9) * 1e3, 4) if nb else 0.0
+        ranks.append(ent)
+    known = [e["self_ring_ms_per_step"] for e in ranks if e["self_ring_ms_per_step"] is not None]
+    slow = max(known) if len(known) == len(ranks) else None
+    link = max(e["link_ms_per_step_at_peak"] for e in ranks)
+    total = n0 * plane
+    return {"plan_only": True, "workload": wl["name"], "grid": wl["grid_txt"], "scheme": wl["scheme"], "dtype": wl["dtype"], "n_gpus": world,
+            "planes_per_rank": counts, "ranks": ranks,
+            "predicted": {
+                "ms_per_step_compute_self_ring": slow,
+                "ms_per_step_link_at_peak": link,
+                "link_hidden_if": "the exchange (per substep: 3 planes each way) finishes under the interior launch; at the xGMI peak of "
+                                  "%.0f GB/s per link it needs %.3f ms per step against %s ms of compute" % (XGMI_LINK_GBS, link, slow),
+                "value_cell_substeps_per_s": (total * 3 / (max(slow, link) * 1e-3)) if slow else None,
+                "basis": "tools/thin_slab_ring.py on one MI355X (RCCL self send/recv, everything but the link): "
+                         + ", ".join("%d planes %.3f ms" % ab for ab in SELF_RING_MS_C4)}}
+
+
 def _agree(dist, ok, device):
     """Collective decision: True only if EVERY rank reports ok (a rank that failed locally must not leave
     the others inside a different collective: ADVICE r01)."""

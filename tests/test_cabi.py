@@ -202,3 +202,41 @@ def test_runtime_hamiltonian_is_selected_by_callable_identity():
     assert native_of(m.hamiltonian, Mine(g).dissipation) is None          # methods of two different objects
     with pytest.raises(ValueError):
         reg.attach(Mine(g), params=[1.0, 2.0])                            # wrong parameter count
+
+
+def test_plan_substep_needs_no_device():
+    """hj_plan_substep runs the launch code up to the enqueue without a GPU: kernel, tiles and chunks of C4 / C5 / a small grid."""
+    from levelsetpy_amd import _ffi
+    from levelsetpy_amd.dist import plan_substep
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+    p = plan_substep([65, 513, 513], [0, 0, 1], "float64", sid, _ffi.HAM_DUBINS_REL, _ffi.STAGE_EULER, 0, 65, True, True)
+    assert p["kernel"] == "fused_pair_kernel" and p["threads"] == 512
+    assert p["tiles"] * p["chunks"] == p["workgroups"] and p["chunks"] * p["chunk_planes"] >= 65
+    assert np.prod(p["tile"]) <= 2048 and len(p["tile"]) == 2
+    # pad planes of the deep-halo stepper: planes beyond the slab are plannable
+    q = plan_substep([65, 513, 513], [0, 0, 1], "float64", sid, _ffi.HAM_DUBINS_REL, _ffi.STAGE_EULER, -6, 71, True, True)
+    assert q["chunks"] * q["chunk_planes"] >= 77
+    p4 = plan_substep([17, 129, 129, 129], [1, 1, 1, 1], "float32", sid, _ffi.HAM_DOUBLE_PENDULUM, _ffi.STAGE_EULER, 3, 14, True, True)
+    assert p4["kernel"] == "fused_pair4_kernel" and len(p4["tile"]) == 3
+    small = plan_substep([51, 51, 51], [0, 0, 1], "float64", sid, _ffi.HAM_DUBINS_REL, _ffi.STAGE_EULER, 0, 51)
+    assert small["kernel"] == "fused_substep_kernel" and small["workgroups"] > 0
+    with pytest.raises(ValueError):       # a 3-D Hamiltonian on a 2-D grid
+        plan_substep([65, 513], [0, 0], "float64", sid, _ffi.HAM_DUBINS_REL, _ffi.STAGE_EULER, 0, 65)
+
+
+def test_bench_plan_only_prints_every_rank_without_a_gpu():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--plan-only"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["plan_only"] and plan["n_gpus"] == 8 and plan["planes_per_rank"] == [65] + [64] * 7
+    assert [e["planes"] for e in plan["ranks"]][:2] == [[0, 65], [65, 129]]
+    assert plan["ranks"][0]["lo"] is None and plan["ranks"][7]["hi"] is None and plan["ranks"][3]["lo"] == 2
+    mid = plan["ranks"][3]
+    assert mid["halo_bytes_sent_per_step"] == 2 * 9 * 513 * 513 * 8
+    assert mid["launches_per_substep"]["edges"]["workgroups"] == 2 * mid["launches_per_substep"]["edges"]["tiles"]
+    assert plan["predicted"]["ms_per_step_compute_self_ring"] > 0
+    assert "rank 7" in r.stderr

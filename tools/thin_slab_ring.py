@@ -2,7 +2,8 @@
 """One rank's slab of the 513^3 grid at N = 2, 4, 8 as a PERIODIC ring through a real RCCL self send/recv on one GPU
 (a (513/N) x 513 x 513 grid, axis 0 periodic): both native schedules with their real launches, streams, events and
 RCCL calls -- only the link is missing (the 'exchange' is a device-local copy).
-usage: thin_slab_ring.py [n] [worlds, e.g. 8 or 2,4,8] [schedules: deep,sub]"""
+"plain" = the same slab grid without the ring (axis 0 wraps inside the kernel, no streams / exchange): the ceiling for any schedule.
+usage: thin_slab_ring.py [n] [worlds, e.g. 8 or 2,4,8] [schedules: deep,sub,plain]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
@@ -25,8 +26,9 @@ for world in worlds:
                      np.array([[n0], [n], [n]], dtype=np.int64), [0, 2], low_mem=True)
     dxs = [float(v) for v in np.asarray(g.dx).ravel()]
     d0 = torch.as_tensor(np.asarray(L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)), device="cuda")
-    for deep in [x == "deep" for x in scheds]:
-        slab = SlabDecomposition(n0, 1, 0, True, self_exchange=True)
+    for sched in scheds:
+        deep = sched == "deep"
+        slab = SlabDecomposition(n0, 1, 0, True, self_exchange=sched != "plain")
         st = NativeSlabStepper(g, slab, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.], dxs, deep=deep)
         st.set_state(d0)
         t = 0.0
@@ -38,6 +40,6 @@ for world in worlds:
         torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / steps
         cells = n0 * n * n
         print("N=%d: %3d-plane slab %-12s %.3f ms/step  frac %.3f   (ideal = undivided/N)" %
-              (world, n0, "deep" if deep else "per-substep", ms, cells * 64 / (ms * 1e-3) / 8e12), flush=True)
+              (world, n0, {"deep": "deep", "sub": "per-substep", "plain": "plain (no ring)"}[sched], ms, cells * 64 / (ms * 1e-3) / 8e12), flush=True)
         st.close()
 dist.destroy_process_group()
