@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--plan-only", action="store_true",
                     help="with --gpus N: print (one JSON line; a table on stderr) what every rank of the N-rank slab leg will do -- slab, "
                          "stepper and schedule, the launches of a substep, halo bytes per step, predicted ms/step -- WITHOUT touching a GPU")
+    ap.add_argument("--single", default=None, help=argparse.SUPPRESS)     # child passes of live_traffic: the main leg times this `also` workload (C3, C5)
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -667,11 +668,11 @@ def source_hash():
 
 
 TRACE_STEPS = 400      # steps of the kernel-trace child pass that are looked at (after its spin-up)
-STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel",
+STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel", "fused_pair4_kernel",
                 "max_d1sq_kernel", "partials_to_values_kernel", "keys_to_values_kernel", "eps_seam_kernel")
 
 
-def live_traffic(a, n=None, scheme=None):
+def live_traffic(a, n=None, scheme=None, single=None):
     """roofline.traffic and roofline.kernel_ms_rocprof measured IN THIS RUN: three child passes of this script under
     rocprofv3 -- `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (they do not fit one pass, MI355X_MICROARCH.md) and a plain
     `--kernel-trace` pass for the kernel durations (counter collection serialises and slows the dispatches, so the
@@ -687,7 +688,9 @@ def live_traffic(a, n=None, scheme=None):
         return None
     scheme = scheme or a.scheme
     vals, dur, t0 = {}, None, time.perf_counter()
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE", None):
+    # single = "C3" / "C5": the counter passes of an `also` workload (round 5: also[...].roofline.traffic measured in the run too); no
+    # duration pass for them -- their roofline is priced on the HIP-event time of the timed leg
+    for ctr in (("FETCH_SIZE", "WRITE_SIZE") if single else ("FETCH_SIZE", "WRITE_SIZE", None)):
         # counter passes: short (every dispatch is serialised and slow under --pmc; byte counts do not depend on the
         # clocks); the duration pass: the timed leg's own spin-up, so that its kernels run at settled clocks
         # (60 steps of spin-up in the counter passes: on grids of >= 40 M cells the library spends up to 9 x 6 = 54 launches per
@@ -698,13 +701,15 @@ def live_traffic(a, n=None, scheme=None):
         # (and it reports the MEDIAN step of its last 400: the mean of a 2 ms tail was hit by a transient once -- 42.4 us per
         # launch where the timed leg and a whole-run trace of the same box both read 38.6-39.0)
         spin, warm, steps = (60, 1, 4) if ctr else (4 * SPINUP_STEPS, 2, TRACE_STEPS)
+        if single:
+            spin = 12          # (16.8 M / 277 M cells: below the 40 M cells of the tile-shape tuner or with compile-time tiles)
         nstep = spin + warm + steps
         d = tempfile.mkdtemp(prefix="hj_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp", HJ_BENCH_SPINUP=str(spin), HJ_BENCH_SETTLE_BLOCKS="0")   # (fixed step count: the rows are dealt to steps by position)
         cmd = [exe] + (["--pmc", ctr] if ctr else []) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also", "--no-live-traffic",
                "--steps", str(steps), "--warmup", str(warm), "--repeats", "1", "--n", str(n or a.n), "--scheme", scheme,
-               "--dtype", a.dtype]
+               "--dtype", a.dtype] + (["--single", single] if single else [])
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
             if ctr:
@@ -715,7 +720,7 @@ def live_traffic(a, n=None, scheme=None):
                             k = r["Kernel_Name"]
                             if r["Counter_Name"] == ctr and any(x in k for x in STEP_KERNELS):
                                 rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"]),
-                                             any(x in k for x in STEP_KERNELS[:5])))
+                                             any(x in k for x in STEP_KERNELS[:6])))
                 rows.sort()
                 per_step = len(rows) // nstep if rows else 0
                 if not per_step:
@@ -733,7 +738,7 @@ def live_traffic(a, n=None, scheme=None):
                         for r in csv.DictReader(fh):
                             if any(x in r["Kernel_Name"] for x in STEP_KERNELS):
                                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
-                                             any(x in r["Kernel_Name"] for x in STEP_KERNELS[:5])))
+                                             any(x in r["Kernel_Name"] for x in STEP_KERNELS[:6])))
                 rows.sort()
                 per_step = len(rows) // nstep if rows else 0
                 if per_step:
@@ -756,7 +761,9 @@ def live_traffic(a, n=None, scheme=None):
     return {"bytes_per_launch": per_step / nsub, "bytes_per_step": per_step, "substep_launches_per_step": nsub,
             "fetch_kib_per_step": vals["FETCH_SIZE"][0], "write_kib_per_step": vals["WRITE_SIZE"][0],
             "rocprof": dur,
-            "source": "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 65 RK3 steps, --kernel-trace: "
+            "source": ("rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 17 RK3 steps; every kernel of the "
+                       "step counted; %.0f s)" % (time.perf_counter() - t0)) if single else
+                      "rocprofv3 child passes of this run (--pmc FETCH_SIZE and --pmc WRITE_SIZE: the last 4 of 65 RK3 steps, --kernel-trace: "
                       "the median step of the last %d of %d; every kernel of the step counted; %.0f s)" % (TRACE_STEPS, 4 * SPINUP_STEPS + 2 + TRACE_STEPS, time.perf_counter() - t0)}
 
 
@@ -944,6 +951,9 @@ def main():
         a.live_also = {x: live_traffic(a, int(x)) for x in a.also.split(",") if x.isdigit()} if a.live else {}
         if a.live and "WENO5" in a.also.split(",") and a.scheme != "WENO5":
             a.live_also["WENO5"] = live_traffic(a, scheme="WENO5")
+        for x in ("C3", "C5"):
+            if a.live and x in a.also.split(","):
+                a.live_also[x] = live_traffic(a, single=x)
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version header at
     # communicator creation, for one) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -1113,7 +1123,7 @@ def run(a, rank, world, local, slab_leg, cpu):
         return out
 
     # ---------------------------------------------------------------- single GPU: BASELINE C2 (+ also)
-    wl = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n)
+    wl = workload(L, _ffi, torch, a.single, None, None, 0) if a.single else workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n)
     r = time_single(torch, _ffi, DeviceGrid, wl, a.steps, a.warmup, a.repeats, SPINUP_STEPS)
     s = summarize(r, a.steps)
     cells = r["cells"]
