@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _ffi
 from . import lazy as _lazy
-from .lazy import HostView
+from .lazy import HostView, DeviceArray
 
 
 def _torch():
@@ -152,6 +152,8 @@ class DeviceGrid(object):
         if isinstance(a, HostView):
             # a result of this package handed straight back (the NumPy caller's loop): consumed where it lives
             a = a.device_tensor() if a.device_tensor() is not None else a.__array__()
+        elif isinstance(a, DeviceArray) and a.device_tensor() is not None:
+            a = a.device_tensor()
         if is_tensor(a):
             t = a
             if t.device != self.device or t.dtype != self.tdtype:
@@ -174,7 +176,7 @@ class DeviceGrid(object):
         if is_tensor(proto):
             return t
         if lazy and _lazy.LAZY and t.is_cuda:
-            return HostView(t.detach())
+            return _lazy.device_array(t) if _lazy.LAZY == "ndarray" else HostView(t.detach())
         t = t.detach()
         nbytes = t.numel() * t.element_size()
         # HJ_PIN_RESULTS=0 turns the page-locked results off; HJ_PIN_MAX_MB caps a single pinned result (default 2048:
@@ -232,8 +234,8 @@ def device_grid(grid, dtype="float64"):
 def array_dtype_name(a):
     """'float32' only when the caller hands float32 data explicitly; the reference path is fp64
     (ghost functions force float64: add_ghost_extrapolate.py:77)."""
-    if isinstance(a, HostView):
-        a = a.device_tensor() if a.device_tensor() is not None else None
+    if isinstance(a, (HostView, DeviceArray)):
+        a = a.device_tensor() if a.device_tensor() is not None else (None if isinstance(a, HostView) else a)
     if a is not None and is_tensor(a):
         return "float32" if str(a.dtype) == "torch.float32" else "float64"
     return "float64"

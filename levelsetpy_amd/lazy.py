@@ -18,18 +18,36 @@ only read their inputs).  Where it differs from an ndarray: `isinstance(y, np.nd
 `flatten` / `ravel` / `squeeze` / `copy` return independent HostViews (not memory-sharing views); the cached host copy
 is read-only while the device tensor is attached (write through the view itself, `y[i] = v`, which detaches it from
 the device first).  `HJ_LAZY_NUMPY=0` turns the handles off: plain ndarrays, a D2H copy per call, as in rounds 1-3.
+
+`HJ_LAZY_NUMPY=ndarray` (set_lazy("ndarray"), round 5): results are DeviceArray -- a GENUINE np.ndarray subclass (isinstance, np.save,
+pickle, the buffer protocol, C extensions all see an ndarray, as with the reference's return values, ode_cfl_3.py:241-272) that
+still remembers the device tensor it was copied from, so passing it back in costs no upload.  It pays the download per call: an
+ndarray's memory is handed out by C code without any Python hook (np.asarray(y) of a subclass is a base-class view made in C, and
+so are memoryview(y) and PyArray_DATA in an extension), so the values have to BE there when the object is returned -- a lazily
+filled ndarray would hand uninitialised memory to exactly the callers that make the subclass worth having.  Half of the PCIe
+traffic of the eager mode, none of HostView's type caveats; HostView stays the default because it is the one that keeps the
+reference's NumPy loop at the GPU's pace.
 """
 import os
 
 import numpy as np
 
-LAZY = os.environ.get("HJ_LAZY_NUMPY", "1") != "0"
+def _mode(v):
+    if isinstance(v, str):
+        v = v.strip().lower()
+        return "ndarray" if v == "ndarray" else (False if v in ("0", "", "off", "false") else True)
+    return bool(v)
+
+
+LAZY = _mode(os.environ.get("HJ_LAZY_NUMPY", "1"))        # True: HostView; "ndarray": DeviceArray; False: plain ndarrays
 
 
 def set_lazy(on):
-    """Switch HostView results for NumPy callers on / off at run time (default: on unless HJ_LAZY_NUMPY=0)."""
+    """What NumPy callers get back from the fused path: True (default unless HJ_LAZY_NUMPY says otherwise) HostView handles,
+    "ndarray" DeviceArray -- a real np.ndarray subclass, downloaded at once, consumed on the device when passed back --,
+    False plain ndarrays."""
     global LAZY
-    LAZY = bool(on)
+    LAZY = _mode(on)
 
 
 def _host_copy(t):
@@ -209,8 +227,87 @@ class HostView(np.lib.mixins.NDArrayOperatorsMixin):
         return (np.array, (self.__array__(),))      # pickles as the ndarray it stands for
 
 
+class DeviceArray(np.ndarray):
+    """A real ndarray (page-locked host memory, values present) that remembers the device tensor it is a copy of (module
+    docstring).  While the tensor is attached the memory is read-only -- a write through some view would silently diverge from
+    what the next call consumes --; writing through the array itself (`y[i] = v`, `out=y`) detaches it first and makes it
+    writable.  Views, slices and copies are plain detached arrays of this type."""
+
+    def __new__(cls, host, tensor=None):
+        obj = np.asarray(host).view(cls)
+        obj._hj_t = tensor
+        if tensor is not None:
+            obj.flags.writeable = False
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._hj_t = None           # only the object the package returned stands for the tensor
+
+    def device_tensor(self):
+        """The tensor this array is a copy of, or None once it was written to (or for any view / copy of it)."""
+        t = getattr(self, "_hj_t", None)
+        if t is not None and self.flags.writeable:       # somebody forced the flag: the host copy may have changed
+            self._hj_t = t = None
+        return t
+
+    def _detach(self):
+        if getattr(self, "_hj_t", None) is not None:
+            self._hj_t = None
+            self.flags.writeable = True
+
+    def __setitem__(self, idx, value):
+        self._detach()
+        np.ndarray.__setitem__(self, idx, value)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        for o in kwargs.get("out", ()) or ():
+            if isinstance(o, DeviceArray):
+                o._detach()
+        strip = lambda x: x.view(np.ndarray) if isinstance(x, DeviceArray) else x      # noqa: E731 -- results are plain ndarrays
+        if "out" in kwargs:
+            kwargs["out"] = tuple(strip(o) for o in kwargs["out"])
+        return getattr(ufunc, method)(*[strip(x) for x in inputs], **kwargs)
+
+    def __reduce__(self):
+        return (np.array, (self.view(np.ndarray),))       # pickles as the plain ndarray it is
+
+    # C-order shape changes of the returned object keep the tensor (the reference's drivers flatten / reshape between calls:
+    # hji_solver.py:542); both sides are views of the same values
+    def _reshaped(self, h, fn_t):
+        t = self.device_tensor()
+        if t is None or not isinstance(h, np.ndarray) or h.base is None:
+            return h
+        return DeviceArray(h, fn_t(t))
+
+    def reshape(self, *shape, **kw):
+        h = np.ndarray.reshape(self, *shape, **kw)
+        if kw.get("order", "C") not in ("C", "A"):
+            return h
+        return self._reshaped(h, lambda t: t.reshape(h.shape))
+
+    def ravel(self, order="C"):
+        h = np.ndarray.ravel(self, order)
+        return h if order not in ("C", "A") else self._reshaped(h, lambda t: t.reshape(-1))
+
+    def squeeze(self, axis=None):
+        h = np.ndarray.squeeze(self, axis)
+        return self._reshaped(h, lambda t: t.reshape(h.shape))
+
+
+def device_array(t):
+    """device tensor -> DeviceArray (the download happens here)."""
+    return DeviceArray(_host_copy(t), t.detach())
+
+
 _META = {np.ndim: lambda v: v.ndim, np.shape: lambda v: v.shape, np.size: lambda v: v.size}
 
 
 def is_lazy(x):
     return isinstance(x, HostView)
+
+
+def attached_tensor(x):
+    """The device tensor behind a result of this package (HostView or DeviceArray), else None."""
+    if isinstance(x, (HostView, DeviceArray)):
+        return x.device_tensor()
+    return None

@@ -440,3 +440,39 @@ def test_fast_eno3_double_integrator_c3_shape_masked_parity(golden):
         L.set_eno_mode('exact')
     diff = np.abs(y.cpu().numpy().reshape(og2.shape) - G["din_rk3_ENO3_y5"].reshape(og2.shape))
     assert float(np.mean(taint)) <= 1e-4 and float(diff[~taint].max()) <= 1e-11, (float(np.mean(taint)), float(diff.max()))
+
+
+# ------------------------------------------------------------------------------ NumPy callers, ndarray-subclass mode (lazy.DeviceArray)
+def test_numpy_loop_with_real_ndarray_results_equals_the_tensor_loop():
+    """set_lazy("ndarray"): the driver loop of the reference (hji_solver.py:542) gets genuine np.ndarray subclass instances back
+    (isinstance / np.save / pickle as with ode_cfl_3.py:241-272's returns), values present, and the next call consumes the device
+    tensor behind them; results equal the tensor-in loop bit for bit."""
+    from levelsetpy_amd import lazy
+    g, og = dubins([33, 31, 29])
+    d0 = O.shape_cylinder(og, 2, None, .5) + 0.02 * np.random.default_rng(2).standard_normal(og.shape)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+    sdr = L.Bundle(dict(innerFunc=L.termLaxFriedrichs, innerData=sd, positive=0))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    old = lazy.LAZY
+    lazy.set_lazy("ndarray")
+    try:
+        y_np = d0.flatten()
+        y_t = torch.as_tensor(y_np, device="cuda")
+        t1 = t2 = 0.
+        for k in range(3):
+            t1, y_np, _ = L.odeCFL3(L.termRestrictUpdate, [t1, 10.], y_np, op, sdr)
+            t2, y_t, _ = L.odeCFL3(L.termRestrictUpdate, [t2, 10.], y_t, op, sdr)
+            assert isinstance(y_np, np.ndarray) and type(y_np) is lazy.DeviceArray and y_np.device_tensor() is not None
+            assert np.array_equal(y_np, y_t.cpu().numpy()) and not y_np.flags.writeable
+            if k == 1:
+                y_np = y_np.reshape(og.shape).reshape(-1)       # the drivers reshape between calls: still attached
+                assert y_np.device_tensor() is not None
+        assert t1 == t2
+        y_np[0] = 7.0                                           # a write detaches; the next call uploads the modified values
+        assert y_np.device_tensor() is None and y_np.flags.writeable
+        t3, y3, _ = L.odeCFL3(L.termRestrictUpdate, [t1, 10.], y_np, op, sdr)
+        y_t[0] = 7.0
+        t4, y4, _ = L.odeCFL3(L.termRestrictUpdate, [t2, 10.], y_t, op, sdr)
+        assert t3 == t4 and np.array_equal(y3, y4.cpu().numpy())
+    finally:
+        lazy.set_lazy(old)

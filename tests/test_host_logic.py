@@ -152,3 +152,56 @@ def test_hostview_metadata_functions_do_not_copy():
     with pytest.raises(ValueError):
         integration._check_shape(L.termRestrictUpdate, v)
     assert v._h is None                                   # the integrators' own checks never look at the values
+
+
+def test_devicearray_is_a_real_ndarray_that_remembers_its_tensor(tmp_path):
+    """HJ_LAZY_NUMPY=ndarray (lazy.DeviceArray): isinstance / np.save / pickle / buffer protocol as with the reference's plain arrays
+    (ode_cfl_3.py:241-272), the device tensor consumed when the array is passed back, writes detach."""
+    import pickle
+    import torch
+    from levelsetpy_amd import lazy
+    from levelsetpy_amd.context import DeviceGrid, array_dtype_name
+    a = np.arange(24, dtype=np.float64).reshape(6, 4) - 7.5
+    t = torch.from_numpy(a.copy())
+    v = lazy.device_array(t)
+    assert isinstance(v, np.ndarray) and type(v) is lazy.DeviceArray and v.shape == (6, 4) and v.dtype == np.float64
+    assert v.device_tensor() is not None and v.device_tensor().data_ptr() == t.data_ptr()
+    assert np.array_equal(np.asarray(v), a) and bytes(memoryview(v)) == a.tobytes()       # the values ARE there (no hook needed)
+    assert type(v + 1) is np.ndarray and np.array_equal(np.abs(v), np.abs(a)) and v.sum() == a.sum()
+    f = tmp_path / "y.npy"
+    np.save(f, v)
+    assert np.array_equal(np.load(f), a) and type(pickle.loads(pickle.dumps(v))) is np.ndarray
+    # read-only while attached: a write through a plain view cannot silently diverge from the tensor
+    assert not v.flags.writeable
+    with pytest.raises(ValueError):
+        np.asarray(v)[0, 0] = 1.0
+    # views and copies are detached; C-order reshapes of the object itself keep the tensor
+    assert v[1:3].device_tensor() is None and v.copy().device_tensor() is None and v.T.device_tensor() is None
+    r = v.reshape(-1, 1)
+    assert type(r) is lazy.DeviceArray and r.device_tensor() is not None and tuple(r.device_tensor().shape) == (24, 1)
+    assert v.ravel().device_tensor() is not None and r.squeeze().device_tensor() is not None
+    assert v.reshape(4, 6, order="F").device_tensor() is None
+    # consumed on the device when passed back: to_device hands out the tensor, not an upload
+
+    class FakeDG(object):
+        pass
+    FakeDG.torch, FakeDG.device, FakeDG.tdtype = torch, t.device, torch.float64
+    assert DeviceGrid.to_device(FakeDG(), v).data_ptr() == t.data_ptr()
+    assert array_dtype_name(lazy.device_array(torch.zeros(3, dtype=torch.float32))) == "float32"
+    # writing through the array itself detaches it and makes it writable; the tensor is never written
+    v[0, 1] = 5.0
+    assert v.device_tensor() is None and v.flags.writeable and v[0, 1] == 5.0
+    out = lazy.device_array(torch.zeros(24, dtype=torch.float64))
+    np.add(np.arange(24.0), 1.0, out=out)
+    assert out.device_tensor() is None and np.array_equal(out, np.arange(24.0) + 1)
+    # the switch
+    old = lazy.LAZY
+    try:
+        lazy.set_lazy("ndarray")
+        assert lazy.LAZY == "ndarray"
+        lazy.set_lazy(False)
+        assert lazy.LAZY is False
+        lazy.set_lazy("1")
+        assert lazy.LAZY is True
+    finally:
+        lazy.set_lazy(old)
