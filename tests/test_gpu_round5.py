@@ -448,6 +448,7 @@ def test_numpy_loop_with_real_ndarray_results_equals_the_tensor_loop():
     (isinstance / np.save / pickle as with ode_cfl_3.py:241-272's returns), values present, and the next call consumes the device
     tensor behind them; results equal the tensor-in loop bit for bit."""
     from levelsetpy_amd import lazy
+    from test_gpu_parity import dubins
     g, og = dubins([33, 31, 29])
     d0 = O.shape_cylinder(og, 2, None, .5) + 0.02 * np.random.default_rng(2).standard_normal(og.shape)
     sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
