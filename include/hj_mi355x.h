@@ -368,6 +368,11 @@ int hj_last_launch(hj_ctx* ctx, int* lds_nbuf_host, int* halo_ahead_host);
 /* Tile extents of the last tiled launch on the plane axes (extents_host[0] = planes per chunk, [d] = cells on axis d, 0 beyond
  * the grid's dimension; all 0 after a direct launch): tests assert that the launch-time tuner rotates through tile shapes. */
 int hj_last_tile(hj_ctx* ctx, int* extents_host /* HJ_MAX_DIM */);
+/* Number of writes to the ctx's per-call state so far (hj_ctx_set_stream / _dissipation / _post_step / _post_arrays).  The Python
+ * layer skips those calls when nothing changed; it compares this counter with the value it saw after its own writes, so that a
+ * second user of the same (cached, shared) ctx cannot leave it with a stale post-step operator or CFL-bound kind.  (No reference
+ * counterpart: the reference passes such state in schemeData on every call, term_restrict_update.py:50-80.) */
+unsigned long long hj_ctx_state_generation(hj_ctx* ctx);
 /* The launch plan of one substep over planes [p0, p1) of axis 0, made WITHOUT a device or a context: what a rank of a slab run will
  * launch (bench.py --gpus N --plan-only prints it for every rank before the node exists).  It runs the launch code of hj_rk_substep up to
  * the point where the kernel would be enqueued -- configuration choice by scheme / grid size, tile search, chunking against num_cus

@@ -84,6 +84,7 @@ SIGNATURES = {
     "hj_last_kernel": (C.c_char_p, [C.c_void_p]),
     "hj_last_launch": (_i, [_vp, _pi, _pi]),
     "hj_last_tile": (_i, [_vp, _pi]),
+    "hj_ctx_state_generation": (C.c_uint64, [_vp]),
     "hj_plan_substep": (_i, [_i, _pi64, _pi, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _pi64, C.c_char_p, _i]),
     "hj_version": (C.c_char_p, []),
 }

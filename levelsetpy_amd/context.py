@@ -132,6 +132,7 @@ class DeviceGrid(object):
         self._work = {}
         self._raw_stream = _raw_stream_getter(torch)
         self._stream_bound = None       # stream handle the ctx was last bound to (bind_stream skips the C call when unchanged)
+        self.bound_gen = -1             # hj_ctx_state_generation right after OUR last write to the ctx's per-call state (forget_if_written_elsewhere)
         self.bound_state = None         # (dissipation kind, post-step state) last written by term._Plan.bind
 
     def _aux(self, slot, tab):
@@ -142,9 +143,18 @@ class DeviceGrid(object):
     def bind_stream(self):
         """Launch on torch's CURRENT stream of this device (asked every call: the caller may have switched streams)."""
         s = self._raw_stream(self.device.index)
+        self.forget_if_written_elsewhere()
         if s != self._stream_bound:
             _ffi.check(self.lib.hj_ctx_set_stream(self.ctx, C.c_void_p(s)))
             self._stream_bound = s
+            self.bound_gen = self.lib.hj_ctx_state_generation(self.ctx)
+
+    def forget_if_written_elsewhere(self):
+        """The ctx is cached and shared: somebody else (a test, a C caller) may have set its stream / dissipation kind / post-step
+        operators since this object last did.  The library counts those writes; a count we did not produce voids what we remember."""
+        if self.lib.hj_ctx_state_generation(self.ctx) != self.bound_gen:
+            self._stream_bound = None
+            self.bound_state = None
 
     def to_device(self, a):
         """NumPy array or torch tensor -> contiguous device tensor of the ctx dtype (flat view ok)."""

@@ -1195,6 +1195,7 @@ void hj_ctx_destroy(hj_ctx* c) {
 int hj_ctx_set_stream(hj_ctx* c, void* s) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
     c->stream = (hipStream_t)s;
+    ++c->state_gen;
     return HJ_OK;
 }
 
@@ -1589,10 +1590,16 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
     return HJ_OK;
 }
 
+// how often the per-call state of the ctx (stream, dissipation kind, post-step operators) has been written: a host layer that caches
+// "the ctx is already set up for this call" compares it with the value it saw after its own writes (another user of the same ctx may
+// have written since: ADVICE r04)
+unsigned long long hj_ctx_state_generation(hj_ctx* c) { return c ? c->state_gen : 0ull; }
+
 int hj_ctx_set_post_step(hj_ctx* c, int op) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
     if (op < 0 || op > 2) return fail(HJ_EINVAL, "unknown post-step operator %d", op);
     c->post_step_op = op;
+    ++c->state_gen;
     return HJ_OK;
 }
 
@@ -1601,6 +1608,7 @@ int hj_ctx_set_post_arrays(hj_ctx* c, int op_a, const void* a, int op_b, const v
     if ((a && (op_a < 1 || op_a > 3)) || (b && (op_b < 1 || op_b > 3))) return fail(HJ_EINVAL, "unknown operator");
     c->post_arr[0] = a; c->post_arr_op[0] = a ? op_a : 0;
     c->post_arr[1] = b; c->post_arr_op[1] = b ? op_b : 0;
+    ++c->state_gen;
     return HJ_OK;
 }
 
@@ -1608,6 +1616,7 @@ int hj_ctx_set_dissipation(hj_ctx* c, int kind) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
     if (kind != HJ_DISS_GLF && kind != HJ_DISS_LOCAL) return fail(HJ_EINVAL, "unknown dissipation kind %d", kind);
     c->diss_local = (kind == HJ_DISS_LOCAL);
+    ++c->state_gen;
     return HJ_OK;
 }
 

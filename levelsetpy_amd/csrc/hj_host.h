@@ -158,6 +158,7 @@ struct hj_ctx {
     int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
     // hj_plan_substep: a host-only context (no device, no allocation) whose launches stop after the tile / chunk plan is made
+    unsigned long long state_gen = 0;               // bumped by every hj_ctx_set_stream / _dissipation / _post_step / _post_arrays (hj_ctx_state_generation)
     int dry = 0;
     struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)

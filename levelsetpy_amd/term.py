@@ -54,6 +54,8 @@ class _Plan(tuple):
         # unchanged state (the common case: one schemeData stepped again and again) costs a tuple compare, not three C calls
         state = (self.diss, post_op,
                  (post_a[0], post_a[1].data_ptr()) if post_a else None, (post_b[0], post_b[1].data_ptr()) if post_b else None)
+        # (another user of the ctx -- a test, a C caller -- may have written this state since: the library counts the writes)
+        dg.forget_if_written_elsewhere()
         if dg.bound_state == state:
             return
         _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, self.diss))
@@ -61,6 +63,7 @@ class _Plan(tuple):
         _ffi.check(dg.lib.hj_ctx_set_post_arrays(dg.ctx, post_a[0] if post_a else 0, dg.ptr(post_a[1]) if post_a else None,
                                                  post_b[0] if post_b else 0, dg.ptr(post_b[1]) if post_b else None))
         dg.bound_state = state
+        dg.bound_gen = dg.lib.hj_ctx_state_generation(dg.ctx)
 
     def static_step_bound(self, dg):
         """stepBound of this (grid, system, dissipation kind): data independent for the native systems, one C call per ctx."""

@@ -477,3 +477,22 @@ def test_numpy_loop_with_real_ndarray_results_equals_the_tensor_loop():
         assert t3 == t4 and np.array_equal(y3, y4.cpu().numpy())
     finally:
         lazy.set_lazy(old)
+
+
+def test_foreign_write_to_the_shared_ctx_is_noticed():
+    """term._Plan.bind skips the hj_ctx_set_* calls when the state it last wrote is unchanged -- another user of the cached ctx
+    (here: this test, through the C ABI) may have written since.  The library counts the writes (hj_ctx_state_generation)."""
+    from levelsetpy_amd.context import device_grid
+    from test_gpu_parity import dubins
+    g, og = dubins([21, 19, 17])
+    d0 = O.shape_cylinder(og, 2, None, .5)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstENO2)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    yd1, sb1, _ = L.termLaxFriedrichs(0., y, sd)
+    dg = device_grid(g)
+    gen = dg.lib.hj_ctx_state_generation(dg.ctx)
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, 1))            # local Lax-Friedrichs: a different stepBound
+    _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, 1))
+    assert dg.lib.hj_ctx_state_generation(dg.ctx) == gen + 2
+    yd2, sb2, _ = L.termLaxFriedrichs(0., y, sd)
+    assert sb1 == sb2 and torch.equal(yd1, yd2)
