@@ -169,7 +169,14 @@ class DeviceGrid(object):
             if t.device != self.device or t.dtype != self.tdtype:
                 t = t.to(device=self.device, dtype=self.tdtype)
             return t.contiguous()
-        h = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        arr = np.ascontiguousarray(a, dtype=np.float64)
+        if arr.flags.writeable:
+            h = torch.from_numpy(arr)
+        else:       # a read-only source (e.g. np.asarray of one of our results): only read here, torch's warning does not apply
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                h = torch.from_numpy(arr)
         # a page-locked source (e.g. an array this package returned) goes over at the DMA rate
         return h.to(device=self.device, dtype=self.tdtype, non_blocking=False)
 
