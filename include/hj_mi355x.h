@@ -338,6 +338,13 @@ int hj_ham_flags(int ham_id, int* flags_host);
 /* stepBound of the stages of the last hj_rk_step on this ctx with an HJ_HAM_RANGE Hamiltonian (sb_host[0..*n_host), n <= 3):
  * ode_cfl_3.py:173-175,215-217 warn when deltaT > min(1, 1.2 factorCFL) * stepBound at the later stages. */
 int hj_rk_last_bounds(hj_ctx* ctx, double* sb_host /* 3 */, int* n_host);
+/* The same without waiting (round 5): hj_rk_step returns while the last stage of a range-dependent step is still running and copies
+ * the later stages' bounds to the host asynchronously; hj_rk_last_bounds waits for them, this call does not -- it reports the NEWEST
+ * step whose bounds have arrived (usually the previous one: they are decoded at the next step's own synchronisation point) together
+ * with that step's deltaT, once (*n_host = 0 when there is nothing new).  The Python integrators raise the reference's "substep
+ * violated CFL" warning (ode_cfl_3.py:173-175, 215-217) from it one step late and drain with hj_rk_last_bounds at the end of a
+ * multi-step call. */
+int hj_rk_prev_bounds(hj_ctx* ctx, double* sb_host /* 3 */, int* n_host, double* dt_host);
 /* Decomposed grids: the range of ONE slab is not the grid's.  hj_range_pass reduces derivL / derivR of the ctx's planes (pads read
  * where the slab has neighbours) into 2*HJ_MAX_DIM order-preserving 64-bit keys at keys_dev ([d] max, [HJ_MAX_DIM-independent ndim + d]
  * -min; an element-wise MAX over ranks of the keys is the reduction); hj_ctx_set_range_source makes later launches read the

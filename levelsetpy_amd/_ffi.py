@@ -73,6 +73,7 @@ SIGNATURES = {
     "hj_ham_register2": (_i, [C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _i, _i, C.c_char_p, C.c_char_p, _pi]),
     "hj_ham_flags": (_i, [_i, _pi]),
     "hj_rk_last_bounds": (_i, [_vp, _pd, _pi]),
+    "hj_rk_prev_bounds": (_i, [_vp, _pd, _pi, _pd]),
     "hj_range_pass": (_i, [_vp, _i, _i, _pd, _vp, _vp]),
     "hj_ctx_set_range_source": (_i, [_vp, _vp]),
     "hj_range_alpha_max": (_i, [_vp, _i, _pd, _pd]),

@@ -1,4 +1,5 @@
 // C ABI of libhj_mi355x.so (see include/hj_mi355x.h).  gfx950 only.
+#include <chrono>
 #include <dlfcn.h>
 
 #include "hj_host.h"
@@ -21,10 +22,15 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
+int alpha_partials(hj_ctx* c) {
+    if (!c->alpha_part) HIP_TRY(hipMalloc((void**)&c->alpha_part, (size_t)ALPHA_BLOCKS_MAX * 8 * sizeof(double)));
+    return HJ_OK;
+}
+
 // a zeroed entry of the range-key ring becomes ctx->range_keys (as next_ring() does for the CFL bounds: a memset launch per pass
 // costs 4 us of launch time, the ring is zeroed once per RANGE_RING passes)
 int next_range_keys(hj_ctx* c) {
-    const size_t entry = 2 * HJ_MAX_DIM;
+    const size_t entry = RANGE_ENTRY;
     if (!c->range_ring) {
         HIP_TRY(hipMalloc((void**)&c->range_ring, sizeof(unsigned long long) * entry * RANGE_RING));
         HIP_TRY(hipMemsetAsync(c->range_ring, 0, sizeof(unsigned long long) * entry * RANGE_RING, c->stream));
@@ -1175,6 +1181,9 @@ int hj_plan_substep(int ndim, const int64_t* N, const int* bc, int dtype, int sc
 
 void hj_ctx_destroy(hj_ctx* c) {
     if (c && c->range_ring) (void)hipFree(c->range_ring);
+    if (c && c->host_words) (void)hipHostFree(c->host_words);
+    if (c && c->dt_dev) (void)hipFree(c->dt_dev);
+    if (c && c->alpha_part) (void)hipFree(c->alpha_part);
     if (!c) return;
     (void)hj_comm_destroy(c);
     for (int d = 0; d < HJ_MAX_DIM; ++d) if (c->coord[d]) (void)hipFree(c->coord[d]);
@@ -1545,7 +1554,8 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         if (amax) for (int d = 0; d < c->ndim; ++d) amax[d] = c->sb_alpha[d];
         return HJ_OK;
     }
-    HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));       // (keys[6]: the kernel's workgroup counter)
+    if ((rc = alpha_partials(c))) return rc;
     const int blocks = (int)std::min<int64_t>((c->total + 255) / 256, 256 * 2);
 #define HJ_AB(T, HAM)                                                                            \
     {                                                                                            \
@@ -1556,10 +1566,11 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         DxArgs DX;                                                                               \
         for (int d = 0; d < HJ_MAX_DIM; ++d) DX.dx[d] = c->dx[d];                                \
         hipLaunchKernelGGL((alpha_bound_kernel<T, HAM<T>>), dim3(blocks), dim3(256), 0,          \
-                           c->stream, G, P, c->keys, DX);                                        \
+                           c->stream, G, P, c->keys, DX, c->alpha_part, c->keys + 6,             \
+                           (unsigned long long*)nullptr, 0ull, DtArgs{0, 0, 0, nullptr});        \
     }
     if (ham >= HJ_HAM_USER_BASE) {
-        if ((rc = user_alpha_bound(c, ham, par, c->keys))) return rc;
+        if ((rc = user_alpha_bound(c, ham, par, c->keys, c->keys + 6))) return rc;
     } else if (c->dtype == HJ_F64) {
         if (ham == HJ_HAM_DUBINS_REL) HJ_AB(double, HamDubinsRel)
         else if (ham == HJ_HAM_DOUBLE_INTEGRATOR) HJ_AB(double, HamDoubleIntegrator)
@@ -1626,6 +1637,26 @@ int hj_ctx_set_dissipation(hj_ctx* c, int kind) {
 // kernel of hj_static_step_bound, a few microseconds), ONE host read, and the first stage is an ordinary fused Euler launch with
 // deltaT known -- no ydot array, no separate y + deltaT*ydot pass.  The later stages are range pass + fused substep with the
 // in-kernel max(alpha) kept; their bounds are read once at the end of the step for the reference's CFL warning (hj_rk_last_bounds).
+// host_words[8..16) -> last_bounds[1..] / prev_bounds (the caller has made sure the copies have completed)
+static int decode_stage_bounds(hj_ctx* c) {
+    const int nst = c->stage_bounds_pending;
+    c->stage_bounds_pending = 0;
+    for (int st = 0; st < nst; ++st) {
+        double inv = 0.0;
+        for (int d = 0; d < c->ndim; ++d) {
+            const unsigned long long k = c->host_words[8 + st * HJ_MAX_DIM + d];
+            if (k == 0) return fail(HJ_ESTATE, "bound slot holds no reduction for dim %d", d);
+            inv += key_to_double(k) / c->dx[d];
+        }
+        c->prev_bounds[1 + st] = 1.0 / inv;
+    }
+    c->prev_bounds[0] = c->last_bounds[0];
+    c->prev_bounds_n = 1 + nst;
+    c->prev_bounds_dt = c->stage_bounds_dt;
+    c->prev_bounds_new = true;
+    return HJ_OK;
+}
+
 static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf, double factor_cfl,
                            double max_step, int restrict_sign, const void* y_in, void* y_out, void* work0, void* work1,
                            double* t_out, double* dt_out) {
@@ -1639,27 +1670,53 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
         r.range_only = true;
         if ((rc = do_substep(c, r, -1))) return rc;
     }
-    double sb1 = 0;
+    double sb1 = 0, dt_step = 0;
     {   // stepBound = 1 / sum_d max_x alpha_d(x, range) / dx_d   (artificial_diss_glf.py:101-109)
-        HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
-        if ((rc = user_alpha_bound(c, ham, par, c->keys, true))) return rc;
-        unsigned long long k[HJ_MAX_DIM];
-        HIP_TRY(hipMemcpyAsync(k, c->keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        double inv = 0.0;
-        for (int d = 0; d < c->ndim; ++d) inv += key_to_double(k[d]) / c->dx[d];
-        sb1 = 1.0 / inv;
+        // Round 5: the bound kernel's keys and workgroup counter are part of the (pre-zeroed) ring entry of the range pass -- no memset
+        // launch --, and its last workgroup writes the result into page-locked host memory that this thread polls: no copy launch, no
+        // stream synchronisation (the step's only host <-> device round trip: 31 -> ~12 us of idle GPU at 201^3)
+        if (!c->host_words) {
+            HIP_TRY(hipHostMalloc((void**)&c->host_words, 16 * sizeof(unsigned long long), hipHostMallocCoherent));
+            memset(c->host_words, 0, 16 * sizeof(unsigned long long));
+            HIP_TRY(hipMalloc((void**)&c->dt_dev, 8 * sizeof(double)));
+        }
+        const unsigned long long seq = ++c->host_seq;
+        volatile unsigned long long* hw = c->host_words;
+        // ... and deltaT = min(factorCFL * stepBound, tspan[1] - t, maxStep) (ode_cfl_3.py:142) is formed ON the device too: the first
+        // stage is enqueued behind the bound kernel before this thread knows the value (FusedArgs::dt_dev) -- the GPU never idles for the
+        // host; the host reads the very same bits from host_words[5..6] for its own bookkeeping and the later stages' arguments
+        const DtArgs dta{factor_cfl, tf - t0, max_step, c->dt_dev};
+        if ((rc = user_alpha_bound(c, ham, par, c->range_keys + RANGE_ALPHA_AT, c->range_keys + RANGE_DONE_AT, true, c->host_words, seq, &dta))) return rc;
+        {
+            SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, std::numeric_limits<double>::quiet_NaN(), y_in, nullptr,
+                          order == 1 ? y_out : work0, nullptr, 0, n0};
+            a.range_ready = true;
+            a.dt_dev = c->dt_dev;
+            if (order == 1) a.post_op = c->post_step_op;
+            if ((rc = do_substep(c, a, -1))) return rc;
+        }
+        const auto t_poll = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(c->host_words + 7, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 1023u) == 0) {
+                // (a failed launch or a lost device must not hang the caller: after 5 s ask the stream)
+                if (std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(5)) {
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (__atomic_load_n(c->host_words + 7, __ATOMIC_ACQUIRE) != seq) return fail(HJ_EHIP, "the bound kernel never published its result");
+                }
+            }
+            __builtin_ia32_pause();
+        }
+        unsigned long long bits_sb = hw[5], bits_dt = hw[6];
+        memcpy(&sb1, &bits_sb, sizeof(double));
+        memcpy(&dt_step, &bits_dt, sizeof(double));
+        // the previous step's later-stage bounds (copied asynchronously at its end, ahead of everything this step enqueued) have landed
+        if (c->stage_bounds_pending) decode_stage_bounds(c);
     }
-    const double dt = std::min(std::min(factor_cfl * sb1, tf - t0), max_step);       // ode_cfl_3.py:142
+    const double dt = dt_step;
     c->last_bounds[0] = sb1;
     c->last_bounds_n = 1;
     void* first = order == 1 ? y_out : work0;
-    {
-        SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, first, nullptr, 0, n0};
-        a.range_ready = true;
-        if (order == 1) a.post_op = c->post_step_op;
-        if ((rc = do_substep(c, a, -1))) return rc;
-    }
     double t = t0 + dt;
     if (order >= 2) {
         const int stage2 = order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF;
@@ -1676,32 +1733,19 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
             const double tHalf = 0.25 * (3 * t0 + t2);
             t = (1.0 / 3.0) * (t0 + 2 * (tHalf + dt));
         }
-        // the later stages' bounds: one more host read at the end of the step (the reference warns when deltaT exceeds them)
+        // the later stages' bounds (the reference warns when deltaT exceeds them, ode_cfl_3.py:173-175, 215-217): copied into page-locked
+        // host memory WITHOUT waiting -- the step returns while its last stage is still running; whoever wants them (hj_rk_last_bounds)
+        // waits then, and the next step decodes them for hj_rk_prev_bounds at its own synchronisation point
         const int pos2 = c->slot_ring[slot2], pos3 = order == 3 ? c->slot_ring[slot3] : pos2;
-        if (order == 3 && pos3 == pos2 + 1) {            // consecutive ring entries: one copy, one synchronisation
-            unsigned long long k[2 * HJ_MAX_DIM];
-            HIP_TRY(hipMemcpyAsync(k, c->ring + (size_t)pos2 * HJ_MAX_DIM, sizeof(k), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            for (int st = 0; st < 2; ++st) {
-                double inv = 0.0;
-                for (int d = 0; d < c->ndim; ++d) {
-                    if (k[st * HJ_MAX_DIM + d] == 0) return fail(HJ_ESTATE, "bound slot holds no reduction for dim %d", d);
-                    inv += key_to_double(k[st * HJ_MAX_DIM + d]) / c->dx[d];
-                }
-                c->last_bounds[1 + st] = 1.0 / inv;
-            }
-            c->last_bounds_n = 3;
+        if (order == 3 && pos3 == pos2 + 1) {            // consecutive ring entries: one copy
+            HIP_TRY(hipMemcpyAsync(c->host_words + 8, c->ring + (size_t)pos2 * HJ_MAX_DIM, 2 * HJ_MAX_DIM * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         } else {
-            double sb2 = 0, sb3 = 0;
-            if ((rc = read_ring(c, pos2, &sb2, nullptr))) return rc;
-            c->last_bounds[1] = sb2;
-            c->last_bounds_n = 2;
-            if (order == 3) {
-                if ((rc = read_ring(c, pos3, &sb3, nullptr))) return rc;
-                c->last_bounds[2] = sb3;
-                c->last_bounds_n = 3;
-            }
+            HIP_TRY(hipMemcpyAsync(c->host_words + 8, c->ring + (size_t)pos2 * HJ_MAX_DIM, HJ_MAX_DIM * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            if (order == 3)
+                HIP_TRY(hipMemcpyAsync(c->host_words + 12, c->ring + (size_t)pos3 * HJ_MAX_DIM, HJ_MAX_DIM * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         }
+        c->stage_bounds_pending = order - 1;
+        c->stage_bounds_dt = dt;
     }
     for (int k = 0; k < 2; ++k) {
         if (!c->post_arr[k]) continue;
@@ -1715,8 +1759,27 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
 
 int hj_rk_last_bounds(hj_ctx* c, double* sb, int* n) {
     if (!c || !sb || !n) return fail(HJ_EINVAL, "null argument");
+    if (c->stage_bounds_pending) {          // the last step's later stages may still be running: this call waits for them
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int nst = c->stage_bounds_pending;
+        int rc = decode_stage_bounds(c);
+        if (rc) return rc;
+        for (int st = 0; st < nst; ++st) c->last_bounds[1 + st] = c->prev_bounds[1 + st];
+        c->last_bounds_n = 1 + nst;
+    }
     *n = c->last_bounds_n;
     for (int k = 0; k < c->last_bounds_n; ++k) sb[k] = c->last_bounds[k];
+    return HJ_OK;
+}
+
+int hj_rk_prev_bounds(hj_ctx* c, double* sb, int* n, double* dt) {
+    if (!c || !sb || !n || !dt) return fail(HJ_EINVAL, "null argument");
+    *n = 0;
+    if (!c->prev_bounds_new) return HJ_OK;
+    c->prev_bounds_new = false;
+    *n = c->prev_bounds_n;
+    *dt = c->prev_bounds_dt;
+    for (int k = 0; k < c->prev_bounds_n; ++k) sb[k] = c->prev_bounds[k];
     return HJ_OK;
 }
 
@@ -1733,7 +1796,7 @@ int hj_range_alpha_max(hj_ctx* c, int ham, const double* par, double* amax) {
     int rc = check_ham(c, ham, par);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->keys, 0, 8 * sizeof(unsigned long long), c->stream));
-    if ((rc = user_alpha_bound(c, ham, par, c->keys, true))) return rc;
+    if ((rc = user_alpha_bound(c, ham, par, c->keys, c->keys + 6, true))) return rc;
     unsigned long long k[HJ_MAX_DIM];
     HIP_TRY(hipMemcpyAsync(k, c->keys, sizeof(k), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

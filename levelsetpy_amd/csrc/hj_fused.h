@@ -145,7 +145,20 @@ template <typename T, int ND> struct FusedArgs {
     // MODE 3 (the RANGE PASS of a substep, round 5): nothing is written but 2*ND keys -- [d] max, [ND + d] -min of derivL_d / derivR_d
     // over the launch's cells (artificial_diss_glf.py:80-88: derivMin / derivMax), for Hamiltonians whose alpha reads them
     unsigned long long* range_keys;
+    // deltaT from DEVICE memory (round 5; Hamiltonians that define DT_DEV, i.e. the run-time ones whose alpha reads the costate range): the
+    // bound kernel that follows the range pass computes deltaT (ode_cfl_3.py:142) and the first stage is already enqueued behind it -- the
+    // host learns the same value from page-locked memory meanwhile, the GPU never waits for it.  null: `dt` above.
+    const double* dt_dev;
 };
+
+// deltaT of this launch (built-in Hamiltonians: the kernel argument, exactly the code of rounds 1-4)
+template <typename H, typename = void> struct ham_dt_dev { static constexpr bool value = false; };
+template <typename H> struct ham_dt_dev<H, typename hj_void<decltype(H::DT_DEV)>::type> { static constexpr bool value = H::DT_DEV; };
+template <typename HAM, typename T, int ND>
+__device__ __forceinline__ T launch_dt(const FusedArgs<T, ND>& A) {
+    if constexpr (ham_dt_dev<HAM>::value) return A.dt_dev != nullptr ? (T)__builtin_nontemporal_load(A.dt_dev) : A.dt;
+    else return A.dt;
+}
 
 // end of a range pass: the per-thread minima / maxima -> 2*ND atomicMax on order-preserving keys (one per workgroup and value)
 template <int ND, int NT, typename T>
@@ -350,6 +363,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const int b = blockIdx.x;
     const int L = logical_block(A);
     if (L < 0) return;
+    const T dt_launch = launch_dt<HAM>(A);
     int chunk_id, rem;
     fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);     // index divisions through a float reciprocal (hj_device.h)
     if (A.timing && threadIdx.x == 0) {
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             T o;
             if (GEN && A.ydot_only) o = ydot;
             else {
-                o = rk_stage_out<NP>(A.stage, A.ca, A.cb, A.dt, y0_c[r], q[r][3], ydot);
+                o = rk_stage_out<NP>(A.stage, A.ca, A.cb, dt_launch, y0_c[r], q[r][3], ydot);
                 // the step started from y0 (stages that read it) or from y itself (Euler step)
                 if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0_c[r] : q[r][3]);
             }

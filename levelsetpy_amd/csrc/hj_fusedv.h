@@ -122,6 +122,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #endif
     const int L = logical_block(A);
     if (L < 0) return;
+    const T dt_launch = launch_dt<HAM>(A);
     // PAIRED CHUNKS (round 4, A.npairs > 0): the main range's chunks 2k and 2k+1 share their boundary plane B; chunk 2k marches
     // DOWN from B - 1, chunk 2k+1 UP from B, and the two workgroups of a pair are neighbours in the logical order (same XCD):
     // both then request the six planes B-3 .. B+2 that fill their register queues in the same microsecond, and the second
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 T o;
                 if (GEN && A.ydot_only) o = ydot;
                 else {
-                    o = rk_stage_out<NP>(A.stage, A.ca, A.cb, A.dt, y0v, q[r][c][3 + OFF], ydot);
+                    o = rk_stage_out<NP>(A.stage, A.ca, A.cb, dt_launch, y0v, q[r][c][3 + OFF], ydot);
                     if (GEN && A.post_op) o = post_step(A.post_op, o, use_y0 ? y0v : q[r][c][3 + OFF]);
                 }
                 if (c == 0) o2.x = o; else o2.y = o;

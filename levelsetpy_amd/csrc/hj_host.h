@@ -37,7 +37,11 @@ int fail(int code, const char* fmt, ...);     // records the message for hj_last
     } while (0)
 
 constexpr int RING_SLOTS = 2048;  // bound-key ring (each entry: HJ_MAX_DIM keys)
-constexpr int RANGE_RING = 1024;  // range-key ring (each entry: 2*HJ_MAX_DIM keys)
+constexpr int RANGE_RING = 1024;  // range-key ring
+// one entry: [0, 2*HJ_MAX_DIM) the range keys of a pass; [8, 8+HJ_MAX_DIM] the max(alpha) keys of the bound kernel that follows it in
+// hj_rk_step (HJ_MAX_DIM per-dimension maxima + the local-LF sum); [13] that kernel's workgroup counter.  All zeroed in bulk.
+constexpr int ALPHA_BLOCKS_MAX = 1024;
+constexpr int RANGE_ENTRY = 16, RANGE_ALPHA_AT = 8, RANGE_DONE_AT = 13;
 
 struct Tiling {
     int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
@@ -133,7 +137,18 @@ struct hj_ctx {
     int f12_pair = 1;                               // stage-fused kernel with two cells per lane (hj_fused12v.h): 0 off, 1 if a tiling exists, 2 or fail
     // Hamiltonians whose alpha reads the costate range (hj_rtc.hip, HJ_HAM_RANGE): 2*HJ_MAX_DIM keys the range pass of a substep writes
     unsigned long long* range_keys = nullptr;       // the entry of range_ring the last range pass wrote (what fill_ham hands to the kernels)
-    unsigned long long* range_ring = nullptr;       // RANGE_RING entries of 2*HJ_MAX_DIM keys, zeroed in bulk (no memset launch per pass)
+    unsigned long long* range_ring = nullptr;       // RANGE_RING entries of RANGE_ENTRY keys, zeroed in bulk (no memset launch per pass)
+    // page-locked host words the device writes for the host to poll / read later (hj_rk_step with a range-dependent alpha):
+    // [0..8) the bound kernel's keys + sequence number (alpha_bound_kernel), [8..16) the later stages' bound keys of the previous step
+    double* dt_dev = nullptr;                       // deltaT of the step in flight, written by alpha_bound_kernel (DtArgs)
+    double* alpha_part = nullptr;                   // per-workgroup partial maxima of alpha_bound_kernel (ALPHA_BLOCKS_MAX x 8)
+    unsigned long long* host_words = nullptr;
+    unsigned long long host_seq = 0;
+    int stage_bounds_pending = 0;                   // stages whose bounds are on their way into host_words[8..] (0: none)
+    double stage_bounds_dt = 0;                     // deltaT of the step they belong to
+    double prev_bounds[3] = {0, 0, 0}, prev_bounds_dt = 0;   // the newest step whose later-stage bounds have been decoded (hj_rk_prev_bounds)
+    int prev_bounds_n = 0;
+    bool prev_bounds_new = false;
     int range_pos = 0;
     const unsigned long long* range_src = nullptr;  // hj_ctx_set_range_source: keys reduced by the caller (over all ranks); the launches then skip their own range pass
     double last_bounds[3] = {0, 0, 0};              // stepBound of the stages of the last hj_rk_step with such a Hamiltonian (hj_rk_last_bounds)
@@ -241,6 +256,7 @@ struct SubstepCall {
     bool range_only = false;
     unsigned long long* range_out = nullptr;
     bool range_ready = false;           // ctx->range_keys already hold the range of this launch's input: no pass of its own
+    const double* dt_dev = nullptr;     // deltaT in device memory (FusedArgs::dt_dev; run-time Hamiltonians with a range-dependent alpha only)
 };
 constexpr int HJ_EPS_ROWS = 256;  // workgroups (= rows) of eps_seam_kernel
 
@@ -296,7 +312,10 @@ bool user_ham_dynamic(int ham);           // alpha depends on the data (the cost
 int user_ham_ndim(int ham);
 int user_ham_npar(int ham);
 int launch_user(hj_ctx* c, const SubstepCall& s);
-int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, bool with_range = false);
+// done / host_out / seq: see alpha_bound_kernel (hj_split.h) -- the last workgroup publishes the keys to page-locked host memory
+int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, unsigned long long* done, bool with_range = false,
+                     unsigned long long* host_out = nullptr, unsigned long long seq = 0, const hj::DtArgs* dt = nullptr);
+int alpha_partials(hj_ctx* c);        // allocates ctx->alpha_part on first use
 
 // the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
 // instantiated in hj_inst.hip

@@ -90,6 +90,7 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
         default: A.ca = T(0); A.cb = T(1); break;
     }
     A.dt = (T)s.dt;
+    A.dt_dev = s.dt_dev;
     A.post_op = s.post_op;
     A.do_clamp = s.restrict_sign != 0;
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();

@@ -113,6 +113,7 @@ static std::string user_source(const UserHam& u, int id) {
          "    static constexpr unsigned PLANE_DEP = 0xFu;     // any alpha may vary along the march\n"
          "    static constexpr int NCOL = " << (u.ncol > 0 ? u.ncol : 1) << ";\n"
          "    static constexpr bool RANGE = " << (rng ? "true" : "false") << ";\n"
+         "    static constexpr bool DT_DEV = RANGE;       // the stage kernels may take deltaT from device memory (FusedArgs::dt_dev)\n"
          "    struct Cell { T x[ND]; T col[NCOL]; };\n"
          "    struct Plane { T x0; T dmin[RANGE ? ND : 1], dmax[RANGE ? ND : 1]; };\n    using Raw = Cell;\n"
          "    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {\n"
@@ -319,6 +320,11 @@ template <typename T, int ND> struct AlphaKernArgs {
     HamTables<T> P;
     unsigned long long* keys;
     DxArgs DX;
+    double* partials;
+    unsigned long long* done;
+    unsigned long long* host_out;
+    unsigned long long seq;
+    DtArgs DT;
 };
 
 static int module_launch(hipFunction_t fn, unsigned grid, unsigned block, size_t lds, hipStream_t st, void* args, size_t nbytes) {
@@ -499,7 +505,8 @@ int launch_user(hj_ctx* c, const SubstepCall& s) {
 }
 
 template <typename T, int ND>
-static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long long* keys, UserHam& u) {
+static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long long* keys, UserHam& u,
+                         unsigned long long* done, unsigned long long* host_out, unsigned long long seq, const DtArgs* dt) {
     constexpr bool F32 = sizeof(T) == 4;
     HIP_TRY(hipSetDevice(c->device));
     UserKernel& ak = u.alpha[c->device * 2 + (F32 ? 1 : 0)];
@@ -513,26 +520,40 @@ static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long lo
     fill_grid<T, ND>(c, K.G);
     fill_ham<T>(c, par, K.P);
     K.keys = keys;
+    {
+        int rc = alpha_partials(c);
+        if (rc) return rc;
+    }
+    K.partials = c->alpha_part;
+    K.done = done; K.host_out = host_out; K.seq = seq;
+    if (dt) K.DT = *dt;
     for (int d = 0; d < HJ_MAX_DIM; ++d) K.DX.dx[d] = c->dx[d];
-    const unsigned blocks = (unsigned)std::min<int64_t>((c->total + 255) / 256, 256 * 2);
-    return module_launch(ak.fn, blocks, 256, 0, c->stream, &K, sizeof(K));
+    // (one workgroup of 512 per CU -- the sweep of tools/experiments/r05_alpha_sweep.py: every further workgroup costs a fence and an atomic; a thread walks a run of planes of one in-plane cell; every workgroup costs one same-address atomic)
+    const unsigned blocks = (unsigned)std::min<int64_t>((c->total + 511) / 512, std::min<int64_t>((int64_t)c->num_cus, ALPHA_BLOCKS_MAX));
+    // HJ_ALPHA_BLOCKS / HJ_ALPHA_THREADS: tuning knobs (tools/experiments/r05_alpha_sweep.py)
+    static const int env_blocks = getenv("HJ_ALPHA_BLOCKS") ? atoi(getenv("HJ_ALPHA_BLOCKS")) : 0;
+    static const int env_threads = getenv("HJ_ALPHA_THREADS") ? atoi(getenv("HJ_ALPHA_THREADS")) : 0;
+    const unsigned nthr = env_threads > 0 ? (unsigned)env_threads : 512u;
+    const unsigned nblk = env_blocks > 0 ? (unsigned)std::min(env_blocks, ALPHA_BLOCKS_MAX) : blocks;
+    return module_launch(ak.fn, nblk, nthr, 0, c->stream, &K, sizeof(K));
 }
 
 // with_range: the caller has just run the range pass of the state in question (ctx->range_keys / range_src): max(alpha) over the grid is
 // then well defined for an HJ_HAM_RANGE Hamiltonian too (alpha never depends on the node's own costate)
-int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, bool with_range) {
+int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, unsigned long long* done, bool with_range,
+                     unsigned long long* host_out, unsigned long long seq, const DtArgs* dt) {
     UserHam* u = user_of(ham);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham);
     if ((u->flags & HJ_HAM_RANGE) && !with_range)
         return fail(HJ_EUNSUPPORTED, "the alpha of '%s' depends on the costate range: its step bound is a property of the data, not of the grid", u->name.c_str());
     if (c->dtype == HJ_F64) {
-        if (c->ndim == 2) return alpha_user_nd<double, 2>(c, ham, par, keys, *u);
-        if (c->ndim == 3) return alpha_user_nd<double, 3>(c, ham, par, keys, *u);
-        if (c->ndim == 4) return alpha_user_nd<double, 4>(c, ham, par, keys, *u);
+        if (c->ndim == 2) return alpha_user_nd<double, 2>(c, ham, par, keys, *u, done, host_out, seq, dt);
+        if (c->ndim == 3) return alpha_user_nd<double, 3>(c, ham, par, keys, *u, done, host_out, seq, dt);
+        if (c->ndim == 4) return alpha_user_nd<double, 4>(c, ham, par, keys, *u, done, host_out, seq, dt);
     } else {
-        if (c->ndim == 2) return alpha_user_nd<float, 2>(c, ham, par, keys, *u);
-        if (c->ndim == 3) return alpha_user_nd<float, 3>(c, ham, par, keys, *u);
-        if (c->ndim == 4) return alpha_user_nd<float, 4>(c, ham, par, keys, *u);
+        if (c->ndim == 2) return alpha_user_nd<float, 2>(c, ham, par, keys, *u, done, host_out, seq, dt);
+        if (c->ndim == 3) return alpha_user_nd<float, 3>(c, ham, par, keys, *u, done, host_out, seq, dt);
+        if (c->ndim == 4) return alpha_user_nd<float, 4>(c, ham, par, keys, *u, done, host_out, seq, dt);
     }
     return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: 2-D, 3-D and 4-D grids");
 }

@@ -369,37 +369,67 @@ __global__ void keys_to_values_kernel(const unsigned long long* keys, T* out, in
     }
 }
 
-// ---- max alpha per dim with p = 0: stepBound of a Hamiltonian whose alpha ignores the data
+// ---- max alpha per dim with p = 0: stepBound of a Hamiltonian whose alpha ignores the data -- and, after a range pass, of one whose alpha
+// reads the costate range (hj_rtc.hip): then the kernel sits between the range pass and the first stage of EVERY step.
+// Round 5: (1) a thread owns one in-plane cell and a run of planes (the column constants -- for the Dubins-like systems cos / sin of the
+// heading -- and the index decode are paid once per run, not once per node); (2) NO same-address atomics for the maxima: 512 workgroups x
+// (ND+1) atomicMax on one cache line were the whole kernel (23.7 us at 201^3 = 2048 atomics x ~12 ns; profiles/r05_range_path.txt) --
+// every workgroup stores its partial maxima, counts itself with ONE atomic add, and the last one reduces the partials; (3) that last
+// workgroup also hands the result to the host through page-locked memory (host_out[0..HJ_MAX_DIM] = the keys, host_out[7] = seq with
+// release semantics): the host polls it instead of launching a copy and waiting for the stream (host_out == nullptr: keys only).
+// `done` must be zero at launch; `partials`: gridDim.x * 8 doubles.
 struct DxArgs { double dx[HJ_MAX_DIM]; };
+// deltaT on the device (hj_rk_step with a range-dependent alpha): min(factorCFL * stepBound, tspan[1] - t, maxStep), ode_cfl_3.py:142,
+// written to *dt_dev for the stage kernels already enqueued behind this one (FusedArgs::dt_dev) and -- as bits -- to host_out[5] (the
+// stepBound) and host_out[6] (deltaT): the host uses THESE values, so both sides step with the same number.  dt_dev == nullptr: off.
+struct DtArgs { double factor, span, max_step; double* dt_dev; };
 template <typename T, typename HAM>
-__global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G, HamTables<T> P,
-                                                          unsigned long long* keys, DxArgs DX) {
+__global__ __launch_bounds__(1024) void alpha_bound_kernel(GridArgs<T, HAM::ND> G, HamTables<T> P,
+                                                          unsigned long long* keys, DxArgs DX, double* partials,
+                                                          unsigned long long* done, unsigned long long* host_out, unsigned long long seq,
+                                                          DtArgs DT) {
     constexpr int ND = HAM::ND;
     const double* dx = DX.dx;
     // m[0..ND): max alpha_d (global LF);  m[ND]: max over nodes of sum_d alpha_d/dx_d (local LF variants)
     double m[ND + 1];
 #pragma unroll
     for (int d = 0; d <= ND; ++d) m[d] = -1e300;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < G.total;
-         t += (long long)gridDim.x * blockDim.x) {
+    const long long n0 = G.n[0], plane_cells = G.total / n0;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    // runs of planes per in-plane cell: as many as the launch has threads for (at least 1, at most one plane per run)
+    const long long nrun = min(n0, max(1ll, nthreads / plane_cells));
+    const long long items = plane_cells * nrun;
+    T one[ND], p[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { one[d] = T(1); p[d] = T(0); }
+    for (long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x; w < items; w += nthreads) {
+        const long long run = w / plane_cells;
+        long long ip = w - run * plane_cells;
         int idx[ND];
-        decode<T, ND>(G, t, idx);
-        T p[ND], H, a[ND];
+        idx[0] = 0;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) p[d] = T(0);
-        T one[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) one[d] = T(1);
-        HAM::eval(P, HAM::cell(P, idx, one), HAM::plane(P, idx[0], one), one, p, H, a);
-        double inv = 0.0;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            m[d] = fmax(m[d], (double)a[d]);
-            inv += (double)a[d] / dx[d];
+        for (int d = ND - 1; d >= 1; --d) {
+            const long long q = ip / G.n[d];
+            idx[d] = (int)(ip - q * G.n[d]);
+            ip = q;
         }
-        m[ND] = fmax(m[ND], inv);
+        const auto cc = HAM::cell(P, idx, one);
+        const int pa = (int)(run * n0 / nrun), pb = (int)((run + 1) * n0 / nrun);
+#pragma unroll 4
+        for (int pl = pa; pl < pb; ++pl) {
+            T H, a[ND];
+            HAM::eval(P, cc, HAM::plane(P, pl, one), one, p, H, a);
+            double inv = 0.0;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                m[d] = fmax(m[d], (double)a[d]);
+                inv += (double)a[d] / dx[d];
+            }
+            m[ND] = fmax(m[ND], inv);
+        }
     }
-    __shared__ double red[4][ND + 1];
+    __shared__ double red[16][ND + 1];       // up to 1024 threads (the loop is a chain of dependent loads per plane: occupancy hides it)
+    __shared__ int last_flag;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 0; d <= ND; ++d) {
@@ -409,9 +439,67 @@ __global__ __launch_bounds__(256) void alpha_bound_kernel(GridArgs<T, HAM::ND> G
     __syncthreads();
     if (threadIdx.x <= ND) {
         const int d = threadIdx.x;
-        const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        // the sum goes to keys[HJ_MAX_DIM], whatever ND is
-        if (w > -1e299) atomicMax(keys + (d == ND ? HJ_MAX_DIM : d), max_key(w));
+        double w = red[0][d];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) w = fmax(w, red[k][d]);
+        __hip_atomic_store(partials + (size_t)blockIdx.x * 8 + d, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: leaves the XCD's L2
+    }
+    // the partial stores come from lanes 0..ND of wave 0.  No fence: __threadfence() is an L2 write-back + invalidate per WAVE that executes
+    // it (3.5 us; with every wave fencing the kernel's time grew with its thread count: 287 us at 1 M threads, r05_run24).  The MI355X
+    // guide's hand-off recipe for sc1 stores: the storing wave waits for its stores, ONE lane adds to the counter with an agent-scope atomic, the workgroup whose add
+    // came last reads with sc1 loads)
+    if (wv == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const unsigned long long before = __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = before == (unsigned long long)gridDim.x - 1ull;
+        }
+    }
+    __syncthreads();
+    if (!last_flag) return;
+#pragma unroll
+    for (int d = 0; d <= ND; ++d) m[d] = -1e300;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+#pragma unroll
+        for (int d = 0; d <= ND; ++d)
+            m[d] = fmax(m[d], __hip_atomic_load(partials + (size_t)b * 8 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d <= ND; ++d) {
+        const double w = wave_max(m[d]);
+        if (lane == 0) red[wv][d] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the sum goes to keys[HJ_MAX_DIM], whatever ND is; a dimension nobody evaluated keeps key 0
+#pragma unroll
+        for (int d = 0; d <= ND; ++d) {
+            double w = red[0][d];
+            for (int kk = 1; kk < (int)(blockDim.x >> 6); ++kk) w = fmax(w, red[kk][d]);
+            const unsigned long long k = w > -1e299 ? max_key(w) : 0ull;
+            keys[d == ND ? HJ_MAX_DIM : d] = k;
+            if (host_out != nullptr) host_out[d == ND ? HJ_MAX_DIM : d] = k;
+        }
+        if (DT.dt_dev != nullptr) {
+            double inv = 0.0;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                double w = red[0][d];
+                for (int kk = 1; kk < (int)(blockDim.x >> 6); ++kk) w = fmax(w, red[kk][d]);
+                inv += w / dx[d];
+            }
+            const double sb = 1.0 / inv;
+            const double dtv = fmin(fmin(DT.factor * sb, DT.span), DT.max_step);
+            __hip_atomic_store(DT.dt_dev, dtv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (host_out != nullptr) {
+                host_out[5] = (unsigned long long)__double_as_longlong(sb);
+                host_out[6] = (unsigned long long)__double_as_longlong(dtv);
+            }
+        }
+        if (host_out != nullptr) {
+            __threadfence_system();
+            __hip_atomic_store(host_out + 7, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

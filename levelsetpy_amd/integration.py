@@ -234,11 +234,9 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
         steps += 1
         if dynamic:
             if order > 1:
-                sbs, nsb = (C.c_double * 3)(), C.c_int()
-                _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
-                for k, which in enumerate(('Second', 'Third')[:order - 1]):
-                    if k + 1 < nsb.value and dtout.value > safetyFactorCFL * sbs[k + 1]:      # ode_cfl_3.py:173-175,215-217
-                        warn('%s substep violated CFL effective number %s' % (which, dtout.value / sbs[k + 1]))
+                # the later stages' bounds arrive asynchronously (the step returns while its last stage runs): warn about whatever has
+                # arrived -- normally the previous step -- and drain after the loop (round 5: no host <-> device round trip here)
+                _warn_late_bounds(lib, ctx, order, safetyFactorCFL, warn, wait=False)
         elif order > 1 and dtout.value > safetyFactorCFL * sb_static:
             for which in ('Second', 'Third')[:order - 1]:
                 warn('%s substep violated CFL effective number %s' % (which, dtout.value / sb_static))
@@ -262,6 +260,8 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
             if steps > 1 and np.any(np.sign(eventValue) != np.sign(eventValueOld)):
                 break
             eventValueOld = eventValue
+    if dynamic and order > 1 and steps > 0 and not single:
+        _warn_late_bounds(lib, ctx, order, safetyFactorCFL, warn, wait=True)      # the last step's (a singleStep call leaves them to the next call)
     if strcmp(options.stats, 'on'):
         dg.sync()
         info('%d steps in %.2g seconds from  %.2f to %.2f.' % (steps, cputime() - startTime, tspan[0], t))
@@ -269,6 +269,27 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     if is_tensor(y0) and steps == 0:
         out = out.clone()          # zero steps taken: do not hand the caller's own tensor back
     return np.float64(t), dg.like(out, y0, lazy=True), schemeData
+
+
+def _warn_late_bounds(lib, ctx, order, safety, warn, wait):
+    """The reference's 'substep violated CFL' warnings (ode_cfl_3.py:173-175, 215-217) for a Hamiltonian whose alpha depends on the
+    data: the later stages' stepBounds of a step reach the host asynchronously.  wait=False: whatever has arrived and has not been
+    reported yet (hj_rk_prev_bounds: at most one step, with its own deltaT); wait=True: the last step's, waiting for its launches."""
+    sbs, nsb, dt = (C.c_double * 3)(), C.c_int(), C.c_double()
+    if wait:
+        _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))      # an older unreported step first
+        _check_bounds(sbs, nsb.value, dt.value, order, safety, warn)
+        _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
+        _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))      # (the wait has just decoded them: take them, with their dt)
+    else:
+        _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))
+    _check_bounds(sbs, nsb.value, dt.value, order, safety, warn)
+
+
+def _check_bounds(sbs, n, dt, order, safety, warn):
+    for k, which in enumerate(('Second', 'Third')[:order - 1]):
+        if k + 1 < n and dt > safety * sbs[k + 1]:
+            warn('%s substep violated CFL effective number %s' % (which, dt / sbs[k + 1]))
 
 
 def integrate_span_device(schemeFunc, schemeData, y, t0, tf, options, stop_tol, post_op=0, order=3,
