@@ -542,7 +542,8 @@ def time_range_ham(L, torch, a):
     return {"%d^3 data-dependent alpha (range pass + fused substep)" % a.n: {
         "workload": "H = |p|^2/2 + c x0 p1, alpha_d = max(|derivMin_d|, |derivMax_d|) (+ |c x0|), %s + GLF: a Hamiltonian registered at run time "
                     "whose alpha reads the costate range (artificial_diss_glf.py:80-99), odeCFL3 singleStep calls on device tensors; "
-                    "two launches per stage + one elementwise launch and one host read of the bound per step" % a.scheme,
+                    "two launches per stage + the bound kernel; deltaT is formed on the device and read by the first stage from device memory, "
+                    "the host polls the same value from page-locked memory (no stream synchronisation inside a step)" % a.scheme,
         "value": res["fused"]["value"], "ms_per_step": res["fused"]["ms_per_step"], "steps": res["fused"]["steps"],
         "roofline_frac": res["fused"]["value"] * bps / 1e9 / HBM_PEAK_GBS,
         "split_path_ms_per_step": res["split"]["ms_per_step"], "vs_split_path": res["fused"]["value"] / res["split"]["value"],
