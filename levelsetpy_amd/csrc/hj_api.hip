@@ -1770,6 +1770,7 @@ int hj_rk_last_bounds(hj_ctx* c, double* sb, int* n) {
         if (rc) return rc;
         for (int st = 0; st < nst; ++st) c->last_bounds[1 + st] = c->prev_bounds[1 + st];
         c->last_bounds_n = 1 + nst;
+        c->prev_bounds_new = false;         // handed out here: hj_rk_prev_bounds does not report them a second time
     }
     *n = c->last_bounds_n;
     for (int k = 0; k < c->last_bounds_n; ++k) sb[k] = c->last_bounds[k];

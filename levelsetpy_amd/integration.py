@@ -261,7 +261,7 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
                 break
             eventValueOld = eventValue
     if dynamic and order > 1 and steps > 0 and not single:
-        _warn_late_bounds(lib, ctx, order, safetyFactorCFL, warn, wait=True)      # the last step's (a singleStep call leaves them to the next call)
+        _warn_late_bounds(lib, ctx, order, safetyFactorCFL, warn, wait=True, dt_last=dtout.value)   # the last step's (a singleStep call leaves them to the next call)
     if strcmp(options.stats, 'on'):
         dg.sync()
         info('%d steps in %.2g seconds from  %.2f to %.2f.' % (steps, cputime() - startTime, tspan[0], t))
@@ -271,19 +271,17 @@ def _integrate_device(order, dev, tspan, y0, options, schemeData):
     return np.float64(t), dg.like(out, y0, lazy=True), schemeData
 
 
-def _warn_late_bounds(lib, ctx, order, safety, warn, wait):
+def _warn_late_bounds(lib, ctx, order, safety, warn, wait, dt_last=None):
     """The reference's 'substep violated CFL' warnings (ode_cfl_3.py:173-175, 215-217) for a Hamiltonian whose alpha depends on the
     data: the later stages' stepBounds of a step reach the host asynchronously.  wait=False: whatever has arrived and has not been
-    reported yet (hj_rk_prev_bounds: at most one step, with its own deltaT); wait=True: the last step's, waiting for its launches."""
+    reported yet (hj_rk_prev_bounds: at most one step, with its own deltaT); wait=True: that, then the last step's (deltaT dt_last),
+    waiting for its launches (hj_rk_last_bounds)."""
     sbs, nsb, dt = (C.c_double * 3)(), C.c_int(), C.c_double()
-    if wait:
-        _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))      # an older unreported step first
-        _check_bounds(sbs, nsb.value, dt.value, order, safety, warn)
-        _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
-        _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))      # (the wait has just decoded them: take them, with their dt)
-    else:
-        _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))
+    _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))
     _check_bounds(sbs, nsb.value, dt.value, order, safety, warn)
+    if wait:
+        _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
+        _check_bounds(sbs, nsb.value, float(dt_last), order, safety, warn)
 
 
 def _check_bounds(sbs, n, dt, order, safety, warn):

@@ -496,3 +496,62 @@ def test_foreign_write_to_the_shared_ctx_is_noticed():
     assert dg.lib.hj_ctx_state_generation(dg.ctx) == gen + 2
     yd2, sb2, _ = L.termLaxFriedrichs(0., y, sd)
     assert sb1 == sb2 and torch.equal(yd1, yd2)
+
+
+def test_range_dependent_step_bounds_arrive_late_but_equal_and_hjipde_solve_runs_the_native_loop(monkeypatch):
+    """hj_rk_step with a range-dependent alpha returns while its last stage runs; the later stages' stepBounds reach the host
+    asynchronously.  hj_rk_prev_bounds (no wait, one step late) and hj_rk_last_bounds (waits) must report the same numbers as a run that
+    waits after every step, and the first stage's bound must be the deltaT / factorCFL the step used.  HJIPDE_solve drives such a system
+    through hj_rk_integrate (the native loop) and lands where the step-by-step loop lands."""
+    from levelsetpy_amd.context import device_grid
+    n = (28, 22, 24)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+    dg = device_grid(g)
+    dg.bind_stream()
+    lib, ctx, sid, par = dg.lib, dg.ctx, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], _ffi.darr([0.7])
+    _ffi.check(lib.hj_ctx_set_dissipation(ctx, 0))
+    _ffi.check(lib.hj_ctx_set_post_step(ctx, 0))
+    _ffi.check(lib.hj_ctx_set_post_arrays(ctx, 0, None, 0, None))
+
+    def run(wait_each):
+        bufs = [torch.as_tensor(d0, device="cuda").clone() for _ in range(3)]
+        w = torch.empty_like(bufs[0])
+        t, rec = 0.0, []
+        tout, dtout = C.c_double(), C.c_double()
+        for k in range(3):
+            cur, nxt = bufs[k % 2], bufs[(k + 1) % 2]
+            _ffi.check(lib.hj_rk_step(ctx, 3, sid, reg.ham_id, par, t, 10.0, 0.8, 1e300, 0, C.c_void_p(cur.data_ptr()), C.c_void_p(nxt.data_ptr()),
+                                      C.c_void_p(nxt.data_ptr()), C.c_void_p(w.data_ptr()), C.byref(tout), C.byref(dtout)))
+            t = tout.value
+            sbs, nsb, dt = (C.c_double * 3)(), C.c_int(), C.c_double()
+            if wait_each:
+                _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
+                rec.append((dtout.value, [sbs[i] for i in range(nsb.value)]))
+            else:
+                _ffi.check(lib.hj_rk_prev_bounds(ctx, sbs, C.byref(nsb), C.byref(dt)))
+                rec.append((dt.value if nsb.value else None, [sbs[i] for i in range(nsb.value)]))
+        if not wait_each:
+            sbs, nsb = (C.c_double * 3)(), C.c_int()
+            _ffi.check(lib.hj_rk_last_bounds(ctx, sbs, C.byref(nsb)))
+            rec.append((dtout.value, [sbs[i] for i in range(nsb.value)]))
+        torch.cuda.synchronize()
+        return t, bufs[3 % 2].clone(), rec
+    ta, ya, ra = run(True)
+    tb, yb, rb = run(False)
+    assert ta == tb and torch.equal(ya, yb)
+    assert all(len(b) == 3 for _, b in ra) and all(abs(dt - 0.8 * b[0]) <= 1e-15 * dt for dt, b in ra)
+    assert rb[0] == (None, [])                       # nothing has arrived right after the first step
+    assert rb[1] == ra[0] and rb[2] == ra[1]         # one step late, same numbers, each with its own deltaT
+    assert rb[3] == ra[2]                            # asked for: waits
+    # HJIPDE_solve: the native loop (hj_rk_integrate -> hj_rk_step per step) against the Python step loop
+    sys_ = reg(g, [0.7], hamiltonian=lambda s, t, data, p, sd: BurgersDrift(g, 0.7).hamiltonian(t, data, p, sd),
+               dissipation=lambda s, t, data, dmin, dmax, sd, dim: BurgersDrift(g, 0.7).dissipation(t, data, dmin, dmax, sd, dim))
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation))
+    outs = []
+    for stepwise in ("0", "1"):
+        monkeypatch.setenv("HJ_HJIPDE_STEPWISE", stepwise)
+        data, tau, _ = L.HJIPDE_solve(d0, [0., 0.01, 0.025], sd, 'minVOverTime', L.Bundle(dict(quiet=True, keepLast=True)))
+        outs.append(np.asarray(data))
+    assert np.array_equal(outs[0], outs[1])
