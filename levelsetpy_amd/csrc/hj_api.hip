@@ -1077,7 +1077,11 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     c->autotune = env_int("HJ_AUTOTUNE", 1);
     c->autotune_min_cells = (long long)env_int("HJ_AUTOTUNE_MIN_MCELLS", 40) * 1000000ll;
     c->autotune_passes = std::max(2, env_int("HJ_AUTOTUNE_PASSES", 6));
-    c->direct_below = env_int("HJ_DIRECT_BELOW", 0);
+    // 3-D grids below ~52^3 run the direct kernel (round 5, same-box A/B at 31^3 ... 101^3, profiles/r05_small_grids.txt: 16.2 against 23.9 us per
+    // RK3 step at 31^3, 18.2 / 24.0 at 41^3, 21.5 / 22.9 at 51^3, 30.6 / 24.9 at 65^3: a tiled launch cannot go below ~7.7 us -- 4 us of
+    // prologue in front of a dozen plane iterations --, a launch of one thread per cell with every stencil load issued at once can); bitwise
+    // the same results.  The test suite sets HJ_DIRECT_BELOW=0: its small grids are there to exercise the tiled kernels.
+    c->direct_below = env_int("HJ_DIRECT_BELOW", ndim == 3 ? 140000 : 0);
     c->f12_pair = env_int("HJ_F12_PAIR", 1);
     c->f12_e1 = env_int("HJ_F12_E1", 0);
     c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on grids of >= 6.5 M cells (light stencils) / 2.5 M (heavy stencils, fp32 4-D) (0: scalar kernel everywhere, 2: pair kernel whatever the size)

@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The library sends 3-D grids below ~52^3 cells to its direct kernel (one thread per cell: faster there).  This suite's small grids exist to
+# exercise the TILED kernels against the oracle, so the switch is off here; test_small_grids_take_the_direct_kernel_by_default checks the
+# default and that both kernels agree bit for bit.
+os.environ.setdefault("HJ_DIRECT_BELOW", "0")
 
 
 def pytest_configure(config):

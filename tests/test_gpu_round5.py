@@ -555,3 +555,28 @@ def test_range_dependent_step_bounds_arrive_late_but_equal_and_hjipde_solve_runs
         data, tau, _ = L.HJIPDE_solve(d0, [0., 0.01, 0.025], sd, 'minVOverTime', L.Bundle(dict(quiet=True, keepLast=True)))
         outs.append(np.asarray(data))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_small_grids_take_the_direct_kernel_by_default(monkeypatch):
+    """Below ~52^3 cells a 3-D grid runs direct_substep_kernel unless HJ_DIRECT_BELOW says otherwise (this suite sets it to 0 to keep its
+    small grids on the tiled kernels); the two kernels give the same bits."""
+    from levelsetpy_amd.context import device_grid
+    from test_gpu_parity import dubins
+    res = {}
+    for below in (None, "0"):
+        if below is None:
+            monkeypatch.delenv("HJ_DIRECT_BELOW", raising=False)
+        else:
+            monkeypatch.setenv("HJ_DIRECT_BELOW", below)
+        for n in (51, 60):
+            g, og = dubins(n)                       # a new grid object: a new context, which reads the knob
+            d0 = O.shape_cylinder(og, 2, None, .5)
+            sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+            op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+            t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], torch.as_tensor(d0.reshape(-1, 1), device="cuda"), op, sd)
+            dg = device_grid(g)
+            res[(below, n)] = (t, y.clone(), dg.lib.hj_last_kernel(dg.ctx))
+    assert res[(None, 51)][2] == b"direct_substep_kernel" and res[("0", 51)][2] == b"fused_substep_kernel"
+    assert res[(None, 60)][2] == b"fused_substep_kernel"
+    for n in (51, 60):
+        assert res[(None, n)][0] == res[("0", n)][0] and torch.equal(res[(None, n)][1], res[("0", n)][1])
