@@ -445,8 +445,9 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
         // small grids (round 3): the direct kernel -- one cell per thread, every stencil load issued at once, no LDS, no
         // barrier chain -- beats a tiled launch that cannot go below ~8.5 us (a 4.5 us setup in front of a dozen plane
         // iterations on a few dozen workgroups).  HJ_DIRECT_BELOW cells (default: see hj_ctx_create).
-        const bool small = c->direct_below > 0 && c->total < c->direct_below && HAM::ND <= 3 &&
-                           s.p0 >= 0 && s.p1 <= c->N[0] && s.q1 <= s.q0;
+        // (not on slabs; not when a tiled configuration was asked for explicitly: HJ_PAIR=2, HJ_PAIR_NT, HJ_NT / HJ_R)
+        const bool small = c->direct_below > 0 && c->total < c->direct_below && HAM::ND <= 3 && !c->halo_lo && !c->halo_hi &&
+                           c->pair != 2 && c->pair_nt <= 0 && !c->cfg_from_env && s.p0 >= 0 && s.p1 <= c->N[0] && s.q1 <= s.q0;
         if (!c->force_direct && !small) {
             const bool produce = SCHEME == HJ_WENO5 && eps_producer(c, s);      // two more LDS planes (hj_fused.h, eps_part)
             KernelCfg k = c->cfg;
