@@ -297,22 +297,37 @@ __device__ __forceinline__ void weno5_right_q(const WenoLine<T>& ln, const WenoK
     rq[1] = weno5_q(ln.t[2], ln.u[4] - ln.u[2], wk);
     rq[2] = weno5_q(ln.t[1], ln.t[1] + T(2) * s2, wk);
 }
+template <typename T> struct WenoCand;
+template <typename T> __device__ __forceinline__ WenoCand<T> weno5_candidates(const WenoLine<T>& ln);
+template <typename T> __device__ __forceinline__ void weno5_combine_cand(const WenoCand<T>& cd, const T* lq, const T* rq, T& pc, T& hd);
 template <typename T>
 __device__ __forceinline__ void weno5_combine(const WenoLine<T>& ln, const T* lq, const T* rq, T& pc, T& hd) {
+    // candidates (x6): left phi1..3 = F1,F2,F3; right psi1 = G1, psi2 = F3, psi3 = F2;  weights x10: (.1,.6,.3)/q_k^2 multiplied through by
+    // q1^2 q2^2 q3^2;  one reciprocal for both quotients (products stay < 1e62 in fp64): v_rcp_f64 (relative error 4.6e-8 on gfx950) + ONE
+    // Newton step = 2.2e-15 (tools/probes/rcp_probe.hip, profiles/r04_weno5_smoothness_terms.txt); the scheme is checked at 1e-11
+    weno5_combine_cand(weno5_candidates(ln), lq, rq, pc, hd);
+}
+// the same in two halves, for a caller that obtains the right-biased values late (from another lane, through LDS): the four candidate
+// values first, so that the line itself need not stay in registers
+template <typename T> struct WenoCand { T F1, F2, F3, G1; };
+template <typename T>
+__device__ __forceinline__ WenoCand<T> weno5_candidates(const WenoLine<T>& ln) {
     const T* u = ln.u;
-    // candidates (x6): left phi1..3 = F1,F2,F3; right psi1 = G1, psi2 = F3, psi3 = F2
-    const T F1 = T(2) * u[0] + (T(-7) * u[1] + T(11) * u[2]);
-    const T F2 = T(5) * u[2] + (T(2) * u[3] - u[1]);
-    const T F3 = T(2) * u[2] + (T(5) * u[3] - u[4]);
-    const T G1 = T(2) * u[5] + (T(-7) * u[4] + T(11) * u[3]);
-    // weights x10: (.1,.6,.3)/q_k^2 multiplied through by q1^2 q2^2 q3^2
+    WenoCand<T> c;
+    c.F1 = T(2) * u[0] + (T(-7) * u[1] + T(11) * u[2]);
+    c.F2 = T(5) * u[2] + (T(2) * u[3] - u[1]);
+    c.F3 = T(2) * u[2] + (T(5) * u[3] - u[4]);
+    c.G1 = T(2) * u[5] + (T(-7) * u[4] + T(11) * u[3]);
+    return c;
+}
+template <typename T>
+__device__ __forceinline__ void weno5_combine_cand(const WenoCand<T>& cd, const T* lq, const T* rq, T& pc, T& hd) {
+    const T F1 = cd.F1, F2 = cd.F2, F3 = cd.F3, G1 = cd.G1;
     const T A1 = lq[1] * lq[2], A2 = T(6) * (lq[0] * lq[2]), A3 = T(3) * (lq[0] * lq[1]);
     const T B1 = rq[1] * rq[2], B2 = T(6) * (rq[0] * rq[2]), B3 = T(3) * (rq[0] * rq[1]);
     const T NL = A1 * F1 + (A2 * F2 + A3 * F3), DL = A1 + (A2 + A3);
     const T NR = B1 * G1 + (B2 * F3 + B3 * F2), DR = B1 + (B2 + B3);
     if constexpr (sizeof(T) == 8) {
-        // one reciprocal for both quotients (products stay < 1e62 in fp64): v_rcp_f64 (relative error 4.6e-8 on gfx950) + ONE Newton step
-        // = 2.2e-15 (tools/probes/rcp_probe.hip, profiles/r04_weno5_smoothness_terms.txt); the scheme is checked at 1e-11
         const T den = DL * DR;
         T rc = __builtin_amdgcn_rcp(den);
         rc = rc + rc * (T(1) - den * rc);

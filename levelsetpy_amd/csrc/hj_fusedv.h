@@ -57,6 +57,12 @@ __device__ __forceinline__ Pair<float>::V buf_load2(__amdgpu_buffer_rsrc_t r, un
 // (tests/test_cabi.py runs it).  -DHJ_ST_ASM: store + wait states as ONE asm statement (2-3 % slower: the
 // compiler no longer counts the store in vmcnt; it also needs the leading s_nop 4, because the hazard recogniser
 // does not look inside asm and the SRD / soffset may just have been restored from a spill lane by v_readlane).
+// 1: the intended WENO5 shares the MIDDLE axis' smoothness values between lanes through LDS (WX below).  Built and measured in round 5 and
+// left OFF: the values are the same bits and 18 fp64 operations per cell go, but the instantiation was at 252 VGPRs -- what has to live
+// across the extra barrier spills (36-68 B of scratch) and the launch is 19 % SLOWER (201^3: 6.23 against 7.70e10; profiles/r05_weno5_eno_fast.txt)
+#ifndef HJ_WENO_LDS_SHARE
+#define HJ_WENO_LDS_SHARE 0
+#endif
 #ifndef HJ_ST_PRE
 #define HJ_ST_PRE 4
 #endif
@@ -451,6 +457,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     // until the next iteration's barrier
     const bool eps_prod = SCHEME == HJ_WENO5 && A.eps_part != nullptr;
     T* const obuf = lds + A.lds_nbuf * lds_plane;
+    // ... and (HJ_WENO_LDS_SHARE=1 builds only: measured slower, see the macro) on 3-D grids the MIDDLE axis shares them too, between lanes: every cell writes its three left-biased values to
+    // an LDS plane each (behind the two planes of the epsilon producer), and after one more barrier takes the three of the cell ONE ROW UP as
+    // its own right-biased ones; the cells of a tile's last row form theirs as before.  18 fp64 operations per cell replaced by 3 + 3
+    // 16-byte LDS accesses per pair; the values are the same bits (weno5_cd_carry's identity, across lanes instead of across planes).
+    constexpr bool WX = WCARRY && ND == 3 && HJ_WENO_LDS_SHARE;
+    T* const qbuf = lds + (A.lds_nbuf + 2) * lds_plane;
     double dmax[ND];
     V oprev[R];
 #pragma unroll
@@ -673,7 +685,38 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                     vb[j] = n2.y;
 #endif
                 }
-                if (d == 1) { sten(IntTag<1>(), va, pc[0][1], hd[0][1], slot_real); sten(IntTag<1>(), vb, pc[1][1], hd[1][1], slot_real); }
+                if constexpr (WX) {
+                    T lqa[3], lqb[3], rqa[3], rqb[3];
+                    WenoCand<T> ca, cb;
+                    {
+                        const WenoLine<T> la = weno5_line(va), lb = weno5_line(vb);
+                        weno5_left_q(la, wk[1], lqa);
+                        weno5_left_q(lb, wk[1], lqb);
+                        ca = weno5_candidates(la);
+                        cb = weno5_candidates(lb);
+                        if (!(nbv[r] & 2u)) {      // a tile's last row has no row above it in LDS: its own right-biased values, as ever
+                            weno5_right_q(la, wk[1], rqa);
+                            weno5_right_q(lb, wk[1], rqb);
+                        }
+                    }
+                    T* const qb = qbuf + own_lds[r];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        V w2;
+                        w2.x = lqa[k]; w2.y = lqb[k];
+                        *reinterpret_cast<V*>(qb + k * lds_plane) = w2;
+                    }
+                    __syncthreads();
+                    if (nbv[r] & 2u) {           // the row above is a row of this tile: its left-biased values, reversed, are ours on the right
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const V n2 = *reinterpret_cast<const V*>(qb + ls[1] + (2 - k) * lds_plane);
+                            rqa[k] = n2.x; rqb[k] = n2.y;
+                        }
+                    }
+                    weno5_combine_cand(ca, lqa, rqa, pc[0][1], hd[0][1]);
+                    weno5_combine_cand(cb, lqb, rqb, pc[1][1], hd[1][1]);
+                } else if (d == 1) { sten(IntTag<1>(), va, pc[0][1], hd[0][1], slot_real); sten(IntTag<1>(), vb, pc[1][1], hd[1][1], slot_real); }
                 else { sten(IntTag<(ND > 3 ? 2 : 1)>(), va, pc[0][d], hd[0][d], slot_real); sten(IntTag<(ND > 3 ? 2 : 1)>(), vb, pc[1][d], hd[1][d], slot_real); }
             }
             {   // the contiguous axis: cells j-3 .. j+4 = [b64][b128][own pair][b128][b64]

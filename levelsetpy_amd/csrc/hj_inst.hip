@@ -506,7 +506,10 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                                       ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0) |
                                       (produce ? 2ll : 0ll);
                 TuneTrial tr;
-                const Tiling tp = tune_begin<HAM::ND>(c, s, kp, 2, c->last_nbuf + (produce ? 2 : 0), key, tr);
+                // (HJ_WENO_LDS_SHARE builds: two planes for the epsilon producer -- kept whether it runs or not -- and three for the smoothness values
+                //  the middle axis shares between lanes: hj_fusedv.h, WX)
+                const int wx_planes = (HJ_WENO_LDS_SHARE && SCHEME == HJ_WENO5 && HAM::ND == 3) ? 5 : (produce ? 2 : 0);
+                const Tiling tp = tune_begin<HAM::ND>(c, s, kp, 2, c->last_nbuf + wx_planes, key, tr);
                 if (tp.ok) {
                     int rc_t = -12345;
 #define X(NT_, R_, KH_, OCC_) if constexpr (cfg_built(SCHEME, HAM::ND, NT_, R_, true, (int)sizeof(T))) { if (rc_t == -12345 && kp.NT == NT_ && kp.R == R_ && kp.KH == KH_ && occp == OCC_) rc_t = launch_tiled<T, HAM, SCHEME, NT_, R_, KH_, OCC_, 2, true>(c, s, tp); }
