@@ -571,10 +571,10 @@ def roofline_obj(r, s, tr, step_bytes, ach=None):
     """The `roofline` object of one workload.  achieved = algorithmic bytes of an RK3 step / the time of the step's
     launches, with that time taken as the LARGER of (a) the HIP-event time of the step on the launch stream, median
     repeat, and (b) the sum of the kernels' durations in the rocprofv3 kernel-trace child pass of this run (VERDICT r02:
-    the two differed by 3-4 %; the fraction must follow from the profile evidence too).  `bound`: the working set of a
-    step (three arrays) against the 256 MiB Infinity Cache -- below it the launches stream from the cache / fabric and
-    "hbm" would mislabel them; the fraction is of the 8 TB/s HBM peak either way (the metric's roofline), the
-    HBM-resident companion is also["513^3 ..."]."""
+    the two differed by 3-4 %; the fraction must follow from the profile evidence too).  `bound` is "hbm": the fraction is of
+    the 8 TB/s HBM peak (the metric's roofline) for every workload; `memory_regime` says where the bytes are served from -- the
+    working set of a step (three arrays) against the 256 MiB Infinity Cache: below it the launches stream from the cache / fabric;
+    the HBM-resident companion of the headline is also["513^3 ..."]."""
     nl = r["launches_per_step"]
     ev_ms = s["dev_step_ms"]
     rp = (tr or {}).get("rocprof") if tr else None
@@ -589,7 +589,9 @@ def roofline_obj(r, s, tr, step_bytes, ach=None):
     if ach and ach.get(regime):
         c, t3 = ach[regime]["copy"] * 1e3, ach[regime]["triad"] * 1e3
         ach_gbs = 8.0 / (2.0 / c + 6.0 / t3) if (nl == 3 and c > 0 and t3 > 0) else t3
-    return {"bound": "hbm" if working_set > 256 * 2 ** 20 else "infinity-cache/fabric",
+    # (`bound` names the roofline the fraction is taken of -- the 8 TB/s HBM peak on algorithmic bytes, for every workload --; where
+    #  the bytes are actually served from is `memory_regime`)
+    return {"bound": "hbm", "memory_regime": regime,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "achievable": ach_gbs, "frac_of_achievable": (achieved / ach_gbs) if ach_gbs else None,
             "achievable_source": (ach["source"] + "; regime: " + regime) if ach_gbs else None,
