@@ -610,34 +610,33 @@ def roofline_obj(r, s, tr, step_bytes, ach=None):
 # fp64 vector peak of MI355X: 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 FMA lanes per clock x 2 flop x 2.4 GHz
 # (MI355X_MICROARCH.md: vector FP32 157.3 TF, fp64 at half rate) = 39.3e12 fp64 lane-operations per second
 VALU_F64_LANE_OPS = 39.3e12
-# fp64 VALU operations per cell-substep of the intended WENO5 kernel (Dubins, 3-D): SQ_INSTS_VALU of the substep kernel x 64
-# lanes / cells, from profiles/r03_weno5_valu.txt (all VALU instructions counted as fp64-rate ones: an upper bound on
-# the fraction)
-WENO5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_WENO5_VALU_OPS", "335"))
+# VALU instructions per cell and plane (= per cell-substep) of the intended WENO5 kernel's plane loop (Dubins, 3-D): 293 in round 5
+# (268 of them fp64; static count on the built library, tools/isa_mix.py -> profiles/r05_isa_mix.txt; 335 by SQ_INSTS_VALU in
+# round 3, before the smoothness terms were shared).  All counted as fp64-rate ones: an upper bound on the fraction
+WENO5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_WENO5_VALU_OPS", "293"))
 
 
 def valu_ceiling(cell_substeps_per_s):
     achieved = cell_substeps_per_s * WENO5_VALU_OPS_PER_CELL
     return {"bound": "valu-fp64", "ops_per_cell_substep": WENO5_VALU_OPS_PER_CELL, "achieved": achieved / 1e12,
             "peak": VALU_F64_LANE_OPS / 1e12, "unit": "Tera fp64 lane-ops/s", "frac": achieved / VALU_F64_LANE_OPS,
-            "source": "SQ_INSTS_VALU x 64 / cells of the substep kernel (profiles/r03_weno5_valu.txt) x measured rate; peak = "
-                      "78.6 TFLOP/s fp64 vector / 2 flop per FMA lane-op"}
+            "source": "VALU instructions per cell of the kernel's plane loop (static count on the built library, profiles/r05_isa_mix.txt) x "
+                      "measured rate; peak = 78.6 TFLOP/s fp64 vector / 2 flop per FMA lane-op"}
 
 
-# C5 (4-D, fp32): 130 VALU lane-operations per cell-substep (SQ_INSTS_VALU x 64 / cells, profiles/r03_c5_counters_single_vs_pair.txt)
-# against 10.67 algorithmic bytes -- beyond the ridge of the roofline (78.6e12 / 8e12 = 9.8 lane-ops per byte): the vector
-# ceiling of this workload (6.0e11 cell-substeps/s) is LOWER than its HBM ceiling (7.5e11).  fp32 vector peak 157.3 TFLOP/s
-# = 78.6e12 lane-operations/s (a packed v_pk_fma_f32 counts as one instruction here: the fraction is a lower bound on the
-# arithmetic actually retired)
+# C5 (4-D, fp32): 57 VALU instructions per cell and plane in round 5's fused_pair4_kernel (static count, profiles/r05_isa_mix.txt; the
+# round-4 kernel retired 130 by SQ_INSTS_VALU) against 10.67 algorithmic bytes = 5.3 per byte; the chip's balance is 78.6e12 / 8e12 = 9.8:
+# the workload is back on the memory side of the ridge -- its vector ceiling (1.4e12 cell-substeps/s) is above its HBM ceiling (7.5e11),
+# and what bounds the kernel is the texture-address path.  fp32 vector peak 157.3 TFLOP/s = 78.6e12 lane-operations/s
+# (a packed v_pk_fma_f32 counts as one instruction here)
 VALU_F32_LANE_OPS = 78.6e12
-C5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C5_VALU_OPS", "130"))
+C5_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C5_VALU_OPS", "57"))
 
 
-# C3 (4096^2, ENO3 in the reference's operation order, fp64): 135 VALU instructions per cell and plane in the plane loop of
-# fused_pair_kernel<double, HamDoubleIntegrator, ENO3, 256, 1, 2, 2, 2> (101 fp64 + 34 selects / moves; tools/kernel_isa_stats.py
-# on the built library, profiles/r04_isa_mix.txt) against 21.33 algorithmic bytes = 6.3 per byte; balance 39.3e12 / 8e12 = 4.9:
+# C3 (4096^2, ENO3 in the reference's operation order, fp64): 132 VALU instructions per cell and plane in the plane loop of
+# fused_pair_kernel<double, HamDoubleIntegrator, ENO3, 256, 1, 2, 2, 2> (tools/isa_mix.py on the built library, profiles/r05_isa_mix.txt) against 21.33 algorithmic bytes = 6.3 per byte; balance 39.3e12 / 8e12 = 4.9:
 # beyond the ridge as well -- vector ceiling 2.9e11 cell-substeps/s, HBM ceiling 3.75e11
-C3_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C3_VALU_OPS", "135"))
+C3_VALU_OPS_PER_CELL = float(os.environ.get("HJ_C3_VALU_OPS", "132"))
 
 
 def valu_ceiling_c3(cell_substeps_per_s):
@@ -645,7 +644,7 @@ def valu_ceiling_c3(cell_substeps_per_s):
     return {"bound": "valu-fp64", "ops_per_cell_substep": C3_VALU_OPS_PER_CELL, "achieved": achieved / 1e12,
             "peak": VALU_F64_LANE_OPS / 1e12, "unit": "Tera fp64 lane-ops/s", "frac": achieved / VALU_F64_LANE_OPS,
             "ceiling_cell_substeps_per_s": VALU_F64_LANE_OPS / C3_VALU_OPS_PER_CELL,
-            "source": "VALU instructions per cell of the kernel's plane loop (static count on the built library, profiles/r04_isa_mix.txt) x "
+            "source": "VALU instructions per cell of the kernel's plane loop (static count on the built library, profiles/r05_isa_mix.txt) x "
                       "measured rate; peak = 78.6 TFLOP/s fp64 vector / 2 flop per FMA lane-op"}
 
 
@@ -654,9 +653,9 @@ def valu_ceiling_c5(cell_substeps_per_s):
     return {"bound": "valu-fp32", "ops_per_cell_substep": C5_VALU_OPS_PER_CELL, "achieved": achieved / 1e12,
             "peak": VALU_F32_LANE_OPS / 1e12, "unit": "Tera fp32 lane-ops/s", "frac": achieved / VALU_F32_LANE_OPS,
             "ceiling_cell_substeps_per_s": VALU_F32_LANE_OPS / C5_VALU_OPS_PER_CELL,
-            "source": "SQ_INSTS_VALU x 64 / cells of the substep kernel (profiles/r03_c5_counters_single_vs_pair.txt) x measured rate; "
-                      "peak = 157.3 TFLOP/s fp32 vector / 2 flop per FMA lane-op; this workload's vector ceiling is below its HBM ceiling "
-                      "(profiles/r04_c5_tile_order.txt)"}
+            "source": "VALU instructions per cell of the kernel's plane loop (static count on the built library, profiles/r05_isa_mix.txt) x measured "
+                      "rate; peak = 157.3 TFLOP/s fp32 vector / 2 flop per FMA lane-op; since round 5 this workload's vector ceiling is ABOVE "
+                      "its HBM ceiling: the HBM fraction is the one that grades it"}
 
 
 def source_hash():
