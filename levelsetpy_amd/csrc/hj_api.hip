@@ -1061,10 +1061,6 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     c->f12_warm = env_int("HJ_F12_WARM", 9);
     c->f12_e2 = env_int("HJ_F12_E2", 0);
     c->tile_cells = env_int("HJ_TILE_CELLS", 0);
-    // non-uniform chunk counts (hj_launch.h, plan_chunks): 0 (default) off -- measured on the 65-plane slab: 512 workgroups in two full rounds run
-    // exactly as fast as 399 in 256 + 143 (0.304 against 0.302 ms/step, profiles/r05_thin_slab.txt): the launch is bound by plane-tiles per
-    // microsecond, not by slots --, 1: launches of <= 128 planes, 2: whenever the model says so
-    c->nonuniform = env_int("HJ_NONUNIFORM", 0);
     // chunks of a tile column marching pairwise in opposite directions (hj_fusedv.h, "PAIRED CHUNKS"): only in -DHJ_MAYDOWN=1 builds
     // (hj_fused.h: measured in round 4 and compiled out -- the support costs every launch more than pairing gains); there -1 (default)
     // = on for 3-D grids below 10 M cells, 0 never, 1 always.  Ignored by the default build.

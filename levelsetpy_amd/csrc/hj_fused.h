@@ -149,12 +149,6 @@ template <typename T, int ND> struct FusedArgs {
     // bound kernel that follows the range pass computes deltaT (ode_cfl_3.py:142) and the first stage is already enqueued behind it -- the
     // host learns the same value from page-locked memory meanwhile, the GPU never waits for it.  null: `dt` above.
     const double* dt_dev;
-    // NON-UNIFORM CHUNK COUNTS (round 5, thin grids): the first n_more tile columns are cut into nchunks1 + 1 chunks of chunk_b planes,
-    // the others into nchunks1 chunks of `chunk` planes -- so that the workgroups fill WHOLE rounds of the resident capacity (65 planes x
-    // 133 tiles on 256 CUs: 113 x 4 + 20 x 3 = 512 workgroups instead of 399 = 256 + 143; profiles/r05_thin_slab.txt).  Logical blocks
-    // [0, nchunks1 * ntiles) are (chunk, tile) as ever, the n_more blocks after them are the extra chunk of tiles 0 .. n_more-1.  Only
-    // for launches of ONE plane range without edge chunks; 0 = uniform.
-    int n_more, chunk_b;
 };
 
 // deltaT of this launch (built-in Hamiltonians: the kernel argument, exactly the code of rounds 1-4)
@@ -233,17 +227,7 @@ template <int ND, typename ARGS> __device__ __forceinline__ void tile_coords(con
 
 // planes [p_begin, p_end) of chunk `chunk_id`: edge ranges first (gated launches), then the main range, then the optional
 // second range (low and high edge planes of a slab in one launch)
-// (block -> (chunk, tile) of a launch with non-uniform chunk counts: FusedArgs::n_more)
-template <typename ARGS> __device__ __forceinline__ void extra_chunk_fix(const ARGS& A, int L, int& chunk_id, int& rem) {
-    if (A.n_more > 0 && chunk_id >= A.nchunks1) { rem = L - A.nchunks1 * A.ntiles; chunk_id = A.nchunks1; }
-}
-template <typename ARGS> __device__ __forceinline__ void chunk_planes(const ARGS& A, int chunk_id, int rem, int& p_begin, int& p_end) {
-    if (A.n_more > 0) {
-        const int len = rem < A.n_more ? A.chunk_b : A.chunk;
-        p_begin = A.plane_begin + chunk_id * len;
-        p_end = min(p_begin + len, A.plane_end);
-        return;
-    }
+template <typename ARGS> __device__ __forceinline__ void chunk_planes(const ARGS& A, int chunk_id, int& p_begin, int& p_end) {
     if (chunk_id < A.nchunks_e) {
         const int w = chunk_id >= A.nchunks_e1 ? 1 : 0;
         p_begin = A.eplane[w][0] + (chunk_id - (w ? A.nchunks_e1 : 0)) * A.echunk;
@@ -382,7 +366,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     const T dt_launch = launch_dt<HAM>(A);
     int chunk_id, rem;
     fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);     // index divisions through a float reciprocal (hj_device.h)
-    extra_chunk_fix(A, L, chunk_id, rem);
     if (A.timing && threadIdx.x == 0) {
         A.timing[4 * L + 0] = wall_clock64();
         A.timing[4 * L + 2] = (unsigned long long)(b & 7);
@@ -400,7 +383,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     }
     // several plane ranges may share a launch (the low and high edge planes of a slab; edges + interior: chunk_planes)
     int p_begin, p_end;
-    chunk_planes(A, chunk_id, rem, p_begin, p_end);
+    chunk_planes(A, chunk_id, p_begin, p_end);
 
     // ---- LDS geometry: halo'd box, last axis contiguous
     // rows of the last axis are A.lpitch apart: E + 6, or E + 32 when LDS allows -- then the jump a

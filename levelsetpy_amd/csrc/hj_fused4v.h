@@ -151,14 +151,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
     if (L < 0) return;
     int chunk_id, rem;
     fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);
-    extra_chunk_fix(A, L, chunk_id, rem);
     int org[ND], tc[ND];
     tile_coords<ND>(A, rem, tc);
     org[1] = min(tc[1] * E1, A.n[1] - E1);
     org[2] = min(tc[2] * E2, A.n[2] - E2);
     org[3] = min(tc[3] * E3, A.n[3] - E3);
     int p_begin, p_end;
-    chunk_planes(A, chunk_id, rem, p_begin, p_end);
+    chunk_planes(A, chunk_id, p_begin, p_end);
     auto clamp_q = [&](int p) { return min(max(p, p_begin - W), p_end + W - 1); };
     auto clamp_c = [&](int p) { return min(max(p, p_begin), p_end - 1); };
     const int tid = threadIdx.x;

@@ -147,7 +147,6 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             down = (r2 & 1) == 0;
         } else {
             fdivmod(L, fdiv_make(A.ntiles), chunk_id, rem);
-            extra_chunk_fix(A, L, chunk_id, rem);
         }
     }
     if (A.timing && threadIdx.x == 0) {         // HJ_TIMING_DUMP: start clock, XCC the hardware put us on, chunk, HW_ID
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         fE[d] = fdiv_make(A.E[d]);
     }
     int p_begin, p_end;
-    chunk_planes(A, chunk_id, rem, p_begin, p_end);
+    chunk_planes(A, chunk_id, p_begin, p_end);
     // march position m = 0, 1, ... <-> plane P(m) = p_begin + m (up) or p_end - 1 - m (down)
     const int p_first = down ? p_end - 1 : p_begin, dirn = down ? -1 : 1;
     auto plane_at = [&](int m) { return p_first + dirn * m; };

@@ -46,7 +46,6 @@ constexpr int RANGE_ENTRY = 16, RANGE_ALPHA_AT = 8, RANGE_DONE_AT = 13;
 struct Tiling {
     int E[HJ_MAX_DIM], ntile[HJ_MAX_DIM];
     int ntiles, chunk, nchunks, nchunks1, nblocks, bpx, lpitch;
-    int n_more = 0, chunk_b = 0;      // non-uniform chunk counts (FusedArgs::n_more), set by plan_chunks
     size_t lds_bytes;
     double score;
     bool ok;
@@ -175,7 +174,6 @@ struct hj_ctx {
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
     // hj_plan_substep: a host-only context (no device, no allocation) whose launches stop after the tile / chunk plan is made
     unsigned long long state_gen = 0;               // bumped by every hj_ctx_set_stream / _dissipation / _post_step / _post_arrays (hj_ctx_state_generation)
-    int nonuniform = 0;                             // HJ_NONUNIFORM: 0 (default) never, 1 launches of <= 128 planes, 2 whenever the model says so
     int dry = 0;
     struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)

@@ -44,8 +44,7 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
         }
         const int occ_blocks = it->second;
         {
-            // (the epsilon producer of the intended WENO5 walks uniform chunk seams: eps_seam_kernel)
-            const int rc_plan = plan_chunks(c, s, t, occ_blocks, ep, 0, !(SCHEME == HJ_WENO5 && eps_producer(c, s)));
+            const int rc_plan = plan_chunks(c, s, t, occ_blocks, ep);
             if (rc_plan) return rc_plan;
         }
         c->last_plan.ntiles = t.ntiles; c->last_plan.nchunks = t.nchunks; c->last_plan.nblocks = t.nblocks; c->last_plan.threads = NT;

@@ -10,36 +10,10 @@ namespace hjh {
 struct EdgePlan { int echunk = 0, ne[2] = {0, 0}, edge_count = 0; };
 
 // chunk_max > 0: no chunk longer than this many planes (kernels whose LDS use grows with the chunk: hj_fused4v.h)
-inline int plan_chunks(hj_ctx* c, const SubstepCall& s, Tiling& t, int occ_blocks, EdgePlan& ep, int64_t chunk_max = 0, bool allow_nonuniform = true) {
+inline int plan_chunks(hj_ctx* c, const SubstepCall& s, Tiling& t, int occ_blocks, EdgePlan& ep, int64_t chunk_max = 0) {
         choose_chunks(c, t, s.p0, s.p1, occ_blocks, chunk_max);
         if (!t.ok) return hjh::fail(HJ_EUNSUPPORTED, "axis-0 plane too large for the tiled kernel");
         t.nchunks1 = t.nchunks;
-        t.n_more = 0; t.chunk_b = 0;
-        // Non-uniform chunk counts (FusedArgs::n_more): fill WHOLE rounds of the resident capacity.  Model: a column cut into k chunks costs
-        // planes + k * warm-up plane-times; the launch costs the total over the capacity plus half the difference of the two chunk lengths
-        // (list scheduling); taken when 7 % better than the best uniform split by the same model.
-        const int64_t P = s.p1 - s.p0;
-        if (allow_nonuniform && c->nonuniform > 0 && !s.gated && s.q1 <= s.q0 && c->target_blocks <= 0 && (c->nonuniform > 1 || P <= 128)) {
-            const int64_t cap = (int64_t)c->num_cus * std::max(1, occ_blocks), w = c->warmup_cost, nt = t.ntiles;
-            const int64_t rounds_u = (t.nblocks + cap - 1) / cap;
-            double best = 0.93 * (double)rounds_u * ((double)t.chunk + (double)w);
-            for (int64_t nch = 1; nch < std::min<int64_t>(P, 64); ++nch) {
-                const int64_t ca = (P + nch - 1) / nch, cb = (P + nch) / (nch + 1);
-                if (cb < c->min_chunk || nch * cb >= P || (nch - 1) * ca >= P) continue;      // every chunk non-empty, none below the minimum
-                if (chunk_max > 0 && ca > chunk_max) continue;
-                for (int64_t r = 1; r * cap <= (nch + 1) * nt; ++r) {
-                    const int64_t more = r * cap - nch * nt;
-                    if (more <= 0 || more >= nt) continue;
-                    const double total = (double)(nt - more) * (double)(P + nch * w) + (double)more * (double)(P + (nch + 1) * w);
-                    const double cost = total / (double)cap + 0.5 * (double)(ca - cb);
-                    if (cost < best) { best = cost; t.n_more = (int)more; t.chunk_b = (int)cb; t.chunk = (int)ca; t.nchunks = t.nchunks1 = (int)nch; }
-                }
-            }
-            if (t.n_more > 0) {
-                t.nblocks = t.nchunks1 * t.ntiles + t.n_more;
-                t.bpx = (t.nblocks + 7) / 8;
-            }
-        }
         if (s.q1 > s.q0) {     // second range: same chunk length
             t.nchunks += (int)((s.q1 - s.q0 + t.chunk - 1) / t.chunk);
             t.nblocks = t.nchunks * t.ntiles;
@@ -117,8 +91,6 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
     }
     A.dt = (T)s.dt;
     A.dt_dev = s.dt_dev;
-    A.n_more = t.n_more;
-    A.chunk_b = t.chunk_b;
     A.post_op = s.post_op;
     A.do_clamp = s.restrict_sign != 0;
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();

@@ -438,7 +438,7 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
         return it->second;
     };
     EdgePlan ep;
-    int rc = plan_chunks(c, s, t, occ_of(k), ep, 0, s.scheme != HJ_WENO5);
+    int rc = plan_chunks(c, s, t, occ_of(k), ep);
     if (rc) return rc;
     PairKernArgs<T, ND> K;
     memset(&K, 0, sizeof(K));
