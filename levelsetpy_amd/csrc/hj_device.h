@@ -775,6 +775,18 @@ __device__ __forceinline__ unsigned long long max_key(double v) {
     unsigned long long b = (unsigned long long)__double_as_longlong(v);
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
+// atomicMax of a workgroup's maximum into a launch-wide key -- after LOOKING: the keys only grow, so a value that does not exceed what an
+// agent-scope load shows can be dropped (a stale load costs an atomic, never a result).  Hundreds of workgroups finishing together used
+// to queue hundreds of same-address atomics (~12 ns each, profiles/r05_range_path.txt) at the very end of a launch; on the shipped
+// systems most workgroups carry the same maxima and now skip theirs (round 5: the kept CFL reduction cost 3-8 % of the 201^3 launch).
+__device__ __forceinline__ void key_max(unsigned long long* p, double v) {
+    const unsigned long long k = max_key(v);
+#if defined(HJ_KEY_MAX_BLIND)        // A/B knob (tune builds): the round-4 form, an atomic whatever the key holds
+    atomicMax(p, k);
+#else
+    if (k > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, k);
+#endif
+}
 
 // Wavefront max / min of a double, every lane receives the result.  DPP data moves (row_shr 1,2,4,8 inside the four
 // 16-lane rows, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 ends up with the

@@ -176,7 +176,7 @@ __device__ __forceinline__ void publish_range(unsigned long long* keys, double (
         if ((int)threadIdx.x < ND) {
             double m = red[0][threadIdx.x];
             for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][threadIdx.x]);
-            atomicMax(keys + half * ND + threadIdx.x, max_key(m));
+            key_max(keys + half * ND + threadIdx.x, m);
         }
     }
 }
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
         if (tid < ND) {
             double m = red[0][tid];
             for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
-            if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+            if (m > -1.0e299) key_max(A.bound + tid, m);
         }
     }
     publish_gate(A, chunk_id);

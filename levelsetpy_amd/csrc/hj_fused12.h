@@ -522,7 +522,7 @@ __global__ __launch_bounds__(NT, OCC) void fused12_kernel(const T* __restrict__ 
         if (tid < ND) {
             double m = red[0][tid];
             for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
-            if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+            if (m > -1.0e299) key_max(A.bound + tid, m);
         }
     }
 }

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair4_kernel(const T* __restric
         if (tid < ND) {
             double m = redd[0][tid];
             for (int w = 1; w < NT / 64; ++w) m = fmax(m, redd[w][tid]);
-            if (m > -1.0e299) atomicMax(A.bound + tid, max_key(m));
+            if (m > -1.0e299) key_max(A.bound + tid, m);
         }
     }
     publish_gate(A, chunk_id);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void upwind_kernel(const T* __restrict__ phi, 
         if (threadIdx.x < 4) {
             const int k = threadIdx.x;
             const double w = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
-            if (w > -1e299) atomicMax(keys + k, max_key(w));
+            if (w > -1e299) key_max(keys + k, w);
         }
     }
 }
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void upwind_all_kernel(const T* __restrict__ y
         if (threadIdx.x < 4 * ND) {
             const int k = threadIdx.x;
             const double w = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
-            if (w > -1e299) atomicMax(A.keys + k, max_key(w));
+            if (w > -1e299) key_max(A.keys + k, w);
         }
     }
 }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
         if (threadIdx.x < ND) {
             const int d = threadIdx.x;
             const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-            if (w > -1e299) atomicMax(A.bound + d, max_key(w / (double)A.sc[d]));
+            if (w > -1e299) key_max(A.bound + d, w / (double)A.sc[d]);
         }
     }
 }
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void lf_split_end_kernel(const SplitEndArgs<T>
     if ((int)threadIdx.x < A.nd && A.alpha[threadIdx.x]) {
         const int d = threadIdx.x;
         const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        if (w > -1e299) atomicMax(A.keys + d, max_key(w));
+        if (w > -1e299) key_max(A.keys + d, w);
     }
 }
 

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void term_kernel(const TermArgs<T, ND> A) {
     if (threadIdx.x <= ND) {
         const int d = threadIdx.x;
         const double w = fmax(fmax(red[0][d], red[1][d]), fmax(red[2][d], red[3][d]));
-        if (w > -1e299) atomicMax(A.keys + d, max_key(w));
+        if (w > -1e299) key_max(A.keys + d, w);
     }
 }
 
