@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity run of the fused HIP path against the CPU oracle (test infrastructure: imports oracle/; not collected by pytest).
-    python tests/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz_parity.py [seconds] [seed] [share of range-dependent run-time Hamiltonian cases, default 0.2]
 Every case: a random system (Dubins 3-D, double integrator 2-D, double pendulum 4-D fp32), random odd / even / prime extents (below,
 at and above the tile sizes), random periodic axes, a random scheme, a random KERNEL forced through the environment knobs the library
 reads when a context is created (tiled one-cell, pair, 4-D compile-time tile k, direct), random noisy initial data; two odeCFL3 /
@@ -23,6 +23,7 @@ from oracle import hj_oracle as O  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+RANGE_SHARE = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2        # share of the cases that run a range-dependent run-time Hamiltonian
 DERIV = {"ENO2": L.upwindFirstENO2, "ENO3": L.upwindFirstENO3, "WENO5_ASSHIPPED": L.upwindFirstWENO5, "WENO5": L.upwindFirstWENO5Intended}
 KNOBS = ("HJ_PAIR", "HJ_FORCE_DIRECT", "HJ_TILE4_SEL", "HJ_PAIR4", "HJ_MIN_CHUNK", "HJ_TILE_CELLS")
 
@@ -33,9 +34,55 @@ def mk(gmin, gmax, N, pd):
     return g, O.Grid(gmin, gmax, [int(n) for n in N], list(pd) if pd else [])
 
 
+_REG = {}
+
+
+def case_range(rng, k):
+    """A run-time Hamiltonian whose alpha reads the costate range (tests/test_gpu_round5.py's BurgersDrift), 2-D / 3-D / 4-D, through
+    odeCFLn single steps (range pass + bound kernel with deltaT on the device + fused stages) against the oracle's general GLF protocol."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_round5 import BurgersDrift, _burgers_src
+    dim = int(rng.integers(2, 5))
+    N = [int(rng.integers(8, {2: 90, 3: 30, 4: 14}[dim])) for _ in range(dim)]
+    pd = [d for d in range(dim) if rng.random() < 0.3]
+    gmin, gmax = [-1.0] * dim, [1.0 - (2.0 / N[d] if d in pd else 0.0) for d in range(dim)]
+    scheme = str(rng.choice(["ENO2", "ENO3", "WENO5_ASSHIPPED", "WENO5"]))
+    g, og = mk(gmin, gmax, N, pd)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[dim - 1]) + 0.02 * rng.standard_normal(N)
+    if dim not in _REG:
+        _REG[dim] = L.register_native_hamiltonian("burgers_drift_%dd" % dim, dim, _burgers_src(dim), nparams=1)
+    sys_ = _REG[dim](g, [0.7], hamiltonian=lambda s, t, data, p, sd: BurgersDrift(g, 0.7).hamiltonian(t, data, p, sd),
+                     dissipation=lambda s, t, data, dmin, dmax, sd, dm: BurgersDrift(g, 0.7).dissipation(t, data, dmin, dmax, sd, dm))
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=DERIV[scheme]))
+    order = int(rng.integers(1, 4))
+    ode = {1: L.odeCFL1, 2: L.odeCFL2, 3: L.odeCFL3}[order]
+    oode = {1: O.ode_cfl_1, 2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    yo, t, to = d0.reshape(-1, 1), 0., 0.
+    for _ in range(2):
+        t, y, _ = ode(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+        to, yo = oode(lambda tt, yy: O.term_lax_friedrichs(og, BurgersDrift(og, 0.7), scheme, tt, yy), [to, 10.], yo, 0.8, single_step=True)
+    dg = device_grid(g, "float64")
+    used = dg.lib.hj_last_kernel(dg.ctx).decode()
+    got = y.cpu().numpy()
+    scale = max(1.0, float(np.abs(yo).max()))
+    err = float(np.abs(got - yo).max()) / scale
+    if scheme.startswith("ENO"):
+        bad = np.abs(got - yo) > 1e-11 * scale
+        ok = float(bad.mean()) <= 2e-3 and err <= 1e-3 and abs(t - to) <= 1e-13 * to
+    else:
+        ok = err <= 1e-11 and abs(t - to) <= 1e-13 * to
+    print("%4d range  N=%-18s pd=%-12s %-16s float64 order %d       kernel %-22s err %.2e %s" % (
+        k, "x".join(map(str, N)), pd, scheme, order, used, err, "ok" if ok else "MISMATCH"), flush=True)
+    return ok, "range:" + used
+
+
 def case(rng, k):
     for kn in KNOBS:
         os.environ.pop(kn, None)
+    if rng.random() < RANGE_SHARE:
+        return case_range(rng, k)
     which = rng.choice(["dubins", "dint", "pend"], p=[0.5, 0.25, 0.25])
     scheme = str(rng.choice(list(DERIV)))
     if which == "dubins":
@@ -51,7 +98,7 @@ def case(rng, k):
         mkp, mko = (lambda g: L.DoubleIntegrator(g, 1)), (lambda og: O.DoubleIntegrator(og, 1))
         dtype = "float64"
     else:
-        N = [int(rng.integers(7, 15)), int(rng.integers(7, 20)), int(rng.integers(7, 20)), int(rng.integers(8, 75))]
+        N = [int(rng.integers(7, 15)), int(rng.integers(7, 20)), int(rng.integers(7, 20)), int(rng.choice([rng.integers(8, 40), rng.integers(34, 140)]))]
         pd = [0, 1, 2, 3] if rng.random() < 0.6 else [d for d in range(4) if rng.random() < 0.5]
         gmin, gmax = [-np.pi, -8., -np.pi, -8.], [np.pi, 8., np.pi, 8.]
         mkp, mko = (lambda g: L.DoublePendulum4D(g, 1.0)), (lambda og: O.DoublePendulum4D(og, 1.0))
