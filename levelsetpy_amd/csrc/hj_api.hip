@@ -878,6 +878,12 @@ int slab_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par,
     if (!aux) return fail(HJ_ESTATE, "hj_comm_init / hj_comm_init_external has not been called");
     if (c->pad0 < D) return fail(HJ_ESTATE, "axis-0 tables cover %d pad planes, order %d needs %d (hj_ctx_set_axis0_pad)", c->pad0, order, D);
     if (n < 2 * D) return fail(HJ_EUNSUPPORTED, "slab of %lld planes is too thin for the deep-halo stepper (needs %d)", (long long)n, 2 * D);
+    // the intended WENO5's epsilon is 1e-6 * max(D1^2) over the WHOLE grid, per stage (upwind_first_weno5a.py:69-70): with the library's own
+    // communicator it is all-reduced below; an external transport (hj_comm_init_external) moves planes only -- a rank-local epsilon would
+    // differ from the undivided run by ~1e-6 without a word (found by tests/fuzz_slabs.py, round 5)
+    if (scheme == HJ_WENO5 && c->external_exchange && c->comm_size > 1)
+        return fail(HJ_EUNSUPPORTED, "the intended WENO5 on slabs with an external transport: its epsilon needs an all-reduce per stage "
+                                     "(use the library's communicator, or dist.SlabIntegrator, which all-reduces it)");
     const void* src[3] = {cur, w0, w1};
     void* dst[3] = {order == 1 ? y_out : w0, order == 2 ? y_out : w1, y_out};
     const int kind[3] = {HJ_STAGE_EULER, order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF, HJ_STAGE_RK3_FULL};

@@ -580,3 +580,26 @@ def test_small_grids_take_the_direct_kernel_by_default(monkeypatch):
     assert res[(None, 60)][2] == b"fused_substep_kernel"
     for n in (51, 60):
         assert res[(None, n)][0] == res[("0", n)][0] and torch.equal(res[(None, n)][1], res[("0", n)][1])
+
+
+def test_deep_halo_stepper_refuses_the_intended_weno5_on_an_external_transport():
+    """The intended WENO5's epsilon is a maximum over the WHOLE grid per stage; an external transport moves planes only.  Before round 5 the
+    deep-halo stepper ran such a case with rank-local epsilons (5e-6 off the undivided run, silently: tests/fuzz_slabs.py found it)."""
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    from test_gpu_parity import dubins
+    g, og = dubins([40, 12, 14])
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    full = torch.as_tensor(O.shape_cylinder(og, 2, None, .5), device="cuda")
+    st = NativeSlabStepper(g, SlabDecomposition(40, 2, 0, False), _ffi.SCHEME_IDS["WENO5"], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.], dxs,
+                           "float64", order=3, deep=True, external=lambda s: None)
+    st.set_state(full[0:20])
+    with pytest.raises(ValueError, match="all-reduce"):
+        st.step(0.)
+    st.close()
+    # the as-shipped arithmetic has no grid-wide quantity: the same set-up steps
+    st = NativeSlabStepper(g, SlabDecomposition(40, 2, 0, False), _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], _ffi.HAM_DUBINS_REL, [1., 1., 1., 2.], dxs,
+                           "float64", order=3, deep=True, external=lambda s: None)
+    st.set_state(full[0:20])
+    t, dt = st.step(0.)
+    assert t > 0
+    st.close()
