@@ -105,7 +105,7 @@ def case(rng, k):
         dtype = "float32" if rng.random() < 0.7 else "float64"
     gmax = [gmax[d] - (gmax[d] - gmin[d]) / N[d] if d in pd else gmax[d] for d in range(len(N))]
     # the kernel, forced
-    kern = str(rng.choice(["default", "pair", "single", "direct", "tile4"]))
+    kern = str(rng.choice(["default", "pair", "single", "direct", "tile4", "split"]))
     if kern == "pair":
         os.environ["HJ_PAIR"] = "2"
     elif kern == "single":
@@ -120,7 +120,13 @@ def case(rng, k):
     g, og = mk(gmin, gmax, N, pd)
     d0 = O.shape_sphere(og, None, 0.45 * min(b - a for a, b in zip(gmin, gmax)) / 2) + 0.05 * rng.standard_normal(N)
     sysp, syso = mkp(g), mko(og)
-    sd = L.Bundle(dict(grid=g, hamFunc=sysp.hamiltonian, partialFunc=sysp.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=DERIV[scheme]))
+    if kern == "split" and dtype == "float64":
+        # foreign callables (here: lambdas around the system's own methods -- not recognised as native, by design): the split path --
+        # derivative kernels, the callbacks on device arrays, the dissipation kernel -- through the generic integrator loop
+        sd = L.Bundle(dict(grid=g, hamFunc=lambda *a: sysp.hamiltonian(*a), partialFunc=lambda *a: sysp.dissipation(*a),
+                           dissFunc=L.artificialDissipationGLF, CoStateCalc=DERIV[scheme]))
+    else:
+        sd = L.Bundle(dict(grid=g, hamFunc=sysp.hamiltonian, partialFunc=sysp.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=DERIV[scheme]))
     order = int(rng.integers(1, 4))
     restrict = bool(rng.random() < 0.25)
     ode = {1: L.odeCFL1, 2: L.odeCFL2, 3: L.odeCFL3}[order]
@@ -146,6 +152,8 @@ def case(rng, k):
         to, yo = oode(oterm, [to, 10.], yo, 0.8, single_step=True)
     dg = device_grid(g, dtype)
     used = dg.lib.hj_last_kernel(dg.ctx).decode()
+    if kern == "split" and dtype == "float64":
+        used = "split"
     got = y.double().cpu().numpy().reshape(-1, 1)
     scale = max(1.0, float(np.abs(yo).max()))
     err = float(np.abs(got - yo).max()) / scale
@@ -156,8 +164,8 @@ def case(rng, k):
         ok = float(bad.mean()) <= 0.01 and err <= 0.05 and abs(t - to) <= 1e-5 * to
     elif dtype == "float32":
         ok = err <= 3e-4 and abs(t - to) <= 1e-5 * to
-    elif scheme.startswith("ENO") and which != "pend":
-        ok = np.array_equal(got, yo) and t == to          # the reference's systems: bit for bit
+    elif scheme.startswith("ENO") and which != "pend" and used != "split":
+        ok = np.array_equal(got, yo) and t == to          # the reference's systems on the fused path: bit for bit
     elif scheme.startswith("ENO"):
         # the build-defined 4-D system evaluates its drift in another order than the oracle's NumPy expression (last-bit differences in
         # H): the ENO selections can flip where candidates tie within rounding -- masked as in the suite's multi-step ENO comparisons
