@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Randomised LARGE grids (test infrastructure; not collected): the kernels the library picks by itself at production sizes -- pair kernel
+with the parked halo ring, the launch-time tile choice, the 4-D compile-time tiles, the chunk planner on odd extents -- against the
+one-thread-per-cell direct kernel (HJ_FORCE_DIRECT=1), BITWISE (both call the same per-cell functions; the direct kernel is what the
+small-grid runs pin to the oracle).  Two odeCFL3 steps per case.
+    python tests/fuzz_big.py [seconds] [seed]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import levelsetpy_amd as L  # noqa: E402
+from levelsetpy_amd import _ffi  # noqa: E402
+from levelsetpy_amd.context import DeviceGrid  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 2468
+
+
+def steps(g, full, scheme, ham, par, dtype, order, nsteps, force_direct):
+    if force_direct:
+        os.environ["HJ_FORCE_DIRECT"] = "1"
+    else:
+        os.environ.pop("HJ_FORCE_DIRECT", None)
+    dg = DeviceGrid(g, dtype)                 # a fresh context reads the knob
+    dg.bind_stream()
+    sid = _ffi.SCHEME_IDS[scheme]
+    cur, nxt, w0, w1 = full.clone(), torch.empty_like(full), torch.empty_like(full), torch.empty_like(full)
+    tout, dtout = C.c_double(), C.c_double()
+    t = 0.
+    for _ in range(nsteps):
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, _ffi.darr(par), t, 1e9, 0.8, 1e300, 0,
+                                     dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+        cur, nxt = nxt, cur
+        t = float(tout.value)
+    torch.cuda.synchronize()
+    kern = dg.lib.hj_last_kernel(dg.ctx).decode()
+    tile = (C.c_int * 4)()
+    dg.lib.hj_last_tile(dg.ctx, tile)
+    return t, cur, kern, [int(v) for v in tile]
+
+
+def case(rng, k):
+    which = str(rng.choice(["dubins", "dint", "pend"], p=[0.55, 0.2, 0.25]))
+    scheme = str(rng.choice(["ENO2", "ENO3", "WENO5_ASSHIPPED", "WENO5"]))
+    order = int(rng.integers(2, 4))
+    gen = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+    if which == "dubins":
+        n = [int(rng.integers(60, 240)) for _ in range(3)]
+        pd = [d for d in range(3) if rng.random() < (0.8 if d == 2 else 0.15)]
+        gmin, gmax = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi]
+        ham, par, dtype = _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], ("float64" if rng.random() < 0.8 else "float32")
+    elif which == "dint":
+        n = [int(rng.integers(300, 4300)), int(rng.integers(300, 4300))]
+        pd = [d for d in range(2) if rng.random() < 0.2]
+        gmin, gmax = [-1., -1.], [1., 1.]
+        ham, par, dtype = _ffi.HAM_DOUBLE_INTEGRATOR, [1.0, 0, 0, 0], "float64"
+    else:
+        n = [int(rng.integers(16, 60)), int(rng.integers(10, 50)), int(rng.integers(10, 50)), int(rng.integers(20, 140))]
+        while np.prod(n) > 3e7:
+            n[int(rng.integers(0, 3))] //= 2
+        pd = [0, 1, 2, 3] if rng.random() < 0.6 else [d for d in range(4) if rng.random() < 0.5]
+        gmin, gmax = [-np.pi, -8., -np.pi, -8.], [np.pi, 8., np.pi, 8.]
+        ham, par, dtype = _ffi.HAM_DOUBLE_PENDULUM, [1.0, 0.0, 0.0, 0.0], ("float32" if rng.random() < 0.8 else "float64")
+        if dtype == "float64" and scheme == "WENO5":
+            scheme = "WENO5_ASSHIPPED"
+    nd = len(n)
+    gmax = [gmax[d] - (gmax[d] - gmin[d]) / n[d] if d in pd else gmax[d] for d in range(nd)]
+    g = L.createGrid(np.array(gmin).reshape(-1, 1), np.array(gmax).reshape(-1, 1), np.array(n, dtype=np.int64).reshape(-1, 1), pd if pd else None, low_mem=True)
+    xs = [torch.as_tensor(np.asarray(v).ravel(), device="cuda") for v in g.vs]
+    shp = lambda d: [(-1 if j == d else 1) for j in range(nd)]  # noqa: E731
+    full = ((xs[0] ** 2).reshape(shp(0)) + (xs[1] ** 2).reshape(shp(1))).sqrt() - 0.5 + 0.05 * torch.sin(3 * xs[nd - 1]).reshape(shp(nd - 1)) \
+        + torch.zeros(n, device="cuda", dtype=torch.float64)
+    full = full + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
+    full = full.to(torch.float64 if dtype == "float64" else torch.float32).contiguous()
+    ta, ya, ka, tile = steps(g, full, scheme, ham, par, dtype, order, 2, False)
+    tb, yb, kb, _ = steps(g, full, scheme, ham, par, dtype, order, 2, True)
+    ok = ta == tb and torch.equal(ya, yb) and kb == "direct_substep_kernel"
+    worst = float((ya - yb).abs().max())
+    print("%4d %-6s N=%-18s pd=%-12s %-16s %-7s order %d kernel %-20s tile %-16s max|diff| %.1e %s" % (
+        k, which, "x".join(map(str, n)), pd, scheme, dtype, order, ka, tile, worst, "ok" if ok else "MISMATCH"), flush=True)
+    del ya, yb, full
+    torch.cuda.empty_cache()
+    return ok, ka
+
+
+t_end = time.time() + budget
+k, used = 0, {}
+while time.time() < t_end:
+    ok, ka = case(np.random.default_rng(seed0 + k), k)
+    used[ka] = used.get(ka, 0) + 1
+    if not ok:
+        print("FAILED: replay with  python tests/fuzz_big.py 1 %d" % (seed0 + k))
+        sys.exit(1)
+    k += 1
+print("big-grid fuzz: %d cases ok in %.0f s; %s" % (k, budget, used))

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("script,args", [("fuzz_parity.py", ["6", "31000", "0.3"]), ("fuzz_slabs.py", ["6", "32000"]),
-                                         ("fuzz_terms.py", ["5", "33000"]), ("fuzz_solver.py", ["5", "34000"])])
+                                         ("fuzz_terms.py", ["5", "33000"]), ("fuzz_solver.py", ["5", "34000"]), ("fuzz_big.py", ["8", "35000"])])
 def test_fuzz_script_runs_clean(script, args):
     # one child process at a time (the GPU box allows few processes on its card)
     r = subprocess.run([sys.executable, os.path.join(HERE, script)] + args, capture_output=True, text=True, timeout=600)
