@@ -52,6 +52,8 @@ def case(rng, k):
     gen = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
     if which == "dubins":
         n = [int(rng.integers(60, 240)) for _ in range(3)]
+        if rng.random() < 0.04:                      # now and then beyond 40 M cells: the launch-time tile tuner rotates through shapes
+            n = [int(rng.integers(340, 372)) for _ in range(3)]
         pd = [d for d in range(3) if rng.random() < (0.8 if d == 2 else 0.15)]
         gmin, gmax = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi]
         ham, par, dtype = _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], ("float64" if rng.random() < 0.8 else "float32")
