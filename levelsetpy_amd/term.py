@@ -18,6 +18,7 @@ from .context import device_grid, array_dtype_name, is_tensor
 from . import dissipation as _diss
 from .dissipation import artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF, glf_device
 from .dynamics import native_of, native_again
+from .user_ham import ATTACH_EPOCH as _ATTACH_EPOCH
 from .spatial import scheme_id_of, upwind_all_dims
 from .utilities import isfield, iscell
 
@@ -101,16 +102,23 @@ def native_plan(schemeData):
         if src[0] is d.get('grid') and src[1] is d.get('dissFunc') and src[2] is d.get('hamFunc') \
                 and src[3] is d.get('partialFunc') and src[4] is fn:
             if plan is None:
-                return None
-            nat = native_again(plan.system)
-            if nat is not None and nat[0] == plan[2] and nat[1] == plan[3] and scheme_id_of(fn) == plan[1]:
-                return plan
+                if src[5] == _attach_epoch():
+                    return None
+                # (an object was attach()ed to a run-time Hamiltonian since: this schemeData may have become native)
+            else:
+                nat = native_again(plan.system)
+                if nat is not None and nat[0] == plan[2] and nat[1] == plan[3] and scheme_id_of(fn) == plan[1]:
+                    return plan
     plan = _classify(sd, fn)
     try:
-        _PLAN_CACHE[sd] = ((d.get('grid'), d.get('dissFunc'), d.get('hamFunc'), d.get('partialFunc'), fn), plan)
+        _PLAN_CACHE[sd] = ((d.get('grid'), d.get('dissFunc'), d.get('hamFunc'), d.get('partialFunc'), fn, _attach_epoch()), plan)
     except TypeError:
         pass
     return plan
+
+
+def _attach_epoch():
+    return _ATTACH_EPOCH[0]
 
 
 def _classify(sd, fn):

@@ -33,6 +33,9 @@ from . import _ffi
 __all__ = ["register_native_hamiltonian", "NativeRegistration", "RegisteredSystem", "kernel_cache_stats"]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# bumped by every attach(): a schemeData that was classified "not native" BEFORE its system object was attached must be looked at again
+# (term.native_plan caches the classification per schemeData)
+ATTACH_EPOCH = [0]
 
 
 def _hiprtc_path():
@@ -124,6 +127,7 @@ class NativeRegistration(object):
             raise ValueError("the system object's class needs hamiltonian() and dissipation() methods")
         att.params(obj)                      # validates the count now
         obj._hj_native = att
+        ATTACH_EPOCH[0] += 1
         return obj
 
 

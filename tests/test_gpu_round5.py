@@ -603,3 +603,22 @@ def test_deep_halo_stepper_refuses_the_intended_weno5_on_an_external_transport()
     t, dt = st.step(0.)
     assert t > 0
     st.close()
+
+
+def test_attach_after_first_use_is_picked_up_by_an_existing_schemedata():
+    """A schemeData that ran on the split path (its system object not yet attached) must take the fused path once the object IS attached:
+    the classification cached per schemeData is revisited when attach() has been called since (round 5: examples/custom_hamiltonian.py
+    ran both of its legs on the split path)."""
+    n = (22, 20, 24)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0], n, None)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.05 * np.sin(3 * og.xs[0])
+    sys_ = BurgersDrift(g, 0.7)
+    sd = sdata(g, sys_, DERIV["WENO5_ASSHIPPED"])
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    a, sba, _ = L.termLaxFriedrichs(0., y, sd)
+    assert not _last_kernel(g).endswith(b"(hipRTC)")
+    L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1).attach(sys_, params=lambda o: [o.c])
+    b, sbb, _ = L.termLaxFriedrichs(0., y, sd)                 # the SAME Bundle
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    close(b.cpu().numpy(), a.cpu().numpy(), 1e-11)
+    assert abs(sba - sbb) <= 1e-12 * sba
