@@ -222,8 +222,13 @@ int hj_static_step_bound(hj_ctx* ctx, int ham_id, const double* ham_params, doub
  * Hamiltonian whose alpha ignores the data the dissipation TERM of all three Lax-Friedrichs variants is
  * the same array, only the bound differs: global LF 1/sum_d max_x alpha_d/dx_d
  * (artificial_diss_glf.py:101-109), local variants 1/max_x sum_d alpha_d(x)/dx_d
- * (diss_local_laxfried.py:116-121, diss_localsq_laxfried.py:99-104, with the reduction the toolbox intends). */
-enum { HJ_DISS_GLF = 0, HJ_DISS_LOCAL = 1 };
+ * (diss_local_laxfried.py:116-121, diss_localsq_laxfried.py:99-104, with the reduction the toolbox intends).
+ * A run-time Hamiltonian whose alpha READS the costate range (HJ_HAM_RANGE) distinguishes the two local variants (round 5): HJ_DISS_LLF
+ * evaluates alpha_i with the range of dimension i replaced by the node's own [min(p_i^-, p_i^+), max(p_i^-, p_i^+)] and the grid-wide
+ * range in the other dimensions (diss_local_laxfried.py:84-111: a range pass + the fused substep per stage), HJ_DISS_LLLF with the node's
+ * own range in every dimension (diss_localsq_laxfried.py:87-90: no range pass at all); the bound is reduced inside the substep kernel,
+ * and hj_rk_step finds it before the first stage with a pass of its own (deltaT depends on it).  HJ_DISS_LOCAL = HJ_DISS_LLF. */
+enum { HJ_DISS_GLF = 0, HJ_DISS_LOCAL = 1, HJ_DISS_LLF = 1, HJ_DISS_LLLF = 2 };
 int hj_ctx_set_dissipation(hj_ctx* ctx, int kind);
 
 /* max over the (unstripped) first-divided-difference table of D1^2, per dim: the 'maxOverGrid'

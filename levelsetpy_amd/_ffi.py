@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("HJ_LIB") or os.path.join(HERE, "csrc", "libhj_mi355x.
 # enums of include/hj_mi355x.h
 BC_EXTRAPOLATE, BC_PERIODIC = 0, 1
 DISS_GLF, DISS_LOCAL = 0, 1
+DISS_LLF, DISS_LLLF = 1, 2          # distinguished by run-time Hamiltonians that read the costate range (hj_mi355x.h)
 POST_NONE, POST_MIN_PREV, POST_MAX_PREV = 0, 1, 2
 ENO2, ENO3, WENO5, WENO5_ASSHIPPED = 0, 1, 2, 3
 HAM_DUBINS_REL, HAM_DOUBLE_INTEGRATOR, HAM_DOUBLE_PENDULUM = 0, 1, 2

@@ -1548,7 +1548,9 @@ int hj_lf_term(hj_ctx* c, int scheme, int ham, const double* par, double t, int 
     if (sb) {
         // local LF variants: alpha of a native Hamiltonian does not depend on the data, so the bound
         // 1/max_x sum_d alpha_d(x)/dx_d is a static property of the grid
-        if (c->diss_local) return hj_static_step_bound(c, ham, par, sb, nullptr);
+        // (a range-reading run-time Hamiltonian has no static bound: its launch reduced max_x sum_d alpha_d / dx_d into the slot, in the
+        //  slot's generic form -- hj_fusedv.h, local_lf)
+        if (c->diss_local && !user_ham_dynamic(ham)) return hj_static_step_bound(c, ham, par, sb, nullptr);
         return read_ring(c, c->slot_ring[slot], sb, nullptr);
     }
     return HJ_OK;
@@ -1635,8 +1637,9 @@ int hj_ctx_set_post_arrays(hj_ctx* c, int op_a, const void* a, int op_b, const v
 
 int hj_ctx_set_dissipation(hj_ctx* c, int kind) {
     if (!c) return fail(HJ_EINVAL, "null ctx");
-    if (kind != HJ_DISS_GLF && kind != HJ_DISS_LOCAL) return fail(HJ_EINVAL, "unknown dissipation kind %d", kind);
-    c->diss_local = (kind == HJ_DISS_LOCAL);
+    if (kind != HJ_DISS_GLF && kind != HJ_DISS_LLF && kind != HJ_DISS_LLLF) return fail(HJ_EINVAL, "unknown dissipation kind %d", kind);
+    c->diss_local = (kind != HJ_DISS_GLF);
+    c->diss_kind = kind;
     ++c->state_gen;
     return HJ_OK;
 }
@@ -1670,12 +1673,12 @@ static int decode_stage_bounds(hj_ctx* c) {
 static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf, double factor_cfl,
                            double max_step, int restrict_sign, const void* y_in, void* y_out, void* work0, void* work1,
                            double* t_out, double* dt_out) {
-    if (c->diss_local) return fail(HJ_EUNSUPPORTED, "range-dependent alpha with the local Lax-Friedrichs variants runs on the split path");
+    const int kind = c->diss_kind;        // GLF: range pass + bound kernel; LLF: range pass + bound pass; LLLF: bound pass only
     if (c->range_src) return fail(HJ_ESTATE, "hj_rk_step with an external range source: step the slab through hj_rk_substep (dist.SlabIntegrator)");
     const int64_t n0 = c->N[0];
     int rc;
     const int slot2 = HJ_BOUND_SLOTS - 2, slot3 = HJ_BOUND_SLOTS - 3;
-    {   // the range of y_in -> ctx->range_keys (a fresh entry of the ring)
+    if (kind != HJ_DISS_LLLF) {   // the range of y_in -> ctx->range_keys (a fresh entry of the ring)
         SubstepCall r{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y_in, nullptr, y_out, nullptr, 0, n0};
         r.range_only = true;
         if ((rc = do_substep(c, r, -1))) return rc;
@@ -1696,7 +1699,22 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
         // stage is enqueued behind the bound kernel before this thread knows the value (FusedArgs::dt_dev) -- the GPU never idles for the
         // host; the host reads the very same bits from host_words[5..6] for its own bookkeeping and the later stages' arguments
         const DtArgs dta{factor_cfl, tf - t0, max_step, c->dt_dev};
-        if ((rc = user_alpha_bound(c, ham, par, c->range_keys + RANGE_ALPHA_AT, c->range_keys + RANGE_DONE_AT, true, c->host_words, seq, &dta))) return rc;
+        if (kind == HJ_DISS_GLF) {
+            if ((rc = user_alpha_bound(c, ham, par, c->range_keys + RANGE_ALPHA_AT, c->range_keys + RANGE_DONE_AT, true, c->host_words, seq, &dta))) return rc;
+        } else {
+            // local variants: alpha depends on the node's own costates -- the bound is a maximum over the STENCIL results: a pass of the
+            // substep kernel that stores nothing (MODE 3 with a bound slot), then one thread turns the slot into deltaT
+            const int slot1 = HJ_BOUND_SLOTS - 4;
+            SubstepCall b{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y_in, nullptr, y_out, nullptr, 0, n0};
+            b.bound_pass = true;
+            b.range_ready = true;
+            if ((rc = do_substep(c, b, slot1))) return rc;
+            DxArgs DX;
+            for (int d = 0; d < HJ_MAX_DIM; ++d) DX.dx[d] = c->dx[d];
+            hipLaunchKernelGGL((bound_to_dt_kernel<0>), dim3(1), dim3(64), 0, c->stream, c->ring + (size_t)c->slot_ring[slot1] * HJ_MAX_DIM, c->ndim, DX, dta,
+                               c->host_words, seq);
+            HIP_TRY(hipGetLastError());
+        }
         {
             SubstepCall a{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, std::numeric_limits<double>::quiet_NaN(), y_in, nullptr,
                           order == 1 ? y_out : work0, nullptr, 0, n0};

@@ -479,6 +479,11 @@ template <typename T> struct HamTables {
     // 2*ND order-preserving keys written by the range pass of the substep (MODE 3 of the tiled kernels): [d] = key(max(derivL_d, derivR_d)
     // over the grid), [ND + d] = key(-min(...)); null for everybody else
     const unsigned long long* range;
+    // ... and the LOCAL Lax-Friedrichs variants for such Hamiltonians (round 5, late; diss_local_laxfried.py:84-121, diss_localsq_laxfried.py:
+    // 87-104): 0 the global range above for every dimension (GLF); 1 (LLF) alpha_i is evaluated with the range of dimension i replaced by
+    // the NODE's own [min(p_i^-, p_i^+), max(p_i^-, p_i^+)]; 2 (LLLF) with the node's own range in EVERY dimension (no range pass at all).
+    // The step bound is then 1 / max_x sum_i alpha_i(x) / dx_i (lf_local_bound_term below).  Ignored by Hamiltonians that do not read the range.
+    int local_mode;
 };
 // value of an order-preserving key (max_key below)
 __device__ __forceinline__ double key_value(unsigned long long k) {
@@ -685,6 +690,41 @@ template <typename...> struct hj_void { typedef void type; };
 template <typename H, typename = void> struct ham_has_rows { static constexpr bool value = false; };
 template <typename H> struct ham_has_rows<H, typename hj_void<typename H::Row>::type> { static constexpr bool value = true; };
 
+// does a Hamiltonian type read the costate range (HamUser with RANGE, hj_rtc.hip)?
+template <typename H, typename = void> struct ham_reads_range { static constexpr bool value = false; };
+template <typename H> struct ham_reads_range<H, typename hj_void<decltype(H::RANGE)>::type> { static constexpr bool value = H::RANGE; };
+
+// H and alpha of one cell under the LOCAL Lax-Friedrichs rules (HamTables::local_mode 1 / 2) for a Hamiltonian that reads the costate range.
+// pc / hd: centred costate and half jump in the stencil's scale (true p^-/+ = sc (pc -/+ hd)), u: the plane constants carrying the GLOBAL range.
+template <bool NP, typename HAM, typename T>
+__device__ __forceinline__ void lf_eval_local(const HamTables<T>& P, const typename HAM::Cell& c, const typename HAM::Plane& u,
+                                              const T* sc, const T* pc, const T* hd, T& H, T* alpha) {
+    constexpr int ND = HAM::ND;
+    T lo[ND], hi[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const T a = sc[d] * (pc[d] - hd[d]), b = sc[d] * (pc[d] + hd[d]);
+        lo[d] = a < b ? a : b;
+        hi[d] = a < b ? b : a;
+    }
+    if (P.local_mode == 2) {
+        typename HAM::Plane v = u;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) { v.dmin[d] = lo[d]; v.dmax[d] = hi[d]; }
+        HAM::template eval<NP>(P, c, v, sc, pc, H, alpha);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            typename HAM::Plane v = u;
+            v.dmin[i] = lo[i]; v.dmax[i] = hi[i];
+            T Hi, ai[ND];
+            HAM::template eval<NP>(P, c, v, sc, pc, Hi, ai);
+            alpha[i] = ai[i];
+            if (i == 0) H = Hi;
+        }
+    }
+}
+
 // ---- the tail of one cell's substep, shared by every kernel (fused, pair, stage-fused, direct)
 // ydot = -(H - sum_d hd_d alpha_d): termLaxFriedrichs / artificialDissipationGLF (term_lax_friedrich.py:111-128,
 // artificial_diss_glf.py:94-100: `diss += 0.5*derivDiff[i]*alpha`, hd = 0.5*(derivR - derivL)); alpha[] comes back
@@ -692,7 +732,12 @@ template <bool NP, typename HAM, typename T>
 __device__ __forceinline__ T lf_ydot(const HamTables<T>& P, const typename HAM::Cell& c, const typename HAM::Plane& u,
                                      const T* sc, const T* pc, const T* hd, T* alpha) {
     T H;
-    HAM::template eval<NP>(P, c, u, sc, pc, H, alpha);
+    if constexpr (ham_reads_range<HAM>::value) {
+        if (P.local_mode != 0) lf_eval_local<NP, HAM>(P, c, u, sc, pc, hd, H, alpha);
+        else HAM::template eval<NP>(P, c, u, sc, pc, H, alpha);
+    } else {
+        HAM::template eval<NP>(P, c, u, sc, pc, H, alpha);
+    }
     if constexpr (NP) {
 #pragma clang fp contract(off)
         T diss = T(0);

@@ -661,6 +661,29 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
+    // LOCAL Lax-Friedrichs with a range-reading Hamiltonian, and the bound pass (see hj_fusedv.h)
+    constexpr bool RR = ham_reads_range<HAM>::value;
+    bool local_lf = false;
+    if constexpr (RR) local_lf = A.ham.local_mode != 0;
+    const bool BPASS = RNG && local_lf && A.bound != nullptr;
+    T lw[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        lw[d] = local_lf ? (A.inv_dx[d] / A.inv_dx[0]) * (A.sc[0] / A.sc[d]) : T(0);
+        if (local_lf && d > 0) amax[d] = 0.0;
+    }
+    auto acc_alpha = [&](const T* alpha) {
+        if (RR && local_lf) {
+            T ssum = T(0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ssum += alpha[d] * lw[d];
+            amax[0] = max_acc(amax[0], (double)ssum);
+        } else {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
+        }
+    };
     T rmn[ND], rmx[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { rmn[d] = -Lim<T>::lowest; rmx[d] = Lim<T>::lowest; }
@@ -768,8 +791,17 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             }
             if constexpr (RNG) {
                 if (r < R - 1 || last_real) {
+                    if (!BPASS) {
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) range_acc(rmn[d], rmx[d], pc[d], hd[d]);      // derivL = sc (pc - hd), derivR = sc (pc + hd); scaled in publish_range
+                        for (int d = 0; d < ND; ++d) range_acc(rmn[d], rmx[d], pc[d], hd[d]);      // derivL = sc (pc - hd), derivR = sc (pc + hd); scaled in publish_range
+                    }
+                    if constexpr (RR && !TERM) {
+                        if (BPASS) {
+                            T Hb, ab[ND];
+                            lf_eval_local<NP, HAM>(A.ham, hcell[r], pl_use, A.sc, pc, hd, Hb, ab);
+                            acc_alpha(ab);
+                        }
+                    }
                 }
                 continue;
             }
@@ -790,9 +822,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
             } else {
                 T alpha[ND];
                 ydot = lf_ydot<NP, HAM>(A.ham, hcell[r], pl_use, A.sc, pc, hd, alpha);
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
+                acc_alpha(alpha);
             }
             // termRestrictUpdate clamp; written so that a NaN stays a NaN
             if (GEN && A.do_clamp) {
@@ -864,8 +894,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_substep_kernel(const T* __restr
 #endif
 
     if constexpr (RNG) {
-        publish_range<ND, NT>(A.range_keys, red, rmn, rmx, A.sc);
-        return;
+        if (!BPASS) {
+            publish_range<ND, NT>(A.range_keys, red, rmn, rmx, A.sc);
+            return;
+        }
     }
     if constexpr (SCHEME == HJ_WENO5) {
         if (eps_prod) {

@@ -594,6 +594,31 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     double amax[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) amax[d] = -1.0e300;
+    // LOCAL Lax-Friedrichs with a Hamiltonian that reads the costate range (HamTables::local_mode, round 5): the bound is 1 / max_x sum_d
+    // alpha_d(x) / dx_d -- the sum travels in slot 0 scaled so that the reader's generic  sum_d key_d / dx_d  returns it, the other slots hold 0.
+    // BPASS: a MODE 3 launch with a bound slot = the pass that finds this maximum BEFORE the first stage (deltaT depends on it); nothing stored.
+    constexpr bool RR = ham_reads_range<HAM>::value;
+    bool local_lf = false;
+    if constexpr (RR) local_lf = A.ham.local_mode != 0;
+    const bool BPASS = RNG && local_lf && A.bound != nullptr;
+    T lw[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        lw[d] = local_lf ? (A.inv_dx[d] / A.inv_dx[0]) * (A.sc[0] / A.sc[d]) : T(0);
+        if (local_lf && d > 0) amax[d] = 0.0;
+    }
+    auto acc_alpha = [&](const T* alpha) {
+        if (RR && local_lf) {
+            T ssum = T(0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ssum += alpha[d] * lw[d];
+            amax[0] = max_acc(amax[0], (double)ssum);
+        } else {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
+        }
+    };
     T rmn[ND], rmx[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { rmn[d] = -Lim<T>::lowest; rmx[d] = Lim<T>::lowest; }
@@ -604,7 +629,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             // derivL = sc (pc - hd), derivR = sc (pc + hd) with the centred costate and half jump the substep forms anyway (sc > 0:
             // the minima / maxima are taken unscaled and scaled once, in publish_range)
             upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pcv, hdv);
-            if (real) range_acc(rmn[d], rmx[d], pcv, hdv);
+            if (real && !BPASS) range_acc(rmn[d], rmx[d], pcv, hdv);
         } else {
             upwind_cd<SCHEME, T>(v, A.K[d], eps[d], wk[d], pcv, hdv);
         }
@@ -739,7 +764,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                     sten(IntTag<LA>(), w + 1, pc[1][LA], hd[1][LA], slot_real);
                 }
             }
-            if constexpr (RNG) continue;
+            if constexpr (RNG) {
+                if constexpr (RR) {
+                    if (BPASS && slot_real) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            T Hb, ab[ND];
+                            lf_eval_local<NP, HAM>(A.ham, hcell[r][c], pl_use, A.sc, pc[c], hd[c], Hb, ab);
+                            acc_alpha(ab);
+                        }
+                    }
+                }
+                continue;
+            }
             V o2;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -751,9 +788,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #else
                 T ydot = lf_ydot<NP, HAM>(A.ham, hcell[r][c], pl_use, A.sc, pc[c], hd[c], alpha);
 #endif
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    if ((HAM::PLANE_DEP >> d) & 1u) amax[d] = max_acc(amax[d], (double)alpha[d]);
+                acc_alpha(alpha);
                 if (GEN && A.do_clamp) {
                     ydot = (ydot < A.clamp_lo) ? A.clamp_lo : ydot;
                     ydot = (ydot > A.clamp_hi) ? A.clamp_hi : ydot;
@@ -822,8 +857,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end
 
     if constexpr (RNG) {
-        publish_range<ND, NT>(A.range_keys, red, rmn, rmx, A.sc);
-        return;
+        if (!BPASS) {
+            publish_range<ND, NT>(A.range_keys, red, rmn, rmx, A.sc);
+            return;
+        }
     }
     if constexpr (SCHEME == HJ_WENO5) {
         if (eps_prod) {

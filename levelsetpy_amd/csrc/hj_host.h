@@ -173,6 +173,7 @@ struct hj_ctx {
     int lds_pitch_add = 0;                          // HJ_LDS_PITCH_ADD (tuning): extra cells of LDS row padding
     int pair_ah = 3;                                // planes the halo ring is parked ahead (HJ_PAIR_AH, 1..3)
     // hj_plan_substep: a host-only context (no device, no allocation) whose launches stop after the tile / chunk plan is made
+    int diss_kind = 0;                              // HJ_DISS_GLF / HJ_DISS_LLF / HJ_DISS_LLLF as set (diss_local: kind != 0); what a range-reading Hamiltonian is evaluated with
     unsigned long long state_gen = 0;               // bumped by every hj_ctx_set_stream / _dissipation / _post_step / _post_arrays (hj_ctx_state_generation)
     int dry = 0;
     struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
@@ -204,6 +205,7 @@ template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTable
         if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
     for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
     H.range = c->range_src ? c->range_src : c->range_keys;
+    H.local_mode = c->diss_kind;
 }
 
 template <typename T, int ND> void fill_grid(const hj_ctx* c, GridArgs<T, ND>& G) {
@@ -256,6 +258,7 @@ struct SubstepCall {
     bool range_only = false;
     unsigned long long* range_out = nullptr;
     bool range_ready = false;           // ctx->range_keys already hold the range of this launch's input: no pass of its own
+    bool bound_pass = false;            // run ONLY the bound pass of the local Lax-Friedrichs variants (MODE 3 with a bound slot): max_x sum_d alpha_d / dx_d
     const double* dt_dev = nullptr;     // deltaT in device memory (FusedArgs::dt_dev; run-time Hamiltonians with a range-dependent alpha only)
 };
 constexpr int HJ_EPS_ROWS = 256;  // workgroups (= rows) of eps_seam_kernel

@@ -463,8 +463,10 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     c->last_kernel = sh.pair ? "fused_pair_kernel (hipRTC)" : "fused_substep_kernel (hipRTC)";
     c->last_E[0] = t.chunk;
     for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < ND ? t.E[d] : 0;
-    if (s.range_only && !dynamic) return fail(HJ_EINVAL, "'%s' does not read the costate range", u.name.c_str());
-    if (dynamic && (s.range_only || !(c->range_src || s.range_ready))) {
+    if ((s.range_only || s.bound_pass) && !dynamic) return fail(HJ_EINVAL, "'%s' does not read the costate range", u.name.c_str());
+    // the local-local variant evaluates alpha with the NODE's own costate range in every dimension: no grid-wide range, no range pass
+    const bool need_range = c->diss_kind != HJ_DISS_LLLF;
+    if (dynamic && !s.bound_pass && (s.range_only || (need_range && !(c->range_src || s.range_ready)))) {
         // the range pass: same tiling, same arguments, MODE 3 -- derivL / derivR of every cell of [p0, p1) reduced into 2*ND keys.
         // Skipped when the caller supplies the range itself (hj_ctx_set_range_source: a slab of a decomposed grid, whose range is
         // the reduction over all ranks).
@@ -484,6 +486,23 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
         if (s.range_only && s.range_out) HIP_TRY(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * 2 * HJ_MAX_DIM, call_stream(c, s)));
         if ((rc = module_launch(kr->fn, grid_blocks, sh.nt, t.lds_bytes, call_stream(c, s), &R3, sizeof(R3)))) return rc;
         if (s.range_only) return HJ_OK;
+    }
+    if (dynamic && !K.A.ham.range) {
+        // (the local-local variant never runs a range pass, but HamUser::plane() decodes the keys it is handed: any zeroed ring entry will do)
+        if ((rc = next_range_keys(c))) return rc;
+        K.A.ham.range = c->range_keys;
+    }
+    if (s.bound_pass) {
+        // the bound pass of the local variants (hj_rk_step, before the first stage): MODE 3 with a bound slot -- the stencils of every
+        // dimension, alpha under the local rule, max_x sum_d alpha_d / dx_d reduced into the slot; nothing stored
+        if (c->diss_kind == HJ_DISS_GLF || !s.bound) return fail(HJ_EINVAL, "bound pass: a local Lax-Friedrichs kind and a bound slot are needed");
+        PairKernArgs<T, ND> B3 = K;
+        B3.out = nullptr;
+        B3.A.range_keys = nullptr;
+        B3.A.gate = nullptr;
+        B3.A.use_y0 = 0; B3.A.ydot_only = 0; B3.A.post_op = 0; B3.A.do_clamp = 0;
+        B3.A.eps_part = nullptr;
+        return module_launch(kr->fn, grid_blocks, sh.nt, t.lds_bytes, call_stream(c, s), &B3, sizeof(B3));
     }
     return module_launch(k->fn, grid_blocks, sh.nt, t.lds_bytes, call_stream(c, s), &K, sizeof(K));
 }

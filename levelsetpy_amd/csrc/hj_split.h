@@ -503,6 +503,23 @@ __global__ __launch_bounds__(1024) void alpha_bound_kernel(GridArgs<T, HAM::ND> 
     }
 }
 
+// deltaT from a reduced bound slot (hj_rk_step, local Lax-Friedrichs variants of a range-reading Hamiltonian: the bound pass of the substep
+// kernel left max_x sum_d alpha_d / dx_d in the slot's generic form): stepBound = 1 / sum_d key_d / dx_d, deltaT as DtArgs says, both to
+// the device word the first stage reads and -- as bits -- to the page-locked words the host polls (see alpha_bound_kernel)
+template <int UNUSED>      // (a template: the header is included by several translation units)
+__global__ void bound_to_dt_kernel(const unsigned long long* keys, int nd, DxArgs DX, DtArgs DT, unsigned long long* host_out, unsigned long long seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double inv = 0.0;
+    for (int d = 0; d < nd; ++d) inv += key_value(__hip_atomic_load(keys + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) / DX.dx[d];
+    const double sb = 1.0 / inv;
+    const double dtv = fmin(fmin(DT.factor * sb, DT.span), DT.max_step);
+    __hip_atomic_store(DT.dt_dev, dtv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host_out[5] = (unsigned long long)__double_as_longlong(sb);
+    host_out[6] = (unsigned long long)__double_as_longlong(dtv);
+    __threadfence_system();
+    __hip_atomic_store(host_out + 7, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- direct (untiled) fused substep: one thread per cell, stencil neighbours straight from
 // global memory (L1/L2 absorb the reuse).  Same arithmetic as fused_substep_kernel.
 template <typename T, int ND> struct DirectArgs {

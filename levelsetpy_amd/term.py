@@ -140,10 +140,10 @@ def _classify(sd, fn):
         return None
     att = getattr(nat[0], "_hj_native", None)
     dynamic = bool(att is not None and getattr(att.reg, "uses_range", False))
-    if dynamic and sd.dissFunc is not artificialDissipationGLF:
-        return None          # per-node ranges of the local variants: the split path (dissipation.py)
-    return _Plan((sd.grid, sid, nat[1], nat[2]),
-                 _ffi.DISS_GLF if sd.dissFunc is artificialDissipationGLF else _ffi.DISS_LOCAL, nat[0], dynamic)
+    # (for a Hamiltonian that ignores the costate range the two local variants coincide; one that reads it gets the per-node ranges of
+    #  diss_local_laxfried.py / diss_localsq_laxfried.py inside the fused kernel: hj_mi355x.h, HJ_DISS_LLF / HJ_DISS_LLLF)
+    kind = {artificialDissipationGLF: _ffi.DISS_GLF, artificialDissipationLLF: _ffi.DISS_LLF, artificialDissipationLLLF: _ffi.DISS_LLLF}[sd.dissFunc]
+    return _Plan((sd.grid, sid, nat[1], nat[2]), kind, nat[0], dynamic)
 
 
 def _fused_term(plan, t, y, restrict_sign):
