@@ -535,6 +535,22 @@ def time_range_ham(L, torch, a):
         assert bool(torch.isfinite(y).all())
         med = statistics.median(walls)
         res[kind] = {"value": y.numel() * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k}
+    local = {}
+    for name, fn in (("LLF", L.artificialDissipationLLF), ("LLLF", L.artificialDissipationLLLF)):
+        try:
+            sd = L.Bundle(dict(grid=g, hamFunc=sysd.hamiltonian, partialFunc=sysd.dissipation, dissFunc=fn, CoStateCalc=calc))
+            y, t = device_sdf(torch, g, 0.5, ignore=(2,)).reshape(-1, 1), 0.0
+            for _ in range(3):
+                t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(y).all())
+            local[name] = 1e3 * (time.perf_counter() - t1) / a.steps
+        except Exception as e:  # noqa: BLE001
+            local[name] = repr(e)
     # the two paths computed the same three steps (1e-11: different operation order in the range reduction and the callbacks)
     dmax = float((ys["fused"][1] - ys["split"][1]).abs().max())
     assert abs(ys["fused"][0] - ys["split"][0]) <= 1e-12 and dmax <= 1e-10, (ys["fused"][0], ys["split"][0], dmax)
@@ -547,7 +563,9 @@ def time_range_ham(L, torch, a):
         "value": res["fused"]["value"], "ms_per_step": res["fused"]["ms_per_step"], "steps": res["fused"]["steps"],
         "roofline_frac": res["fused"]["value"] * bps / 1e9 / HBM_PEAK_GBS,
         "split_path_ms_per_step": res["split"]["ms_per_step"], "vs_split_path": res["fused"]["value"] / res["split"]["value"],
-        "fused_vs_split_max_abs_diff_after_3_steps": dmax}}
+        "fused_vs_split_max_abs_diff_after_3_steps": dmax,
+        # the same system under the LOCAL Lax-Friedrichs variants (per-node costate ranges inside the fused kernel, round 5): fused only
+        "local_variants_fused_ms_per_step": local}}
 
 
 def summarize(r, steps):
