@@ -2,10 +2,10 @@
 """BASELINE C4 (513^3 Dubins, fp64) and C5 (129^4 pendulum, fp32) against the CPU oracle at FULL size, once (minutes of one host core:
 too slow for the suite, which checks these sizes through size-independent properties).  C4: one odeCFL3 step through the drop-in
 API against oracle.ode_cfl_3; C5: one termLaxFriedrichs evaluation against oracle.term_lax_friedrichs (fp32 product, fp64 oracle).
-Test infrastructure: imports oracle/.  usage: full_size_oracle_check.py [c4|c5|both]"""
+Test infrastructure: imports oracle/.  usage: tests/diag/full_size_oracle_check.py [c4|c5|both]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import levelsetpy_amd as L
 from oracle import hj_oracle as O

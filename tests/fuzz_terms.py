@@ -132,7 +132,7 @@ def case(rng, k):
     err = float(np.abs(yd.cpu().numpy() - yo).max()) / scale
     # termReinit's bound is max |S g_d / max(|g|, eps)| per dimension: at a cell where every one-sided derivative is rounding noise (|g| below
     # eps: the clamp decides) the quotient is 0 or |S| depending on the last bit of g -- such a cell can own the maximum (seed 5015: the
-    # bounds differ by 1.2e-5 with ydot equal to 3e-16, seed 57706: by 1.3e-3; tools/experiments/r05_reinit_diag.py)
+    # bounds differ by 1.2e-5 with ydot equal to 3e-16, seed 57706: by 1.3e-3; tests/diag/r05_reinit_diag.py)
     # -- so the product's bound has to lie between the oracle's with and without such cells
     if kind == "reinit":
         sb_hi = reinit_bound_without_noise_cells(og, phi, phi, scheme, order)
