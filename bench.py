@@ -11,8 +11,11 @@ default 51), and `value` is the MEDIAN window (inter-quartile range and min/max 
 
 N = 1 (default): BASELINE C2, the 201^3 grid.  The same run also times, each with its own spin-up and
 reported under "also" with its own roofline fraction: the intended WENO5 arithmetic at 201^3, the
-single-GPU 513^3 grid (C4's N = 1 point), C3 (double integrator 4096^2, ENO3) and C5 (double
-pendulum 129^4 fp32, all axes periodic).
+single-GPU 513^3 grid (C4's N = 1 point), C3 (double integrator 4096^2, ENO3; "C3 fast": the opt-in lean ENO arithmetic) and C5 (double
+pendulum 129^4 fp32, all axes periodic) -- C3 / C5 / 513^3 / WENO5 with their own PMC traffic passes --, the headline with the CFL reduction kept
+in every launch, the drop-in API legs, a run-time Hamiltonian, the split path, and a Hamiltonian whose alpha reads the costate range (fused
+against split, plus the local Lax-Friedrichs variants).
+`--gpus N --plan-only`: no GPU is touched -- every rank's slab, stepper, launches, halo bytes and predicted ms/step of the N-rank leg.
 N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE C4 -- the 513^3 grid
 slab-decomposed along axis 0 over the N ranks (65/64-plane slabs at N = 8), halo planes exchanged with
 ncclSend/ncclRecv over RCCL, STRONG scaling (`--global-n 513`, the default for N > 1; every N
