@@ -355,6 +355,12 @@ int hj_rk_prev_bounds(hj_ctx* ctx, double* sb_host /* 3 */, int* n_host, double*
  * -min; an element-wise MAX over ranks of the keys is the reduction); hj_ctx_set_range_source makes later launches read the
  * range from such keys instead of running their own pass (NULL: back to per-launch passes).  No reference counterpart. */
 int hj_range_pass(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, const void* y, void* keys_dev);
+/* The local Lax-Friedrichs kinds (HJ_DISS_LLF / HJ_DISS_LLLF) of an HJ_HAM_RANGE Hamiltonian: alpha depends on every node's own costates,
+ * so stepBound is a maximum over the stencil results.  hj_bound_pass runs the substep kernel over the ctx's planes storing nothing and
+ * returns 1 / max_x sum_d alpha_d(x) / dx_d (diss_local_laxfried.py:120-128, diss_localsq_laxfried.py:99-107) -- of ONE slab when the
+ * ctx is one: the grid's bound is the MIN over ranks (dist.SlabIntegrator(dynamic=True, diss=...)).  LLF reads the grid-wide range in
+ * the other dimensions from hj_ctx_set_range_source when one is set, else from a range pass of its own.  Synchronises the stream. */
+int hj_bound_pass(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, const void* y, double* step_bound_host);
 int hj_ctx_set_range_source(hj_ctx* ctx, const void* keys_dev);
 /* max over this ctx's nodes of alpha_d(x, range) for the range currently in force (the source set above, else the last pass):
  * amax_host[0..ndim); artificial_diss_glf.py:101-107 -- what the ranks all-reduce for deltaT.  One host synchronisation. */

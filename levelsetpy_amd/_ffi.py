@@ -76,6 +76,7 @@ SIGNATURES = {
     "hj_rk_last_bounds": (_i, [_vp, _pd, _pi]),
     "hj_rk_prev_bounds": (_i, [_vp, _pd, _pi, _pd]),
     "hj_range_pass": (_i, [_vp, _i, _i, _pd, _vp, _vp]),
+    "hj_bound_pass": (_i, [_vp, _i, _i, _pd, _vp, _pd]),
     "hj_ctx_set_range_source": (_i, [_vp, _vp]),
     "hj_range_alpha_max": (_i, [_vp, _i, _pd, _pd]),
     "hj_ham_info": (_i, [_i, _pi, _pi, _pi]),

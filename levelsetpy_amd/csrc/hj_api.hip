@@ -1842,6 +1842,24 @@ int hj_range_pass(hj_ctx* c, int scheme, int ham, const double* par, const void*
     return do_substep(c, s, -1);
 }
 
+int hj_bound_pass(hj_ctx* c, int scheme, int ham, const double* par, const void* y, double* sb_host) {
+    if (!c || !y || !sb_host) return fail(HJ_EINVAL, "null argument");
+    if (!user_ham_dynamic(ham)) return fail(HJ_EINVAL, "Hamiltonian %d does not read the costate range", ham);
+    if (c->diss_kind == HJ_DISS_GLF) return fail(HJ_ESTATE, "the bound pass belongs to the local Lax-Friedrichs kinds (hj_ctx_set_dissipation); the global one has hj_range_alpha_max");
+    int rc;
+    if (c->diss_kind != HJ_DISS_LLLF && !c->range_src) {     // LLF reads the grid-wide range in the other dimensions: this ctx's own, unless told
+        SubstepCall r{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y, nullptr, c->keys /* unused as an array */, nullptr, 0, c->N[0]};
+        r.range_only = true;
+        if ((rc = do_substep(c, r, -1))) return rc;
+    }
+    const int slot = HJ_BOUND_SLOTS - 4;
+    SubstepCall b{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y, nullptr, c->keys /* nothing is stored */, nullptr, 0, c->N[0]};
+    b.bound_pass = true;
+    b.range_ready = true;
+    if ((rc = do_substep(c, b, slot))) return rc;
+    return read_ring(c, c->slot_ring[slot], sb_host, nullptr);
+}
+
 int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, double t0, double tf,
                double factor_cfl, double max_step, int restrict_sign, const void* y_in, void* y_out,
                void* work0, void* work1, double* t_out, double* dt_out) {

@@ -128,13 +128,18 @@ class SlabIntegrator(object):
     }
 
     def __init__(self, slab, backend, dx, order=3, factor_cfl=0.8, group=None, needs_eps=False,
-                 exchanger=None, allreduce_max=None, dynamic=False):
+                 exchanger=None, allreduce_max=None, dynamic=False, diss="glf"):
         """exchanger / allreduce_max: transport overrides (tests run several ranks inside one
         process); default is torch.distributed (RCCL on GPUs, gloo on CPU).
         dynamic: the Hamiltonian's alpha depends on the costate range (user_ham.register_native_hamiltonian with dmin / dmax:
         artificial_diss_glf.py:80-99).  The range is a property of the WHOLE grid: before every substep each rank reduces
         derivL / derivR of its slab (backend.range_pass, pads in place), the ranks all-reduce (MAX) and every launch of the substep
-        reads the reduced range (backend.set_range); deltaT comes from the all-reduced max(alpha) of the first stage's range."""
+        reads the reduced range (backend.set_range); deltaT comes from the all-reduced max(alpha) of the first stage's range.
+        diss (with dynamic): "glf" as above; "llf" / "lllf" = artificialDissipationLLF / LLLF of such a Hamiltonian
+        (diss_local_laxfried.py:108-128, diss_localsq_laxfried.py:87-107): alpha is evaluated with every node's OWN costate range in
+        dimension i (LLF: the all-reduced grid range in the others; LLLF: the node's own everywhere -- no range pass, no range
+        all-reduce), so stepBound is 1 / max over ALL ranks of max_x sum_i alpha_i(x) / dx_i: a bound pass of the slab before the first
+        stage (backend.local_bound) and one scalar all-reduce."""
         import torch
         self.torch = torch
         self.slab, self.be, self.order, self.factor_cfl = slab, backend, order, factor_cfl
@@ -148,7 +153,13 @@ class SlabIntegrator(object):
         self._allreduce_max = allreduce_max
         self.buf = {k: backend.alloc() for k in ("cur", "w0", "w1", "nxt")}
         self.dynamic, self.dx = bool(dynamic), [float(v) for v in dx]
+        self.diss = str(diss).lower()
+        if self.diss not in ("glf", "llf", "lllf"):
+            raise ValueError("diss must be 'glf', 'llf' or 'lllf'")
+        if self.diss != "glf" and not self.dynamic:
+            raise ValueError("diss='%s' belongs to dynamic=True (native systems: the backend's static local bound)" % self.diss)
         if self.dynamic:
+            backend.set_dissipation(self.diss)
             self.alpha_max, self.step_bound = None, None       # per step (step())
             return
         # stepBound = 1 / sum_d max_grid(alpha_d)/dx_d with the max over ALL ranks
@@ -189,11 +200,18 @@ class SlabIntegrator(object):
                 self._eps(y)
             if self.dynamic:
                 # the costate range of the stage's input over the whole grid, then (first stage) deltaT from max(alpha) of that range
-                rng = be.range_pass(y)
-                if s.world > 1:
-                    self._allreduce_max(rng)
-                be.set_range(rng)
-                if k == 0:
+                if self.diss != "lllf":
+                    rng = be.range_pass(y)
+                    if s.world > 1:
+                        self._allreduce_max(rng)
+                    be.set_range(rng)
+                if k == 0 and self.diss != "glf":
+                    inv = self.torch.tensor([1.0 / be.local_bound(y)], dtype=self.torch.float64, device=be.device)
+                    if s.world > 1:
+                        self._allreduce_max(inv)
+                    self.step_bound = 1.0 / float(inv.cpu()[0])
+                    dt = min(self.factor_cfl * self.step_bound, tf - t, max_step)      # ode_cfl_3.py:142
+                elif k == 0:
                     amax = self.torch.tensor(be.alpha_max_now(), dtype=self.torch.float64, device=be.device)
                     if s.world > 1:
                         self._allreduce_max(amax)
@@ -284,6 +302,16 @@ class HipSlabBackend(object):
         am = (C.c_double * 4)()
         _ffi.check(dg.lib.hj_range_alpha_max(dg.ctx, self.ham, self.par, am))
         return [am[d] for d in range(dg.dim)]
+
+    def set_dissipation(self, kind):
+        _ffi.check(self.dg.lib.hj_ctx_set_dissipation(self.dg.ctx, {"glf": _ffi.DISS_GLF, "llf": _ffi.DISS_LLF, "lllf": _ffi.DISS_LLLF}[kind]))
+
+    def local_bound(self, y):
+        """1 / max_x sum_d alpha_d(x) / dx_d over this slab under the local rule (hj_bound_pass; LLF: after set_range)."""
+        dg = self.dg
+        sb = C.c_double()
+        _ffi.check(dg.lib.hj_bound_pass(dg.ctx, self.sid, self.ham, self.par, self._interior_ptr(y), C.byref(sb)))
+        return sb.value
 
     def max_d1sq(self, y):
         dg = self.dg

@@ -48,7 +48,7 @@ class OracleSlabBackend(object):
     def substep(self, stage, dt, y, y0, out, p0, p1):
         yi = y[HALO:HALO + self.n].numpy()
         ydot, _ = O.term_lax_friedrichs(self.g, self.sys, self.scheme, 0., yi.reshape(-1), self._halo(y),
-                                        self.eps, deriv_range=getattr(self, "deriv_range", None))
+                                        self.eps, deriv_range=getattr(self, "deriv_range", None), diss=getattr(self, "diss", "glf"))
         ye = yi + dt * ydot.reshape(yi.shape)
         if stage == _ffi.STAGE_EULER:
             o = ye
@@ -79,6 +79,14 @@ class OracleSlabBackend(object):
     def alpha_max_now(self):
         lo, hi = self.deriv_range
         return [float(np.max(self.sys.dissipation(0, None, lo, hi, None, d))) for d in range(self.g.dim)]
+
+    def set_dissipation(self, kind):
+        self.diss = kind
+
+    def local_bound(self, y):
+        yi = y[HALO:HALO + self.n].numpy()
+        return O.term_lax_friedrichs(self.g, self.sys, self.scheme, 0., yi.reshape(-1), self._halo(y), self.eps,
+                                     deriv_range=getattr(self, "deriv_range", None), diss=self.diss)[1]
 
     def max_d1sq(self, y):
         yi = y[HALO:HALO + self.n].numpy()
@@ -289,11 +297,14 @@ class BurgersDriftOracle(object):
         return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * self.grid.xs[0] * p[1]
 
     def dissipation(self, t, data, dmin, dmax, sd, dim):
-        a = max(abs(float(dmin[dim])), abs(float(dmax[dim])))
+        a = np.maximum(np.abs(dmin[dim]), np.abs(dmax[dim]))        # scalars (GLF) or the node's own range as arrays (LLF / LLLF)
+        if np.ndim(a) == 0:
+            a = float(a)
         return a + np.abs(self.c * self.grid.xs[0]) if dim == 1 else a
 
 
-CASES_DYN = [("WENO5_ASSHIPPED", False, 3), ("ENO3", True, 2), ("WENO5", False, 3)]
+CASES_DYN = [("WENO5_ASSHIPPED", False, 3, "glf"), ("ENO3", True, 2, "glf"), ("WENO5", False, 3, "glf"),
+             ("WENO5_ASSHIPPED", True, 3, "llf"), ("ENO2", False, 2, "lllf"), ("WENO5", False, 3, "llf")]
 
 
 def _worker_dyn(rank, world, port, q):
@@ -302,13 +313,14 @@ def _worker_dyn(rank, world, port, q):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        for ci, (scheme, periodic0, order) in enumerate(CASES_DYN):
+        for ci, (scheme, periodic0, order, kind) in enumerate(CASES_DYN):
             pd = [0, 2] if periodic0 else [2]
             og = O.Grid([-1., -1., -1.], [1. - (2. / N[0] if periodic0 else 0.), 1., 1. - 2. / N[2]], N, pd)
             data = O.shape_sphere(og, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
             slab = SlabDecomposition(N[0], world, rank, periodic0)
             be = OracleSlabBackend(og, slab, scheme, make_sys=lambda g: BurgersDriftOracle(g, 0.7))
-            integ = SlabIntegrator(slab, be, [float(v) for v in og.dx.ravel()], order, 0.8, needs_eps=(scheme == "WENO5"), dynamic=True)
+            integ = SlabIntegrator(slab, be, [float(v) for v in og.dx.ravel()], order, 0.8, needs_eps=(scheme == "WENO5"), dynamic=True,
+                                   diss=kind)
             integ.set_state(torch.from_numpy(np.ascontiguousarray(data[slab.begin:slab.end])))
             t = 0.0
             for _ in range(NSTEPS):
@@ -321,7 +333,8 @@ def _worker_dyn(rank, world, port, q):
 @pytest.mark.parametrize("world", [2, 3])
 def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
     """A Hamiltonian whose alpha reads derivMin / derivMax, slab-decomposed: every substep all-reduces the 2*D range values of the
-    slabs, the first stage of a step all-reduces max(alpha) for deltaT; the decomposed run equals the undivided oracle run."""
+    slabs, the first stage of a step all-reduces max(alpha) for deltaT; the decomposed run equals the undivided oracle run.
+    The local variants (diss='llf' / 'lllf': alpha from the node's own range) all-reduce one scalar, max_x sum_i alpha_i / dx_i, instead."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -332,12 +345,12 @@ def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for ci, (scheme, periodic0, order) in enumerate(CASES_DYN):
+    for ci, (scheme, periodic0, order, kind) in enumerate(CASES_DYN):
         pd = [0, 2] if periodic0 else [2]
         og = O.Grid([-1., -1., -1.], [1. - (2. / N[0] if periodic0 else 0.), 1., 1. - 2. / N[2]], N, pd)
         data = O.shape_sphere(og, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
         sys_ = BurgersDriftOracle(og, 0.7)
-        term = lambda t, y: O.term_lax_friedrichs(og, sys_, scheme, t, y)  # noqa: E731
+        term = lambda t, y: O.term_lax_friedrichs(og, sys_, scheme, t, y, diss=kind)  # noqa: E731
         ode = {2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
         y, t_ref, sb_last = data.reshape(-1, 1), 0.0, None
         for _ in range(NSTEPS):
@@ -350,7 +363,7 @@ def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
             got[b:e] = ys
             assert abs(t - t_ref) <= 1e-13 * t_ref, (t, t_ref)
             assert abs(sb - sb_last) <= 1e-13 * sb_last
-        assert np.max(np.abs(got - y.reshape(N))) <= 1e-11, (scheme, periodic0, order, world)
+        assert np.max(np.abs(got - y.reshape(N))) <= 1e-11, (scheme, periodic0, order, kind, world)
 
 
 def test_slab_decomposition_bookkeeping():

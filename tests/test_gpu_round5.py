@@ -359,6 +359,88 @@ def test_range_dependent_alpha_virtual_ranks_equal_undivided(world, periodic0):
         assert float((ys - ref[b:e]).abs().max()) <= 1e-13, (r, float((ys - ref[b:e]).abs().max()))
 
 
+@pytest.mark.parametrize("kind,scheme,world,periodic0", [("llf", "WENO5_ASSHIPPED", 2, True), ("lllf", "WENO5_ASSHIPPED", 3, False),
+                                                         ("llf", "WENO5", 3, False), ("lllf", "ENO2", 2, True)])
+def test_local_lax_friedrichs_range_reading_virtual_ranks_equal_undivided(kind, scheme, world, periodic0):
+    """dist.SlabIntegrator(dynamic=True, diss='llf' | 'lllf') + HipSlabBackend: the local variants of a range-reading Hamiltonian on a
+    decomposed grid.  LLF all-reduces the range before every substep as GLF does, LLLF exchanges no range at all; deltaT comes from ONE
+    all-reduced scalar, max over the slabs of max_x sum_i alpha_i(x) / dx_i (hj_bound_pass).  Two RK3 steps equal the undivided grid
+    through odeCFL3 with artificialDissipationLLF / LLLF."""
+    import threading
+    from test_gpu_round4 import ThreadRing
+    from levelsetpy_amd.dist import SlabDecomposition, SlabIntegrator, HipSlabBackend
+    n = (30, 22, 24)
+    pd = [0, 2] if periodic0 else 2
+    g, og = mk([-1.0] * 3, [1.0 - (2.0 / n[0] if periodic0 else 0.0), 1.0, 1.0 - 2.0 / n[2]], n, pd)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+    sys_ = BurgersDriftLocal(g, 0.7)
+    reg.attach(sys_, params=lambda o: [o.c])
+    full = torch.as_tensor(d0, device="cuda")
+    diss = {"llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss, CoStateCalc=DERIV[scheme]))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y, t_ref = full.reshape(-1, 1), 0.
+    for _ in range(2):
+        t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    ref = y.reshape(n)
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    tr = ThreadRing(world)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                slab = SlabDecomposition(n[0], world, rank, periodic0, self_exchange=periodic0)
+                be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS[scheme], reg.ham_id, [0.7], "float64")
+                integ = SlabIntegrator(slab, be, dxs, 3, 0.8, exchanger=tr.exchanger(slab), allreduce_max=tr.allreduce_max(rank),
+                                       needs_eps=(scheme == "WENO5"), dynamic=True, diss=kind)
+                integ.set_state(full[slab.begin:slab.end])
+                t = 0.
+                for _ in range(2):
+                    t, dt = integ.step(t)
+                be.sync()
+                out[rank] = (slab.begin, slab.end, t, integ.state().clone())
+                be.sync()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            tr.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errs, errs
+    tol = 1e-3 if scheme.startswith("ENO") else 1e-12
+    for r in range(world):
+        b, e, t, ys = out[r]
+        assert abs(t - t_ref) <= 1e-13 * t_ref, (t, t_ref)
+        diff = (ys - ref[b:e]).abs()
+        assert float(diff.max()) <= tol and float((diff > 1e-12).double().mean()) <= 2e-3, (r, float(diff.max()))
+
+
+def test_bound_pass_needs_a_local_kind_and_a_range_reading_hamiltonian():
+    n = (24, 20, 22)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0], n, None)
+    dg = DeviceGrid(g, "float64")
+    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+    y = torch.as_tensor(O.shape_sphere(og, None, 0.5), device="cuda")
+    sb = C.c_double()
+    par = _ffi.darr([0.7])
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_GLF))
+    assert dg.lib.hj_bound_pass(dg.ctx, sid, reg.ham_id, par, C.c_void_p(y.data_ptr()), C.byref(sb)) == -4      # HJ_ESTATE
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_LLF))
+    assert dg.lib.hj_bound_pass(dg.ctx, sid, _ffi.HAM_DUBINS_REL, _ffi.darr([1., 1., 1., 2.]), C.c_void_p(y.data_ptr()), C.byref(sb)) == -1   # HJ_EINVAL
+    # a single ctx without an external range: LLF runs its own range pass; the bound equals termLaxFriedrichs's
+    _ffi.check(dg.lib.hj_bound_pass(dg.ctx, sid, reg.ham_id, par, C.c_void_p(y.data_ptr()), C.byref(sb)))
+    _, sbo = O.term_lax_friedrichs(og, BurgersDriftLocal(og, 0.7), "WENO5_ASSHIPPED", 0., O.shape_sphere(og, None, 0.5).reshape(-1, 1), diss="llf")
+    assert abs(sb.value - sbo) <= 1e-12 * sbo, (sb.value, sbo)
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_GLF))
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
