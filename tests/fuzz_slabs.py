@@ -5,7 +5,10 @@ undivided grid, BITWISE.
 Every case: the 3-D Dubins grid in fp64 (axis 0 extrapolated: the end ranks have one neighbour) or the 4-D pendulum grid in fp32 (all
 periodic: a closed ring), random extents, a random number of ranks with the planes split unevenly, a random scheme and RK order; either
 the native deep-halo stepper (hj_slab_rk_step_deep; pad planes moved by this script) or the per-substep schedule (SlabIntegrator +
-HipSlabBackend over in-process thread ranks); three steps; every rank's planes must equal the undivided run's bit for bit."""
+HipSlabBackend over in-process thread ranks); three steps; every rank's planes must equal the undivided run's bit for bit.
+A fifth of the cases step a run-time Hamiltonian whose alpha reads the costate range (global, local or local-local Lax-Friedrichs:
+SlabIntegrator(dynamic=True, diss=...)) on a 3-D grid with axis 0 periodic or not; there deltaT is formed from all-reduced values in
+another order than hj_rk_step's device code forms it, so the comparison is to 1e-12 of the largest value, not bitwise."""
 import ctypes as C
 import os
 import sys
@@ -29,9 +32,21 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 777
 
 
-def undivided(g, full, scheme, ham, par, dtype, order, steps, dt_cap=1e300):
+def _burgers_src(dim):
+    s = "H = par[0] * x[0] * p[1];\n"
+    for d in range(dim):
+        s += "H += 0.5 * p[%d] * p[%d];  alpha[%d] = fmax(fabs(dmin[%d]), fabs(dmax[%d]));\n" % (d, d, d, d, d)
+    return s + "alpha[1] += fabs(par[0] * x[0]);\n"
+
+
+KINDS = {"glf": _ffi.DISS_GLF, "llf": _ffi.DISS_LLF, "lllf": _ffi.DISS_LLLF}
+
+
+def undivided(g, full, scheme, ham, par, dtype, order, steps, dt_cap=1e300, kind=None):
     dg = DeviceGrid(g, dtype)
     dg.bind_stream()
+    if kind is not None:
+        _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, KINDS[kind]))
     sid = _ffi.SCHEME_IDS[scheme]
     cur, nxt, w0, w1 = full.clone(), torch.empty_like(full), torch.empty_like(full), torch.empty_like(full)
     tout, dtout = C.c_double(), C.c_double()
@@ -49,9 +64,14 @@ def case(rng, k):
     four = rng.random() < 0.4
     order = int(rng.integers(1, 4))
     deep = rng.random() < 0.5
+    dyn = str(rng.choice(["glf", "llf", "lllf"])) if rng.random() < 0.2 else None
+    if dyn:
+        four, deep = False, False
     # (the intended WENO5 needs an all-reduce of its epsilon per stage: the deep stepper refuses it on an external transport -- this
     #  script's pad mover --, found by this script in round 5; the per-substep schedule all-reduces it through the thread ring)
     scheme = str(rng.choice(["ENO2", "ENO3", "WENO5_ASSHIPPED"] + ([] if (four or deep) else ["WENO5"])))
+    if dyn:
+        scheme = str(rng.choice(["ENO2", "WENO5_ASSHIPPED", "WENO5"]))     # (ENO3's divided-difference choices flip on rounding-level changes of deltaT)
     world = int(rng.choice([1, 2, 3, 4, 5, 8]))
     thin = 6 * order if deep else 3                      # the thinnest slab the stepper takes
     n0 = world * int(rng.integers(thin, thin + 12)) + int(rng.integers(0, world))
@@ -60,6 +80,20 @@ def case(rng, k):
         g, _ = pendulum_grid(n, low_mem=True)
         full = sphere4(g, noise=0.01, seed=int(rng.integers(1 << 30)))
         ham, par, dtype, periodic0 = _ffi.HAM_DOUBLE_PENDULUM, PAR_PENDULUM, "float32", True
+    elif dyn:
+        periodic0 = bool(rng.random() < 0.5)
+        n = (n0, int(rng.integers(8, 36)), int(rng.integers(8, 36)))
+        pd = [0, 2] if periodic0 else 2
+        g = L.createGrid(np.array([[-1., -1., -1.]]).T, np.array([[1. - (2. / n[0] if periodic0 else 0.), 1., 1. - 2. / n[2]]]).T,
+                         np.array(n, dtype=np.int64).reshape(-1, 1), pd, low_mem=True)
+        xs = [torch.as_tensor(np.asarray(v).ravel(), device="cuda") for v in g.vs]
+        gen = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+        full = ((xs[0] ** 2).reshape(-1, 1, 1) + (xs[1] ** 2).reshape(1, -1, 1) + (xs[2] ** 2).reshape(1, 1, -1)).sqrt() - 0.5 \
+            + 0.1 * torch.sin(3 * xs[0]).reshape(-1, 1, 1) * torch.cos(2 * xs[2]).reshape(1, 1, -1) \
+            + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
+        full = full.contiguous()
+        reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+        ham, par, dtype = reg.ham_id, [0.7], "float64"
     else:
         n = (n0, int(rng.integers(8, 40)), int(rng.integers(8, 40)))
         g = L.createGrid(np.array([[-.75, -1.25, -np.pi]]).T, np.array([[3.25, 1.25, np.pi * (1 - 2 / n[2])]]).T,
@@ -117,7 +151,7 @@ def case(rng, k):
                     slab = SlabDecomposition(n[0], world, rank, periodic0, self_exchange=periodic0)
                     be = HipSlabBackend(g, slab, sid, ham, par, dtype)
                     integ = SlabIntegrator(slab, be, dxs, order, 0.8, needs_eps=(scheme == "WENO5"), exchanger=tr.exchanger(slab),
-                                           allreduce_max=tr.allreduce_max(rank))
+                                           allreduce_max=tr.allreduce_max(rank), dynamic=bool(dyn), diss=dyn or "glf")
                     integ.set_state(full[slab.begin:slab.end])
                     tt = 0.
                     for _ in range(steps):
@@ -136,11 +170,19 @@ def case(rng, k):
         assert not errs, errs
         got = [(out[r][0], out[r][1], out[r][2]) for r in range(world)]
         t = out[0][3]
-    t_ref, ref = undivided(g, full, scheme, ham, par, dtype, order, steps)
-    ok = abs(t_ref - t) <= 1e-15 and all(torch.equal(y, ref[b:e]) for b, e, y in got)
+    t_ref, ref = undivided(g, full, scheme, ham, par, dtype, order, steps, kind=dyn)
     worst = max(float((y - ref[b:e]).abs().max()) for b, e, y in got)
+    if dyn:
+        if scheme == "ENO2":        # a rounding-level difference of deltaT may flip a stencil choice at isolated nodes
+            frac = max(float(((y - ref[b:e]).abs() > 1e-12).double().mean()) for b, e, y in got)
+            ok = abs(t_ref - t) <= 1e-13 * t_ref and frac <= 2e-3 and worst <= 1e-3
+        else:
+            ok = abs(t_ref - t) <= 1e-13 * t_ref and worst <= 1e-12 * float(ref.abs().max())
+    else:
+        ok = abs(t_ref - t) <= 1e-15 and all(torch.equal(y, ref[b:e]) for b, e, y in got)
     print("%4d %s N=%-16s world %d (%s) %-16s order %d %-12s max|diff| %.2e %s" % (
-        k, "4-D fp32" if four else "3-D fp64", "x".join(map(str, n)), world, "/".join(str(e - b) for b, e, _ in got), scheme, order,
+        k, "4-D fp32" if four else ("3-D range-alpha " + dyn if dyn else "3-D fp64"), "x".join(map(str, n)), world,
+        "/".join(str(e - b) for b, e, _ in got), scheme, order,
         "deep-halo" if deep else "per-substep", worst, "ok" if ok else "MISMATCH"), flush=True)
     return ok
 
