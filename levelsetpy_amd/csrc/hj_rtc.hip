@@ -24,6 +24,8 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
+#include <deque>
+#include <mutex>
 #include <sstream>
 #include "hj_launch.h"
 #include "hj_fusedv.h"
@@ -91,16 +93,23 @@ struct UserHam {
     bool no_big_lds = false;                // the runtime refused > 64 KB of dynamic LDS for a module function
     std::map<int, UserKernel> alpha;        // key: device * 2 + fp32
 };
-static std::vector<UserHam> g_user;
+// Registered Hamiltonians live in a deque (registration never moves an element another thread may be launching) and every entry point that
+// looks at or extends the per-Hamiltonian kernel tables takes g_rtc_mu: kernels are compiled lazily at the first launch, and several host
+// threads driving their own contexts (virtual ranks in one process: tests/fuzz_slabs.py found the race in round 5 -- eight threads met in
+// the first compile of the same kernel) must see either no kernel or a complete one.  The launches themselves are asynchronous: the lock is
+// held for microseconds once the kernels exist.
+static std::deque<UserHam> g_user;
+static std::recursive_mutex g_rtc_mu;
+#define HJ_RTC_LOCK std::lock_guard<std::recursive_mutex> hj_rtc_guard(g_rtc_mu)
 
 static UserHam* user_of(int ham) {
     const int i = ham - HJ_HAM_USER_BASE;
     return (i >= 0 && i < (int)g_user.size()) ? &g_user[(size_t)i] : nullptr;
 }
-bool user_ham_valid(int ham) { return user_of(ham) != nullptr; }
-bool user_ham_dynamic(int ham) { const UserHam* u = user_of(ham); return u && (u->flags & HJ_HAM_RANGE); }
-int user_ham_ndim(int ham) { const UserHam* u = user_of(ham); return u ? u->ndim : -1; }
-int user_ham_npar(int ham) { const UserHam* u = user_of(ham); return u ? u->nparams : 0; }
+bool user_ham_valid(int ham) { HJ_RTC_LOCK; return user_of(ham) != nullptr; }
+bool user_ham_dynamic(int ham) { HJ_RTC_LOCK; const UserHam* u = user_of(ham); return u && (u->flags & HJ_HAM_RANGE); }
+int user_ham_ndim(int ham) { HJ_RTC_LOCK; const UserHam* u = user_of(ham); return u ? u->ndim : -1; }
+int user_ham_npar(int ham) { HJ_RTC_LOCK; const UserHam* u = user_of(ham); return u ? u->nparams : 0; }
 
 // the translation unit hipRTC compiles: the kernel headers + the Hamiltonian type around the caller's expression
 static std::string user_source(const UserHam& u, int id) {
@@ -508,6 +517,7 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
 }
 
 int launch_user(hj_ctx* c, const SubstepCall& s) {
+    HJ_RTC_LOCK;
     UserHam* u = user_of(s.ham);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", s.ham);
     if (c->ndim != u->ndim) return fail(HJ_EINVAL, "Hamiltonian '%s' is %d-dimensional, the grid has dim %d", u->name.c_str(), u->ndim, c->ndim);
@@ -561,6 +571,7 @@ static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long lo
 // then well defined for an HJ_HAM_RANGE Hamiltonian too (alpha never depends on the node's own costate)
 int user_alpha_bound(hj_ctx* c, int ham, const double* par, unsigned long long* keys, unsigned long long* done, bool with_range,
                      unsigned long long* host_out, unsigned long long seq, const DtArgs* dt) {
+    HJ_RTC_LOCK;
     UserHam* u = user_of(ham);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham);
     if ((u->flags & HJ_HAM_RANGE) && !with_range)
@@ -586,6 +597,7 @@ extern "C" {
 int hj_ham_register2(const char* name, int ndim, int nparams, const char* body, const char* column_body, int ncol, int flags,
                      const char* include_dir, const char* hiprtc_path, int* ham_id) {
     if (!name || !body || !include_dir || !ham_id) return fail(HJ_EINVAL, "null argument");
+    HJ_RTC_LOCK;
     // the name goes into #line directives of the generated source (compiler messages then point into the caller's text)
     for (const char* ch = name; *ch; ++ch)
         if (*ch == '"' || *ch == '\\' || (unsigned char)*ch < 32) return fail(HJ_EINVAL, "the name of a Hamiltonian must not contain quotes, backslashes or control characters");
@@ -622,6 +634,7 @@ int hj_ham_register(const char* name, int ndim, int nparams, const char* body, c
 }
 
 int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built) {
+    HJ_RTC_LOCK;
     const UserHam* u = user_of(ham_id);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
     if (ndim) *ndim = u->ndim;
@@ -636,6 +649,7 @@ int hj_ham_info(int ham_id, int* ndim, int* nparams, int* kernels_built) {
 }
 
 int hj_ham_flags(int ham_id, int* flags) {
+    HJ_RTC_LOCK;
     const UserHam* u = user_of(ham_id);
     if (!u || !flags) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
     *flags = u->flags;
@@ -643,6 +657,7 @@ int hj_ham_flags(int ham_id, int* flags) {
 }
 
 int hj_ham_cache_stats(int* compiled, int* loaded_from_cache) {
+    HJ_RTC_LOCK;
     if (compiled) *compiled = g_rtc_compiles;
     if (loaded_from_cache) *loaded_from_cache = g_rtc_cache_hits;
     return HJ_OK;
@@ -650,6 +665,7 @@ int hj_ham_cache_stats(int* compiled, int* loaded_from_cache) {
 
 // compile without launching (needs no GPU: hipRTC cross-compiles for gfx950) -- the check a registration can run up front
 int hj_ham_compile_check(int ham_id, int scheme) {
+    HJ_RTC_LOCK;
     UserHam* u = user_of(ham_id);
     if (!u) return fail(HJ_EINVAL, "unknown Hamiltonian id %d", ham_id);
     if (scheme < 0 || scheme > HJ_ENO3_FAST) return fail(HJ_EINVAL, "unknown scheme %d", scheme);

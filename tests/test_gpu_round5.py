@@ -441,6 +441,58 @@ def test_bound_pass_needs_a_local_kind_and_a_range_reading_hamiltonian():
     _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_GLF))
 
 
+def test_run_time_kernels_first_compiled_by_several_threads_at_once():
+    """Kernels of a run-time Hamiltonian are compiled at their first launch.  Six host threads (virtual ranks, each with a context of its own)
+    meeting in that FIRST launch must all get complete kernels: the per-Hamiltonian kernel tables are guarded (hj_rtc.hip, g_rtc_mu; round 5 --
+    tests/fuzz_slabs.py met an 'invalid argument' launch when eight threads raced through the first compile).  The expression is new to the
+    process (its own name and constant), the undivided reference runs AFTER the threads."""
+    import threading
+    from test_gpu_round4 import ThreadRing
+    from levelsetpy_amd.dist import SlabDecomposition, SlabIntegrator, HipSlabBackend
+    n, world = (48, 20, 22), 6
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    src = _burgers_src(3).replace("0.5 * p[0] * p[0]", "0.501 * p[0] * p[0]")
+    reg = L.register_native_hamiltonian("burgers_drift_race_3d", 3, src, nparams=1)
+    full = torch.as_tensor(d0, device="cuda")
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    tr = ThreadRing(world)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                slab = SlabDecomposition(n[0], world, rank, False)
+                be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, [0.7], "float64")
+                integ = SlabIntegrator(slab, be, dxs, 2, 0.8, exchanger=tr.exchanger(slab), allreduce_max=tr.allreduce_max(rank), dynamic=True)
+                integ.set_state(full[slab.begin:slab.end])
+                t, dt = integ.step(0.)
+                be.sync()
+                out[rank] = (slab.begin, slab.end, t, integ.state().clone())
+                be.sync()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            tr.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errs, errs
+    dg = DeviceGrid(g, "float64")
+    cur, nxt, w0, w1 = full.clone(), torch.empty_like(full), torch.empty_like(full), torch.empty_like(full)
+    tout, dtout = C.c_double(), C.c_double()
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_GLF))
+    _ffi.check(dg.lib.hj_rk_step(dg.ctx, 2, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, _ffi.darr([0.7]), 0., 1e9, 0.8, 1e300, 0,
+                                 dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+    torch.cuda.synchronize()
+    for r in range(world):
+        b, e, t, ys = out[r]
+        assert abs(t - tout.value) <= 1e-14 * tout.value
+        assert float((ys - nxt[b:e]).abs().max()) <= 1e-13
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
