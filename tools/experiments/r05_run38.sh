@@ -1,11 +1,9 @@
 #!/bin/bash
-# C5: chunks per tile column with round 5's kernel (HJ_MIN_CHUNK caps the count: 129 -> 1 chunk, 60 -> 2 (the chooser's pick), 40 -> 3, 30 -> 4)
+# late round 5: the fuzz scripts once more on the final library (the slab script from the seed whose first range-alpha case met the compile race)
 mkdir -p gpurun_out
-out=gpurun_out/r38_c5_chunks.txt; : > $out
-for rep in 1 2; do
-for mc in 129 60 40 30; do
-  v=$(HJ_MIN_CHUNK=$mc HJ_DEBUG=1 C5_STEPS=12 C5_WARMUP=4 timeout -k 10 200 python tools/bench_configs.py c5 2>&1 | grep -E "^C5|pair4 tiling" | sed 's/C5 double pendulum 129^4 (one GPU)           float32 WENO5_ASSHIPPED //' | tr '\n' ' ')
-  echo "rep $rep HJ_MIN_CHUNK=$mc: $v" >> $out
-done
-done
-cut -c1-330 $out
+o=gpurun_out/r38_fuzz.txt; : > $o
+timeout -k 10 300 python tests/fuzz_slabs.py 150 32000 > gpurun_out/r38_slabs.log 2>&1; echo "fuzz_slabs rc=$? $(tail -1 gpurun_out/r38_slabs.log) range-alpha cases: $(grep -c range-alpha gpurun_out/r38_slabs.log)" >> $o
+timeout -k 10 200 python tests/fuzz_parity.py 90 91000 0.3 > gpurun_out/r38_parity.log 2>&1; echo "fuzz_parity rc=$? $(tail -1 gpurun_out/r38_parity.log)" >> $o
+timeout -k 10 200 python tests/fuzz_terms.py 60 93000 > gpurun_out/r38_terms.log 2>&1; echo "fuzz_terms rc=$? $(tail -1 gpurun_out/r38_terms.log)" >> $o
+timeout -k 10 200 python tests/fuzz_solver.py 60 94000 > gpurun_out/r38_solver.log 2>&1; echo "fuzz_solver rc=$? $(tail -1 gpurun_out/r38_solver.log)" >> $o
+cat $o
