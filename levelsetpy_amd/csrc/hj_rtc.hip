@@ -489,6 +489,11 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
         R3.out = nullptr;
         R3.A.bound = nullptr;
         R3.A.range_keys = keys;
+        // HamUser::plane() decodes the range it is handed in every instantiation, MODE 3 included (the compiler may hoist those loads above the
+        // branch that needs them).  hj_range_pass on a context that has no range yet (a slab's first pass, before hj_ctx_set_range_source) used to
+        // hand it a null pointer: a load from address 0 once an expression kept the loads alive (found late in round 5 by the first Hamiltonian
+        // whose alpha_i reads another dimension's range).  The keys being written are as good as any: this pass does not use the decoded values.
+        if (!R3.A.ham.range) R3.A.ham.range = keys;
         R3.A.gate = nullptr;
         R3.A.use_y0 = 0; R3.A.ydot_only = 0; R3.A.post_op = 0; R3.A.do_clamp = 0;
         R3.A.eps_part = nullptr;

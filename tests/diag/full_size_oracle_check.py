@@ -2,7 +2,9 @@
 """BASELINE C4 (513^3 Dubins, fp64) and C5 (129^4 pendulum, fp32) against the CPU oracle at FULL size, once (minutes of one host core:
 too slow for the suite, which checks these sizes through size-independent properties).  C4: one odeCFL3 step through the drop-in
 API against oracle.ode_cfl_3; C5: one termLaxFriedrichs evaluation against oracle.term_lax_friedrichs (fp32 product, fp64 oracle).
-Test infrastructure: imports oracle/.  usage: tests/diag/full_size_oracle_check.py [c4|c5|both]"""
+"range": a run-time Hamiltonian whose alpha reads the costate range, 201^3 fp64 (the size of the bench's range leg: the two-pairs-per-thread
+run-time kernels), one odeCFL3 step under artificialDissipationGLF / LLF / LLLF against the oracle, WENO5_ASSHIPPED and the intended WENO5.
+Test infrastructure: imports oracle/.  usage: tests/diag/full_size_oracle_check.py [c4|c5|both|range]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -70,4 +72,41 @@ if what in ("c5", "both"):
     print("C5 %d^4 termLaxFriedrichs (fp32) vs oracle (fp64): max |diff| = %.3e = %.2e of max |ydot| %.3f; stepBound rel. diff %.2e; oracle %.0f s" %
           (q, diff, diff / scale, scale, abs(sb - sbo) / sbo, time.time() - t0), flush=True)
     assert diff <= 1e-4 * scale and abs(sb - sbo) <= 1e-5 * sbo
+if what == "range":
+    class Drift(object):            # H = |p|^2/2 + c x0 p1; alpha_d = max(|dmin_d|, |dmax_d|) (+ |c x0| for d = 1); scalars (GLF) or arrays (LLF / LLLF)
+        def __init__(self, grid, c):
+            self.grid, self.c = grid, c
+
+        def hamiltonian(self, t, data, p, sd=None):
+            return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * np.asarray(self.grid.xs[0]) * p[1]
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            a = np.maximum(np.abs(dmin[dim]), np.abs(dmax[dim]))
+            return a + np.abs(self.c * np.asarray(self.grid.xs[0])) if dim == 1 else a
+    src = "H = par[0] * x[0] * p[1];\n" + "".join(
+        "H += 0.5 * p[%d] * p[%d];  alpha[%d] = fmax(fabs(dmin[%d]), fabs(dmax[%d]));\n" % (d, d, d, d, d) for d in range(3)) + "alpha[1] += fabs(par[0] * x[0]);\n"
+    n = int(os.environ.get("N", "201"))
+    lo, hi = [-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n]
+    g = L.createGrid(np.array([lo]).T, np.array([hi]).T, n * np.ones((3, 1), dtype=np.int64), 2)
+    og = O.Grid(lo, hi, [n, n, n], [2])
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, src, nparams=1)
+    sysn = Drift(g, 0.7)
+    reg.attach(sysn, params=lambda o: [o.c])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    kinds = (("glf", L.artificialDissipationGLF), ("llf", L.artificialDissipationLLF), ("lllf", L.artificialDissipationLLLF))
+    for scheme, deriv in (("WENO5_ASSHIPPED", L.upwindFirstWENO5), ("WENO5", L.upwindFirstWENO5Intended)):
+        for kind, diss in kinds:
+            sd = L.Bundle(dict(grid=g, hamFunc=sysn.hamiltonian, partialFunc=sysn.dissipation, dissFunc=diss, CoStateCalc=deriv))
+            t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], torch.as_tensor(d0.reshape(-1, 1), device="cuda"), op, sd)
+            dgs = g.__dict__["_hj_device"]
+            dgx = dgs[next(iter(dgs))] if isinstance(dgs, dict) else dgs
+            kern = dgx.lib.hj_last_kernel(dgx.ctx).decode()
+            t0 = time.time()
+            osys = Drift(og, 0.7)
+            to, yo = O.ode_cfl_3(lambda tt, yy: O.term_lax_friedrichs(og, osys, scheme, tt, yy, diss=kind), [0., 10.], d0.reshape(-1, 1), 0.8, single_step=True)
+            diff = float(np.abs(y.cpu().numpy() - yo).max())
+            print("range-alpha %d^3 %-16s %-4s one odeCFL3 step vs oracle: max |diff| = %.3e (max |y| %.3f), t %.16e / %.16e, oracle %.0f s %s" % (
+                n, scheme, kind, diff, float(np.abs(yo).max()), t, to, time.time() - t0, kern), flush=True)
+            assert diff <= 1e-11 and abs(t - to) <= 1e-13 * to
 print("full-size oracle check: ok")

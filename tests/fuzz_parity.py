@@ -41,8 +41,11 @@ def case_range(rng, k):
     """A run-time Hamiltonian whose alpha reads the costate range (tests/test_gpu_round5.py's BurgersDrift), 2-D / 3-D / 4-D, through
     odeCFLn single steps (range pass + bound kernel with deltaT on the device + fused stages) against the oracle's general GLF protocol."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_round5 import BurgersDriftLocal as BurgersDrift, _burgers_src
+    from test_gpu_round5 import BurgersDriftLocal, _burgers_src, CoupledBurgers, _coupled_src
     dim = int(rng.integers(2, 5))
+    # half of the cases: alpha_0 / alpha_1 read the range of the OTHER dimension (the case in which LLF and LLLF differ)
+    coupled = bool(rng.random() < 0.5)
+    BurgersDrift, par0 = (CoupledBurgers, 0.6) if coupled else (BurgersDriftLocal, 0.7)
     # the dissipation variant: global range (GLF), per-node range in dimension i (LLF), per-node everywhere (LLLF)
     dk = str(rng.choice(["glf", "llf", "lllf"]))
     dfn = {"glf": L.artificialDissipationGLF, "llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[dk]
@@ -52,10 +55,12 @@ def case_range(rng, k):
     scheme = str(rng.choice(["ENO2", "ENO3", "WENO5_ASSHIPPED", "WENO5"]))
     g, og = mk(gmin, gmax, N, pd)
     d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[dim - 1]) + 0.02 * rng.standard_normal(N)
-    if dim not in _REG:
-        _REG[dim] = L.register_native_hamiltonian("burgers_drift_%dd" % dim, dim, _burgers_src(dim), nparams=1)
-    sys_ = _REG[dim](g, [0.7], hamiltonian=lambda s, t, data, p, sd: BurgersDrift(g, 0.7).hamiltonian(t, data, p, sd),
-                     dissipation=lambda s, t, data, dmin, dmax, sd, dm: BurgersDrift(g, 0.7).dissipation(t, data, dmin, dmax, sd, dm))
+    rk = (dim, coupled)
+    if rk not in _REG:
+        _REG[rk] = L.register_native_hamiltonian(("coupled_burgers_%dd" if coupled else "burgers_drift_%dd") % dim, dim,
+                                                 (_coupled_src if coupled else _burgers_src)(dim), nparams=1)
+    sys_ = _REG[rk](g, [par0], hamiltonian=lambda s, t, data, p, sd: BurgersDrift(g, par0).hamiltonian(t, data, p, sd),
+                    dissipation=lambda s, t, data, dmin, dmax, sd, dm: BurgersDrift(g, par0).dissipation(t, data, dmin, dmax, sd, dm))
     sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=dfn, CoStateCalc=DERIV[scheme]))
     order = int(rng.integers(1, 4))
     ode = {1: L.odeCFL1, 2: L.odeCFL2, 3: L.odeCFL3}[order]
@@ -65,7 +70,7 @@ def case_range(rng, k):
     yo, t, to = d0.reshape(-1, 1), 0., 0.
     for _ in range(2):
         t, y, _ = ode(L.termLaxFriedrichs, [t, 10.], y, op, sd)
-        to, yo = oode(lambda tt, yy: O.term_lax_friedrichs(og, BurgersDrift(og, 0.7), scheme, tt, yy, diss=dk), [to, 10.], yo, 0.8, single_step=True)
+        to, yo = oode(lambda tt, yy: O.term_lax_friedrichs(og, BurgersDrift(og, par0), scheme, tt, yy, diss=dk), [to, 10.], yo, 0.8, single_step=True)
     dg = device_grid(g, "float64")
     used = dg.lib.hj_last_kernel(dg.ctx).decode()
     got = y.cpu().numpy()
@@ -78,7 +83,7 @@ def case_range(rng, k):
         ok = err <= 1e-11 and abs(t - to) <= 1e-12 * to
     print("%4d range  N=%-18s pd=%-12s %-16s float64 order %d %-4s  kernel %-22s err %.2e %s" % (
         k, "x".join(map(str, N)), pd, scheme, order, dk, used, err, "ok" if ok else "MISMATCH"), flush=True)
-    return ok, "range-%s:%s" % (dk, used)
+    return ok, "range-%s%s:%s" % (dk, "-coupled" if coupled else "", used)
 
 
 def case(rng, k):

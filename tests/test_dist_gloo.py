@@ -303,8 +303,26 @@ class BurgersDriftOracle(object):
         return a + np.abs(self.c * self.grid.xs[0]) if dim == 1 else a
 
 
-CASES_DYN = [("WENO5_ASSHIPPED", False, 3, "glf"), ("ENO3", True, 2, "glf"), ("WENO5", False, 3, "glf"),
-             ("WENO5_ASSHIPPED", True, 3, "llf"), ("ENO2", False, 2, "lllf"), ("WENO5", False, 3, "llf")]
+class CoupledOracle(object):
+    """H = |p|^2/2 + c p0 p1: alpha_0 = max|p0| + |c| max|p1|, alpha_1 = max|p1| + |c| max|p0| -- alpha_i reads the range of ANOTHER dimension, so under
+    LLF the grid-wide (all-reduced) range of that dimension matters on every rank, and LLF / LLLF differ."""
+
+    def __init__(self, grid, c):
+        self.grid, self.c = grid, c
+
+    def hamiltonian(self, t, data, p, sd=None):
+        return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * p[0] * p[1]
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        am = lambda d: np.maximum(np.abs(dmin[d]), np.abs(dmax[d]))  # noqa: E731
+        a = am(dim) + (abs(self.c) * am(1 - dim) if dim < 2 else 0.0)
+        return float(a) if np.ndim(a) == 0 else a
+
+
+SYSTEMS = {"drift": lambda g: BurgersDriftOracle(g, 0.7), "coupled": lambda g: CoupledOracle(g, 0.6)}
+CASES_DYN = [("WENO5_ASSHIPPED", False, 3, "glf", "drift"), ("ENO3", True, 2, "glf", "drift"), ("WENO5", False, 3, "glf", "drift"),
+             ("WENO5_ASSHIPPED", True, 3, "llf", "drift"), ("ENO2", False, 2, "lllf", "drift"), ("WENO5", False, 3, "llf", "coupled"),
+             ("WENO5_ASSHIPPED", False, 3, "llf", "coupled"), ("WENO5_ASSHIPPED", True, 2, "lllf", "coupled"), ("WENO5_ASSHIPPED", False, 2, "glf", "coupled")]
 
 
 def _worker_dyn(rank, world, port, q):
@@ -313,12 +331,12 @@ def _worker_dyn(rank, world, port, q):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        for ci, (scheme, periodic0, order, kind) in enumerate(CASES_DYN):
+        for ci, (scheme, periodic0, order, kind, sysname) in enumerate(CASES_DYN):
             pd = [0, 2] if periodic0 else [2]
             og = O.Grid([-1., -1., -1.], [1. - (2. / N[0] if periodic0 else 0.), 1., 1. - 2. / N[2]], N, pd)
             data = O.shape_sphere(og, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
             slab = SlabDecomposition(N[0], world, rank, periodic0)
-            be = OracleSlabBackend(og, slab, scheme, make_sys=lambda g: BurgersDriftOracle(g, 0.7))
+            be = OracleSlabBackend(og, slab, scheme, make_sys=SYSTEMS[sysname])
             integ = SlabIntegrator(slab, be, [float(v) for v in og.dx.ravel()], order, 0.8, needs_eps=(scheme == "WENO5"), dynamic=True,
                                    diss=kind)
             integ.set_state(torch.from_numpy(np.ascontiguousarray(data[slab.begin:slab.end])))
@@ -345,11 +363,11 @@ def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for ci, (scheme, periodic0, order, kind) in enumerate(CASES_DYN):
+    for ci, (scheme, periodic0, order, kind, sysname) in enumerate(CASES_DYN):
         pd = [0, 2] if periodic0 else [2]
         og = O.Grid([-1., -1., -1.], [1. - (2. / N[0] if periodic0 else 0.), 1., 1. - 2. / N[2]], N, pd)
         data = O.shape_sphere(og, None, .5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
-        sys_ = BurgersDriftOracle(og, 0.7)
+        sys_ = SYSTEMS[sysname](og)
         term = lambda t, y: O.term_lax_friedrichs(og, sys_, scheme, t, y, diss=kind)  # noqa: E731
         ode = {2: O.ode_cfl_2, 3: O.ode_cfl_3}[order]
         y, t_ref, sb_last = data.reshape(-1, 1), 0.0, None
@@ -363,7 +381,7 @@ def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
             got[b:e] = ys
             assert abs(t - t_ref) <= 1e-13 * t_ref, (t, t_ref)
             assert abs(sb - sb_last) <= 1e-13 * sb_last
-        assert np.max(np.abs(got - y.reshape(N))) <= 1e-11, (scheme, periodic0, order, kind, world)
+        assert np.max(np.abs(got - y.reshape(N))) <= 1e-11, (scheme, periodic0, order, kind, sysname, world)
 
 
 def test_slab_decomposition_bookkeeping():

@@ -493,6 +493,149 @@ def test_run_time_kernels_first_compiled_by_several_threads_at_once():
         assert float((ys - nxt[b:e]).abs().max()) <= 1e-13
 
 
+# ------------------------------------------------------------------------------ alpha_i that reads the range of ANOTHER dimension
+class CoupledBurgers(object):
+    """H = sum_d p_d^2 / 2 + c p_0 p_1:  dH/dp_0 = p_0 + c p_1, so alpha_0 = max|p_0| + |c| max|p_1| and alpha_1 = max|p_1| + |c| max|p_0| over the
+    ranges handed in -- the case in which the three Lax-Friedrichs variants really differ: GLF takes both maxima over the grid, LLF the node's own
+    range in dimension i and the GRID's in the other (diss_local_laxfried.py:108-111), LLLF the node's own in both (diss_localsq_laxfried.py:87-90).
+    The entries of derivMin / derivMax arrive as scalars, arrays, or a mixture (NumPy for the oracle, torch on the split path)."""
+
+    def __init__(self, grid, c):
+        self.grid, self.c = grid, c
+
+    def hamiltonian(self, t, data, p, sd=None):
+        h = self.c * p[0] * p[1]
+        for d in range(len(p)):
+            h = h + 0.5 * p[d] * p[d]
+        return h
+
+    @staticmethod
+    def _amax(lo, hi, like):
+        if _is_t(lo) or _is_t(hi):
+            lo = lo if _is_t(lo) else torch.as_tensor(float(lo), device=like.device, dtype=like.dtype)
+            hi = hi if _is_t(hi) else torch.as_tensor(float(hi), device=like.device, dtype=like.dtype)
+            return torch.maximum(lo.abs(), hi.abs())
+        return np.maximum(np.abs(lo), np.abs(hi))
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        a = self._amax(dmin[dim], dmax[dim], data)
+        if dim > 1:
+            return a
+        other = 1 - dim
+        return a + abs(self.c) * self._amax(dmin[other], dmax[other], data)
+
+
+def _coupled_src(dim):
+    s = "H = par[0] * p[0] * p[1];\n"
+    for d in range(dim):
+        s += "H += 0.5 * p[%d] * p[%d];  alpha[%d] = fmax(fabs(dmin[%d]), fabs(dmax[%d]));\n" % (d, d, d, d, d)
+    s += "alpha[0] += fabs(par[0]) * fmax(fabs(dmin[1]), fabs(dmax[1]));\n"
+    return s + "alpha[1] += fabs(par[0]) * fmax(fabs(dmin[0]), fabs(dmax[0]));\n"
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "WENO5_ASSHIPPED", "WENO5"])
+@pytest.mark.parametrize("n,pd", [((44, 37), 1), ((21, 23, 26), 2), ((9, 8, 10, 11), None)])
+def test_cross_dimension_alpha_under_glf_llf_lllf_fused_vs_oracle_and_split(scheme, n, pd):
+    """alpha_0 reads the range of dimension 1 and vice versa: under LLF the OTHER dimension's range must be the grid's, under LLLF the node's own --
+    the three variants give three different terms and bounds (asserted), each equal to the oracle's and to the split path (the same object's
+    callbacks on device arrays).  BurgersDrift above cannot tell LLF from LLLF (its alpha_i reads dimension i only)."""
+    dim = len(n)
+    g, og = mk([-1.0] * dim, [1.0 - (2.0 / n[d] if pd == d else 0) for d in range(dim)], n, pd)
+    rng = np.random.default_rng(7)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[dim - 1]) + 0.02 * rng.standard_normal(n)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    diss_of = {"glf": L.artificialDissipationGLF, "llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}
+    sys_ = CoupledBurgers(g, 0.6)
+
+    def sd_of(kind):
+        return L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss_of[kind], CoStateCalc=DERIV[scheme]))
+    split = {k: L.termLaxFriedrichs(0., y, sd_of(k))[:2] for k in diss_of}                 # not attached yet: the split path
+    L.register_native_hamiltonian("coupled_burgers_%dd" % dim, dim, _coupled_src(dim), nparams=1).attach(sys_, params=lambda o: [o.c])
+    fused, bounds = {}, {}
+    for kind in diss_of:
+        f, sb_f, _ = L.termLaxFriedrichs(0., y, sd_of(kind))
+        assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+        yo, sbo = O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), scheme, 0., d0.reshape(-1, 1), diss=kind)
+        close(f.cpu().numpy(), yo, 1e-11, what="fused vs oracle, " + kind)
+        close(split[kind][0].cpu().numpy(), yo, 1e-11, what="split vs oracle, " + kind)
+        assert abs(sb_f - sbo) <= 1e-12 * sbo and abs(split[kind][1] - sbo) <= 1e-12 * sbo, (kind, sb_f, split[kind][1], sbo)
+        fused[kind], bounds[kind] = f, sb_f
+    # the three variants are three different terms here
+    assert float((fused["llf"] - fused["lllf"]).abs().max()) > 1e-6 and float((fused["glf"] - fused["llf"]).abs().max()) > 1e-6
+    assert bounds["glf"] < bounds["llf"] < bounds["lllf"]
+    # ... and through the integrators (deltaT from the variant's own bound)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    for kind in ("llf", "lllf"):
+        yy, t, yo2, to = y, 0., d0.reshape(-1, 1), 0.
+        for _ in range(2):
+            t, yy, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], yy, op, sd_of(kind))
+            to, yo2 = O.ode_cfl_3(lambda tt, v: O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), scheme, tt, v, diss=kind), [to, 10.], yo2, 0.8, single_step=True)
+        assert abs(t - to) <= 1e-12 * to, (kind, t, to)
+        if scheme.startswith("ENO"):
+            diff = np.abs(yy.cpu().numpy() - yo2)
+            assert np.mean(diff > 1e-11) <= 2e-3 and diff.max() <= 1e-3
+        else:
+            close(yy.cpu().numpy(), yo2, 1e-11, what="2 steps, " + kind)
+
+
+@pytest.mark.parametrize("kind,world,periodic0", [("llf", 3, False), ("llf", 2, True), ("lllf", 3, False), ("glf", 2, True)])
+def test_cross_dimension_alpha_virtual_ranks_equal_undivided(kind, world, periodic0):
+    """The same Hamiltonian across slabs: under LLF a rank whose slab does not hold the grid's extreme costates of dimension 1 gets them only from the
+    all-reduced range (hj_ctx_set_range_source) -- with a rank-local range alpha_0 would come out too small there.  Two RK3 steps, every rank equal to
+    the undivided grid through odeCFL3."""
+    import threading
+    from test_gpu_round4 import ThreadRing
+    from levelsetpy_amd.dist import SlabDecomposition, SlabIntegrator, HipSlabBackend
+    n = (33, 22, 24)
+    pd = [0, 2] if periodic0 else 2
+    g, og = mk([-1.0] * 3, [1.0 - (2.0 / n[0] if periodic0 else 0.0), 1.0, 1.0 - 2.0 / n[2]], n, pd)
+    # steep in dimension 1 near x0 = -1 only: the first slab holds the extreme of dimension 1, the others do not
+    d0 = O.shape_sphere(og, None, 0.5) + 0.3 * np.exp(-8 * (og.xs[0] + 1.0) ** 2) * np.sin(5 * og.xs[1]) + 0.1 * np.cos(2 * og.xs[2])
+    reg = L.register_native_hamiltonian("coupled_burgers_3d", 3, _coupled_src(3), nparams=1)
+    sys_ = CoupledBurgers(g, 0.6)
+    reg.attach(sys_, params=lambda o: [o.c])
+    full = torch.as_tensor(d0, device="cuda")
+    diss = {"glf": L.artificialDissipationGLF, "llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss, CoStateCalc=DERIV["WENO5_ASSHIPPED"]))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y, t_ref = full.reshape(-1, 1), 0.
+    for _ in range(2):
+        t_ref, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t_ref, 10.], y, op, sd)
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    ref = y.reshape(n)
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    tr = ThreadRing(world)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                slab = SlabDecomposition(n[0], world, rank, periodic0, self_exchange=periodic0)
+                be = HipSlabBackend(g, slab, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, [0.6], "float64")
+                integ = SlabIntegrator(slab, be, dxs, 3, 0.8, exchanger=tr.exchanger(slab), allreduce_max=tr.allreduce_max(rank), dynamic=True, diss=kind)
+                integ.set_state(full[slab.begin:slab.end])
+                t = 0.
+                for _ in range(2):
+                    t, dt = integ.step(t)
+                be.sync()
+                out[rank] = (slab.begin, slab.end, t, integ.state().clone())
+                be.sync()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            tr.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errs, errs
+    for r in range(world):
+        b, e, t, ys = out[r]
+        assert abs(t - t_ref) <= 1e-13 * t_ref, (t, t_ref)
+        assert float((ys - ref[b:e]).abs().max()) <= 1e-12, (r, float((ys - ref[b:e]).abs().max()))
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
