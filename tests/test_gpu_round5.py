@@ -636,6 +636,34 @@ def test_cross_dimension_alpha_virtual_ranks_equal_undivided(kind, world, period
         assert float((ys - ref[b:e]).abs().max()) <= 1e-12, (r, float((ys - ref[b:e]).abs().max()))
 
 
+@pytest.mark.parametrize("kind", ["glf", "llf", "lllf"])
+@pytest.mark.parametrize("n,pd", [((40, 36), 1), ((21, 23, 26), 2), ((9, 8, 10, 11), None)])
+def test_range_reading_hamiltonian_in_fp32_vs_fp64_oracle(kind, n, pd):
+    """The range path in single precision (run-time kernels are built per dtype; the range keys stay fp64 keys of fp32 costates): the cross-dimension
+    Hamiltonian under the three Lax-Friedrichs variants, term and one odeCFL3 step, against the fp64 oracle at fp32 tolerances."""
+    dim = len(n)
+    g, og = mk([-1.0] * dim, [1.0 - (2.0 / n[d] if pd == d else 0) for d in range(dim)], n, pd)
+    d0 = (O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[dim - 1])).astype(np.float32)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    assert y.dtype == torch.float32
+    diss = {"glf": L.artificialDissipationGLF, "llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sys_ = CoupledBurgers(g, 0.6)
+    L.register_native_hamiltonian("coupled_burgers_%dd" % dim, dim, _coupled_src(dim), nparams=1).attach(sys_, params=lambda o: [o.c])
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss, CoStateCalc=DERIV["WENO5_ASSHIPPED"]))
+    f, sb, _ = L.termLaxFriedrichs(0., y, sd)
+    assert _last_kernel(g).endswith(b"(hipRTC)") and f.dtype == torch.float32, _last_kernel(g)
+    d64 = d0.astype(np.float64).reshape(-1, 1)
+    yo, sbo = O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), "WENO5_ASSHIPPED", 0., d64, diss=kind)
+    scale = float(np.abs(yo).max())
+    assert float(np.abs(f.cpu().numpy().astype(np.float64) - yo).max()) <= 2e-4 * scale
+    assert abs(sb - sbo) <= 1e-4 * sbo, (sb, sbo)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sd)
+    to, yo1 = O.ode_cfl_3(lambda tt, v: O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), "WENO5_ASSHIPPED", tt, v, diss=kind), [0., 10.], d64, 0.8, single_step=True)
+    assert y1.dtype == torch.float32 and abs(t - to) <= 1e-4 * to, (t, to)
+    assert float(np.abs(y1.cpu().numpy().astype(np.float64) - yo1).max()) <= 1e-5 * max(1.0, float(np.abs(yo1).max()))
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
