@@ -90,22 +90,25 @@ def case(rng, k):
         ham, par, dtype, periodic0 = _ffi.HAM_DOUBLE_PENDULUM, PAR_PENDULUM, "float32", True
     elif dyn:
         periodic0 = bool(rng.random() < 0.5)
-        n = (n0, int(rng.integers(8, 36)), int(rng.integers(8, 36)))
-        pd = [0, 2] if periodic0 else 2
-        g = L.createGrid(np.array([[-1., -1., -1.]]).T, np.array([[1. - (2. / n[0] if periodic0 else 0.), 1., 1. - 2. / n[2]]]).T,
+        dd = int(rng.choice([2, 3, 3, 4]))                      # (round 5, late: 2-D and 4-D slabs too)
+        n = {2: (n0, int(rng.integers(12, 90))), 3: (n0, int(rng.integers(8, 36)), int(rng.integers(8, 36))),
+             4: (n0, int(rng.integers(6, 10)), int(rng.integers(6, 12)), int(rng.integers(8, 24)))}[dd]
+        pd = ([0] if periodic0 else []) + [dd - 1]
+        g = L.createGrid(-np.ones((dd, 1)), np.array([[1. - (2. / n[d] if d in pd else 0.) for d in range(dd)]]).T,
                          np.array(n, dtype=np.int64).reshape(-1, 1), pd, low_mem=True)
         xs = [torch.as_tensor(np.asarray(v).ravel(), device="cuda") for v in g.vs]
         gen = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
-        full = ((xs[0] ** 2).reshape(-1, 1, 1) + (xs[1] ** 2).reshape(1, -1, 1) + (xs[2] ** 2).reshape(1, 1, -1)).sqrt() - 0.5 \
-            + 0.1 * torch.sin(3 * xs[0]).reshape(-1, 1, 1) * torch.cos(2 * xs[2]).reshape(1, 1, -1) \
+        shp = lambda d: [-1 if k == d else 1 for k in range(dd)]  # noqa: E731
+        r2 = sum((xs[d] ** 2).reshape(shp(d)) for d in range(dd))
+        full = r2.sqrt() - 0.5 + 0.1 * torch.sin(3 * xs[0]).reshape(shp(0)) * torch.cos(2 * xs[dd - 1]).reshape(shp(dd - 1)) \
             + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
         full = full.contiguous()
         if rng.random() < 0.5:
-            reg = L.register_native_hamiltonian("coupled_burgers_3d", 3, _coupled_src(3), nparams=1)
+            reg = L.register_native_hamiltonian("coupled_burgers_%dd" % dd, dd, _coupled_src(dd), nparams=1)
             ham, par, dtype = reg.ham_id, [0.6], "float64"
             dyn = dyn + "+"         # (printed: the coupled expression)
         else:
-            reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+            reg = L.register_native_hamiltonian("burgers_drift_%dd" % dd, dd, _burgers_src(dd), nparams=1)
             ham, par, dtype = reg.ham_id, [0.7], "float64"
     else:
         n = (n0, int(rng.integers(8, 40)), int(rng.integers(8, 40)))
@@ -194,7 +197,7 @@ def case(rng, k):
     else:
         ok = abs(t_ref - t) <= 1e-15 and all(torch.equal(y, ref[b:e]) for b, e, y in got)
     print("%4d %s N=%-16s world %d (%s) %-16s order %d %-12s max|diff| %.2e %s" % (
-        k, "4-D fp32" if four else ("3-D range-alpha " + dyn if dyn else "3-D fp64"), "x".join(map(str, n)), world,
+        k, "4-D fp32" if four else ("%d-D range-alpha " % len(n) + dyn if dyn else "3-D fp64"), "x".join(map(str, n)), world,
         "/".join(str(e - b) for b, e, _ in got), scheme, order,
         "deep-halo" if deep else "per-substep", worst, "ok" if ok else "MISMATCH"), flush=True)
     return ok
