@@ -73,25 +73,26 @@ if what in ("c5", "both"):
           (q, diff, diff / scale, scale, abs(sb - sbo) / sbo, time.time() - t0), flush=True)
     assert diff <= 1e-4 * scale and abs(sb - sbo) <= 1e-5 * sbo
 if what == "range":
-    class Drift(object):            # H = |p|^2/2 + c x0 p1; alpha_d = max(|dmin_d|, |dmax_d|) (+ |c x0| for d = 1); scalars (GLF) or arrays (LLF / LLLF)
-        def __init__(self, grid, c):
+    class Drift(object):            # H = |p|^2/2 + c p0 p1: alpha_0 = max|p0| + |c| max|p1|, alpha_1 = max|p1| + |c| max|p0| over the ranges handed in --
+        def __init__(self, grid, c):    # alpha_i reads ANOTHER dimension's range, so GLF / LLF / LLLF are three different schemes; scalars or arrays
             self.grid, self.c = grid, c
 
         def hamiltonian(self, t, data, p, sd=None):
-            return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * np.asarray(self.grid.xs[0]) * p[1]
+            return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * p[0] * p[1]
 
         def dissipation(self, t, data, dmin, dmax, sd, dim):
-            a = np.maximum(np.abs(dmin[dim]), np.abs(dmax[dim]))
-            return a + np.abs(self.c * np.asarray(self.grid.xs[0])) if dim == 1 else a
-    src = "H = par[0] * x[0] * p[1];\n" + "".join(
-        "H += 0.5 * p[%d] * p[%d];  alpha[%d] = fmax(fabs(dmin[%d]), fabs(dmax[%d]));\n" % (d, d, d, d, d) for d in range(3)) + "alpha[1] += fabs(par[0] * x[0]);\n"
+            am = lambda d: np.maximum(np.abs(dmin[d]), np.abs(dmax[d]))  # noqa: E731
+            return am(dim) + (abs(self.c) * am(1 - dim) if dim < 2 else 0.0)
+    src = "H = par[0] * p[0] * p[1];\n" + "".join(
+        "H += 0.5 * p[%d] * p[%d];  alpha[%d] = fmax(fabs(dmin[%d]), fabs(dmax[%d]));\n" % (d, d, d, d, d) for d in range(3)) + \
+        "alpha[0] += fabs(par[0]) * fmax(fabs(dmin[1]), fabs(dmax[1]));\nalpha[1] += fabs(par[0]) * fmax(fabs(dmin[0]), fabs(dmax[0]));\n"
     n = int(os.environ.get("N", "201"))
     lo, hi = [-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n]
     g = L.createGrid(np.array([lo]).T, np.array([hi]).T, n * np.ones((3, 1), dtype=np.int64), 2)
     og = O.Grid(lo, hi, [n, n, n], [2])
     d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
-    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, src, nparams=1)
-    sysn = Drift(g, 0.7)
+    reg = L.register_native_hamiltonian("coupled_burgers_3d", 3, src, nparams=1)
+    sysn = Drift(g, 0.6)
     reg.attach(sysn, params=lambda o: [o.c])
     op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
     kinds = (("glf", L.artificialDissipationGLF), ("llf", L.artificialDissipationLLF), ("lllf", L.artificialDissipationLLLF))
@@ -103,7 +104,7 @@ if what == "range":
             dgx = dgs[next(iter(dgs))] if isinstance(dgs, dict) else dgs
             kern = dgx.lib.hj_last_kernel(dgx.ctx).decode()
             t0 = time.time()
-            osys = Drift(og, 0.7)
+            osys = Drift(og, 0.6)
             to, yo = O.ode_cfl_3(lambda tt, yy: O.term_lax_friedrichs(og, osys, scheme, tt, yy, diss=kind), [0., 10.], d0.reshape(-1, 1), 0.8, single_step=True)
             diff = float(np.abs(y.cpu().numpy() - yo).max())
             print("range-alpha %d^3 %-16s %-4s one odeCFL3 step vs oracle: max |diff| = %.3e (max |y| %.3f), t %.16e / %.16e, oracle %.0f s %s" % (
