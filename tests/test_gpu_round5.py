@@ -664,6 +664,37 @@ def test_range_reading_hamiltonian_in_fp32_vs_fp64_oracle(kind, n, pd):
     assert float(np.abs(y1.cpu().numpy().astype(np.float64) - yo1).max()) <= 1e-5 * max(1.0, float(np.abs(yo1).max()))
 
 
+@pytest.mark.parametrize("kind", ["glf", "llf", "lllf"])
+@pytest.mark.parametrize("positive", [0, 1])
+def test_restrict_update_around_a_range_reading_hamiltonian(kind, positive):
+    """termRestrictUpdate(termLaxFriedrichs) with the cross-dimension Hamiltonian: the flag-carrying instantiation of the run-time kernels (MODE 0: the
+    clamp of ydot) together with the range pass and the local evaluation; term and two odeCFL2 steps against the oracle."""
+    n = (22, 25, 24)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    y = torch.as_tensor(d0.reshape(-1), device="cuda")                 # (N,) vectors, as the air3D-style drivers call it
+    diss = {"glf": L.artificialDissipationGLF, "llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sys_ = CoupledBurgers(g, 0.6)
+    L.register_native_hamiltonian("coupled_burgers_3d", 3, _coupled_src(3), nparams=1).attach(sys_, params=lambda o: [o.c])
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss, CoStateCalc=DERIV["WENO5_ASSHIPPED"]))
+    sdr = L.Bundle(dict(innerFunc=L.termLaxFriedrichs, innerData=sd, positive=positive))
+    inner = lambda tt, v: O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), "WENO5_ASSHIPPED", tt, v, diss=kind)  # noqa: E731
+    oterm = O.term_restrict_update(inner, positive=bool(positive))
+    f, sb, _ = L.termRestrictUpdate(0., y, sdr)
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    yo, sbo = oterm(0., d0.reshape(-1))
+    close(f.cpu().numpy().reshape(-1), np.asarray(yo).reshape(-1), 1e-11, what="restricted term")
+    assert abs(sb - sbo) <= 1e-12 * sbo
+    assert (f >= 0).all() if positive else (f <= 0).all()
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    yy, t, yo2, to = y, 0., d0.reshape(-1), 0.
+    for _ in range(2):
+        t, yy, _ = L.odeCFL2(L.termRestrictUpdate, [t, 10.], yy, op, sdr)
+        to, yo2 = O.ode_cfl_2(oterm, [to, 10.], yo2, 0.8, single_step=True)
+    assert abs(t - to) <= 1e-12 * to
+    close(yy.cpu().numpy().reshape(-1), np.asarray(yo2).reshape(-1), 1e-11, what="2 restricted RK2 steps")
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
