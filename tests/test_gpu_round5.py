@@ -695,6 +695,59 @@ def test_restrict_update_around_a_range_reading_hamiltonian(kind, positive):
     close(yy.cpu().numpy().reshape(-1), np.asarray(yo2).reshape(-1), 1e-11, what="2 restricted RK2 steps")
 
 
+@pytest.mark.parametrize("mode", ["minVOverTime", "maxVOverTime"])
+def test_hjipde_solve_native_loop_with_a_cross_dimension_alpha_equals_the_step_loop_and_the_oracle(mode, monkeypatch):
+    """HJIPDE_solve over two tau intervals with the cross-dimension Hamiltonian (the solver installs artificialDissipationGLF itself, as the
+    reference does: hji_solver.py:433-434): the native loop (hj_rk_integrate: range pass, bound kernel, deltaT on the device, the min / max with the
+    step's start folded into the last stage) against the Python step loop, and against an oracle loop written out here (ode_cfl_3 single steps + the
+    reference's post-step min / max)."""
+    n = (24, 22, 20)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    sys_ = CoupledBurgers(g, 0.6)
+    L.register_native_hamiltonian("coupled_burgers_3d", 3, _coupled_src(3), nparams=1).attach(sys_, params=lambda o: [o.c])
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation))
+    tau = [0., 0.004, 0.009]
+    outs = []
+    for stepwise in ("0", "1"):
+        monkeypatch.setenv("HJ_HJIPDE_STEPWISE", stepwise)
+        data, _, _ = L.HJIPDE_solve(d0, tau, sd, mode, L.Bundle(dict(quiet=True, keepLast=True)))
+        outs.append(np.asarray(data))
+    assert np.array_equal(outs[0], outs[1])
+    term = lambda tt, v: O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), "WENO5_ASSHIPPED", tt, v)  # noqa: E731
+    yo = d0.reshape(-1, 1)
+    for i in range(1, len(tau)):
+        t = tau[i - 1]
+        while t < tau[i] - 1e-4:                      # hji_solver.py:185,536 (small = 1e-4)
+            y_prev = yo
+            t, yo = O.ode_cfl_3(term, [t, tau[i]], yo, 0.8, single_step=True)
+            yo = np.minimum(yo, y_prev) if mode == "minVOverTime" else np.maximum(yo, y_prev)
+    close(outs[0].reshape(-1), yo.reshape(-1), 1e-11, what="HJIPDE_solve vs oracle loop")
+
+
+@pytest.mark.parametrize("kind", ["glf", "llf", "lllf"])
+@pytest.mark.parametrize("order", [2, 3])
+def test_multi_step_span_with_a_cross_dimension_alpha_vs_oracle(kind, order):
+    """odeCFLn over a whole span (singleStep off: the native multi-step loop, hj_rk_integrate -> one dynamic step after the other, each with its
+    range pass / bound pass and deltaT formed on the device, the last one shortened to land on tspan[1]) under each Lax-Friedrichs variant."""
+    n = (24, 22, 20)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    diss = {"glf": L.artificialDissipationGLF, "llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sys_ = CoupledBurgers(g, 0.6)
+    L.register_native_hamiltonian("coupled_burgers_3d", 3, _coupled_src(3), nparams=1).attach(sys_, params=lambda o: [o.c])
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss, CoStateCalc=DERIV["WENO5_ASSHIPPED"]))
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8)))
+    ode, oode = {2: (L.odeCFL2, O.ode_cfl_2), 3: (L.odeCFL3, O.ode_cfl_3)}[order]
+    t, y, _ = ode(L.termLaxFriedrichs, [0., 0.011], torch.as_tensor(d0.reshape(-1, 1), device="cuda"), op, sd)
+    assert _last_kernel(g).endswith(b"(hipRTC)"), _last_kernel(g)
+    to, yo = oode(lambda tt, v: O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), "WENO5_ASSHIPPED", tt, v, diss=kind), [0., 0.011], d0.reshape(-1, 1), 0.8)
+    t = float(np.asarray(t).ravel()[-1])
+    to = float(np.asarray(to).ravel()[-1])
+    assert abs(t - to) <= 1e-13 and abs(t - 0.011) <= 1e-12, (t, to)
+    close(y.cpu().numpy().reshape(-1), np.asarray(yo).reshape(-1), 1e-11, what="multi-step span")
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
