@@ -271,3 +271,113 @@ def test_compiled_kernels_are_cached_on_disk(tmp_path):
     off = run("0")
     assert off["stats"] == [first["stats"][0], 0] and off["sha"] == first["sha"]
     assert [(f.name, f.stat().st_mtime_ns, f.stat().st_size) for f in sorted(cache.glob("*.hjco"))] == stamp
+
+
+# ------------------------------------------------------------------------------ the big shape of the run-time kernels (grids of 6.5 M cells and more)
+def _tile_cells(dg):
+    e = (C.c_int * 4)()
+    _ffi.check(dg.lib.hj_last_tile(dg.ctx, e))
+    return int(e[1]) * max(1, int(e[2]))
+
+
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO2"])
+def test_runtime_kernels_in_the_big_shape_equal_the_builtin_kernels(scheme):
+    """From 6.5 M cells the run-time kernels of a light stencil take the shape the built-in ones run there (512 threads x 2 pairs + the parked halo
+    ring; hj_rtc.hip, shape 1) -- every other test of this suite is below that size.  190 x 186 x 188 Dubins grid: the term and one odeCFL3 step of the
+    run-time expression against the built-in system (the same arithmetic in the same kernel template)."""
+    g, og = dubins([190, 186, 188])
+    d0 = O.shape_cylinder(og, 2, None, .5) + 0.03 * np.random.default_rng(2).standard_normal(og.shape)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    user = L.register_native_hamiltonian("dubins_rel_rt", 3, DUBINS_REL_SRC, nparams=4, column_src=DUBINS_REL_COL, ncol=2)(g, [1.0, 1.0, 1.0, 2.0])
+    builtin = L.DubinsVehicleRel(g, 1, 1)
+    dg = device_grid(g)
+    yd_u, sb_u, _ = L.termLaxFriedrichs(0., y, sdata(g, user, DERIV[scheme]))
+    assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel (hipRTC)" and _tile_cells(dg) > 1024, (dg.lib.hj_last_kernel(dg.ctx), _tile_cells(dg))
+    yd_b, sb_b, _ = L.termLaxFriedrichs(0., y, sdata(g, builtin, DERIV[scheme]))
+    assert abs(sb_u - sb_b) <= 1e-14 * sb_b
+    assert float((yd_u - yd_b).abs().max()) <= 1e-12 * float(yd_b.abs().max())
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    tu, yu, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sdata(g, user, DERIV[scheme]))
+    tb, yb, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sdata(g, builtin, DERIV[scheme]))
+    assert abs(tu - tb) <= 1e-14
+    diff = (yu - yb).abs()
+    if scheme.startswith("WENO"):
+        assert float(diff.max()) <= 1e-12
+    else:
+        assert float((diff > 1e-11).double().mean()) <= 2e-3 and float(diff.max()) <= 1e-3
+
+
+class WavyPy(object):
+    """A deliberately heavy expression (double-precision sines, cosines and exponentials of the coordinates in every coefficient): at two pairs per
+    thread it may not fit the register file, in which case the library falls back to the small shape for it (hj_rtc.hip, big_spills)."""
+
+    def __init__(self, grid, c):
+        self.grid, self.c = grid, c
+
+    def coeffs(self):
+        x0, x1, x2 = (np.asarray(v) for v in self.grid.xs)
+        a = np.sin(x0) * np.cos(x1) + np.exp(-x2 * x2)
+        b = np.cos(x0 + 0.5 * x1) * np.sin(2 * x2) - 0.3 * np.exp(-x0 * x0)
+        w = np.sin(x1 - x2) * np.cos(0.7 * x0) + 0.2
+        return a, b, w
+
+    def hamiltonian(self, t, data, p, sd=None):
+        a, b, w = self.coeffs()
+        return a * p[0] + b * p[1] + w * p[2] + self.c * (np.abs(p[0]) + np.abs(p[2]))
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        a, b, w = self.coeffs()
+        return [np.abs(a) + self.c, np.abs(b), np.abs(w) + self.c][dim]
+
+
+WAVY_SRC = """
+    const T a = sin(x[0]) * cos(x[1]) + exp(-x[2] * x[2]);
+    const T b = cos(x[0] + T(0.5) * x[1]) * sin(T(2) * x[2]) - T(0.3) * exp(-x[0] * x[0]);
+    const T w = sin(x[1] - x[2]) * cos(T(0.7) * x[0]) + T(0.2);
+    H = a * p[0] + b * p[1] + w * p[2] + par[0] * (fabs(p[0]) + fabs(p[2]));
+    alpha[0] = fabs(a) + par[0]; alpha[1] = fabs(b); alpha[2] = fabs(w) + par[0];
+"""
+
+
+def test_a_heavy_runtime_expression_on_a_big_grid_vs_oracle():
+    """The same size with an expression that is expensive in registers: whichever shape the library ends up with (the big one, or the small one after the
+    big one was found to need scratch), the term and its bound equal the oracle's; the shape taken is reported."""
+    n = (190, 186, 188)
+    g, og = mk([-1.0, -1.2, -0.9], [1.0, 1.2, 0.9 * (1 - 2 / n[2])], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    user = L.register_native_hamiltonian("wavy_3d", 3, WAVY_SRC, nparams=1)(g, [0.4])
+    dg = device_grid(g)
+    yd, sb, _ = L.termLaxFriedrichs(0., y, sdata(g, user, DERIV["WENO5_ASSHIPPED"]))
+    assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel (hipRTC)"
+    print("heavy expression at %d cells: tile of %d cells (%s shape)" % (int(np.prod(n)), _tile_cells(dg), "big" if _tile_cells(dg) > 1024 else "small"))
+    yo, sbo = O.term_lax_friedrichs(og, WavyPy(og, 0.4), "WENO5_ASSHIPPED", 0., d0.reshape(-1, 1))
+    close(yd.cpu().numpy(), yo, 1e-11, what="heavy expression vs oracle")
+    assert abs(sb - sbo) <= 1e-12 * sbo
+    # a second call takes the remembered shape; one RK2 step lands where the oracle lands
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t, y1, _ = L.odeCFL2(L.termLaxFriedrichs, [0., 10.], y, op, sdata(g, user, DERIV["WENO5_ASSHIPPED"]))
+    to, yo1 = O.ode_cfl_2(lambda tt, v: O.term_lax_friedrichs(og, WavyPy(og, 0.4), "WENO5_ASSHIPPED", tt, v), [0., 10.], d0.reshape(-1, 1), 0.8, single_step=True)
+    assert abs(t - to) <= 1e-13 * to
+    close(y1.cpu().numpy(), yo1, 1e-11, what="heavy expression, one RK2 step")
+
+
+@pytest.mark.parametrize("kind", ["llf", "lllf"])
+def test_a_range_reading_expression_on_a_big_grid_vs_oracle(kind):
+    """... and the range path at that size (range pass, local evaluation, in-kernel bound in the big shape): the cross-dimension Hamiltonian of
+    test_gpu_round5.py, term and bound against the oracle."""
+    from test_gpu_round5 import CoupledBurgers, _coupled_src
+    n = (190, 186, 188)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.1 * np.sin(3 * og.xs[0]) * np.cos(2 * og.xs[2])
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    sys_ = CoupledBurgers(g, 0.6)
+    L.register_native_hamiltonian("coupled_burgers_3d", 3, _coupled_src(3), nparams=1).attach(sys_, params=lambda o: [o.c])
+    diss = {"llf": L.artificialDissipationLLF, "lllf": L.artificialDissipationLLLF}[kind]
+    sd = L.Bundle(dict(grid=g, hamFunc=sys_.hamiltonian, partialFunc=sys_.dissipation, dissFunc=diss, CoStateCalc=DERIV["WENO5_ASSHIPPED"]))
+    dg = device_grid(g)
+    yd, sb, _ = L.termLaxFriedrichs(0., y, sd)
+    assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel (hipRTC)" and _tile_cells(dg) > 1024
+    yo, sbo = O.term_lax_friedrichs(og, CoupledBurgers(og, 0.6), "WENO5_ASSHIPPED", 0., d0.reshape(-1, 1), diss=kind)
+    close(yd.cpu().numpy(), yo, 1e-11, what="range path, big shape")
+    assert abs(sb - sbo) <= 1e-12 * sbo
