@@ -280,29 +280,31 @@ def _tile_cells(dg):
     return int(e[1]) * max(1, int(e[2]))
 
 
-@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO2"])
-def test_runtime_kernels_in_the_big_shape_equal_the_builtin_kernels(scheme):
+@pytest.mark.parametrize("scheme,dtype", [("WENO5_ASSHIPPED", "float64"), ("ENO2", "float64"), ("WENO5_ASSHIPPED", "float32")])
+def test_runtime_kernels_in_the_big_shape_equal_the_builtin_kernels(scheme, dtype):
     """From 6.5 M cells the run-time kernels of a light stencil take the shape the built-in ones run there (512 threads x 2 pairs + the parked halo
     ring; hj_rtc.hip, shape 1) -- every other test of this suite is below that size.  190 x 186 x 188 Dubins grid: the term and one odeCFL3 step of the
     run-time expression against the built-in system (the same arithmetic in the same kernel template)."""
     g, og = dubins([190, 186, 188])
     d0 = O.shape_cylinder(og, 2, None, .5) + 0.03 * np.random.default_rng(2).standard_normal(og.shape)
-    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda", dtype=getattr(torch, dtype))
+    tol = 1e-12 if dtype == "float64" else 2e-6          # (fp32: the same template and arithmetic, the compiler may contract differently)
     user = L.register_native_hamiltonian("dubins_rel_rt", 3, DUBINS_REL_SRC, nparams=4, column_src=DUBINS_REL_COL, ncol=2)(g, [1.0, 1.0, 1.0, 2.0])
     builtin = L.DubinsVehicleRel(g, 1, 1)
-    dg = device_grid(g)
+    dg = device_grid(g, dtype)
     yd_u, sb_u, _ = L.termLaxFriedrichs(0., y, sdata(g, user, DERIV[scheme]))
+    assert yd_u.dtype == y.dtype
     assert dg.lib.hj_last_kernel(dg.ctx) == b"fused_pair_kernel (hipRTC)" and _tile_cells(dg) > 1024, (dg.lib.hj_last_kernel(dg.ctx), _tile_cells(dg))
     yd_b, sb_b, _ = L.termLaxFriedrichs(0., y, sdata(g, builtin, DERIV[scheme]))
-    assert abs(sb_u - sb_b) <= 1e-14 * sb_b
-    assert float((yd_u - yd_b).abs().max()) <= 1e-12 * float(yd_b.abs().max())
+    assert abs(sb_u - sb_b) <= (1e-14 if dtype == "float64" else 1e-6) * sb_b
+    assert float((yd_u - yd_b).abs().max()) <= tol * float(yd_b.abs().max())
     op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
     tu, yu, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sdata(g, user, DERIV[scheme]))
     tb, yb, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sdata(g, builtin, DERIV[scheme]))
-    assert abs(tu - tb) <= 1e-14
+    assert abs(tu - tb) <= (1e-14 if dtype == "float64" else 1e-9)
     diff = (yu - yb).abs()
     if scheme.startswith("WENO"):
-        assert float(diff.max()) <= 1e-12
+        assert float(diff.max()) <= tol * 10
     else:
         assert float((diff > 1e-11).double().mean()) <= 2e-3 and float(diff.max()) <= 1e-3
 
