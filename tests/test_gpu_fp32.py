@@ -45,7 +45,7 @@ CASES = {
 }
 
 
-def _setup(system, shape):
+def _setup(system, shape, rounded=True):
     if system == "dubins":
         g, og = dubins(list(shape))
         sys_, osys = L.DubinsVehicleRel(g, 1, 1), O.DubinsRel(og, 1, 1)
@@ -54,7 +54,7 @@ def _setup(system, shape):
         g, og = mk([-1., -1.5], [1., 1.5], shape, None)
         sys_, osys = L.DoubleIntegrator(g, 1.25), O.DoubleIntegrator(og, 1.25)
         d0 = O.shape_sphere(og, None, .45) + 0.05 * np.sin(4 * og.xs[0]) * np.cos(3 * og.xs[1])
-    return g, og, sys_, osys, d0.astype(np.float32)
+    return g, og, sys_, osys, (d0.astype(np.float32) if rounded else d0)
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -213,3 +213,83 @@ def test_fp32_split_path_terms_and_gradients():
         scale = float(b.abs().max())
         # (termReinit's sign function and Godunov switches are discontinuous in the data: isolated cells may take the other branch in fp32)
         assert np.mean(ra > 5e-4 * scale) <= (5e-3 if name == "reinit" else 1e-4) and (name == "reinit" or ra.max() <= 5e-4 * scale), (name, ra.max(), scale)
+
+
+# ------------------------------------------------------------------------------ the 4-D fp32 kernel with compile-time tiles: every tile, the other light stencils
+@pytest.mark.parametrize("scheme", ["ENO2", "WENO5_ASSHIPPED", "ENO2_FAST"])
+@pytest.mark.parametrize("n,pd,tile", [((30, 24, 26, 140), (0, 1, 2, 3), (5, 6, 66)), ((200, 4, 40, 80), (0, 1, 2, 3), (3, 5, 66)),
+                                       ((40, 40, 40, 40), (0, 1, 2, 3), (5, 6, 34)), ((30, 24, 26, 140), (0, 2), (5, 6, 66))])
+def test_pair4_kernel_every_tile_and_light_stencil_equals_the_generic_pair_kernel(n, pd, tile, scheme, monkeypatch):
+    """fused_pair4_kernel (hj_fused4v.h) is instantiated per tile (5x6x66, 3x5x66, 5x6x34), light stencil (ENO2, as-shipped WENO5, fast ENO2), boundary
+    class (all-periodic or not) and stage class; the C5 tests run ONE of them.  Here each tile on a grid that selects it (2.5 M cells and more), each
+    stencil, periodic and mixed boundaries, the term (flag-carrying instantiation) and an RK3 step (the plain-stage instantiations) against the generic
+    pair kernel (HJ_PAIR4=0) on the same data: the same per-cell arithmetic, equal at fp32 rounding."""
+    import ctypes as C
+    from levelsetpy_amd import _ffi
+    from levelsetpy_amd.context import DeviceGrid
+    from test_gpu_configs import pendulum_grid
+    from test_gpu_round4 import sphere4, PAR_PENDULUM
+    fast = scheme.endswith("_FAST")
+    sid = {"ENO2": _ffi.SCHEME_IDS["ENO2"], "WENO5_ASSHIPPED": _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], "ENO2_FAST": 4}[scheme]
+    res = {}
+    for pair4 in ("1", "0"):
+        monkeypatch.setenv("HJ_PAIR4", pair4)
+        g, _ = pendulum_grid(n, pd=pd, low_mem=True)
+        dg = DeviceGrid(g, "float32")
+        dg.bind_stream()
+        y = sphere4(g, noise=0.01, seed=3)
+        par = _ffi.darr(PAR_PENDULUM)
+        yd, sb = torch.empty_like(y), C.c_double()
+        _ffi.check(dg.lib.hj_lf_term(dg.ctx, sid, _ffi.HAM_DOUBLE_PENDULUM, par, 0., 0, dg.ptr(y), dg.ptr(yd), C.byref(sb)))
+        kern = dg.lib.hj_last_kernel(dg.ctx)
+        e = (C.c_int * 4)()
+        _ffi.check(dg.lib.hj_last_tile(dg.ctx, e))
+        if pair4 == "1":
+            assert kern == b"fused_pair4_kernel" and (e[1], e[2], e[3]) == tile, (kern, list(e))
+        else:
+            assert kern == b"fused_pair_kernel", kern
+        nxt, w0, w1 = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        tout, dtout = C.c_double(), C.c_double()
+        _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, sid, _ffi.HAM_DOUBLE_PENDULUM, par, 0., 1e9, 0.8, 1e300, 0, dg.ptr(y), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1),
+                                     C.byref(tout), C.byref(dtout)))
+        torch.cuda.synchronize()
+        res[pair4] = (yd, sb.value, nxt, tout.value, y)
+    a, b = res["1"], res["0"]
+    assert abs(a[1] - b[1]) <= 1e-6 * b[1] and abs(a[3] - b[3]) <= 1e-6 * b[3]
+    scale = float(b[0].abs().max())
+    d = (a[0] - b[0]).abs()
+    if fast or scheme == "ENO2":
+        assert float((d > 1e-4 * scale).float().mean()) <= 1e-3 and float(d.max()) <= 0.2 * scale, (float(d.max()), scale)
+    else:
+        assert float(d.max()) <= 1e-4 * scale, (float(d.max()), scale)
+    d2 = (a[2] - b[2]).abs()
+    assert float((d2 > 2e-6).float().mean()) <= 1e-3 and float(d2.max()) <= 1e-3, float(d2.max())
+    assert bool(torch.isfinite(a[2]).all()) and float((a[2] - a[4]).abs().max()) > 1e-5          # the step moved the data
+
+
+@pytest.mark.parametrize("scheme", ["ENO2", "ENO3"])
+@pytest.mark.parametrize("system,size", [("dubins", "mid"), ("integrator", "big"), ("dubins", "small"), ("dubins", "big")])
+def test_fp64_fast_eno_mode_across_size_classes(system, size, scheme, monkeypatch):
+    """set_eno_mode('fast') in double precision on every size class (direct, one-cell-per-lane, pair kernel): the lean arithmetic against the
+    reference-order one -- the same stencil choice except where two divided differences tie to rounding, so equal to ~1e-12 nearly everywhere."""
+    if size == "small":
+        monkeypatch.setenv("HJ_DIRECT_BELOW", "140000")
+    # (data NOT rounded to fp32: on the fine grids the third differences of fp32-rounded data are rounding noise, and every stencil choice a tie)
+    g, og, sys_, osys, d0 = _setup(system, CASES[system][size], rounded=False)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    sd = sdata(g, sys_, DERIV[scheme])
+    exact, sbe, _ = L.termLaxFriedrichs(0., y, sd)
+    L.set_eno_mode('fast')
+    try:
+        fast, sbf, _ = L.termLaxFriedrichs(0., y, sd)
+        op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+        tf, yf, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sd)
+    finally:
+        L.set_eno_mode('exact')
+    te, ye, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sd)
+    assert abs(sbe - sbf) <= 1e-13 * sbe and abs(te - tf) <= 1e-13 * te
+    scale = float(exact.abs().max())
+    d = (fast - exact).abs()
+    assert float((d > 1e-10 * scale).double().mean()) <= 2e-3 and float(d.max()) <= 0.2 * scale, (float((d > 1e-10 * scale).double().mean()), float(d.max()))
+    d2 = (yf - ye).abs()
+    assert float((d2 > 1e-11).double().mean()) <= 2e-3 and float(d2.max()) <= 1e-3
