@@ -98,13 +98,13 @@ def case(rng, k):
         pd = [d for d in range(3) if rng.random() < (0.8 if d == 2 else 0.2)]
         gmin, gmax = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi]
         mkp, mko = (lambda g: L.DubinsVehicleRel(g, 1, 1)), (lambda og: O.DubinsRel(og, 1, 1))
-        dtype = "float64"
+        dtype = "float32" if rng.random() < 0.3 else "float64"         # (round 5, late: single precision on the 2-D / 3-D systems too)
     elif which == "dint":
         N = [int(rng.integers(9, 160)) for _ in range(2)]
         pd = [d for d in range(2) if rng.random() < 0.2]
         gmin, gmax = [-1., -1.], [1., 1.]
         mkp, mko = (lambda g: L.DoubleIntegrator(g, 1)), (lambda og: O.DoubleIntegrator(og, 1))
-        dtype = "float64"
+        dtype = "float32" if rng.random() < 0.3 else "float64"
     else:
         N = [int(rng.integers(7, 15)), int(rng.integers(7, 20)), int(rng.integers(7, 20)), int(rng.choice([rng.integers(8, 40), rng.integers(34, 140)]))]
         pd = [0, 1, 2, 3] if rng.random() < 0.6 else [d for d in range(4) if rng.random() < 0.5]
