@@ -118,8 +118,10 @@ def case(rng, k):
         gen = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
         full = ((xs[0] ** 2).reshape(-1, 1, 1) + (xs[1] ** 2).reshape(1, -1, 1)).sqrt() - 0.5 + 0.05 * torch.sin(3 * xs[2]).reshape(1, 1, -1) \
             + 0.02 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
-        full = full.contiguous()
         ham, par, dtype, periodic0 = _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], "float64", False
+        if rng.random() < 0.3:                                  # (round 5, late: the 3-D system in single precision too)
+            dtype, full = "float32", full.float()
+        full = full.contiguous()
     dxs = [float(v) for v in np.asarray(g.dx).ravel()]
     sid = _ffi.SCHEME_IDS[scheme]
     steps = 3
@@ -197,7 +199,7 @@ def case(rng, k):
     else:
         ok = abs(t_ref - t) <= 1e-15 and all(torch.equal(y, ref[b:e]) for b, e, y in got)
     print("%4d %s N=%-16s world %d (%s) %-16s order %d %-12s max|diff| %.2e %s" % (
-        k, "4-D fp32" if four else ("%d-D range-alpha " % len(n) + dyn if dyn else "3-D fp64"), "x".join(map(str, n)), world,
+        k, "4-D fp32" if four else ("%d-D range-alpha " % len(n) + dyn if dyn else "3-D " + ("fp32" if dtype == "float32" else "fp64")), "x".join(map(str, n)), world,
         "/".join(str(e - b) for b, e, _ in got), scheme, order,
         "deep-halo" if deep else "per-substep", worst, "ok" if ok else "MISMATCH"), flush=True)
     return ok
