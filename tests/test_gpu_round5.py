@@ -748,6 +748,41 @@ def test_multi_step_span_with_a_cross_dimension_alpha_vs_oracle(kind, order):
     close(y.cpu().numpy().reshape(-1), np.asarray(yo).reshape(-1), 1e-11, what="multi-step span")
 
 
+def test_strided_inputs_are_read_in_logical_order():
+    """Callers hand over whatever layout they have: a strided view of a larger tensor, a column of a 2-column array, a Fortran-ordered NumPy array, an
+    fp64 array for an fp64 problem stored with a byte offset.  The reference reads them through y.reshape(grid.shape) -- logical order -- and so must the
+    drop-in (context.to_device makes a contiguous copy); results equal the contiguous call bit for bit, and the caller's array is not written."""
+    from test_gpu_parity import dubins
+    g, og = dubins([26, 24, 22])
+    d0 = O.shape_cylinder(og, 2, None, .5) + 0.05 * np.sin(3 * og.xs[0])
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), L.upwindFirstWENO5)
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    ref_term = L.termLaxFriedrichs(0., y, sd)[0]
+    t_ref, ref_step, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], y, op, sd)
+    wide = torch.zeros((y.numel(), 3), device="cuda", dtype=torch.float64)
+    wide[:, 1] = y.reshape(-1)
+    col = wide[:, 1:2]                                            # (N, 1) with stride 3
+    assert not col.is_contiguous()
+    every_other = torch.zeros(2 * y.numel(), device="cuda", dtype=torch.float64)
+    every_other[::2] = y.reshape(-1)
+    keep = wide.clone()
+    for view in (col, every_other[::2].reshape(-1, 1)):
+        assert torch.equal(L.termLaxFriedrichs(0., view, sd)[0].reshape(-1), ref_term.reshape(-1))
+        t, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], view, op, sd)
+        assert t == t_ref and torch.equal(y1.reshape(-1), ref_step.reshape(-1))
+    assert torch.equal(wide, keep)
+    # NumPy: Fortran order, and a view into a larger buffer
+    f = np.asfortranarray(d0)
+    assert not f.flags.c_contiguous
+    buf = np.zeros((d0.size, 2))
+    buf[:, 0] = d0.reshape(-1)
+    for arr in (f, buf[:, 0:1]):
+        t, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [0., 10.], arr.reshape(-1, 1) if arr.ndim == 3 else arr, op, sd)
+        assert t == t_ref and np.array_equal(np.asarray(y1).reshape(-1), ref_step.cpu().numpy().reshape(-1))
+    assert np.array_equal(buf[:, 0], d0.reshape(-1)) and np.array_equal(f, d0)
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
