@@ -875,6 +875,10 @@ int slab_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par,
         }
         return HJ_OK;
     }
+    // (as in slab_substep: every launch of such a Hamiltonian would reduce the range of ITS planes -- a rank-local range, silently different from
+    //  the undivided grid's)
+    if (user_ham_dynamic(ham))
+        return fail(HJ_EUNSUPPORTED, "a range-dependent alpha needs the costate range of ALL ranks before a substep: use dist.SlabIntegrator (dynamic=True), not the native stepper");
     if (!aux) return fail(HJ_ESTATE, "hj_comm_init / hj_comm_init_external has not been called");
     if (c->pad0 < D) return fail(HJ_ESTATE, "axis-0 tables cover %d pad planes, order %d needs %d (hj_ctx_set_axis0_pad)", c->pad0, order, D);
     if (n < 2 * D) return fail(HJ_EUNSUPPORTED, "slab of %lld planes is too thin for the deep-halo stepper (needs %d)", (long long)n, 2 * D);

@@ -783,6 +783,23 @@ def test_strided_inputs_are_read_in_logical_order():
     assert np.array_equal(buf[:, 0], d0.reshape(-1)) and np.array_equal(f, d0)
 
 
+def test_native_slab_steppers_refuse_a_range_reading_hamiltonian():
+    """hj_slab_rk_step / hj_slab_rk_step_deep on a slab with neighbours and a Hamiltonian whose alpha reads the costate range: every launch would reduce
+    the range of its own planes -- a rank-local range, silently different from the undivided grid's.  Both refuse (dist.SlabIntegrator(dynamic=True)
+    all-reduces the range); the deep stepper did not until late in round 5."""
+    n = (40, 20, 22)
+    g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0 - 2.0 / n[2]], n, 2)
+    reg = L.register_native_hamiltonian("burgers_drift_3d", 3, _burgers_src(3), nparams=1)
+    dg = DeviceGrid(g, "float64", None, (10, 30, True, True))
+    bufs = [torch.zeros((20 + 18,) + n[1:], device="cuda", dtype=torch.float64) for _ in range(4)]
+    ptr = [C.c_void_p(b[9:].data_ptr()) for b in bufs]
+    par = _ffi.darr([0.7])
+    for fn in (dg.lib.hj_slab_rk_step_deep, dg.lib.hj_slab_rk_step):
+        rc = fn(dg.ctx, 3, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, par, 1e-3, 0, ptr[0], ptr[1], ptr[2], ptr[3])
+        assert rc == -3, rc                                   # HJ_EUNSUPPORTED
+        assert b"range" in dg.lib.hj_last_error()
+
+
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
 def _dilate(mask, r):
     """cells within r of a marked cell along any axis (box dilation: an upper bound of the domain of dependence of a substep)"""
