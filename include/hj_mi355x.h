@@ -353,7 +353,9 @@ int hj_rk_prev_bounds(hj_ctx* ctx, double* sb_host /* 3 */, int* n_host, double*
 /* Decomposed grids: the range of ONE slab is not the grid's.  hj_range_pass reduces derivL / derivR of the ctx's planes (pads read
  * where the slab has neighbours) into 2*HJ_MAX_DIM order-preserving 64-bit keys at keys_dev ([d] max, [HJ_MAX_DIM-independent ndim + d]
  * -min; an element-wise MAX over ranks of the keys is the reduction); hj_ctx_set_range_source makes later launches read the
- * range from such keys instead of running their own pass (NULL: back to per-launch passes).  No reference counterpart. */
+ * range from such keys instead of running their own pass (NULL: back to per-launch passes).  A context that IS a slab with neighbours refuses
+ * to launch such a Hamiltonian before a range source has been set (HJ_ESTATE: its own pass would give a rank-local range), and the native slab
+ * steppers refuse it altogether (HJ_EUNSUPPORTED: dist.SlabIntegrator(dynamic=True) is the path).  No reference counterpart. */
 int hj_range_pass(hj_ctx* ctx, int scheme, int ham_id, const double* ham_params, const void* y, void* keys_dev);
 /* The local Lax-Friedrichs kinds (HJ_DISS_LLF / HJ_DISS_LLLF) of an HJ_HAM_RANGE Hamiltonian: alpha depends on every node's own costates,
  * so stepBound is a maximum over the stencil results.  hj_bound_pass runs the substep kernel over the ctx's planes storing nothing and

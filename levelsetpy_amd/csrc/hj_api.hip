@@ -1851,6 +1851,8 @@ int hj_bound_pass(hj_ctx* c, int scheme, int ham, const double* par, const void*
     if (!user_ham_dynamic(ham)) return fail(HJ_EINVAL, "Hamiltonian %d does not read the costate range", ham);
     if (c->diss_kind == HJ_DISS_GLF) return fail(HJ_ESTATE, "the bound pass belongs to the local Lax-Friedrichs kinds (hj_ctx_set_dissipation); the global one has hj_range_alpha_max");
     int rc;
+    if (c->diss_kind != HJ_DISS_LLLF && !c->range_src && (c->halo_lo || c->halo_hi))
+        return fail(HJ_ESTATE, "LLF on a slab reads the range of the WHOLE grid in the other dimensions: hj_range_pass, reduce over the ranks, hj_ctx_set_range_source first");
     if (c->diss_kind != HJ_DISS_LLLF && !c->range_src) {     // LLF reads the grid-wide range in the other dimensions: this ctx's own, unless told
         SubstepCall r{scheme, ham, HJ_STAGE_YDOT, 0, par, 0.0, y, nullptr, c->keys /* unused as an array */, nullptr, 0, c->N[0]};
         r.range_only = true;

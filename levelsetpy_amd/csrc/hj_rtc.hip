@@ -480,6 +480,10 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
         // Skipped when the caller supplies the range itself (hj_ctx_set_range_source: a slab of a decomposed grid, whose range is
         // the reduction over all ranks).
         if (s.gated) return fail(HJ_EUNSUPPORTED, "Hamiltonians with a range-dependent alpha do not run in gated slab launches");
+        // a slab with neighbours: a pass of its own planes would give a rank-local range where the grid's is meant (only hj_range_pass, whose
+        // result the caller reduces over the ranks, may run one)
+        if (!s.range_only && (c->halo_lo || c->halo_hi))
+            return fail(HJ_ESTATE, "a slab's launches of '%s' read the range of the WHOLE grid: hj_range_pass, reduce over the ranks, hj_ctx_set_range_source first", u.name.c_str());
         if (!(s.range_only && s.range_out)) {
             if ((rc = next_range_keys(c))) return rc;           // a zeroed entry of the ring: no memset launch
             K.A.ham.range = c->range_keys;                      // (fill_ham ran before the ring advanced)

@@ -798,6 +798,20 @@ def test_native_slab_steppers_refuse_a_range_reading_hamiltonian():
         rc = fn(dg.ctx, 3, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, par, 1e-3, 0, ptr[0], ptr[1], ptr[2], ptr[3])
         assert rc == -3, rc                                   # HJ_EUNSUPPORTED
         assert b"range" in dg.lib.hj_last_error()
+    # ... and a plain substep / an LLF bound pass on such a slab before the all-reduced range has been set (dist.SlabIntegrator always sets it)
+    rc = dg.lib.hj_rk_substep(dg.ctx, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, par, 0., _ffi.STAGE_EULER, 1e-3, 0, ptr[0], C.c_void_p(0), ptr[1], 0, 0, 20)
+    assert rc == -4 and b"WHOLE grid" in dg.lib.hj_last_error(), (rc, dg.lib.hj_last_error())       # HJ_ESTATE
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_LLF))
+    sb = C.c_double()
+    rc = dg.lib.hj_bound_pass(dg.ctx, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, par, ptr[0], C.byref(sb))
+    assert rc == -4 and b"WHOLE grid" in dg.lib.hj_last_error(), (rc, dg.lib.hj_last_error())
+    _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, _ffi.DISS_GLF))
+    keys = torch.zeros(8, dtype=torch.int64, device="cuda")
+    _ffi.check(dg.lib.hj_range_pass(dg.ctx, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, par, ptr[0], C.c_void_p(keys.data_ptr())))      # the pass itself runs
+    _ffi.check(dg.lib.hj_ctx_set_range_source(dg.ctx, C.c_void_p(keys.data_ptr())))
+    _ffi.check(dg.lib.hj_rk_substep(dg.ctx, _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], reg.ham_id, par, 0., _ffi.STAGE_EULER, 1e-3, 0, ptr[0], C.c_void_p(0), ptr[1], 0, 0, 20))
+    _ffi.check(dg.lib.hj_ctx_set_range_source(dg.ctx, C.c_void_p(0)))
+    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------ opt-in fast ENO arithmetic (set_eno_mode('fast'))
