@@ -15,3 +15,7 @@ HJ_LIB=$out/libhj_asan.so LD_PRELOAD=$rt ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIO
   python -m pytest tests/test_cabi.py tests/test_host_logic.py tests/test_bench_launcher.py -q -s -m "not gpu" > $out/cpu_tests.log 2>&1 || true
 tail -1 $out/cpu_tests.log
 echo "sanitizer reports: $(grep -c 'runtime error\|AddressSanitizer' $out/cpu_tests.log)"
+# UBSan alone also runs on the GPU box (no interceptors): build with  -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize=vptr , link with
+# -fsanitize=undefined -fno-sanitize=vptr into an in-tree directory (gpurun_out/ does not travel), and run
+#   HJ_LIB=<that library> LD_PRELOAD=<libclang_rt.ubsan_standalone-x86_64.so> python -m pytest tests -m gpu --deselect tests/test_gpu_fuzz.py
+# (profiles/r05_host_sanitizers.txt: 620 passed, 0 reports)
