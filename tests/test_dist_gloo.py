@@ -348,7 +348,7 @@ def _worker_dyn(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_range_dependent_alpha_over_ranks_equals_single_domain(world):
     """A Hamiltonian whose alpha reads derivMin / derivMax, slab-decomposed: every substep all-reduces the 2*D range values of the
     slabs, the first stage of a step all-reduces max(alpha) for deltaT; the decomposed run equals the undivided oracle run.
