@@ -1210,6 +1210,7 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->flag) (void)hipFree(c->flag);
     if (c->partials) (void)hipFree(c->partials);
     for (int i = 0; i < 2; ++i) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
+    if (c->ev_bounds) (void)hipEventDestroy(c->ev_bounds);
     if (c->eps_prod) (void)hipFree(c->eps_prod);
     if (c->eps_rows) (void)hipFree(c->eps_rows);
     delete c;
@@ -1743,7 +1744,11 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
         memcpy(&sb1, &bits_sb, sizeof(double));
         memcpy(&dt_step, &bits_dt, sizeof(double));
         // the previous step's later-stage bounds (copied asynchronously at its end, ahead of everything this step enqueued) have landed
-        if (c->stage_bounds_pending) decode_stage_bounds(c);
+        // -- on the stream they were issued on; the caller may have re-bound the ctx to another stream since (hj_ctx_set_stream): the event says so
+        if (c->stage_bounds_pending) {
+            if (c->ev_bounds) HIP_TRY(hipEventSynchronize(c->ev_bounds));
+            if ((rc = decode_stage_bounds(c))) return rc;
+        }
     }
     const double dt = dt_step;
     c->last_bounds[0] = sb1;
@@ -1776,6 +1781,8 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
             if (order == 3)
                 HIP_TRY(hipMemcpyAsync(c->host_words + 12, c->ring + (size_t)pos3 * HJ_MAX_DIM, HJ_MAX_DIM * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         }
+        if (!c->ev_bounds) HIP_TRY(hipEventCreateWithFlags(&c->ev_bounds, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_bounds, c->stream));
         c->stage_bounds_pending = order - 1;
         c->stage_bounds_dt = dt;
     }
@@ -1792,7 +1799,8 @@ static int rk_step_dynamic(hj_ctx* c, int order, int scheme, int ham, const doub
 int hj_rk_last_bounds(hj_ctx* c, double* sb, int* n) {
     if (!c || !sb || !n) return fail(HJ_EINVAL, "null argument");
     if (c->stage_bounds_pending) {          // the last step's later stages may still be running: this call waits for them
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->ev_bounds) HIP_TRY(hipEventSynchronize(c->ev_bounds));      // (the stream the copies went out on, whatever the ctx is bound to now)
+        else HIP_TRY(hipStreamSynchronize(c->stream));
         const int nst = c->stage_bounds_pending;
         int rc = decode_stage_bounds(c);
         if (rc) return rc;

@@ -145,6 +145,7 @@ struct hj_ctx {
     unsigned long long* host_words = nullptr;
     unsigned long long host_seq = 0;
     int stage_bounds_pending = 0;                   // stages whose bounds are on their way into host_words[8..] (0: none)
+    hipEvent_t ev_bounds = nullptr;                 // recorded behind those copies, on the stream they were issued on
     double stage_bounds_dt = 0;                     // deltaT of the step they belong to
     double prev_bounds[3] = {0, 0, 0}, prev_bounds_dt = 0;   // the newest step whose later-stage bounds have been decoded (hj_rk_prev_bounds)
     int prev_bounds_n = 0;

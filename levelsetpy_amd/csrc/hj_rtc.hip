@@ -89,7 +89,7 @@ struct UserHam {
     int ndim = 0, nparams = 0, ncol = 0, flags = 0;
     // key: ((((device * 2 + fp32) * 4 + scheme) * 4 + MODE) * 4 + shape)    shape: 0 small pair, 1 big pair, 2 one cell per lane (4-D fp64)
     std::map<long long, UserKernel> substep;
-    std::map<int, bool> big_spills;         // key: (fp32 * 4 + scheme) * 4 + MODE -- the big shape needed scratch for this expression
+    std::map<int, bool> big_spills;         // key: (fp32 * 8 + scheme) * 4 + MODE -- the big shape needed scratch for this expression
     bool no_big_lds = false;                // the runtime refused > 64 KB of dynamic LDS for a module function
     std::map<int, UserKernel> alpha;        // key: device * 2 + fp32
 };
@@ -211,7 +211,11 @@ static unsigned long long headers_hash(const std::string& include_dir, unsigned 
     std::string text;
     for (const char* f : files) {
         if (read_file(include_dir + f, text)) h = fnv1a(text.data(), text.size(), h);
-        else ok = false;
+        else {
+            // the key cannot cover this header's text: the caller keeps the disk cache OFF for this include directory (and says so once)
+            ok = false;
+            fprintf(stderr, "[hj] run-time kernels: cannot read %s%s -- the on-disk code-object cache is disabled\n", include_dir.c_str(), f);
+        }
     }
     memo[key] = std::make_pair(h, ok);
     return h;
@@ -379,12 +383,13 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
     const bool light = light_scheme(s.scheme);
     const bool dynamic = (u.flags & HJ_HAM_RANGE) != 0;
-    const int spill_key = ((F32 ? 1 : 0) * 4 + s.scheme) * 4 + mode;
+    const int spill_key = ((F32 ? 1 : 0) * 8 + s.scheme) * 4 + mode;      // (scheme ids run to HJ_ENO3_FAST = 5: radix 8)
     int shape = 0;
     if (ND == 4) shape = (F32 && light) ? 3 : 2;
     else if (light && c->total >= 6500000 && c->pair != 0 && !u.big_spills[spill_key]) shape = 1;
     auto kernel_of = [&](int shp, int md) -> UserKernel& {
-        return u.substep[((((long long)c->device * 2 + (F32 ? 1 : 0)) * 4 + s.scheme) * 4 + md) * 4 + shp];
+        static_assert(HJ_ENO3_FAST < 8, "kernel-table key: scheme radix");
+        return u.substep[((((long long)c->device * 2 + (F32 ? 1 : 0)) * 8 + s.scheme) * 4 + md) * 4 + shp];
     };
     UserKernel* k = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -571,7 +576,8 @@ static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long lo
     // HJ_ALPHA_BLOCKS / HJ_ALPHA_THREADS: tuning knobs (tools/experiments/r05_alpha_sweep.py)
     static const int env_blocks = getenv("HJ_ALPHA_BLOCKS") ? atoi(getenv("HJ_ALPHA_BLOCKS")) : 0;
     static const int env_threads = getenv("HJ_ALPHA_THREADS") ? atoi(getenv("HJ_ALPHA_THREADS")) : 0;
-    const unsigned nthr = env_threads > 0 ? (unsigned)env_threads : 512u;
+    // (alpha_bound_kernel's launch bound and its reduction scratch hold 1024 threads = 16 waves; whole waves only)
+    const unsigned nthr = env_threads > 0 ? (unsigned)std::max(64, std::min(1024, env_threads & ~63)) : 512u;
     const unsigned nblk = env_blocks > 0 ? (unsigned)std::min(env_blocks, ALPHA_BLOCKS_MAX) : blocks;
     return module_launch(ak.fn, nblk, nthr, 0, c->stream, &K, sizeof(K));
 }

@@ -450,12 +450,15 @@ __global__ __launch_bounds__(1024) void alpha_bound_kernel(GridArgs<T, HAM::ND> 
     if (wv == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            const unsigned long long before = __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // RELEASE at agent scope: ONE fence per workgroup -- the wave that stored the partials orders them before its
+            // count, by the HIP memory model rather than by what the sc1 stores happen to do on gfx950 (the s_waitcnt above stays: it is free)
+            const unsigned long long before = __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             last_flag = before == (unsigned long long)gridDim.x - 1ull;
         }
     }
     __syncthreads();
     if (!last_flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ... and the last workgroup acquires before it reads the others' partials
 #pragma unroll
     for (int d = 0; d <= ND; ++d) m[d] = -1e300;
     for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {

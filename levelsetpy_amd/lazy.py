@@ -233,27 +233,40 @@ class DeviceArray(np.ndarray):
     what the next call consumes --; writing through the array itself (`y[i] = v`, `out=y`) detaches it first and makes it
     writable.  Views, slices and copies are plain detached arrays of this type."""
 
-    def __new__(cls, host, tensor=None):
+    def __new__(cls, host, tensor=None, cell=None):
         obj = np.asarray(host).view(cls)
         obj._hj_t = tensor
+        # ALIASES (reshape / ravel / squeeze of an attached array) share the host memory, so they share ONE attachment cell:
+        # a write through any of them detaches all of them (ADVICE r05: `z = y.reshape(..); z[0, 0] = v` used to leave y
+        # attached to a tensor that no longer matched the memory both look at)
+        obj._hj_cell = (cell if cell is not None else [True]) if tensor is not None else None
         if tensor is not None:
             obj.flags.writeable = False
         return obj
 
     def __array_finalize__(self, obj):
-        self._hj_t = None           # only the object the package returned stands for the tensor
+        self._hj_t = None           # only the object the package returned (and its shape aliases) stands for the tensor
+        self._hj_cell = None
 
     def device_tensor(self):
-        """The tensor this array is a copy of, or None once it was written to (or for any view / copy of it)."""
+        """The tensor this array is a copy of, or None once it -- or an alias of it -- was written to (or for any view / copy of it)."""
         t = getattr(self, "_hj_t", None)
-        if t is not None and self.flags.writeable:       # somebody forced the flag: the host copy may have changed
+        if t is None:
+            return None
+        cell = getattr(self, "_hj_cell", None)
+        if cell is None or not cell[0] or self.flags.writeable:      # an alias wrote, or somebody forced the flag: the host copy may have changed
+            if cell is not None:
+                cell[0] = False
             self._hj_t = t = None
         return t
 
     def _detach(self):
-        if getattr(self, "_hj_t", None) is not None:
-            self._hj_t = None
-            self.flags.writeable = True
+        cell = getattr(self, "_hj_cell", None)
+        if cell is None:             # a plain view / copy: nothing to detach (a view of attached memory stays read-only)
+            return
+        cell[0] = False              # every alias of this memory is detached with it
+        self._hj_t = None
+        self.flags.writeable = True
 
     def __setitem__(self, idx, value):
         self._detach()
@@ -277,7 +290,7 @@ class DeviceArray(np.ndarray):
         t = self.device_tensor()
         if t is None or not isinstance(h, np.ndarray) or h.base is None:
             return h
-        return DeviceArray(h, fn_t(t))
+        return DeviceArray(h, fn_t(t), self._hj_cell)
 
     def reshape(self, *shape, **kw):
         h = np.ndarray.reshape(self, *shape, **kw)

@@ -194,6 +194,22 @@ def test_devicearray_is_a_real_ndarray_that_remembers_its_tensor(tmp_path):
     out = lazy.device_array(torch.zeros(24, dtype=torch.float64))
     np.add(np.arange(24.0), 1.0, out=out)
     assert out.device_tensor() is None and np.array_equal(out, np.arange(24.0) + 1)
+    # aliases share ONE attachment: a write through a reshape / ravel / squeeze alias detaches the original too, and the
+    # other way round -- both look at the same host memory, neither may go on standing for a tensor that no longer matches it
+    y = lazy.device_array(torch.zeros(4, 3, dtype=torch.float64))
+    z = y.reshape(-1)
+    z[0] = 99.0
+    assert z.device_tensor() is None and y.device_tensor() is None and y[0, 0] == 99.0
+    y[1, 1] = 5.0                                   # ... and the original is writable as well now
+    assert z[4] == 5.0
+    y = lazy.device_array(torch.zeros(4, 3, dtype=torch.float64))
+    z, q = y.ravel(), y.reshape(3, 4).squeeze()
+    y[0, 0] = 7.0
+    assert z.device_tensor() is None and q.device_tensor() is None and z[0] == 7.0 and q[0, 0] == 7.0
+    y = lazy.device_array(torch.zeros(4, 3, dtype=torch.float64))
+    z = y.reshape(12)
+    np.add(z, 1.0, out=z)
+    assert y.device_tensor() is None and y[3, 2] == 1.0
     # the switch
     old = lazy.LAZY
     try:
