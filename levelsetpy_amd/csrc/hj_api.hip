@@ -53,7 +53,8 @@ int next_range_keys(hj_ctx* c) {
 // (cells + halo)/cells / lane_utilisation, then the axis-0 chunking.
 // vec = 2: the pair kernel (hj_fusedv.h) -- k.R counts PAIRS per thread, the extent of the last axis is even, its LDS
 // rows are E + 8 cells apart (left pad 4)
-static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all);
+static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all,
+                                   const int64_t* dims = nullptr);
 
 Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all) {
     if (all) return make_tiling_uncached(c, k, p0, p1, vec, nbuf, all);
@@ -63,7 +64,18 @@ Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, 
     return it->second;
 }
 
-static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all) {
+// the tiling of a TRANSPOSED launch (hj_fusedv.h, XP): `dims` are the extents in KERNEL order -- dims[1] is the length of the window on the
+// slab axis, the others the grid's -- cached per window length
+Tiling make_tiling_dims(const hj_ctx* c, const KernelCfg& k, int vec, int nbuf, const int64_t* dims) {
+    const long long key = (1ll << 62) | ((long long)k.NT << 48) | ((long long)k.R << 44) | ((long long)k.KH << 40) | ((long long)vec << 36) | ((long long)nbuf << 32) |
+                          (long long)(dims[1] & 0xffffffffll);
+    auto it = c->tiling_cache.find(key);
+    if (it == c->tiling_cache.end()) it = c->tiling_cache.emplace(key, make_tiling_uncached(c, k, 0, dims[0], vec, nbuf, nullptr, dims)).first;
+    return it->second;
+}
+
+static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec, int nbuf, std::vector<Tiling>* all,
+                                   const int64_t* dims) {
     const int nd = c->ndim;
     std::map<int, Tiling> per_row;     // best tiling per extent of the last axis (autotuner candidates)
     // HJ_TILE_CELLS (tuning): cap the tile below what the configuration holds -- more, smaller workgroups (thin slabs)
@@ -72,7 +84,7 @@ static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t 
     best.ok = false;
     best.score = 1e300;
     int n[HJ_MAX_DIM];
-    for (int d = 0; d < nd; ++d) n[d] = (int)c->N[d];
+    for (int d = 0; d < nd; ++d) n[d] = (int)(dims ? dims[d] : c->N[d]);
     std::vector<int> cand[HJ_MAX_DIM];
     for (int d = 1; d < nd; ++d) {
         for (int parts = 1; parts <= 64; ++parts) {
@@ -182,12 +194,13 @@ static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t 
 // Axis-0 chunking: blocks = ntiles * nchunks should fill the GPU in whole "rounds" of resident
 // workgroups (capacity = CUs * workgroups per CU for this kernel), and every chunk pays 6 warm-up
 // planes of loads.  Pick the chunk count that minimises  rounds * (chunk + warm-up cost).
-void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu, int64_t chunk_max) {
+void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu, int64_t chunk_max, double march_bytes, double fixed_bytes) {
     const int64_t planes = p1 - p0;
     const int64_t capacity = (int64_t)c->num_cus * std::max(1, blocks_per_cu);
     // one buffer descriptor spans a chunk plus 3 planes either side: keep it below 4 GiB
-    const double plane_bytes = (double)(c->total / c->N[0]) * (double)c->esz;
-    int64_t chunk_cap = (int64_t)(4294967295.0 / plane_bytes) - 2 * HJ_STENCIL;
+    // (march_bytes > 0: a transposed launch -- bytes per step of the march and the fixed part of the span, FusedArgs::xspan)
+    const double plane_bytes = march_bytes > 0 ? march_bytes : (double)(c->total / c->N[0]) * (double)c->esz;
+    int64_t chunk_cap = (int64_t)((4294967295.0 - fixed_bytes) / plane_bytes) - 2 * HJ_STENCIL;
     if (chunk_max > 0) chunk_cap = std::min(chunk_cap, chunk_max);
     if (chunk_cap < 1) { t.ok = false; return; }
     int64_t best_nch = 1;
@@ -233,6 +246,21 @@ extern template int launch_stage12<double, HamDoublePendulum<double>>(hj_ctx*, c
 extern template int launch_stage12<float, HamDubinsRel<float>>(hj_ctx*, const Stage12Call&);
 extern template int launch_stage12<float, HamDoubleIntegrator<float>>(hj_ctx*, const Stage12Call&);
 extern template int launch_stage12<float, HamDoublePendulum<float>>(hj_ctx*, const Stage12Call&);
+
+// should the plane range [p0, p1) be computed by the TRANSPOSED launch (march along axis 1, hj_fusedv.h XP)?  Auto rule (HJ_XP=1), by
+// measurement (profiles/r06_thin_slab.txt): a 3-D range that is thin against axis 1 AND has the GPU to itself -- a thin grid or a slab
+// without neighbours: 65 x 513 x 513 runs 0.286 ms per RK3 step transposed against 0.302 on the axis-0 march (399 short workgroups in two
+// rounds against 252 equal ones in one).  NOT the interior launch of a slab that exchanges halos: there the edge launch and the RCCL kernel
+// share the GPU with it, and a launch whose 256 workgroups all end together leaves them no CU until its end -- the step is bound by the
+// chain exchange -> edges -> exchange either way (0.363 against 0.362 ms; the timelines are in the profile).  HJ_XP=2 forces it everywhere.
+bool xp_wanted(const hj_ctx* c, int64_t p0, int64_t p1) {
+    if (c->xp_mode == 0 || c->ndim != 3) return false;
+    if (c->xp_mode == 2) return true;
+    if (c->halo_lo || c->halo_hi) return false;
+    const int64_t w = p1 - p0;
+    const int64_t lim = c->xp_max_planes > 0 ? c->xp_max_planes : 100;
+    return w >= 8 && w <= lim && c->N[1] >= 3 * w && c->total >= 6500000;
+}
 
 }  // namespace hjh
 
@@ -468,6 +496,9 @@ int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
         s.bound = next_ring(c, user_slot, &rc);
         if (rc) return rc;
     }
+    if (c->xp_mode == 2) s.xp = true;          // HJ_XP=2 (tests): every launch that has a transposed form takes it
+    else if (!s.xp) s.xp = xp_wanted(c, s.p0, s.p1);      // thin grids / slabs without neighbours (the rule above)
+    if (c->xp_mode == 0) s.xp = false;
     return c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
 }
 
@@ -732,6 +763,7 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
     const int64_t hi_b = c->halo_hi ? std::max<int64_t>(n - HJ_STENCIL, lo_e) : n;
     if (!talk) {
         SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, 0, n};
+        s.xp = xp_wanted(c, 0, n);
         rc = do_substep(c, s, -1);
         if (scheme == HJ_WENO5) c->weno_src = nullptr;
         return rc;
@@ -784,6 +816,7 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
         c->slab_pending = 1;
         if (hi_b > lo_e) {
             SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, lo_e, hi_b};
+            s.xp = xp_wanted(c, lo_e, hi_b);
             if ((rc = do_substep(c, s, -1))) return rc;
         }
         if (scheme == HJ_WENO5) c->weno_src = nullptr;
@@ -812,6 +845,7 @@ int slab_substep(hj_ctx* c, int scheme, int ham, const double* par, int stage, d
     c->slab_pending = 1;
     if (hi_b > lo_e) {
         SubstepCall s{scheme, ham, stage, rs, par, dt, y, y0, out, nullptr, lo_e, hi_b};
+        s.xp = xp_wanted(c, lo_e, hi_b);
         if ((rc = do_substep(c, s, -1))) return rc;
     }
     if (scheme == HJ_WENO5) c->weno_src = nullptr;
@@ -871,6 +905,7 @@ int slab_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par,
         const int kind1[3] = {HJ_STAGE_EULER, order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF, HJ_STAGE_RK3_FULL};
         for (int st = 1; st <= order; ++st) {
             SubstepCall s{scheme, ham, kind1[st - 1], rs, par, dt, src1[st - 1], st == 1 ? nullptr : cur, dst1[st - 1], nullptr, 0, n};
+            s.xp = xp_wanted(c, 0, n);
             if ((rc = do_substep(c, s, -1))) return rc;
         }
         return HJ_OK;
@@ -920,6 +955,7 @@ int slab_step_deep(hj_ctx* c, int order, int scheme, int ham, const double* par,
         }
         if (i1 > i0) {
             SubstepCall s{scheme, ham, kind[st - 1], rs, par, dt, src[st - 1], y0, dst[st - 1], nullptr, i0, i1};
+            s.xp = xp_wanted(c, i0, i1);
             c->launch_stop = c->ext_events ? c->ev_int[st - 1] : nullptr;
             rc = do_substep(c, s, -1);
             const bool signalled = c->ext_events && c->launch_stop == nullptr;   // consumed by the tiled launch
@@ -1100,6 +1136,8 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     // planes the ring is parked ahead: 3 aligns it exactly with the neighbours' own loads (best from 251^3 up); on the
     // 201^3-class grids 2 is 0.7 % faster (one plane less to fetch synchronously in the setup; same-box A/B r02_run43.sh)
     c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
+    c->xp_mode = std::max(0, std::min(2, env_int("HJ_XP", 1)));          // transposed march (hj_instx.hip): 0 never, 1 thin slab windows, 2 wherever it exists
+    c->xp_max_planes = env_int("HJ_XP_MAX_PLANES", 0);
     c->lds_pitch_add = env_int("HJ_LDS_PITCH_ADD", 0) & ~1;
     {
         // per-substep slab schedule: "serial" or "overlap" (rounds 1-2); default by slab thickness -- on the single-GPU self
@@ -1532,6 +1570,8 @@ int hj_rk_substep(hj_ctx* c, int scheme, int ham, const double* par, double t, i
     if (!c) return fail(HJ_EINVAL, "null ctx");
     if (bound_slot < 0 || bound_slot >= HJ_BOUND_SLOTS) return fail(HJ_EINVAL, "bound_slot out of range");
     SubstepCall s{scheme, ham, stage, restrict_sign, par, dt, y, y0, out, nullptr, p0, p1};
+    // a plane range of a SLAB (dist.HipSlabBackend drives the per-substep schedule through this entry): thin ranges march along axis 1
+    if (c->halo_lo || c->halo_hi) s.xp = xp_wanted(c, p0, p1);
     return do_substep(c, s, bound_slot);
 }
 

@@ -685,8 +685,84 @@ template <typename T> struct HamDoublePendulum {
         eval_row(P, tcell(c, sc), row(pl.s1, pl.c1, c.s2, c.c2, sc), sc, q, H, alpha);
     }
 };
-// does a Hamiltonian type factor its coefficients into rows (Row / row() / tcell() / eval_row(), as HamDoublePendulum does)?
 template <typename...> struct hj_void { typedef void type; };
+// ---- TRANSPOSED MARCH (round 6).  A thin axis-0 slab (65 planes of 513 x 513 at N = 8) starves the axis-0 march: 133 tile columns x 3
+// chunks = 399 workgroups on 256 CUs, 6 warm-up planes per 21-plane chunk (profiles/r05_thin_slab.txt).  Hamiltonian types that declare
+// XPOSED describe the SAME system to a kernel whose axes (march, tile axis 1, rest) are the grid's (1, 0, rest): the slab axis becomes a tile
+// axis, the march runs along the long axis 1.  Everything such a type sees is in KERNEL order (idx, sc, q, alpha); it produces the very values
+// of its twin, and the dissipation sum / the published bound keys stay in GRID order (ham_gaxis) so that the results are bitwise equal.
+template <typename H, typename = void> struct ham_xp { static constexpr bool value = false; };
+template <typename H> struct ham_xp<H, typename hj_void<decltype(H::XPOSED)>::type> { static constexpr bool value = H::XPOSED; };
+// kernel axis <-> grid axis (the swap of 0 and 1 is its own inverse)
+template <typename H> __host__ __device__ constexpr int ham_gaxis(int k) { return ham_xp<H>::value ? (k == 0 ? 1 : (k == 1 ? 0 : k)) : k; }
+
+template <typename T> struct HamDubinsRelX {
+    static constexpr int ND = 3;
+    static constexpr int ID = HJ_HAM_DUBINS_REL;
+    static constexpr bool XPOSED = true;
+    // kernel axis 1 = grid axis 0: alpha_x = |v_e - v_p cos x3| + |w x2| varies along the march (x2 is the march coordinate now);
+    // kernel axis 0 = grid axis 1: alpha_y = |v_p sin x3| + |w x1| is a column constant
+    static constexpr unsigned PLANE_DEP = 0x2;
+    // sg0 = sc[1], sg1 = sc[0] (the scales of grid axes 0 and 1):  a' = sg0 a, b' = sg1 b, x0' = sg1 x0;  alpha1 = |b'| + sg1 |w x0|
+    struct Cell { T a, b, x0, absa, alpha1; };
+    struct Plane { T x1, awx1; };             // sg0 x1, |w x1|
+    struct Raw { T c, s, x0; };
+    __device__ static __forceinline__ Raw cell_raw(const HamTables<T>& P, const int* idx) {
+        return Raw{P.aux[0][idx[2]], P.aux[1][idx[2]], P.coord[0][idx[1]]};
+    }
+    __device__ static __forceinline__ Raw cell_raw_next(const HamTables<T>& P, const int* idx, const Raw& first) {
+        return Raw{P.aux[0][idx[2]], P.aux[1][idx[2]], first.x0};
+    }
+    __device__ static __forceinline__ Cell cell_fin(const HamTables<T>& P, const Raw& r, const T* sc) {
+        // every value as HamDubinsRel forms it (cell_fin / plane there), one rounding per operation
+#pragma clang fp contract(off)
+        Cell c;
+        const T a = P.par[0] - P.par[1] * r.c;
+        const T b = P.par[1] * r.s;
+        c.absa = t_abs(a);
+        c.a = sc[1] * a;
+        c.b = sc[0] * b;
+        c.x0 = sc[0] * r.x0;
+        const T wx0 = P.par[2] * r.x0;
+        const T awx0 = sc[0] * t_abs(wx0);
+        c.alpha1 = t_abs(c.b) + awx0;
+        return c;
+    }
+    __device__ static __forceinline__ Cell cell(const HamTables<T>& P, const int* idx, const T* sc) {
+        return cell_fin(P, cell_raw(P, idx), sc);
+    }
+    __device__ static __forceinline__ Plane plane(const HamTables<T>& P, int im, const T* sc) {
+#pragma clang fp contract(off)
+        Plane u;
+        const T x1 = P.coord[1][im];
+        u.x1 = sc[1] * x1;
+        const T wx1 = P.par[2] * x1;
+        u.awx1 = t_abs(wx1);
+        return u;
+    }
+    // q, alpha: KERNEL order (q[0] belongs to grid axis 1, q[1] to grid axis 0); the expression is HamDubinsRel::eval's, term by term
+    template <bool NP = false>
+    __device__ static __forceinline__ void eval(const HamTables<T>& P, const Cell& c, const Plane& u,
+                                                const T* sc, const T* q, T& H, T* alpha) {
+        const T w = P.par[2];
+        const T p2 = sc[2] * q[2];
+        if constexpr (NP) {
+#pragma clang fp contract(off)
+            H = q[1] * c.a - q[0] * c.b - w * t_abs(q[1] * u.x1 - q[0] * c.x0 - p2) + w * t_abs(p2);
+        } else {
+            H = q[1] * c.a - q[0] * c.b - w * t_abs(q[1] * u.x1 - q[0] * c.x0 - p2) + w * t_abs(p2);
+        }
+        {
+#pragma clang fp contract(off)
+            const T sum = c.absa + u.awx1;
+            alpha[1] = sc[1] * sum;
+        }
+        alpha[0] = c.alpha1;
+        alpha[2] = sc[2] * P.par[3];
+    }
+};
+
+// does a Hamiltonian type factor its coefficients into rows (Row / row() / tcell() / eval_row(), as HamDoublePendulum does)?
 template <typename H, typename = void> struct ham_has_rows { static constexpr bool value = false; };
 template <typename H> struct ham_has_rows<H, typename hj_void<typename H::Row>::type> { static constexpr bool value = true; };
 
@@ -742,12 +818,12 @@ __device__ __forceinline__ T lf_ydot(const HamTables<T>& P, const typename HAM::
 #pragma clang fp contract(off)
         T diss = T(0);
 #pragma unroll
-        for (int d = 0; d < HAM::ND; ++d) diss = diss + hd[d] * alpha[d];
+        for (int g = 0; g < HAM::ND; ++g) diss = diss + hd[ham_gaxis<HAM>(g)] * alpha[ham_gaxis<HAM>(g)];      // grid order (ham_xp)
         return -(H - diss);
     } else {
         T diss = T(0);
 #pragma unroll
-        for (int d = 0; d < HAM::ND; ++d) diss += hd[d] * alpha[d];
+        for (int g = 0; g < HAM::ND; ++g) diss += hd[ham_gaxis<HAM>(g)] * alpha[ham_gaxis<HAM>(g)];              // grid order (ham_xp)
         return -(H - diss);
     }
 }
@@ -761,12 +837,12 @@ __device__ __forceinline__ T lf_ydot_row(const HamTables<T>& P, const typename H
 #pragma clang fp contract(off)
         T diss = T(0);
 #pragma unroll
-        for (int d = 0; d < HAM::ND; ++d) diss = diss + hd[d] * alpha[d];
+        for (int g = 0; g < HAM::ND; ++g) diss = diss + hd[ham_gaxis<HAM>(g)] * alpha[ham_gaxis<HAM>(g)];      // grid order (ham_xp)
         return -(H - diss);
     } else {
         T diss = T(0);
 #pragma unroll
-        for (int d = 0; d < HAM::ND; ++d) diss += hd[d] * alpha[d];
+        for (int g = 0; g < HAM::ND; ++g) diss += hd[ham_gaxis<HAM>(g)] * alpha[ham_gaxis<HAM>(g)];              // grid order (ham_xp)
         return -(H - diss);
     }
 }

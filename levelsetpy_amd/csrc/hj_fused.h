@@ -149,6 +149,14 @@ template <typename T, int ND> struct FusedArgs {
     // bound kernel that follows the range pass computes deltaT (ode_cfl_3.py:142) and the first stage is already enqueued behind it -- the
     // host learns the same value from page-locked memory meanwhile, the GPU never waits for it.  null: `dt` above.
     const double* dt_dev;
+    // TRANSPOSED MARCH (round 6; Hamiltonian types with XPOSED, hj_device.h): the kernel's axes (march, tile axis 1, ...) are the grid's
+    // (1, 0, ...).  Every per-axis field above is in KERNEL order; halo_lo / halo_hi describe the MARCH axis (never a slab axis then: 0).
+    // The slab axis is tile axis 1: the launch computes the WINDOW [xwin0, xwin1) of it (a plane range of the slab, possibly reaching into
+    // the pad planes), cells outside [0, n[1]) are real data where xh_lo / xh_hi say so (pad planes of the slab) and ghost / periodic
+    // otherwise; per-lane byte offsets are relative to index xbase (<= 0) of that axis, xspan = bytes from there to the last row the
+    // window's halo can touch (march offset excluded).  Unused (0) in ordinary launches.
+    int xwin0, xwin1, xbase, xh_lo, xh_hi;
+    unsigned xspan;
 };
 
 // deltaT of this launch (built-in Hamiltonians: the kernel argument, exactly the code of rounds 1-4)

@@ -106,12 +106,17 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     constexpr bool GEN = (MODE == 0);
     constexpr bool RNG = (MODE == 3);           // range pass (FusedArgs::range_keys): derivL / derivR reduced to minima / maxima, nothing stored
     constexpr bool NP = np_order(SCHEME);       // ENO2 / ENO3: every operation rounded as NumPy rounds it (hj_device.h)
+    // TRANSPOSED MARCH (round 6; hj_device.h, ham_xp): the march axis is the grid's axis 1 and tile axis 1 its axis 0 -- the slab axis -- of which
+    // the launch computes the window [A.xwin0, A.xwin1); FusedArgs is filled in kernel order, byte offsets along tile axis 1 are relative to A.xbase
+    constexpr bool XP = ham_xp<HAM>::value;
+    static_assert(!XP || (ND == 3 && MODE != 3), "transposed march: 3-D substeps");
     using V = typename Pair<T>::V;
     const bool use_y0 = GEN ? (A.use_y0 != 0) : (MODE == 2);
     extern __shared__ __align__(16) unsigned char hj_smem[];
     double (*red)[ND] = reinterpret_cast<double (*)[ND]>(hj_smem);
     T* lds = reinterpret_cast<T*>(hj_smem + 512);
     static_assert((NT / 64) * ND * 8 <= 512, "reduction scratch");
+    const int xb = XP ? A.xbase : 0;            // index of tile axis 1 that byte offset 0 stands for
 
 #if HJ_EARLY_ARGS
     // Round 4: the setup below reads ~45 fields of the 700-byte kernel-argument block.  The compiler places each scalar load next to
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
     for (int d = ND - 1; d >= 1; --d) {
         org[d] = min(tc[d] * A.E[d], A.n[d] - A.E[d]);
+        if (XP && d == 1) org[d] = A.xwin0 + min(tc[d] * A.E[d], (A.xwin1 - A.xwin0) - A.E[d]);      // tiles of the window, the last one shifted back inside it
         fE[d] = fdiv_make(A.E[d]);
     }
     int p_begin, p_end;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             const int gi = org[d] + j;
             idx[d] = gi;
             lo += (j + pad_of(d)) * ls[d];
-            g += gi * A.pstride[d];
+            g += (d == 1 ? gi - xb : gi) * A.pstride[d];
             if (j + (d == LA ? 2 : 1) < A.E[d]) nbv[r] |= 1u << d;
         }
         own_lds[r] = lo;
@@ -223,10 +229,14 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     // ---- loaders of the own pairs, issued ahead of the rest of the setup (as in the scalar kernel)
     const unsigned plane_bytes = (unsigned)(A.stride0 * (long long)sizeof(T));
     const int p_lo = p_begin - HJ_STENCIL;
-    const unsigned span = (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;
-    const __amdgpu_buffer_rsrc_t ry = make_srd(y + (long long)p_lo * A.stride0, span);
-    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
-    const __amdgpu_buffer_rsrc_t rout = make_srd(out + (long long)p_lo * A.stride0, span);
+    // (transposed: a "plane" of the march is one ROW per index of tile axis 1, pstride[1] elements apart: the descriptors start at index xb of
+    //  that axis and reach over the rows the window and its halo can touch)
+    const long long xoff = XP ? (long long)xb * A.pstride[1] : 0ll;
+    const unsigned xspan = XP ? A.xspan : 0u;
+    const unsigned span = xspan + (unsigned)(p_end + HJ_STENCIL - p_lo) * plane_bytes;
+    const __amdgpu_buffer_rsrc_t ry = make_srd(y + xoff + (long long)p_lo * A.stride0, span);
+    const __amdgpu_buffer_rsrc_t ry0 = make_srd(y0 + xoff + (long long)p_lo * A.stride0, use_y0 ? span : 0u);
+    const __amdgpu_buffer_rsrc_t rout = make_srd(out + xoff + (long long)p_lo * A.stride0, span);
     auto load_own = [&](int p, V* dst) {
         const bool direct = (p >= 0 || A.halo_lo) && (p < A.n[0] || A.halo_hi);
         if (direct) {
@@ -235,12 +245,12 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             for (int r = 0; r < R; ++r) dst[r] = buf_load2(ry, own_g[r], so, T());
         } else {
             const PlaneSrc<T> s = plane_src<T, ND>(A, p);
-            const __amdgpu_buffer_rsrc_t rb = make_srd(y + s.off, plane_bytes);
+            const __amdgpu_buffer_rsrc_t rb = make_srd(y + xoff + s.off, xspan + plane_bytes);
             if (!s.ghost) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) dst[r] = buf_load2(rb, own_g[r], 0u, T());
             } else {
-                const __amdgpu_buffer_rsrc_t ri = make_srd(y + s.off_in, plane_bytes);
+                const __amdgpu_buffer_rsrc_t ri = make_srd(y + xoff + s.off_in, xspan + plane_bytes);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const V e = buf_load2(rb, own_g[r], 0u, T()), in = buf_load2(ri, own_g[r], 0u, T());
@@ -398,22 +408,23 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                     fdivmod(c, fE[e], qe, j);
                     c = qe;
                     lo += (j + pad_of(e)) * ls[e];
-                    g += (org[e] + j) * A.pstride[e];
+                    g += (org[e] + j - (e == 1 ? xb : 0)) * A.pstride[e];
                 }
                 lo += (jd + pad_of(d)) * ls[d];
                 int gi = org[d] + jd;
                 const int nd = A.n[d];
                 int dlt = 0;
                 T km = T(0);
-                if (gi < 0) {
+                // (transposed, tile axis 1 = the slab axis: beyond the slab's own planes lie its PAD planes where xh_lo / xh_hi say so -- real data)
+                if (gi < 0 && !(XP && d == 1 && A.xh_lo)) {
                     if (A.bc[d] == HJ_BC_PERIODIC) gi += nd;
                     else { km = T(-gi) * A.km[d]; dlt = A.pstride[d]; gi = 0; }
-                } else if (gi >= nd) {
+                } else if (gi >= nd && !(XP && d == 1 && A.xh_hi)) {
                     if (A.bc[d] == HJ_BC_PERIODIC) gi -= nd;
                     else { km = T(gi - nd + 1) * A.km[d]; dlt = -A.pstride[d]; gi = nd - 1; }
                 }
                 h_lds[k] = lo;
-                h_src[k] = (unsigned)(g + gi * A.pstride[d]) * (unsigned)sizeof(T);
+                h_src[k] = (unsigned)(g + (gi - (d == 1 ? xb : 0)) * A.pstride[d]) * (unsigned)sizeof(T);
                 h_dlt[k] = dlt * (int)sizeof(T);
                 h_km[k] = km;
             }
@@ -423,8 +434,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     // HJ_STENCIL cells past both ends of the tile)
     bool tile_ghost = false;
 #pragma unroll
-    for (int d = 1; d < ND; ++d)
-        tile_ghost = tile_ghost || (A.bc[d] != HJ_BC_PERIODIC && (org[d] < HJ_STENCIL || org[d] + A.E[d] + HJ_STENCIL > A.n[d]));
+    for (int d = 1; d < ND; ++d) {
+        const bool below = org[d] < HJ_STENCIL && !(XP && d == 1 && A.xh_lo), above = org[d] + A.E[d] + HJ_STENCIL > A.n[d] && !(XP && d == 1 && A.xh_hi);
+        tile_ghost = tile_ghost || (A.bc[d] != HJ_BC_PERIODIC && (below || above));
+    }
     if (A.timing && threadIdx.x == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 2] = wall_clock64();
 
     T eps[ND];
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (A.eps_nrows > 0) fold_eps_rows<T, ND, NT>(A.eps_rows, A.eps_nrows, red, eps);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            if (A.eps_nrows <= 0) eps[d] = T(1e-6) * A.max_d1sq[d] + Lim<T>::tiny;
+            if (A.eps_nrows <= 0) eps[d] = T(1e-6) * A.max_d1sq[ham_gaxis<HAM>(d)] + Lim<T>::tiny;      // (the values are stored in grid order)
             wk[d] = weno_consts<T>(eps[d], A.K[d]);
         }
     }
@@ -907,7 +920,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         if (tid < ND) {
             double m = red[0][tid];
             for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w][tid]);
-            if (m > -1.0e299) key_max(A.bound + tid, m);
+            if (m > -1.0e299) key_max(A.bound + (XP ? (tid == 0 ? 1 : (tid == 1 ? 0 : tid)) : tid), m);      // the keys are in grid order
         }
     }
     publish_gate(A, chunk_id);

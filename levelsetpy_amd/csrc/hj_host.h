@@ -176,6 +176,10 @@ struct hj_ctx {
     // hj_plan_substep: a host-only context (no device, no allocation) whose launches stop after the tile / chunk plan is made
     int diss_kind = 0;                              // HJ_DISS_GLF / HJ_DISS_LLF / HJ_DISS_LLLF as set (diss_local: kind != 0); what a range-reading Hamiltonian is evaluated with
     unsigned long long state_gen = 0;               // bumped by every hj_ctx_set_stream / _dissipation / _post_step / _post_arrays (hj_ctx_state_generation)
+    // HJ_XP: 0 never march along axis 1, 1 (default) slab launches whose window is thin against axis 1 (xp_wanted, hj_api.hip), 2 every launch
+    // that has a transposed instantiation (tests: bitwise against the axis-0 march on any grid)
+    int xp_mode = 1;
+    int xp_max_planes = 0;                          // HJ_XP_MAX_PLANES: auto mode takes windows of at most this many planes (0: the built-in rule)
     int dry = 0;
     struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)
@@ -194,7 +198,8 @@ using namespace hj;
 
 int env_int(const char* name, int dflt);
 Tiling make_tiling(const hj_ctx* c, const KernelCfg& k, int64_t p0, int64_t p1, int vec = 1, int nbuf = 2, std::vector<Tiling>* all = nullptr);
-void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu, int64_t chunk_max = 0);
+void choose_chunks(const hj_ctx* c, Tiling& t, int64_t p0, int64_t p1, int blocks_per_cu, int64_t chunk_max = 0, double march_bytes = 0, double fixed_bytes = 0);
+Tiling make_tiling_dims(const hj_ctx* c, const KernelCfg& k, int vec, int nbuf, const int64_t* dims);      // transposed launches (kernel-order extents)
 int cfg_kh(int nd, int nt, int r);
 int eps_rows_to_vals(hj_ctx* c, const double* rows, int nrows, hipStream_t stream);   // rows -> ctx->weno_vals (kernels that do not fold)
 
@@ -261,6 +266,9 @@ struct SubstepCall {
     bool range_ready = false;           // ctx->range_keys already hold the range of this launch's input: no pass of its own
     bool bound_pass = false;            // run ONLY the bound pass of the local Lax-Friedrichs variants (MODE 3 with a bound slot): max_x sum_d alpha_d / dx_d
     const double* dt_dev = nullptr;     // deltaT in device memory (FusedArgs::dt_dev; run-time Hamiltonians with a range-dependent alpha only)
+    // TRANSPOSED MARCH (round 6): the caller would like [p0, p1) computed by a launch that marches along grid axis 1 and tiles the slab axis
+    // (hj_fusedv.h, XP) -- taken where a transposed instantiation exists for the call (launch_cfg), else the ordinary launch: same bits either way
+    bool xp = false;
 };
 constexpr int HJ_EPS_ROWS = 256;  // workgroups (= rows) of eps_seam_kernel
 
@@ -324,6 +332,12 @@ int alpha_partials(hj_ctx* c);        // allocates ctx->alpha_part on first use
 // the fused (tiled) or direct substep kernel of one (dtype, Hamiltonian): defined and explicitly
 // instantiated in hj_inst.hip
 template <typename T, typename HAM> int launch_scheme(hj_ctx* c, const SubstepCall& s);
+// the TRANSPOSED launch of a substep (hj_instx.hip: march along grid axis 1, the slab axis tiled): HJ_OK, an error, or HJ_XP_FALLBACK when
+// the call has no transposed form (the caller then takes the ordinary launch -- same bits).  Instantiated for the pairs xp_available names.
+constexpr int HJ_XP_FALLBACK = -7777;
+template <typename T, typename HAM> int launch_xp(hj_ctx* c, const SubstepCall& s);
+template <typename T, typename HAM> constexpr bool xp_available() { return HAM::ID == HJ_HAM_DUBINS_REL && !ham_xp<HAM>::value; }
+bool xp_wanted(const hj_ctx* c, int64_t p0, int64_t p1);
 
 // two RK stages in one launch (hj_fused12.h): out = ca*y + cb*(y1 + dt*L(y1)), y1 = y + dt*L(y)
 struct Stage12Call {

@@ -541,8 +541,18 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
     return launch_direct<T, HAM, SCHEME>(c, s);
 }
 
+extern template int launch_xp<double, HamDubinsRel<double>>(hj_ctx*, const SubstepCall&);
+extern template int launch_xp<float, HamDubinsRel<float>>(hj_ctx*, const SubstepCall&);
+
 template <typename T, typename HAM>
 int launch_scheme(hj_ctx* c, const SubstepCall& s) {
+    if constexpr (xp_available<T, HAM>()) {
+        // the caller asked for the transposed march (thin slabs; HJ_XP=2): taken where the call has such a form, else the launch below
+        if (s.xp && c->xp_mode != 0 && !c->force_direct && !c->cfg_from_env && c->pair != 0) {
+            const int rc_x = launch_xp<T, HAM>(c, s);
+            if (rc_x != HJ_XP_FALLBACK) return rc_x;
+        }
+    }
     switch (s.scheme) {
         case HJ_ENO2: return launch_cfg<T, HAM, HJ_ENO2>(c, s);
         case HJ_ENO3: return launch_cfg<T, HAM, HJ_ENO3>(c, s);

@@ -584,6 +584,9 @@ def slab_workload(L, name, world, args, global_n):
 # grid, WENO5_ASSHIPPED, fp64; profiles/r04_thin_slab_gated.txt, profiles/r05_thin_slab.txt): planes -> ms per RK3 step of the schedule
 # bench_slab picks for that thickness.  Everything but the link is in these numbers.
 SELF_RING_MS_C4 = [(64, 0.357), (65, 0.362), (129, 0.616), (257, 1.099), (513, 1.745)]
+# ... and the slabs of C5 (129^4 fp32, planes of 129^3 cells, all axes periodic; round 6, profiles/r06_thin_slab.txt): per-substep schedule
+# (the deep-halo stepper is slower on every one of them: 9 of a 17-plane slab's planes would be recomputed)
+SELF_RING_MS_C5 = [(17, 0.787), (33, 1.148), (65, 2.051), (129, 3.40)]
 XGMI_LINK_GBS = 153.0        # per link and neighbour, peak (the pool's figure for MI355X: 7 links x ~153 GB/s per GPU)
 
 
@@ -657,10 +660,16 @@ def plan_slab_run(args, world, global_n=513, workload="C4", num_cus=256):
                 "interior": plan_substep(Nl, bc, wl["dtype"], sid, wl["ham"], _ffi.STAGE_EULER, lo_e, hi_b, lo, hi, num_cus),
                 "edges": edges, "edge_ranges": [[0, lo_e]] * int(lo) + [[hi_b, n]] * int(hi)}
         # prediction: the self-ring table (C4's 513^2-cell planes), scaled by plane size for other grids
+        table, plane0 = None, 1.0
         if wl["name"] == "C4" and wl["scheme"] == "WENO5_ASSHIPPED" and wl["dtype"] == "float64":
-            xs = [a for a, _ in SELF_RING_MS_C4]
-            ys = [b for _, b in SELF_RING_MS_C4]
-            ms = float(np.interp(n, xs, ys)) * (plane / float(513 * 513))
+            table, plane0 = SELF_RING_MS_C4, float(513 * 513)
+        elif wl["name"] == "C5":
+            table, plane0 = SELF_RING_MS_C5, float(129 ** 3)
+        if table is not None:
+            xs = [a for a, _ in table]
+            ys = [b for _, b in table]
+            # (below the thinnest measured slab: that slab's time scaled by the plane count -- an optimistic guess, the edges do not shrink)
+            ms = float(np.interp(n, xs, ys)) * (plane / plane0) * (min(1.0, n / float(xs[0])))
             ent["self_ring_ms_per_step"] = round(ms, 4)
         else:
             ent["self_ring_ms_per_step"] = None
@@ -680,7 +689,7 @@ def plan_slab_run(args, world, global_n=513, workload="C4", num_cus=256):
                                   "%.0f GB/s per link it needs %.3f ms per step against %s ms of compute" % (XGMI_LINK_GBS, link, slow),
                 "value_cell_substeps_per_s": (total * 3 / (max(slow, link) * 1e-3)) if slow else None,
                 "basis": "tools/thin_slab_ring.py on one MI355X (RCCL self send/recv, everything but the link): "
-                         + ", ".join("%d planes %.3f ms" % ab for ab in SELF_RING_MS_C4)}}
+                         + ", ".join("%d planes %.3f ms" % ab for ab in (SELF_RING_MS_C5 if wl["name"] == "C5" else SELF_RING_MS_C4))}}
 
 
 def _agree(dist, ok, device):
