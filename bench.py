@@ -273,69 +273,120 @@ def workload(L, _ffi, torch, name, scheme, dtype, n):
     raise ValueError(name)
 
 
-def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
-    """R repeats of K odeCFL3 steps (hj_rk_step: 3 launches, three arrays) on one GPU.  Returns a dict with
-    the wall seconds and HIP-event milliseconds of every repeat."""
-    desc, g, ham, par, scheme, dtype, d0 = wl
-    dg = DeviceGrid(g, dtype)
-    dg.bind_stream()
-    lib = dg.lib
-    sid = _ffi.SCHEME_IDS[scheme]
-    cur, nxt, w1 = d0.clone(), dg.empty(), dg.empty()
-    tout, dtout = C.c_double(), C.c_double()
-    parv = (C.c_double * 4)(*par)
-    state = {"cur": cur, "nxt": nxt, "t": 0.0}
+class StepRunner(object):
+    """One odeCFL3 step per call (hj_rk_step: 3 launches, three arrays) on a context of its own.  `env`: environment the context is
+    created under (the library reads its knobs in hj_ctx_create); `share`: another runner whose state arrays this one steps too."""
 
-    def one():
+    def __init__(self, torch, _ffi, DeviceGrid, wl, env=None, share=None):
+        self.desc, g, self.ham, par, self.scheme, self.dtype, d0 = wl
+        old = {}
+        for k, v in (env or {}).items():
+            old[k] = os.environ.get(k)
+            os.environ[k] = v
+        try:
+            self.dg = DeviceGrid(g, self.dtype)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        self.dg.bind_stream()
+        self.lib = self.dg.lib
+        self.sid = _ffi.SCHEME_IDS[self.scheme]
+        self.state = share.state if share is not None else {"cur": d0.clone(), "nxt": self.dg.empty(), "w1": self.dg.empty(), "t": 0.0}
+        self.tout, self.dtout = C.c_double(), C.c_double()
+        self.parv = (C.c_double * 4)(*par)
+
+    def one(self):
         # three arrays are enough for RK3: the first stage buffer doubles as the output (stage 3 reads w1
         # and y0 = cur only), which keeps the 201^3 working set (195 MB) inside the 256 MB Infinity Cache
-        rc = lib.hj_rk_step(dg.ctx, 3, sid, ham, parv, state["t"], 1e9, 0.8, 1e300, 0, dg.ptr(state["cur"]),
-                            dg.ptr(state["nxt"]), dg.ptr(state["nxt"]), dg.ptr(w1), C.byref(tout), C.byref(dtout))
+        st, dg = self.state, self.dg
+        rc = self.lib.hj_rk_step(dg.ctx, 3, self.sid, self.ham, self.parv, st["t"], 1e9, 0.8, 1e300, 0, dg.ptr(st["cur"]),
+                                 dg.ptr(st["nxt"]), dg.ptr(st["nxt"]), dg.ptr(st["w1"]), C.byref(self.tout), C.byref(self.dtout))
         if rc != 0:
-            raise RuntimeError(lib.hj_last_error().decode())
-        state["cur"], state["nxt"], state["t"] = state["nxt"], state["cur"], float(tout.value)
+            raise RuntimeError(self.lib.hj_last_error().decode())
+        st["cur"], st["nxt"], st["t"] = st["nxt"], st["cur"], float(self.tout.value)
 
-    # device spin-up (untimed, reported as config.spinup_steps): the GPU's clocks need a few tens of
-    # milliseconds of load to reach their steady state; without it a short --steps run measures the ramp
-    for _ in range(spinup):
-        one()
-    # ... and until the clocks have SETTLED: untimed blocks of K steps until three in a row agree within 0.5 % (at most
-    # HJ_BENCH_SETTLE_BLOCKS = 60 blocks).  A fixed 300-step spin-up (33 ms at 201^3) was not always enough after the child passes
-    # that precede this leg: a run whose 25 windows drifted by 2 % reported the headline 5 % below what the later legs of the
-    # SAME run measured with the same kernels (profiles/r04_bench_default.json vs gpurun r04_run12)
-    settle, last = 0, []
-    for _ in range(int(os.environ.get("HJ_BENCH_SETTLE_BLOCKS", "60"))):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one()
-        torch.cuda.synchronize()
-        last.append(time.perf_counter() - t0)
-        settle += steps
-        if len(last) >= 3 and max(last[-3:]) - min(last[-3:]) <= 0.005 * min(last[-3:]):
-            break
-    for _ in range(warmup):
-        one()
-    walls, devs = [], []
-    for _ in range(repeats):
+    def window(self, torch, steps):
+        """(wall seconds, HIP-event milliseconds) of exactly `steps` steps between synchronisations"""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
         for _ in range(steps):
-            one()
+            self.one()
         e1.record()
         torch.cuda.synchronize()
-        walls.append(time.perf_counter() - t0)
-        devs.append(e0.elapsed_time(e1))
-    assert bool(torch.isfinite(state["cur"]).all()), "non-finite state after the timed steps (%s)" % desc
-    nl, fused = C.c_int(3), C.c_int(0)
-    if lib.hj_rk_plan(dg.ctx, 3, sid, ham, parv, 0, C.byref(nl), C.byref(fused)) != 0:
-        raise RuntimeError(lib.hj_last_error().decode())
-    launches = nl.value                      # launches of one RK3 step as hj_rk_step issues it on this ctx
-    kern = lib.hj_last_kernel(dg.ctx)
-    return {"desc": desc, "cells": dg.numel, "dtype": dtype, "scheme": scheme, "walls": walls, "devs": devs, "settle_steps": settle,
-            "launches_per_step": int(launches), "stage_fused": int(fused.value), "kernel": kern.decode() if kern else "?"}
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    def settle(self, torch, steps, spinup):
+        # device spin-up (untimed, reported as config.spinup_steps): the GPU's clocks need a few tens of
+        # milliseconds of load to reach their steady state; without it a short --steps run measures the ramp
+        for _ in range(spinup):
+            self.one()
+        # ... and until the clocks have SETTLED: untimed blocks of K steps until three in a row agree within 0.5 % (at most
+        # HJ_BENCH_SETTLE_BLOCKS = 60 blocks).  A fixed 300-step spin-up (33 ms at 201^3) was not always enough after the child passes
+        # that precede this leg: a run whose 25 windows drifted by 2 % reported the headline 5 % below what the later legs of the
+        # SAME run measured with the same kernels (profiles/r04_bench_default.json vs gpurun r04_run12)
+        settle, last = 0, []
+        for _ in range(int(os.environ.get("HJ_BENCH_SETTLE_BLOCKS", "60"))):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.one()
+            torch.cuda.synchronize()
+            last.append(time.perf_counter() - t0)
+            settle += steps
+            if len(last) >= 3 and max(last[-3:]) - min(last[-3:]) <= 0.005 * min(last[-3:]):
+                break
+        return settle
+
+    def result(self, torch, walls, devs, settle):
+        assert bool(torch.isfinite(self.state["cur"]).all()), "non-finite state after the timed steps (%s)" % self.desc
+        nl, fused = C.c_int(3), C.c_int(0)
+        if self.lib.hj_rk_plan(self.dg.ctx, 3, self.sid, self.ham, self.parv, 0, C.byref(nl), C.byref(fused)) != 0:
+            raise RuntimeError(self.lib.hj_last_error().decode())
+        kern = self.lib.hj_last_kernel(self.dg.ctx)
+        return {"desc": self.desc, "cells": self.dg.numel, "dtype": self.dtype, "scheme": self.scheme, "walls": walls, "devs": devs,
+                "settle_steps": settle, "launches_per_step": int(nl.value), "stage_fused": int(fused.value),
+                "kernel": kern.decode() if kern else "?"}
+
+
+def time_single(torch, _ffi, DeviceGrid, wl, steps, warmup, repeats, spinup):
+    """R repeats of K odeCFL3 steps (hj_rk_step: 3 launches, three arrays) on one GPU.  Returns a dict with
+    the wall seconds and HIP-event milliseconds of every repeat."""
+    rn = StepRunner(torch, _ffi, DeviceGrid, wl)
+    settle = rn.settle(torch, steps, spinup)
+    for _ in range(warmup):
+        rn.one()
+    walls, devs = [], []
+    for _ in range(repeats):
+        w, d = rn.window(torch, steps)
+        walls.append(w)
+        devs.append(d)
+    return rn.result(torch, walls, devs, settle)
+
+
+def time_interleaved(torch, _ffi, DeviceGrid, wl, env_b, steps, warmup, repeats, spinup):
+    """A/B in ONE run: the default context (A) and a context created under `env_b` (B) step the SAME three arrays, a window of K steps
+    each in turn -- same clocks, same cache state, same neighbours on the box.  Returns (result A, result B).  (the
+    kept-CFL leg, timed minutes after the headline, read -8.3 % in the driver's run and -2.1 % in a same-box A/B.)"""
+    ra = StepRunner(torch, _ffi, DeviceGrid, wl)
+    rb = StepRunner(torch, _ffi, DeviceGrid, wl, env=env_b, share=ra)
+    settle = ra.settle(torch, steps, spinup)
+    for _ in range(warmup):
+        ra.one()
+        rb.one()
+    wa, da, wb, db = [], [], [], []
+    for _ in range(repeats):
+        w, d = ra.window(torch, steps)
+        wa.append(w)
+        da.append(d)
+        w, d = rb.window(torch, steps)
+        wb.append(w)
+        db.append(d)
+    return ra.result(torch, wa, da, settle), rb.result(torch, wb, db, settle)
 
 
 def quartiles(xs):
@@ -981,7 +1032,7 @@ def main():
         a.live_also = {x: live_traffic(a, int(x)) for x in a.also.split(",") if x.isdigit()} if a.live else {}
         if a.live and "WENO5" in a.also.split(",") and a.scheme != "WENO5":
             a.live_also["WENO5"] = live_traffic(a, scheme="WENO5")
-        for x in ("C3", "C5"):
+        for x in ("C3", "C3 fast", "C5"):
             if a.live and x in a.also.split(","):
                 a.live_also[x] = live_traffic(a, single=x)
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version header at
@@ -1119,7 +1170,9 @@ def run(a, rank, world, local, slab_leg, cpu):
                          "kernel": "%s (rank 0's launches of one RK3 step on its slab: %s)" % (res["kernel"], res["launches"]),
                          "kernel_ms": dev_step_ms, "algorithmic_bytes_per_launch": res["local_cells"] * 3 * bps},
             "per_gpu_value": value / world,
-            "also": {"slab_check_max_abs_diff": res.get("slab_check_max_abs_diff")},
+            "also": {"slab_check_max_abs_diff": res.get("slab_check_max_abs_diff"), "stepper": res.get("transport"),
+                     # the exchange alone and the launches alone on this rank (and the slowest / fastest rank): link or kernel?
+                     "time_of_a_step": res.get("diagnostics")},
         }
         # The companion point of the scaling curve, same ranks, same communicator set-up: BASELINE's metric names 201^3 and
         # configs[3] names 513^3, so the strong-scaling line also carries the WEAK-scaling figure (a 201-plane slab of an
@@ -1146,6 +1199,46 @@ def run(a, rank, world, local, slab_leg, cpu):
                                     "roofline_frac_per_gpu": (v2 / world) * bps / 1e9 / HBM_PEAK_GBS}
             except Exception as e:  # noqa: BLE001
                 out["also"]["companion_leg_error"] = repr(e)
+            if getattr(a, "_dog2", None) is not None:
+                a._dog2.cancel()
+            a._partial = None
+        # The OTHER native stepper on the same slabs (per-substep exchange <-> one deep-halo exchange per step), same protocol: which of
+        # the two is faster depends on the link, and the choice above was made on a one-GPU self ring.  `value` is the faster one, the
+        # other stays in `also`.  A failure here costs this extra figure only.
+        alt = res.get("alternate_transport")
+        if alt and not a.no_also and os.environ.get("HJ_BENCH_SLAB_ALT", "1") != "0":
+            a._partial = out
+            if hasattr(a, "_arm_companion"):
+                a._arm_companion()
+            try:
+                import copy as _copy
+                a3 = _copy.copy(a)
+                a3.repeats = min(9, a.repeats)
+                os.environ["HJ_BENCH_SPINUP"] = str(min(60, SPINUP_STEPS))
+                try:
+                    r3 = hjdist.bench_slab(a3, rank, world, global_n=gn, workload=wname, transport=alt, diagnostics=False)
+                finally:
+                    os.environ["HJ_BENCH_SPINUP"] = str(SPINUP_STEPS)
+                tw3 = torch.tensor(r3["walls"], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tw3, op=dist.ReduceOp.MAX)
+                med3 = statistics.median([float(v) for v in tw3.cpu()])
+                v3 = r3["total_cells"] * 3 * a.steps / med3
+                first = {"stepper": res.get("transport"), "value": out["value"], "ms_per_step": out["ms_per_step"], "parallelism": res["parallelism"]}
+                second = {"stepper": alt, "value": v3, "ms_per_step": 1e3 * med3 / a.steps, "parallelism": r3["parallelism"],
+                          "slab_check_max_abs_diff": r3.get("slab_check_max_abs_diff"), "repeats": a3.repeats}
+                if v3 > out["value"]:
+                    dev3 = r3["devs"][0] / a.steps
+                    out["value"], out["ms_per_step"], out["per_gpu_value"] = v3, 1e3 * med3 / a.steps, v3 / world
+                    out["config"]["parallelism"] = r3["parallelism"]
+                    out["roofline"]["achieved"] = r3["local_cells"] * 3 * bps / (dev3 * 1e-3) / 1e9
+                    out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+                    out["roofline"]["kernel_ms"] = dev3
+                    out["also"]["stepper"] = alt
+                    out["also"]["the other stepper (slower here)"] = first
+                else:
+                    out["also"]["the other stepper (slower here)"] = second
+            except Exception as e:  # noqa: BLE001
+                out["also"]["other_stepper_error"] = repr(e)
             if getattr(a, "_dog2", None) is not None:
                 a._dog2.cancel()
             a._partial = None
@@ -1180,6 +1273,10 @@ def run(a, rank, world, local, slab_leg, cpu):
         "roofline": roofline_obj(r, s, tr, cells * 3 * bps, a.achievable),
         "per_gpu_value": s["value"],
     }
+    # (`frac` prices the DEVICE time of the step's launches -- HIP events / kernel trace --, `value` the wall time of the K-step window;
+    #  the same fraction on the wall clock, i.e. what follows from `value` alone:)
+    out["roofline"]["frac_from_value"] = s["value"] * bps / 1e9 / HBM_PEAK_GBS
+    out["roofline"]["frac_note"] = "frac: algorithmic bytes / device time of a step's launches; frac_from_value: value x 21.33 B (fp64) / 8 TB/s (wall clock)"
     if a.achievable:
         out["achievable_streaming_rates"] = a.achievable
     also = {}
@@ -1190,16 +1287,17 @@ def run(a, rank, world, local, slab_leg, cpu):
                     # the headline launches skip the in-kernel CFL reduction (alpha of the native Hamiltonians is data
                     # independent: hj_rk_step takes dt from hj_static_step_bound, identical by test); this is the same
                     # step with every launch reducing its bound anyway (HJ_KEEP_BOUNDS=1, read when a ctx is created)
-                    os.environ["HJ_KEEP_BOUNDS"] = "1"
-                    try:
-                        wl2 = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n)
-                        r2 = time_single(torch, _ffi, DeviceGrid, wl2, a.steps, a.warmup, min(15, a.repeats), SPINUP_STEPS)
-                    finally:
-                        del os.environ["HJ_KEEP_BOUNDS"]
-                    s2 = summarize(r2, a.steps)
+                    wl2 = workload(L, _ffi, torch, "dubins", a.scheme, a.dtype, a.n)
+                    rA, r2 = time_interleaved(torch, _ffi, DeviceGrid, wl2, {"HJ_KEEP_BOUNDS": "1"}, a.steps, a.warmup, min(21, a.repeats), SPINUP_STEPS)
+                    sA, s2 = summarize(rA, a.steps), summarize(r2, a.steps)
                     also["%d^3 with the CFL reduction kept in every launch" % a.n] = {
-                        "value": s2["value"], "ms_per_step": s2["ms_per_step"], "roofline_frac": s2["frac"], "repeats": s2["repeats"],
+                        "value": s2["value"], "ms_per_step": s2["ms_per_step"], "roofline_frac": s2["frac"],
+                        "roofline_frac_from_value": s2["value"] * bps / 1e9 / HBM_PEAK_GBS, "repeats": s2["repeats"],
+                        "interleaved_with": {"what": "windows of the default launches on the same arrays, alternating (same clocks, same cache state)",
+                                             "value": sA["value"], "ms_per_step": sA["ms_per_step"]},
+                        "vs_headline_interleaved": s2["value"] / sA["value"],
                         "vs_headline": s2["value"] / s["value"]}
+                    del rA
                     out["config"]["cfl_reduction_kept_value"] = s2["value"]
                     del r2, wl2
                     continue
@@ -1251,6 +1349,16 @@ def run(a, rank, world, local, slab_leg, cpu):
         out["cpu_baseline"] = cpu.run()
         # the oracle's state at the headline size, already paid for by the baseline leg, checks the product path
         out["parity"] = gpu_parity(L, torch, cpu.c2, a.scheme)
+    # LAST in the line (a log tail of a few thousand characters keeps it): one entry per leg -- name, value, fraction of 8 TB/s on the
+    # wall clock, ms per step
+    summ = ["headline %d^3 %s: %.4g  frac %.3f  %.4f ms" % (a.n, a.scheme, s["value"], out["roofline"]["frac_from_value"], s["ms_per_step"])]
+    for k, v in also.items():
+        if isinstance(v, dict) and "value" in v and "ms_per_step" in v:
+            b = BYTES_PER_SUBSTEP["float32" if v.get("dtype") == "f32" else "float64"]
+            summ.append("%s: %.4g  frac %.3f  %.4f ms" % (k[:60], v["value"], v["value"] * b / 1e9 / HBM_PEAK_GBS, v["ms_per_step"]))
+        elif isinstance(v, dict) and "error" in v:
+            summ.append("%s: ERROR %s" % (k[:60], str(v["error"])[:80]))
+    out["summary"] = summ
     return out
 
 

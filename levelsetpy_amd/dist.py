@@ -692,6 +692,10 @@ def plan_slab_run(args, world, global_n=513, workload="C4", num_cus=256):
                          + ", ".join("%d planes %.3f ms" % ab for ab in (SELF_RING_MS_C5 if wl["name"] == "C5" else SELF_RING_MS_C4))}}
 
 
+def plane_cells(wl):
+    return int(wl["plane"])
+
+
 def _agree(dist, ok, device):
     """Collective decision: True only if EVERY rank reports ok (a rank that failed locally must not leave
     the others inside a different collective: ADVICE r01)."""
@@ -707,7 +711,7 @@ def _agree3(dist, ok, device):
     return "all" if not any_failed else ("some" if any_ok else "none")
 
 
-def bench_slab(args, rank, world, global_n=513, workload="C4"):
+def bench_slab(args, rank, world, global_n=513, workload="C4", transport=None, diagnostics=True):
     """bench.py's slab leg.  Workload C4 (default) -- global_n > 0: STRONG scaling of the global_n^3 Dubins grid (BASELINE
     C4: 513^3, slabs of 65/64 planes at 8 ranks); global_n == 0: weak scaling, every rank owns an n^3 slab.  Workload C5:
     the 4-D double-pendulum grid (129^4 fp32, all axes periodic; 17/16-plane slabs at 8 ranks), strong scaling."""
@@ -742,7 +746,7 @@ def bench_slab(args, rank, world, global_n=513, workload="C4"):
     # ranks never sit in different collectives.  A set-up that failed on EVERY rank moves on to the next transport; one
     # that failed on some ranks only (communicator creation half done) cannot be recovered from and aborts the run with
     # a non-zero exit.
-    want = os.environ.get("HJ_SLAB_TRANSPORT")
+    want = transport or os.environ.get("HJ_SLAB_TRANSPORT")
     # the deep-halo schedule pays 18 redundant planes per slab and step: only worth it on thick slabs
     thick = min(slab.counts) >= 128 and wl["name"] == "C4"
     order = [want] if want else ((["native-deep"] if thick else []) + ["native", "torch"])
@@ -823,6 +827,56 @@ def bench_slab(args, rank, world, global_n=513, workload="C4"):
         dist.barrier()
         walls.append(time.perf_counter() - t0)
         devs.append(e0.elapsed_time(e1))
+    # ---- where the time of a step goes, for the FIRST real N > 1 run: the exchange alone and the launches alone, 20
+    # iterations each, per rank (max over ranks beside it) -- a bad scaling curve can then be read as link or kernel without a second lease.
+    # Every rank runs the same sequence; a failure is recorded, never raised (the timed figure above is already taken).
+    diag = None
+    if diagnostics and isinstance(integ, NativeSlabStepper) and integ.external is None:
+        diag = {}
+        try:
+            lib, ctx, nloc = integ.dg.lib, integ.dg.ctx, integ.n
+            _ffi.check(lib.hj_slab_join(ctx))
+            torch.cuda.synchronize()
+
+            def timed(fn, iters=20):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0d = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t0d) / iters
+                both = torch.tensor([ms, -ms], dtype=torch.float64, device=device)
+                dist.all_reduce(both, op=dist.ReduceOp.MAX)
+                return {"this_rank_ms": round(ms, 4), "max_over_ranks_ms": round(float(both[0]), 4), "min_over_ranks_ms": round(-float(both[1]), 4)}
+
+            def exch():
+                integ._exchange(integ.buf["cur"])
+                _ffi.check(lib.hj_slab_join(ctx))
+            if slab.halo_lo or slab.halo_hi:
+                planes = integ.pad
+                diag["exchange_only"] = dict(timed(exch), planes_each_way=planes, bytes_each_way=planes * plane_cells(wl) * (8 if dtype == "float64" else 4),
+                                             what="the halo exchange of one %s, alone (send + receive to each neighbour, then the join)"
+                                                  % ("RK3 step (deep halo)" if integ.deep else "substep"))
+            lo_e = 3 if slab.halo_lo else 0
+            hi_b = nloc - 3 if slab.halo_hi else nloc
+            b = integ.buf
+
+            def sub(p0, p1):
+                def f():
+                    _ffi.check(lib.hj_rk_substep(ctx, sid, ham, integ.par, 0.0, _ffi.STAGE_RK3_FULL, 1e-4, 0, integ._ip(b["cur"]),
+                                                 integ._ip(b["cur"]), integ._ip(b["w1"]), 5, int(p0), int(p1)))
+                return f
+            if hi_b > lo_e:
+                diag["interior_launch_only"] = dict(timed(sub(lo_e, hi_b)), planes=[lo_e, hi_b], kernel=(lib.hj_last_kernel(ctx) or b"?").decode(),
+                                                    what="one substep over the planes that need no pad, alone")
+            if lo_e > 0:
+                diag["low_edge_launch_only"] = dict(timed(sub(0, lo_e)), planes=[0, lo_e])
+            if hi_b < nloc:
+                diag["high_edge_launch_only"] = dict(timed(sub(hi_b, nloc)), planes=[hi_b, nloc])
+            diag["whole_slab_launch_only"] = dict(timed(sub(0, nloc)), planes=[0, nloc], kernel=(lib.hj_last_kernel(ctx) or b"?").decode())
+        except Exception as e:  # noqa: BLE001
+            diag["error"] = repr(e)
     ok = bool(torch.isfinite(integ.state()).all())
     # ranks of the transport that moved the halos: RCCL's own count (ncclCommCount) for the native steppers, the
     # process group's for the torch.distributed one
@@ -833,7 +887,9 @@ def bench_slab(args, rank, world, global_n=513, workload="C4"):
     assert ok, "non-finite state after the timed steps"
     plane = wl["plane"]
     deep = bool(getattr(integ, "deep", False))
-    return {"walls": walls, "devs": devs, "total_cells": n0 * plane, "local_cells": slab.n_local * plane,
+    return {"walls": walls, "devs": devs, "total_cells": n0 * plane, "local_cells": slab.n_local * plane, "transport": kind, "diagnostics": diag,
+            "alternate_transport": (None if kind == "torch" else ("native" if kind == "native-deep" else
+                                                                 ("native-deep" if min(slab.counts) >= 18 else None))),
             "planes": "/".join(str(c) for c in sorted(set(slab.counts), reverse=True)),
             "slab_check_max_abs_diff": check, "nranks": nranks, "workload": wl,
             "kernel": kern.decode() if kern else "?",

@@ -290,3 +290,34 @@ def test_native_rccl_self_ring_on_the_transposed_march_bitwise(n, scheme, deep, 
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ the DEFAULT small-grid path against the oracle
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("n,pd", [((51, 51, 51), 2), ((24, 31, 40), (0, 2)), ((12, 50, 40), None)])
+def test_small_grids_on_the_default_direct_kernel_vs_oracle(scheme, n, pd, monkeypatch):
+    """tests/conftest.py sets HJ_DIRECT_BELOW=0 so that the suite's small grids exercise the TILED kernels; the PRODUCT sends 3-D grids below
+    140 000 cells (C1: 51^3, every notebook of the reference) to direct_substep_kernel.  Here the switch is at its default: five odeCFL3 steps
+    through the drop-in API against the oracle's full array -- ENO2 / ENO3 bit for bit, the WENO5 arithmetics 1e-11 -- and the kernel asserted."""
+    from levelsetpy_amd.context import device_grid
+    from test_gpu_parity import sdata, DERIV, close
+    monkeypatch.delenv("HJ_DIRECT_BELOW", raising=False)
+    g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+    d0 = L.shapeCylinder(g, 2, np.zeros((3, 1)), .5)
+    sd = sdata(g, L.DubinsVehicleRel(g, 1, 1), DERIV[scheme])
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    osys = O.DubinsRel(og, 1, 1)
+    term = lambda tt, yy: O.term_lax_friedrichs(og, osys, scheme, tt, yy)  # noqa: E731
+    y, t = d0.reshape(-1, 1), 0.
+    yo, to = d0.reshape(-1, 1), 0.
+    for _ in range(5):
+        t, y, _ = L.odeCFL3(L.termLaxFriedrichs, [t, 10.], y, op, sd)
+        to, yo = O.ode_cfl_3(term, [to, 10.], yo, 0.8, single_step=True)
+    dg = device_grid(g)
+    assert dg.lib.hj_last_kernel(dg.ctx) == b"direct_substep_kernel", dg.lib.hj_last_kernel(dg.ctx)
+    assert abs(t - to) <= 1e-14
+    if scheme.startswith("ENO"):
+        assert t == to
+        assert np.array_equal(y, yo), "%s: %d cells differ, max %.3e" % (scheme, int((np.asarray(y) != yo).sum()), float(np.abs(np.asarray(y) - yo).max()))
+    else:
+        close(np.asarray(y), yo, 1e-11, what=scheme)
