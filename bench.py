@@ -742,7 +742,7 @@ def source_hash():
 
 
 TRACE_STEPS = 400      # steps of the kernel-trace child pass that are looked at (after its spin-up)
-STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel", "fused_pair4_kernel",
+STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel", "fused_pair4_kernel", "fused_flat4_kernel",
                 "max_d1sq_kernel", "partials_to_values_kernel", "keys_to_values_kernel", "eps_seam_kernel")
 
 

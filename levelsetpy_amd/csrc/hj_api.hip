@@ -1129,6 +1129,8 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     c->pair = env_int("HJ_PAIR", 1);          // two-cells-per-lane kernel on grids of >= 6.5 M cells (light stencils) / 2.5 M (heavy stencils, fp32 4-D) (0: scalar kernel everywhere, 2: pair kernel whatever the size)
     c->tile4_sel = env_int("HJ_TILE4_SEL", -1);
     c->pair4 = env_int("HJ_PAIR4", 1);        // 4-D fp32 light stencils: the compile-time-tile kernel (hj_fused4v.h); 0: the generic pair kernel
+    c->flat4 = env_int("HJ_FLAT4", 1);
+    c->flat4_sel = env_int("HJ_FLAT4_SEL", -1);
     c->pair_nt = env_int("HJ_PAIR_NT", 0);
     c->pair_r = env_int("HJ_PAIR_R", 0);
     c->pair_kh = env_int("HJ_PAIR_KH", 0);

@@ -8,6 +8,7 @@
 #include "hj_fusedv.h"
 #include "hj_fused12v.h"
 #include "hj_fused4v.h"
+#include "hj_flat4v.h"
 #include "hj_launch.h"
 
 namespace hjh {
@@ -281,6 +282,106 @@ int launch_pair4(hj_ctx* c, const SubstepCall& s) {
 #undef HJ_P4
 }
 
+// ---- the 4-D fp32 kernel with full-row tiles and 16-byte row loads (hj_flat4v.h; round 6): (threads, pairs per thread, E1, E2, LDS row
+// pitch P3, waves/SIMD hint).  Taken ahead of the compile-time tiles above when the grid's contiguous axis fits a row of the box.
+#ifndef HJ_FLAT4
+#define HJ_FLAT4(X) X(512, 2, 3, 5, 140, 2)
+#endif
+inline bool flat4_fits(const hj_ctx* c, int nt, int r, int e1, int e2, int p3) {
+    if (!(c->ndim == 4 && c->dtype == HJ_F32 && c->N[1] >= e1 && c->N[2] >= e2 && c->total < (1ll << 31))) return false;
+    const long long n3 = c->N[3], halfp = (n3 + 1) / 2, ch = (n3 + 3) / 4, nr = (long long)e1 * e2, nh = 6ll * (e1 + e2);
+    return n3 >= 8 && n3 <= p3 - HJ_VPAD - 4 && nr * halfp <= (long long)nt * r && nr * ch <= nt && nh * ch <= 4ll * nt;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int E1, int E2, int P3, int OCC, bool PG, int MODE>
+int launch_flat4_mode(hj_ctx* c, const SubstepCall& s) {
+    using G = hj::Flat4<E1, E2, P3>;
+    constexpr bool ROWS = hj::ham_has_rows<HAM>::value;
+    constexpr int ER = hj::RowAxis<HAM, ROWS>::value == 1 ? E1 : E2;
+    auto kern = fused_flat4_kernel<T, HAM, SCHEME, NT, R, E1, E2, P3, OCC, PG, MODE>;
+    Tiling t;
+    memset(&t, 0, sizeof(t));
+    t.ok = true;
+    const int Ed[4] = {1, E1, E2, (int)c->N[3]};
+    t.ntiles = 1;
+    for (int d = 0; d < HJ_MAX_DIM; ++d) { t.E[d] = 1; t.ntile[d] = 1; }
+    for (int d = 1; d < 4; ++d) {
+        t.E[d] = Ed[d];
+        t.ntile[d] = (int)((c->N[d] + Ed[d] - 1) / Ed[d]);
+        t.ntiles *= t.ntile[d];
+    }
+    t.lpitch = P3;
+    const size_t base_lds = 512 + (2 * (size_t)G::PLANE + 2 * (size_t)G::STAGE) * sizeof(T);
+    const int wg_per_cu = std::max(1, std::min(OCC * 256 / NT, (int)((size_t)(160 * 1024) / (base_lds + 4096))));
+    const size_t lds_cap = (size_t)(160 * 1024) / wg_per_cu - 256;
+    int64_t chunk_max = 0;
+    if (ROWS) {
+        if (base_lds + (size_t)ER * G::ROWF * sizeof(T) * 8 > lds_cap) return hjh::fail(HJ_EUNSUPPORTED, "4-D full-row tile leaves no LDS for the row table");
+        chunk_max = (int64_t)((lds_cap - base_lds) / ((size_t)ER * G::ROWF * sizeof(T)));
+    }
+    EdgePlan ep;
+    {
+        const int rc_plan = plan_chunks(c, s, t, wg_per_cu, ep, chunk_max);
+        if (rc_plan) return rc_plan;
+    }
+    t.lds_bytes = base_lds + (ROWS ? (size_t)t.chunk * ER * G::ROWF * sizeof(T) : 0);
+    c->last_plan.ntiles = t.ntiles; c->last_plan.nchunks = t.nchunks; c->last_plan.nblocks = t.nblocks; c->last_plan.threads = NT;
+    c->last_plan.wg_per_cu = wg_per_cu; c->last_plan.lds_bytes = t.lds_bytes;
+    c->last_kernel = "fused_flat4_kernel";
+    c->last_E[0] = t.chunk;
+    for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = t.E[d];
+    if (c->dry) return HJ_OK;
+    if (c->debug) {
+        fprintf(stderr, "[hj] flat4 tiling NT=%d R=%d OCC=%d E=(%d,%d,whole rows of %d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d lds=%zu PG=%d MODE=%d\n",
+                NT, R, OCC, E1, E2, (int)c->N[3], P3, t.ntiles, t.chunk, t.nchunks, t.nblocks, t.lds_bytes, (int)PG, MODE);
+        c->debug = 0;
+    }
+    FusedArgs<T, 4> A;
+    memset(&A, 0, sizeof(A));
+    A.bound = s.bound;
+    unsigned grid_blocks = 0;
+    {
+        const int rc_fill = fill_fused_args<T, 4>(c, s, t, ep, SCHEME, true, A, grid_blocks);
+        if (rc_fill) return rc_fill;
+    }
+    A.lds_nbuf = 2;
+    A.halo_ahead = 0;
+    A.npairs = 0;
+    c->last_nbuf = 2;
+    if (t.lds_bytes > 64 * 1024) {
+        static std::mutex mu;
+        static std::map<std::pair<int, const void*>, size_t> granted_by_kernel;
+        std::lock_guard<std::mutex> lock(mu);
+        size_t& granted = granted_by_kernel[std::make_pair(c->device, reinterpret_cast<const void*>(kern))];
+        if (granted < t.lds_bytes) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+            granted = t.lds_bytes;
+        }
+    }
+    if (c->launch_stop) {
+        hipExtLaunchKernelGGL(kern, dim3(grid_blocks), dim3(NT), (unsigned)t.lds_bytes, call_stream(c, s), nullptr, c->launch_stop, 0,
+                              (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
+        c->launch_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid_blocks), dim3(NT), t.lds_bytes, call_stream(c, s), (const T*)s.y, (const T*)s.y0, (T*)s.out, A);
+    }
+    HIP_TRY(hipGetLastError());
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME, int NT, int R, int E1, int E2, int P3, int OCC>
+int launch_flat4(hj_ctx* c, const SubstepCall& s) {
+    const bool pg = c->bc[1] != HJ_BC_PERIODIC || c->bc[2] != HJ_BC_PERIODIC || c->bc[3] != HJ_BC_PERIODIC;
+    const bool plain = s.stage != HJ_STAGE_YDOT && s.restrict_sign == 0 && s.post_op == 0 && !c->no_plain;
+    const int mode = plain ? (s.stage == HJ_STAGE_EULER ? 1 : 2) : 0;
+#define HJ_F4(PG_, MODE_) return launch_flat4_mode<T, HAM, SCHEME, NT, R, E1, E2, P3, OCC, PG_, MODE_>(c, s)
+    if (pg) { if (mode == 1) HJ_F4(true, 1); if (mode == 2) HJ_F4(true, 2); HJ_F4(true, 0); }
+    if (mode == 1) HJ_F4(false, 1);
+    if (mode == 2) HJ_F4(false, 2);
+    HJ_F4(false, 0);
+#undef HJ_F4
+}
+
 // (threads, PAIRS per thread, halo slots per thread, waves/SIMD hint) of the pair kernel
 #ifndef HJ_CONFIGS_PAIR
 #define HJ_CONFIGS_PAIR(X) X(256, 1, 2, 2) X(512, 2, 2, 2)
@@ -475,6 +576,13 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             const long long pair_from = (HAM::ND <= 3 && light_cfg(SCHEME, HAM::ND)) ? 6500000 : 2500000;
             // 4-D, fp32, light stencil: the compile-time-tile kernel (hj_fused4v.h) when its tile fits the grid (HJ_PAIR4=0: the generic pair kernel)
             if constexpr (HAM::ND == 4 && sizeof(T) == 4 && light_scheme(SCHEME)) {
+                if (c->pair != 0 && c->flat4 != 0 && c->pair_nt <= 0 && (c->total >= pair_from || c->pair == 2)) {
+                    // full-row tiles with 16-byte row loads (hj_flat4v.h, round 6) when the contiguous axis fits a row of the box (HJ_FLAT4=0: never)
+                    int kf = 0;          // (HJ_FLAT4_SEL = k: only the k-th shape of the list, for A/B runs)
+#define X(NT_, R_, E1_, E2_, P3_, OCC_) if ((c->flat4_sel < 0 || c->flat4_sel == kf) && flat4_fits(c, NT_, R_, E1_, E2_, P3_)) return launch_flat4<T, HAM, SCHEME, NT_, R_, E1_, E2_, P3_, OCC_>(c, s); ++kf;
+                    HJ_FLAT4(X)
+#undef X
+                }
                 if (c->pair != 0 && c->pair4 != 0 && c->pair_nt <= 0 && (c->total >= pair_from || c->pair == 2)) {
                     // the first tile of the list that fits (HJ_TILE4_SEL = k: only the k-th, for A/B runs)
                     int k4 = 0;

@@ -25,7 +25,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 RANGE_SHARE = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2        # share of the cases that run a range-dependent run-time Hamiltonian
 DERIV = {"ENO2": L.upwindFirstENO2, "ENO3": L.upwindFirstENO3, "WENO5_ASSHIPPED": L.upwindFirstWENO5, "WENO5": L.upwindFirstWENO5Intended}
-KNOBS = ("HJ_PAIR", "HJ_FORCE_DIRECT", "HJ_TILE4_SEL", "HJ_PAIR4", "HJ_MIN_CHUNK", "HJ_TILE_CELLS")
+KNOBS = ("HJ_PAIR", "HJ_FORCE_DIRECT", "HJ_TILE4_SEL", "HJ_PAIR4", "HJ_FLAT4", "HJ_MIN_CHUNK", "HJ_TILE_CELLS", "HJ_XP")
 
 
 def mk(gmin, gmax, N, pd):
@@ -113,9 +113,15 @@ def case(rng, k):
         dtype = "float32" if rng.random() < 0.7 else "float64"
     gmax = [gmax[d] - (gmax[d] - gmin[d]) / N[d] if d in pd else gmax[d] for d in range(len(N))]
     # the kernel, forced
-    kern = str(rng.choice(["default", "pair", "single", "direct", "tile4", "split"]))
+    kern = str(rng.choice(["default", "pair", "single", "direct", "tile4", "split", "flat4", "xp"]))
     if kern == "pair":
         os.environ["HJ_PAIR"] = "2"
+        os.environ["HJ_FLAT4"] = "0"
+    elif kern == "flat4":                   # round 6: the 4-D full-row kernel wherever the last axis fits (other grids: whatever "pair" runs)
+        os.environ["HJ_PAIR"] = "2"
+    elif kern == "xp":                      # round 6: the transposed march wherever a launch has that form (3-D Dubins)
+        os.environ["HJ_PAIR"] = "2"
+        os.environ["HJ_XP"] = "2"
     elif kern == "single":
         os.environ["HJ_PAIR"] = "0"
     elif kern == "direct":
@@ -123,6 +129,7 @@ def case(rng, k):
     elif kern == "tile4":
         os.environ["HJ_PAIR"] = "2"
         os.environ["HJ_TILE4_SEL"] = str(int(rng.integers(0, 3)))
+        os.environ["HJ_FLAT4"] = "0"
     if rng.random() < 0.3:
         os.environ["HJ_MIN_CHUNK"] = str(int(rng.integers(1, 6)))
     g, og = mk(gmin, gmax, N, pd)

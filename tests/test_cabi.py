@@ -217,7 +217,7 @@ def test_plan_substep_needs_no_device():
     q = plan_substep([65, 513, 513], [0, 0, 1], "float64", sid, _ffi.HAM_DUBINS_REL, _ffi.STAGE_EULER, -6, 71, True, True)
     assert q["chunks"] * q["chunk_planes"] >= 77
     p4 = plan_substep([17, 129, 129, 129], [1, 1, 1, 1], "float32", sid, _ffi.HAM_DOUBLE_PENDULUM, _ffi.STAGE_EULER, 3, 14, True, True)
-    assert p4["kernel"] == "fused_pair4_kernel" and len(p4["tile"]) == 3
+    assert p4["kernel"] == "fused_flat4_kernel" and p4["tile"] == [3, 5, 129]      # full rows of the contiguous axis (hj_flat4v.h)
     small = plan_substep([51, 51, 51], [0, 0, 1], "float64", sid, _ffi.HAM_DUBINS_REL, _ffi.STAGE_EULER, 0, 51)
     assert small["kernel"] == "fused_substep_kernel" and small["workgroups"] > 0
     with pytest.raises(ValueError):       # a 3-D Hamiltonian on a 2-D grid

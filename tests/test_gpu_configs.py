@@ -192,7 +192,7 @@ def test_c5_129_to_the_4_fp32_all_periodic_properties(monkeypatch):
     par = [1.0, 0., 0., 0.]
     dt = 2e-4
     outs = {}
-    for name, force, pair, kern in (("default", "0", None, b"fused_pair4_kernel"), ("single", "0", "0", b"fused_substep_kernel"),
+    for name, force, pair, kern in (("default", "0", None, b"fused_flat4_kernel"), ("single", "0", "0", b"fused_substep_kernel"),
                                     ("direct", "1", None, b"direct_substep_kernel")):
         monkeypatch.setenv("HJ_FORCE_DIRECT", force)
         if pair is None:

@@ -232,6 +232,7 @@ def test_pair4_kernel_every_tile_and_light_stencil_equals_the_generic_pair_kerne
     fast = scheme.endswith("_FAST")
     sid = {"ENO2": _ffi.SCHEME_IDS["ENO2"], "WENO5_ASSHIPPED": _ffi.SCHEME_IDS["WENO5_ASSHIPPED"], "ENO2_FAST": 4}[scheme]
     res = {}
+    monkeypatch.setenv("HJ_FLAT4", "0")        # (the full-row kernel of round 6 would take these grids first: tests/test_gpu_round6.py)
     for pair4 in ("1", "0"):
         monkeypatch.setenv("HJ_PAIR4", pair4)
         g, _ = pendulum_grid(n, pd=pd, low_mem=True)

@@ -28,6 +28,13 @@ def _substep_rs(dg, scheme, ham, par, stage, dt, y, y0, out, restrict_sign):
                                     dg.ptr(y), dg.ptr(y0) if y0 is not None else None, dg.ptr(out), 3, 0, dg.shape[0]))
 
 
+@pytest.fixture(autouse=True)
+def _compile_time_tile_kernel(monkeypatch):
+    """This file's 4-D tests are about fused_pair4_kernel (hj_fused4v.h).  Since round 6 grids whose last axis fits a row of the LDS box take
+    fused_flat4_kernel (hj_flat4v.h) first -- tests/test_gpu_round6.py covers that one; here it is switched off."""
+    monkeypatch.setenv("HJ_FLAT4", "0")
+
+
 def _last_kernel(g):
     dg = g.__dict__["_hj_device"]
     dg = dg[next(iter(dg))] if isinstance(dg, dict) else dg

@@ -321,3 +321,144 @@ def test_small_grids_on_the_default_direct_kernel_vs_oracle(scheme, n, pd, monke
         assert np.array_equal(y, yo), "%s: %d cells differ, max %.3e" % (scheme, int((np.asarray(y) != yo).sum()), float(np.abs(np.asarray(y) - yo).max()))
     else:
         close(np.asarray(y), yo, 1e-11, what=scheme)
+
+
+# ------------------------------------------------------------------------------ the 4-D full-row kernel (csrc/hj_flat4v.h)
+def _p4_field(og, n, seed=5):
+    rng = np.random.default_rng(seed)
+    return O.shape_sphere(og, None, 1.5) + 0.05 * np.sin(2 * og.xs[0]) * np.cos(og.xs[2]) + 0.02 * rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO2"])
+@pytest.mark.parametrize("n,pd", [((8, 7, 9, 41), (0, 1, 2, 3)),        # all periodic, ODD last axis: single-cell slots at the row ends, wrap through the row's pad
+                                  ((8, 7, 9, 40), (0, 1, 2, 3)),        # all periodic, even last axis
+                                  ((7, 11, 6, 37), (0, 2)),             # axes 1 and 3 extrapolated: ghost rows, ghosts of an odd row's ends
+                                  ((9, 5, 13, 34), None),               # nothing periodic, even rows; axis 2 exactly ... several tiles, axis 1 one
+                                  ((6, 12, 8, 129), (1, 3)),            # C5's row length; axis 0 extrapolated (ghost planes staged), axis 2 extrapolated
+                                  ((5, 3, 5, 131), (0, 1, 2, 3))])      # the longest row a box holds at its pitch, one tile per plane
+def test_flat4_kernel_vs_fp64_oracle_pair4_and_direct(scheme, n, pd, monkeypatch):
+    """termLaxFriedrichs on 4-D fp32 grids through fused_flat4_kernel (whole rows of the contiguous axis, 16-byte row loads) against the fp64
+    oracle (1e-4 of max |ydot|; ENO2 masked as in round 5) and BITWISE against the compile-time-tile kernel, the generic pair kernel and the
+    direct kernel -- the same per-cell arithmetic whatever the data path."""
+    from test_gpu_configs import pendulum_grid
+    from test_gpu_parity import sdata, DERIV
+    g, og = pendulum_grid(n, pd)
+    data = _p4_field(og, n)
+    yo, sbo = O.term_lax_friedrichs(og, O.DoublePendulum4D(og, 1.0), scheme, 0., data.reshape(-1, 1))
+    scale = float(np.max(np.abs(yo)))
+    y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
+    got = {}
+    want = {"flat4": b"fused_flat4_kernel", "pair": b"fused_pair_kernel", "direct": b"direct_substep_kernel"}
+    for name in ("flat4", "pair", "direct"):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if name == "direct" else "0")
+        monkeypatch.setenv("HJ_PAIR", "2")
+        monkeypatch.setenv("HJ_PAIR4", "0")
+        monkeypatch.setenv("HJ_FLAT4", "1" if name == "flat4" else "0")
+        g.__dict__.pop("_hj_device", None)
+        yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
+        dg = g.__dict__["_hj_device"]
+        dg = dg[next(iter(dg))] if isinstance(dg, dict) else dg
+        assert dg.lib.hj_last_kernel(dg.ctx) == want[name], (name, dg.lib.hj_last_kernel(dg.ctx))
+        assert abs(sb - sbo) <= 1e-5 * sbo, (name, sb, sbo)
+        got[name] = yd.cpu().numpy().astype(np.float64)
+    g.__dict__.pop("_hj_device", None)
+    rel = np.abs(got["flat4"] - yo) / scale
+    if scheme.startswith("WENO"):
+        assert rel.max() <= 1e-4, rel.max()
+    else:
+        assert np.mean(rel > 1e-4) <= 2e-3 and rel.max() <= 0.2, (float(np.mean(rel > 1e-4)), rel.max())
+    for name in ("pair", "direct"):
+        assert np.array_equal(got["flat4"], got[name]), (name, int((got["flat4"] != got[name]).sum()), float(np.max(np.abs(got["flat4"] - got[name]))))
+
+
+@pytest.mark.parametrize("n,pd", [((37, 10, 12, 67), (0, 1, 2, 3)), ((23, 7, 9, 50), (0, 2))])
+def test_flat4_rk3_steps_clamp_ranges_and_bound(n, pd, monkeypatch):
+    """hj_rk_substep through the full-row kernel: the Euler / with-y0 / general (clamped) instantiations equal the direct kernel bit for bit, a
+    stage computed as three plane ranges equals one launch, the in-kernel CFL maxima equal the definition (the dummy second cell of an odd
+    row's last slot must not leak into them)."""
+    from test_gpu_configs import pendulum_grid
+    g, og = pendulum_grid(n, pd)
+    d0 = torch.as_tensor(_p4_field(og, n, 7), device="cuda", dtype=torch.float32).contiguous()
+    par = [1.0, 0., 0., 0.]
+    dt = 2e-3
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+
+    def sub(dg, stage, y, y0, out, p0=0, p1=None, slot=3, rs=0):
+        _ffi.check(dg.lib.hj_rk_substep(dg.ctx, sid, _ffi.HAM_DOUBLE_PENDULUM, _ffi.darr(par), 0., stage, dt, rs, dg.ptr(y),
+                                        dg.ptr(y0) if y0 is not None else None, dg.ptr(out), slot, p0, n[0] if p1 is None else p1))
+    outs = {}
+    for name, force in (("flat4", "0"), ("direct", "1")):
+        monkeypatch.setenv("HJ_FORCE_DIRECT", force)
+        monkeypatch.setenv("HJ_PAIR", "2")
+        dg = DeviceGrid(g, "float32")
+        dg.bind_stream()
+        a, b, c, r = dg.empty(), dg.empty(), dg.empty(), dg.empty()
+        sub(dg, _ffi.STAGE_EULER, d0, None, a)
+        sub(dg, _ffi.STAGE_RK3_HALF, a, d0, b)
+        sub(dg, _ffi.STAGE_RK3_FULL, b, d0, c)
+        assert dg.lib.hj_last_kernel(dg.ctx) == (b"fused_flat4_kernel" if force == "0" else b"direct_substep_kernel")
+        sub(dg, _ffi.STAGE_RK3_FULL, b, d0, r, rs=-1)
+        if force == "0":
+            c2 = torch.zeros_like(c)
+            for k, (p0, p1) in enumerate([(0, 5), (5, 19), (19, n[0])]):
+                sub(dg, _ffi.STAGE_RK3_FULL, b, d0, c2, p0, p1, slot=4 + k)
+            dg.sync()
+            assert torch.equal(c, c2), float((c - c2).abs().max())
+            sb, am = C.c_double(), (C.c_double * 4)()
+            _ffi.check(dg.lib.hj_read_step_bound(dg.ctx, 3, C.byref(sb), am))
+            f = O.DoublePendulum4D(og, 1.0).drift()
+            ref = [float(np.max(np.abs(f[0]))), float(np.max(np.abs(f[1]))) + 1.0, float(np.max(np.abs(f[2]))), float(np.max(np.abs(f[3]))) + 1.0]
+            for d in range(4):
+                assert abs(am[d] - ref[d]) <= 3e-6 * ref[d], (d, am[d], ref[d])
+        dg.sync()
+        outs[name] = (a, b, c, r)
+    for k in range(4):
+        assert torch.equal(outs["flat4"][k], outs["direct"][k]), (k, float((outs["flat4"][k] - outs["direct"][k]).abs().max()))
+    assert float((outs["flat4"][2] - outs["flat4"][3]).abs().max()) > 0      # the clamp did something
+
+
+def test_flat4_long_axis0_chunks_the_row_table_and_slab_ring(monkeypatch):
+    """Several chunks per tile column (each with its own row table) on a long axis 0; and the deep-halo stepper on a ring of three virtual ranks
+    (pad planes, plane windows beyond the slab) bitwise equal to the undivided grid -- all through the full-row kernel."""
+    from test_gpu_configs import pendulum_grid
+    from test_gpu_round4 import sphere4, undivided_steps, PAR_PENDULUM
+    from levelsetpy_amd.dist import SlabDecomposition, NativeSlabStepper
+    monkeypatch.setenv("HJ_PAIR", "2")
+    n = (61, 6, 7, 45)
+    g, _ = pendulum_grid(n, low_mem=True)
+    full = sphere4(g, noise=0.01, seed=9)
+    dxs = [float(v) for v in np.asarray(g.dx).ravel()]
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+    world = 3
+    steppers = []
+    for r in range(world):
+        slab = SlabDecomposition(n[0], world, r, True)
+        steppers.append(NativeSlabStepper(g, slab, sid, _ffi.HAM_DOUBLE_PENDULUM, PAR_PENDULUM, dxs, "float32", order=3, deep=True, external=lambda st: None))
+    amax = [max(st.alpha_local[d] for st in steppers) for d in range(4)]
+    for st in steppers:
+        st.set_alpha_max(amax)
+
+    def move_pads():
+        torch.cuda.synchronize()
+        for st in steppers:
+            D, nl, sl = st.pad, st.n, st.slab
+            nb = steppers[sl.hi]
+            st.buf["cur"][D + nl:D + nl + D].copy_(nb.buf["cur"][nb.pad:nb.pad + D])
+            nb = steppers[sl.lo]
+            st.buf["cur"][0:D].copy_(nb.buf["cur"][nb.pad + nb.n - D:nb.pad + nb.n])
+        torch.cuda.synchronize()
+    for st in steppers:
+        st.set_state(full[st.slab.begin:st.slab.end])
+    move_pads()
+    t = 0.
+    for _ in range(3):
+        ts = [st.step(t) for st in steppers]
+        move_pads()
+        t, dt = ts[0]
+    assert steppers[0].dg.lib.hj_last_kernel(steppers[0].dg.ctx) == b"fused_flat4_kernel"
+    t_ref, ref = undivided_steps(g, full, "WENO5_ASSHIPPED", 3, 3, dt)
+    assert abs(t_ref - t) <= 1e-15
+    for st in steppers:
+        got, want = st.state(), ref[st.slab.begin:st.slab.end]
+        assert torch.equal(got, want), "rank %d differs by %g" % (st.slab.rank, float((got - want).abs().max()))
+        st.close()

@@ -19,6 +19,7 @@ KERNELS = [
     (r"fused_pair_kernel<double, hj::HamDoubleIntegrator<double>, 1, 256, 1, 2, 2, 2>", "C3 (4096^2 ENO3, bit-exact arithmetic), stages 2-3", 2),
     (r"fused_pair_kernel<double, hj::HamDoubleIntegrator<double>, 5, 512, 2, 2, 2, 2>", "C3 fast (ENO3 in the lean arithmetic, two pairs per thread), stages 2-3", 4),
     (r"fused_pair4_kernel<float, hj::HamDoublePendulum<float>, 3, 512, 2, 5, 6, 66, 2, false, 2>", "C5 (129^4 fp32 pendulum), stages 2-3: compile-time tile 5x6x66", 4),
+    (r"fused_flat4_kernel<float, hj::HamDoublePendulum<float>, 3, 512, 2, 3, 5, 140, 2, false, 2>", "C5, stages 2-3: full-row kernel 3x5 rows (round 6)", 4),
 ]
 out = os.path.join(ROOT, "profiles", "%s_isa_mix.txt" % tag)
 with tempfile.TemporaryDirectory(dir="/tmp") as tmp, open(out, "w") as fh:
