@@ -238,6 +238,12 @@ extern template int launch_scheme<double, HamDoublePendulum<double>>(hj_ctx*, co
 extern template int launch_scheme<float, HamDubinsRel<float>>(hj_ctx*, const SubstepCall&);
 extern template int launch_scheme<float, HamDoubleIntegrator<float>>(hj_ctx*, const SubstepCall&);
 extern template int launch_scheme<float, HamDoublePendulum<float>>(hj_ctx*, const SubstepCall&);
+extern template int launch_coop<double, HamDubinsRel<double>>(hj_ctx*, const CoopCall&);
+extern template int launch_coop<double, HamDoubleIntegrator<double>>(hj_ctx*, const CoopCall&);
+extern template int launch_coop<double, HamDoublePendulum<double>>(hj_ctx*, const CoopCall&);
+extern template int launch_coop<float, HamDubinsRel<float>>(hj_ctx*, const CoopCall&);
+extern template int launch_coop<float, HamDoubleIntegrator<float>>(hj_ctx*, const CoopCall&);
+extern template int launch_coop<float, HamDoublePendulum<float>>(hj_ctx*, const CoopCall&);
 extern template int launch_term_tiled<double, 2>(hj_ctx*, int, const SubstepCall&);
 extern template int launch_term_tiled<double, 3>(hj_ctx*, int, const SubstepCall&);
 extern template int launch_stage12<double, HamDubinsRel<double>>(hj_ctx*, const Stage12Call&);
@@ -500,6 +506,45 @@ int do_substep(hj_ctx* c, SubstepCall& s, int user_slot) {
     else if (!s.xp) s.xp = xp_wanted(c, s.p0, s.p1);      // thin grids / slabs without neighbours (the rule above)
     if (c->xp_mode == 0) s.xp = false;
     return c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
+}
+
+// hj_rk_step on a SMALL grid (what launch_cfg sends to direct_substep_kernel): the whole step as one cooperative launch (coop_rk_kernel).
+// HJ_XP_FALLBACK: not applicable -- the caller issues the stages one launch each.
+template <typename T> int coop_ham(hj_ctx* c, const CoopCall& s) {
+    switch (s.ham) {
+        case HJ_HAM_DUBINS_REL: return launch_coop<T, HamDubinsRel<T>>(c, s);
+        case HJ_HAM_DOUBLE_INTEGRATOR: return launch_coop<T, HamDoubleIntegrator<T>>(c, s);
+        case HJ_HAM_DOUBLE_PENDULUM: return launch_coop<T, HamDoublePendulum<T>>(c, s);
+    }
+    return HJ_XP_FALLBACK;
+}
+bool coop_applies(const hj_ctx* c, int order, int scheme, int ham) {
+    if (!c->coop || order < 2 || scheme == HJ_WENO5 || c->dry || c->keep_bounds || c->halo_lo || c->halo_hi || c->ndim > 3) return false;
+    // (only where the ordinary step is `order` launches of the direct kernel: launch_cfg's small-grid rule)
+    if (!(c->direct_below > 0 && c->total < c->direct_below) || c->force_direct || c->pair == 2 || c->pair_nt > 0 || c->cfg_from_env || c->timing_dump)
+        return false;
+    return ham == HJ_HAM_DUBINS_REL || ham == HJ_HAM_DOUBLE_INTEGRATOR || ham == HJ_HAM_DOUBLE_PENDULUM;
+}
+int try_coop_step(hj_ctx* c, int order, int scheme, int ham, const double* par, double dt, int restrict_sign, const void* y_in, void* y_out,
+                  void* work0, void* work1) {
+    if (!coop_applies(c, order, scheme, ham)) return HJ_XP_FALLBACK;
+    if (order == 3 && (work1 == y_out || work1 == y_in || work0 == y_in)) return HJ_XP_FALLBACK;
+    if (c->coop_ok < 0) {
+        int v = 0;
+        c->coop_ok = (hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, c->device) == hipSuccess && v) ? 1 : 0;
+    }
+    if (!c->coop_ok) return HJ_XP_FALLBACK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;           // (a cooperative launch inside a stream capture: not tried)
+    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return HJ_XP_FALLBACK; }
+    int rc = check_ham(c, ham, par);
+    if (rc) return rc;
+    if (!c->coop_sync) {
+        HIP_TRY(hipMalloc(&c->coop_sync, sizeof(CoopSync)));
+        HIP_TRY(hipMemset(c->coop_sync, 0, sizeof(CoopSync)));
+    }
+    CoopCall s{scheme, ham, order, restrict_sign, c->post_step_op, par, dt, y_in, order == 2 ? work0 : work0, order == 2 ? y_out : work1, y_out};
+    c->eps_ready = false;
+    return c->dtype == HJ_F64 ? coop_ham<double>(c, s) : coop_ham<float>(c, s);
 }
 
 template <typename T> int stage12_ham(hj_ctx* c, const Stage12Call& s) {
@@ -1131,6 +1176,7 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     c->pair4 = env_int("HJ_PAIR4", 1);        // 4-D fp32 light stencils: the compile-time-tile kernel (hj_fused4v.h); 0: the generic pair kernel
     c->flat4 = env_int("HJ_FLAT4", 1);
     c->flat4_sel = env_int("HJ_FLAT4_SEL", -1);
+    c->coop = env_int("HJ_COOP", 0);       // opt-in: measured SLOWER than the stage launches above ~40^3 (profiles/r06_small_grids.txt)
     c->pair_nt = env_int("HJ_PAIR_NT", 0);
     c->pair_r = env_int("HJ_PAIR_R", 0);
     c->pair_kh = env_int("HJ_PAIR_KH", 0);
@@ -1251,6 +1297,7 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->partials) (void)hipFree(c->partials);
     for (int i = 0; i < 2; ++i) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
     if (c->ev_bounds) (void)hipEventDestroy(c->ev_bounds);
+    if (c->coop_sync) (void)hipFree(c->coop_sync);
     if (c->eps_prod) (void)hipFree(c->eps_prod);
     if (c->eps_rows) (void)hipFree(c->eps_rows);
     delete c;
@@ -1937,7 +1984,14 @@ int hj_rk_step(hj_ctx* c, int order, int scheme, int ham, const double* par, dou
     // intended WENO5: every stage's launch reduces max(D1^2) of its output for the next stage's epsilon (no pre-pass between
     // the stages); across steps only inside hj_rk_integrate, where nobody else touches the state (eps_chain_*)
     const bool chain_in = c->eps_chain_in, chain_out = c->eps_chain_out && !c->post_arr[0] && !c->post_arr[1];
-    if (order == 1) {
+    const int rc_coop = (order >= 2 && !fuse) ? try_coop_step(c, order, scheme, ham, par, dt, restrict_sign, y_in, y_out, work0, work1) : HJ_XP_FALLBACK;
+    if (rc_coop != HJ_XP_FALLBACK && rc_coop != HJ_OK) return rc_coop;
+    if (rc_coop == HJ_OK) {
+        // small grid: the whole step was ONE cooperative launch (hj_split.h, coop_rk_kernel); the times as below
+        const double t1 = t0 + dt, t2 = t1 + dt;
+        if (order == 2) t = 0.5 * (t0 + t2);
+        else { const double tHalf = 0.25 * (3 * t0 + t2); t = (1.0 / 3.0) * (t0 + 2 * (tHalf + dt)); }
+    } else if (order == 1) {
         SubstepCall s{scheme, ham, HJ_STAGE_EULER, restrict_sign, par, dt, y_in, nullptr, y_out, nullptr, 0, n0};
         s.post_op = c->post_step_op;
         s.eps_from_prev = chain_in; s.want_eps = chain_out;
@@ -2016,6 +2070,7 @@ int hj_rk_plan(hj_ctx* c, int order, int scheme, int ham, const double* par, int
     const bool f = use_stage12(c, order, scheme, ham, par, restrict_sign);
     if (launches) {
         *launches = f ? order - 1 : order;
+        if (!f && coop_applies(c, order, scheme, ham) && c->coop_ok != 0) *launches = 1;      // small grids: one cooperative launch (coop_rk_kernel)
         if (scheme == HJ_WENO5) {
             // the epsilon pre-pass (2 launches) in front of every stage -- or, when the tiled kernels reduce max(D1^2) of their
             // own output (HJ_EPS_FUSE, whole-grid launches of a single domain), in front of the first stage only, with one

@@ -181,6 +181,12 @@ struct hj_ctx {
     // HJ_XP: 0 never march along axis 1, 1 (default) slab launches whose window is thin against axis 1 (xp_wanted, hj_api.hip), 2 every launch
     // that has a transposed instantiation (tests: bitwise against the axis-0 march on any grid)
     int xp_mode = 1;
+    // HJ_COOP (default 0 -- built, bitwise equal, measured slower: a grid barrier costs 4-6 us, a kernel boundary 1.5-1.9): hj_rk_step of order
+    // 2 / 3 on grids the direct kernel runs is ONE launch with grid barriers between the stages (1: plain launch, 2: hipLaunchCooperativeKernel)
+    int coop = 0;
+    void* coop_sync = nullptr;                      // CoopSync (device): barrier counters, only ever growing
+    unsigned long long coop_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, coop_all = 0;      // what they read once every launch issued so far has run
+    int coop_ok = -1;                               // device attribute hipDeviceAttributeCooperativeLaunch (-1: not asked yet)
     int xp_max_planes = 0;                          // HJ_XP_MAX_PLANES: auto mode takes windows of at most this many planes (0: the built-in rule)
     int dry = 0;
     struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
@@ -340,6 +346,17 @@ constexpr int HJ_XP_FALLBACK = -7777;
 template <typename T, typename HAM> int launch_xp(hj_ctx* c, const SubstepCall& s);
 template <typename T, typename HAM> constexpr bool xp_available() { return HAM::ID == HJ_HAM_DUBINS_REL && !ham_xp<HAM>::value; }
 bool xp_wanted(const hj_ctx* c, int64_t p0, int64_t p1);
+
+// a whole odeCFL2 / odeCFL3 step of a small grid in ONE cooperative launch (hj_split.h, coop_rk_kernel): HJ_OK, an error, or HJ_XP_FALLBACK
+// (no instantiation / the grid does not fit the resident workgroups): the caller then issues the stages one launch each -- same bits
+struct CoopCall {
+    int scheme, ham, order, restrict_sign, post_op;
+    const double* par;
+    double dt;
+    const void* y;
+    void *s1, *s2, *out;
+};
+template <typename T, typename HAM> int launch_coop(hj_ctx* c, const CoopCall& s);
 
 // two RK stages in one launch (hj_fused12.h): out = ca*y + cb*(y1 + dt*L(y1)), y1 = y + dt*L(y)
 struct Stage12Call {

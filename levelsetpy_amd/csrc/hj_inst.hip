@@ -529,6 +529,88 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     return HJ_OK;
 }
 
+// ---- one cooperative launch for a whole odeCFL2 / odeCFL3 step of a SMALL grid (hj_split.h, coop_rk_kernel; round 6)
+template <typename T, typename HAM, int SCHEME, int CPT>
+int launch_coop_cpt(hj_ctx* c, const CoopCall& s, int nblocks) {
+    constexpr int ND = HAM::ND;
+    auto kern = coop_rk_kernel<T, HAM, SCHEME, CPT>;
+    CoopArgs<T, ND> A;
+    memset(&A, 0, sizeof(A));
+    A.y = (const T*)s.y; A.s1 = (T*)s.s1; A.s2 = (T*)s.s2; A.out = (T*)s.out;
+    fill_grid<T, ND>(c, A.G);
+    for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
+    A.order = s.order; A.restrict_sign = s.restrict_sign; A.post_op = s.post_op;
+    A.dt = (T)s.dt;
+    fill_ham<T>(c, s.par, A.ham);
+    A.sync = (CoopSync*)c->coop_sync;
+    unsigned nper[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nx = 0;
+    for (int b = 0; b < nblocks; ++b) nper[b & 7]++;
+    for (int x = 0; x < 8; ++x) { A.nper_xcd[x] = nper[x]; A.base_xcd[x] = c->coop_xcd[x]; if (nper[x]) ++nx; }
+    A.nxcd = nx;
+    A.base_all = c->coop_all;
+    void* args[1] = {&A};
+    // (a PLAIN launch: the grid was sized against the occupancy query above, so every workgroup is resident as under hipLaunchCooperativeKernel --
+    //  which costs the host 15-19 us more per launch, MI355X_MICROARCH.md "coop-launch" -- PROVIDED nothing else holds CUs of this device:
+    //  HJ_COOP=2 asks for the checked cooperative launch instead)
+    if (c->coop == 2) {
+        if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(nblocks), dim3(256), args, 0, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            c->coop = 0;
+            return HJ_XP_FALLBACK;
+        }
+    } else {
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), 0, c->stream, A);
+        HIP_TRY(hipGetLastError());
+    }
+    // what this launch adds to the counters (order - 1 barriers)
+    for (int x = 0; x < 8; ++x) c->coop_xcd[x] += (unsigned long long)(s.order - 1) * nper[x];
+    c->coop_all += (unsigned long long)(s.order - 1) * nx;
+    c->last_kernel = "coop_rk_kernel";
+    for (int d = 0; d < HJ_MAX_DIM; ++d) c->last_E[d] = 0;
+    return HJ_OK;
+}
+
+template <typename T, typename HAM, int SCHEME>
+int launch_coop_scheme(hj_ctx* c, const CoopCall& s) {
+    // resident workgroups of the 1-cell instantiation decide the shape: as many 256-thread workgroups as fit at once, then 1, 2 or 4
+    // cells per thread (51^3 = 132 651 cells: 519 workgroups x 1 cell when three fit per CU)
+    const long long total = c->total;
+    auto cap_of = [&](const void* k) {
+        auto it = c->occ_cache.find(std::make_pair(k, (size_t)0));
+        if (it == c->occ_cache.end()) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, 0) != hipSuccess || nb < 1) nb = 1;
+            it = c->occ_cache.emplace(std::make_pair(k, (size_t)0), nb).first;
+        }
+        return (long long)it->second * c->num_cus;
+    };
+    const long long need1 = (total + 255) / 256;
+    const void* k1 = reinterpret_cast<const void*>(coop_rk_kernel<T, HAM, SCHEME, 1>);
+    const void* k2 = reinterpret_cast<const void*>(coop_rk_kernel<T, HAM, SCHEME, 2>);
+    const void* k4 = reinterpret_cast<const void*>(coop_rk_kernel<T, HAM, SCHEME, 4>);
+    if (need1 <= cap_of(k1)) return launch_coop_cpt<T, HAM, SCHEME, 1>(c, s, (int)need1);
+    const long long need2 = (total + 511) / 512;
+    if (need2 <= cap_of(k2)) return launch_coop_cpt<T, HAM, SCHEME, 2>(c, s, (int)need2);
+    const long long need4 = (total + 1023) / 1024;
+    if (need4 <= cap_of(k4)) return launch_coop_cpt<T, HAM, SCHEME, 4>(c, s, (int)need4);
+    return HJ_XP_FALLBACK;
+}
+
+template <typename T, typename HAM>
+int launch_coop(hj_ctx* c, const CoopCall& s) {
+    if constexpr (HAM::ND > 3) return HJ_XP_FALLBACK;
+    else {
+        switch (s.scheme) {
+            case HJ_ENO2: return launch_coop_scheme<T, HAM, HJ_ENO2>(c, s);
+            case HJ_ENO3: return launch_coop_scheme<T, HAM, HJ_ENO3>(c, s);
+            case HJ_WENO5_ASSHIPPED: return launch_coop_scheme<T, HAM, HJ_WENO5_ASSHIPPED>(c, s);
+            case HJ_ENO2_FAST: return launch_coop_scheme<T, HAM, HJ_ENO2_FAST>(c, s);
+            case HJ_ENO3_FAST: return launch_coop_scheme<T, HAM, HJ_ENO3_FAST>(c, s);
+        }
+        return HJ_XP_FALLBACK;
+    }
+}
+
 template <typename T, typename HAM, int SCHEME>
 int launch_cfg(hj_ctx* c, const SubstepCall& s) {
 #if defined(HJ_TUNE_BUILD) && HJ_TUNE_BUILD == 2
@@ -1033,6 +1115,7 @@ int launch_term_tiled(hj_ctx* c, int kind, const SubstepCall& s) {
 template int launch_term_tiled<HJ_INST_T, HJ_INST_TERM_ND>(hj_ctx*, int, const SubstepCall&);
 #else
 template int launch_scheme<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const SubstepCall&);
+template int launch_coop<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const CoopCall&);
 template int launch_stage12<HJ_INST_T, hj::HJ_INST_HAM<HJ_INST_T>>(hj_ctx*, const Stage12Call&);
 #endif
 

@@ -719,6 +719,120 @@ __global__ __launch_bounds__(256) void direct_substep_kernel(const DirectArgs<T,
 }
 
 
+// ---- ONE launch for a whole odeCFL2 / odeCFL3 step on SMALL grids (round 6).
+// 51^3 (BASELINE C1, every notebook of the reference: ValueFuncs/hji_solver.py:536-542 steps it one odeCFL3 call at a time) costs three
+// dependent launches of direct_substep_kernel at the launch floor (7.3 us each: dispatch, argument loads, index arithmetic, table loads, the
+// stencil gather, arithmetic, store -- a chain of latencies, 0.05 of 8 TB/s).  Here the stages run inside one cooperative launch, a grid-wide
+// barrier between them; a thread keeps its cell's index arithmetic and Hamiltonian constants across the stages.  Same per-cell functions
+// and stage expressions as direct_substep_kernel: the results are its results bit for bit.
+// MEASURED (profiles/r06_small_grids.txt) and left OPT-IN (HJ_COOP=1): 51^3 30.1 us per RK3 step against 21.6 for the three launches, 41^3 21.8
+// against 17.9, 31^3 15.1 against 15.5 -- a grid barrier over 519 workgroups costs more (4-6 us, MI355X_MICROARCH.md "barrier-xcd") than the
+// kernel boundary it replaces (1.5-1.9 us), and hipLaunchCooperativeKernel another 15-19 us of host time per launch (75 us per step).
+//
+// Barrier (every workgroup is resident: hipLaunchCooperativeKernel): the stage output is stored with agent-scope (sc1, write-through)
+// stores; every wave drains its stores, the workgroup meets, ONE lane releases at agent scope and adds 1 to the counter of its XCD (32 adds
+// per counter, not 256 same-address ones: ~12 ns each, profiles/r05_range_path.txt); the last arriver of an XCD adds to the global
+// counter, everybody polls that; after the barrier every wave acquires (invalidates the XCD-local L2 lines of the stage buffers).
+// The counters only grow: `base` is what they read when the launch starts (the host keeps count; launches on a ctx are stream ordered).
+struct CoopSync {
+    unsigned long long xcd[8][16];      // one cache line per XCD: arrivals of its workgroups
+    unsigned long long all[16];         // XCDs that are complete
+};
+template <typename T, int ND> struct CoopArgs {
+    const T* y;                         // state at the start of the step
+    T* s1;                              // y1 = y + dt L(y)                      (order 1: the result)
+    T* s2;                              // order 2: the result; order 3: y_half = (3 y + y1 + dt L(y1)) / 4
+    T* out;                             // order 3: the result
+    GridArgs<T, ND> G;
+    int order, restrict_sign, post_op;
+    T dt;
+    T sc[ND];
+    HamTables<T> ham;
+    CoopSync* sync;
+    unsigned long long base_xcd[8], base_all;      // counter values when the launch starts
+    unsigned nper_xcd[8];                          // workgroups on each XCD (blockIdx & 7)
+    unsigned nxcd;                                 // XCDs that have a workgroup
+};
+
+__device__ __forceinline__ void coop_grid_barrier(CoopSync* S, const unsigned long long* base_xcd, unsigned long long base_all,
+                                                  const unsigned* nper, unsigned nxcd, unsigned phase /* 1, 2, .. */) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stage stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned x = blockIdx.x & 7u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned long long seen = __hip_atomic_fetch_add(&S->xcd[x][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen + 1ull == base_xcd[x] + (unsigned long long)phase * nper[x])
+            __hip_atomic_fetch_add(&S->all[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long want = base_all + (unsigned long long)phase * nxcd;
+        while (__hip_atomic_load(&S->all[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+        // ONE lane acquires for the workgroup (the invalidate is per CU; every wave doing it costs 4x: MI355X_MICROARCH.md), the others read after the barrier
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+template <typename T, typename HAM, int SCHEME, int CPT>
+__global__ __launch_bounds__(256) void coop_rk_kernel(const CoopArgs<T, HAM::ND> A) {
+    constexpr int ND = HAM::ND;
+    constexpr bool NP = np_order(SCHEME);
+    static_assert(SCHEME != HJ_WENO5, "the intended WENO5 needs a grid-wide reduction between the stages");
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    const long long t0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    // this thread's cells (CPT of them at most): index, Hamiltonian constants -- kept across the stages
+    int idx[CPT][ND];
+    typename HAM::Cell hc[CPT];
+    typename HAM::Plane hp[CPT];
+    bool real[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const long long t = t0 + k * nthreads;
+        real[k] = t < A.G.total;
+        decode<T, ND>(A.G, real[k] ? t : 0, idx[k]);
+        hc[k] = HAM::cell(A.ham, idx[k], A.sc);
+        hp[k] = HAM::plane(A.ham, idx[k][0], A.sc);
+    }
+    T eps[ND];
+    WenoK<T> wk[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { eps[d] = T(0); wk[d].c13 = T(0); wk[d].c4 = T(0); }
+    T ystart[CPT];
+    for (int st = 1; st <= A.order; ++st) {
+        // stage st: source, destination, stage expression (hj_launch.h: fill_fused_args)
+        const T* src = st == 1 ? A.y : (st == 2 ? A.s1 : A.s2);
+        T* dst = st == A.order ? (A.order == 1 ? A.s1 : (A.order == 2 ? A.s2 : A.out)) : (st == 1 ? A.s1 : A.s2);
+        const int stage = st == 1 ? HJ_STAGE_EULER : (st == 2 ? (A.order == 2 ? HJ_STAGE_RK2_FULL : HJ_STAGE_RK3_HALF) : HJ_STAGE_RK3_FULL);
+        T ca = T(0), cb = T(1);
+        if (stage == HJ_STAGE_RK3_HALF) { ca = T(0.75); cb = T(0.25); }
+        else if (stage == HJ_STAGE_RK3_FULL) { ca = T(1.0 / 3.0); cb = T(2.0 / 3.0); }
+        else if (stage == HJ_STAGE_RK2_FULL) { ca = T(0.5); cb = T(0.5); }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (!real[k]) continue;
+            const long long t = t0 + k * nthreads;
+            const T* pc0 = src + t;
+            T v[ND][7];
+            const T centre = pc0[0];
+            if (st == 1) ystart[k] = centre;
+            const T y0v = st == 1 ? T(0) : ystart[k];
+            gather_stencils<T, ND>(A.G, pc0, idx[k], centre, v);
+            T pc[ND], hd[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) upwind_cd<SCHEME, T>(v[d], A.G.K[d], eps[d], wk[d], pc[d], hd[d]);
+            T alpha[ND];
+            T ydot = lf_ydot<NP, HAM>(A.ham, hc[k], hp[k], A.sc, pc, hd, alpha);
+            if (A.restrict_sign > 0) ydot = (ydot < T(0)) ? T(0) : ydot;
+            else if (A.restrict_sign < 0) ydot = (ydot > T(0)) ? T(0) : ydot;
+            T o = rk_stage_out<NP>(stage, ca, cb, A.dt, y0v, centre, ydot);
+            if (st == A.order && A.post_op) o = post_step(A.post_op, o, st == 1 ? centre : y0v);
+            if (st == A.order) dst[t] = o;
+            else __hip_atomic_store(dst + t, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // read by other XCDs after the barrier
+        }
+        if (st < A.order) coop_grid_barrier(A.sync, A.base_xcd, A.base_all, A.nper_xcd, A.nxcd, (unsigned)st);
+    }
+}
+
 // ---- split-path epilogue: what termLaxFriedrichs / artificialDissipationGLF do AFTER the user's hamFunc /
 // partialFunc callbacks have run (term_lax_friedrich.py:122-128, artificial_diss_glf.py:91-104), as one pass:
 //     diss = sum_d (0.5*(derivR_d - derivL_d))*alpha_d          (in dimension order, like the reference's loop)

@@ -245,15 +245,18 @@ def test_fp32_4d_tiled_and_direct_vs_fp64_oracle(scheme, n, pd, monkeypatch):
     y32 = torch.as_tensor(data.reshape(-1, 1), device="cuda", dtype=torch.float32)
     got = {}
     # "0": one cell per lane (1024,1,3,2,2); "1": direct; "pair": two cells per lane (256,2,6,2: 5 pair + 1 single halo slots per thread), built for the light stencils
-    variants = ("0", "1", "pair") if scheme in ("WENO5_ASSHIPPED", "ENO2") else ("0", "1")
+    # "flat" (round 6): the full-row kernel (hj_flat4v.h) where the last axis has at least 8 cells, else the pair kernel again
+    variants = ("0", "1", "pair", "flat") if scheme in ("WENO5_ASSHIPPED", "ENO2") else ("0", "1")
     for force in variants:
         monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if force == "1" else "0")
-        monkeypatch.setenv("HJ_PAIR", "2" if force == "pair" else "0")
+        monkeypatch.setenv("HJ_PAIR", "2" if force in ("pair", "flat") else "0")
+        monkeypatch.setenv("HJ_FLAT4", "1" if force == "flat" else "0")
         g.__dict__.pop("_hj_device", None)
         yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
         dg = g.__dict__["_hj_device"]
         dg = dg[next(iter(dg))] if isinstance(dg, dict) else dg
-        assert dg.lib.hj_last_kernel(dg.ctx) == {"0": b"fused_substep_kernel", "1": b"direct_substep_kernel", "pair": b"fused_pair_kernel"}[force]
+        assert dg.lib.hj_last_kernel(dg.ctx) == {"0": b"fused_substep_kernel", "1": b"direct_substep_kernel", "pair": b"fused_pair_kernel",
+                                                 "flat": b"fused_flat4_kernel" if n[3] >= 8 else b"fused_pair_kernel"}[force]
         assert yd.dtype == torch.float32
         assert abs(sb - sbo) <= 1e-5 * sbo
         got[force] = yd.cpu().numpy().astype(np.float64)

@@ -462,3 +462,51 @@ def test_flat4_long_axis0_chunks_the_row_table_and_slab_ring(monkeypatch):
         got, want = st.state(), ref[st.slab.begin:st.slab.end]
         assert torch.equal(got, want), "rank %d differs by %g" % (st.slab.rank, float((got - want).abs().max()))
         st.close()
+
+
+# ------------------------------------------------------------------------------ one cooperative launch per step on small grids (coop_rk_kernel)
+@pytest.mark.parametrize("scheme", ["WENO5_ASSHIPPED", "ENO2", "ENO3"])
+@pytest.mark.parametrize("order", [2, 3])
+@pytest.mark.parametrize("which,n,pd", [("dubins", (51, 51, 51), 2), ("dubins", (24, 31, 40), (0, 2)), ("dubins", (12, 50, 40), None), ("dint", (160, 300), None),
+                                        ("dubins32", (33, 40, 21), 2)])
+def test_one_cooperative_launch_per_step_equals_the_stage_launches_bitwise(scheme, order, which, n, pd, monkeypatch):
+    """hj_rk_step of order 2 / 3 on a grid the direct kernel runs is ONE launch (coop_rk_kernel: the stages inside it, a grid barrier between
+    them) with HJ_COOP=1 (default) and `order` launches of direct_substep_kernel with HJ_COOP=0: ten steps, the same bits, the same times;
+    with a termRestrictUpdate clamp and a fused post-step minimum on the way."""
+    monkeypatch.delenv("HJ_DIRECT_BELOW", raising=False)
+    if which == "dint":
+        monkeypatch.setenv("HJ_DIRECT_BELOW", "200000")        # (2-D grids have no small-grid switch by default)
+        g, og = mk([-1, -1], [1, 1], n, pd)
+        ham, par = _ffi.HAM_DOUBLE_INTEGRATOR, [1., 0., 0., 0.]
+        data = O.shape_sphere(og, None, .3)
+    else:
+        g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, pd)
+        ham, par = _ffi.HAM_DUBINS_REL, PAR
+        data = O.shape_cylinder(og, 2, None, .5)
+    dtype, tdt = ("float32", torch.float32) if which.endswith("32") else ("float64", torch.float64)
+    y = torch.as_tensor(data + 0.02 * np.random.default_rng(3).standard_normal(og.shape), device="cuda").to(tdt)
+    sid = _ffi.SCHEME_IDS[scheme]
+    res = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("HJ_COOP", coop)
+        dg = DeviceGrid(g, dtype)
+        dg.bind_stream()
+        _ffi.check(dg.lib.hj_ctx_set_post_step(dg.ctx, 1))
+        cur, nxt, w1 = y.clone(), torch.empty_like(y), torch.empty_like(y)
+        tout, dtout = C.c_double(), C.c_double()
+        t = 0.
+        for k in range(10):
+            # (the callers' own aliasing: for RK3 the first stage buffer doubles as the output)
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, order, sid, ham, _ffi.darr(par), t, 1e9, 0.8, 1e300, -1 if k % 2 else 0, dg.ptr(cur), dg.ptr(nxt),
+                                         dg.ptr(nxt) if order == 3 else dg.ptr(w1), dg.ptr(w1), C.byref(tout), C.byref(dtout)))
+            cur, nxt = nxt, cur
+            t = float(tout.value)
+        dg.sync()
+        assert dg.lib.hj_last_kernel(dg.ctx) == (b"coop_rk_kernel" if coop == "1" else b"direct_substep_kernel"), dg.lib.hj_last_kernel(dg.ctx)
+        nl, fused = C.c_int(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_plan(dg.ctx, order, sid, ham, _ffi.darr(par), 0, C.byref(nl), C.byref(fused)))
+        assert nl.value == (1 if coop == "1" else order)
+        res[coop] = (t, cur.clone())
+    assert res["1"][0] == res["0"][0]
+    assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
+    assert bool(torch.isfinite(res["1"][1]).all())
