@@ -510,3 +510,32 @@ def test_one_cooperative_launch_per_step_equals_the_stage_launches_bitwise(schem
     assert res["1"][0] == res["0"][0]
     assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
     assert bool(torch.isfinite(res["1"][1]).all())
+
+
+# ------------------------------------------------------------------------------ the run-time kernel table's key
+def test_runtime_kernel_table_keeps_fast_eno_fp64_and_eno_fp32_apart():
+    """Scheme ids run to HJ_ENO3_FAST = 5; the key of the run-time kernel table packed them with radix 4, so (fp64, ENO2_FAST = 4) collided with
+    (fp32, ENO2 = 0) and a later fp32 launch reused the cached DOUBLE kernel with a float argument block.  One registered Hamiltonian, ENO2_FAST
+    in fp64 first, then ENO2 in fp32, same grid and mode: each must equal the built-in system's result in its own precision."""
+    from test_gpu_user_ham import DUBINS_REL_SRC, DUBINS_REL_COL
+    n = (30, 28, 26)
+    g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, 2)
+    d0 = O.shape_cylinder(og, 2, None, .5) + 0.03 * np.random.default_rng(2).standard_normal(og.shape)
+    reg = L.register_native_hamiltonian("dubins_rel_rt_keys", 3, DUBINS_REL_SRC, nparams=4, column_src=DUBINS_REL_COL, ncol=2)
+    out = {}
+    for dtype, sid in (("float64", 4), ("float32", _ffi.SCHEME_IDS["ENO2"]), ("float64", _ffi.SCHEME_IDS["ENO2"]), ("float32", 4)):
+        for ham in ("user", "builtin"):
+            dg = DeviceGrid(g, dtype)
+            dg.bind_stream()
+            y = torch.as_tensor(d0, device="cuda", dtype=getattr(torch, dtype))
+            o = torch.empty_like(y)
+            hid = reg.ham_id if ham == "user" else _ffi.HAM_DUBINS_REL
+            _ffi.check(dg.lib.hj_rk_substep(dg.ctx, sid, hid, _ffi.darr(PAR), 0., _ffi.STAGE_EULER, 2e-3, 0, dg.ptr(y), None, dg.ptr(o), 3, 0, n[0]))
+            dg.sync()
+            assert bool(torch.isfinite(o).all()), (dtype, sid, ham)
+            out[(dtype, sid, ham)] = o
+    for dtype, sid in (("float64", 4), ("float32", _ffi.SCHEME_IDS["ENO2"]), ("float64", _ffi.SCHEME_IDS["ENO2"]), ("float32", 4)):
+        a, b = out[(dtype, sid, "user")], out[(dtype, sid, "builtin")]
+        tol = 1e-11 if dtype == "float64" else 2e-5
+        d = (a - b).abs()
+        assert float((d > tol).double().mean()) <= 2e-3 and float(d.max()) <= 1e-2, (dtype, sid, float(d.max()))
