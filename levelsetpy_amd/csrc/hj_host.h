@@ -312,6 +312,9 @@ constexpr bool light_scheme(int scheme) { return scheme == HJ_WENO5_ASSHIPPED ||
 // ... and on 2-D grids the lean ENO3 (HJ_ENO3_FAST) as well: 227-241 VGPRs without scratch in the two-pairs-per-thread shape (3-D: 260 B of scratch)
 constexpr bool light_cfg(int scheme, int nd) { return light_scheme(scheme) || (scheme == HJ_ENO3_FAST && nd == 2); }
 // is configuration (NT, R) of the one-cell-per-lane / pair kernel compiled for this scheme?
+#ifndef HJ_PAIR_EXTRA      // tuning builds: further (threads, pairs per thread) shapes of the pair kernel for the light stencils
+#define HJ_PAIR_EXTRA(nt, r) false
+#endif
 constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz = 8) {
 #ifdef HJ_ALL_CONFIGS
     return true;
@@ -320,7 +323,7 @@ constexpr bool cfg_built(int scheme, int nd, int nt, int r, bool pair, int esz =
     // (two independent workgroups per CU); fp64 512 x 1 cell (two cells spill 68-308 B and are 20-100 % slower for every stencil
     // but ENO2, tools/experiments/r03_run44.sh).  The other combinations spill and nobody selects them.
     if (nd == 4) return pair ? (esz == 4 && light_scheme(scheme)) : (esz == 4 ? nt == 1024 : (nt == 512 && r == 1));
-    if (pair) return light_cfg(scheme, nd) ? (nt == 512 && r == 2) || (nt == 256 && r == 1) : (nt == 256 && r == 1);
+    if (pair) return light_cfg(scheme, nd) ? (nt == 512 && r == 2) || (nt == 256 && r == 1) || HJ_PAIR_EXTRA(nt, r) : (nt == 256 && r == 1);
     return light_scheme(scheme) ? true : (nt == 256 && r == 2);
 #endif
 }
