@@ -94,7 +94,15 @@ __device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsr
 #ifndef HJ_EARLY_ARGS
 #define HJ_EARLY_ARGS 1
 #endif
+// TWO PLANES PER BARRIER (round 6 experiment): the two plane iterations of a loop pass stage their centre planes and halo rings first, meet at ONE
+// barrier, then compute both -- half the synchronisations of the per-plane chain barrier -> LDS reads -> arithmetic -> store (profiles/r06_stage1_bound.txt).
+// Needs 4 + halo_ahead LDS plane buffers instead of 2 + halo_ahead (the host side sizes them: hj_inst.hip).  Light stencils only (the intended
+// WENO5's epsilon producer reads the previous plane's outputs behind the plane's own barrier).
+#ifndef HJ_TWO_PLANES
+#define HJ_TWO_PLANES 0
+#endif
 template <int K> struct IntTag { static constexpr int value = K; };
+constexpr bool light_scheme_dev(int s) { return s == HJ_WENO5_ASSHIPPED || s == HJ_ENO2 || s == HJ_ENO2_FAST; }
 constexpr int HJ_VPAD = 4;      // left pad of an LDS row (cells): even, so that tile cell 0 of a row is 16-byte aligned
 
 template <typename T, typename HAM, int SCHEME, int NT, int R, int KH, int OCC, int MODE = 0>
@@ -652,13 +660,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
     int ring_c = 0;                                            // LDS buffer of the plane the next iteration computes
-    auto body = [&](auto off_tag, int m, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
+    constexpr bool TWOB = HJ_TWO_PLANES && light_scheme_dev(SCHEME) && !HJ_MAYDOWN && ND <= 3 && MODE != 3 && !ham_xp<HAM>::value;
+    int ring_of[2] = {0, 0};                                   // TWOB: the buffer each plane of the pass was staged in
+    // PH: 0 the whole plane iteration (staging, barrier, compute); 1 the staging only, 2 the compute only (TWOB: one barrier per PASS between them)
+    auto body = [&](auto off_tag, auto ph_tag, int m, V* own_c, V* own_n, T* hal_c, T* hin_c, V* halp_c, V* hinp_c, V* y0_c, typename HAM::Plane& pl_c) {
         constexpr int OFF = decltype(off_tag)::value;          // window [OFF, OFF + 7) of the queue is planes P(m - 3) .. P(m + 3)
+        constexpr int PH = decltype(ph_tag)::value;
         const int p = plane_at(m);                              // the plane this iteration computes
 #ifdef HJ_STAMP
         const unsigned long long st0 = __builtin_readcyclecounter();
 #endif
-        T* buf = lds + ring_c * lds_plane;                      // plane p
+        if constexpr (PH != 2) ring_of[OFF] = ring_c;
+        T* buf = lds + ring_of[OFF] * lds_plane;                // plane p
+      if constexpr (PH != 2) {
         int ring_h = ring_c + AH;
         if (ring_h >= NB) ring_h -= NB;
         T* bufh = lds + ring_h * lds_plane;                     // plane p + AH: where hal_c goes
@@ -674,11 +688,13 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 *reinterpret_cast<V*>(buf + own_lds[r]) = c2;
             }
         park_halo(bufh, hal_c, hin_c, halp_c, hinp_c);
+      }
+      if constexpr (PH == 1) return;
 #ifdef HJ_STAMP
         const unsigned long long st1 = __builtin_readcyclecounter();
 #endif
 #ifndef HJ_ABLATE_NOSYNC        // timing experiment only (results are wrong without the barrier)
-        __syncthreads();
+        if constexpr (PH == 0) __syncthreads();
 #endif
 #ifdef HJ_STAMP
         const unsigned long long st2 = __builtin_readcyclecounter();
@@ -843,8 +859,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if constexpr (OFF == 0) {            // the pass's first plane: the new plane joins behind the window, nothing moves
-                q[r][0][7] = own_c[r].x;
-                q[r][1][7] = own_c[r].y;
+                if constexpr (PH == 0) {         // (TWOB: appended when the pass begins, before its second staging reuses the register set)
+                    q[r][0][7] = own_c[r].x;
+                    q[r][1][7] = own_c[r].y;
+                }
             } else {                              // its second plane: two places down, ready for the next pass
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { q[r][0][j] = q[r][0][j + 2]; q[r][1][j] = q[r][1][j + 2]; }
@@ -863,8 +881,19 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 5] = wall_clock64();   // loop start
     const int nplanes = p_end - p_begin;
     for (int m = 0; m < nplanes; m += PD) {
-        body(IntTag<0>(), m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
-        if (m + 1 < nplanes) body(IntTag<1>(), m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
+        if constexpr (TWOB) {
+            const bool two = m + 1 < nplanes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { q[r][0][7] = own[0][r].x; q[r][1][7] = own[0][r].y; }      // plane P(m + 4), requested a pass ago
+            body(IntTag<0>(), IntTag<1>(), m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
+            if (two) body(IntTag<1>(), IntTag<1>(), m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
+            __syncthreads();
+            body(IntTag<0>(), IntTag<2>(), m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
+            if (two) body(IntTag<1>(), IntTag<2>(), m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
+        } else {
+            body(IntTag<0>(), IntTag<0>(), m, own[0], own[1], hal[0], hin[0], halp[0], hinp[0], y0s[0], pls[0]);
+            if (m + 1 < nplanes) body(IntTag<1>(), IntTag<0>(), m + 1, own[1], own[0], hal[1], hin[1], halp[1], hinp[1], y0s[1], pls[1]);
+        }
         if (A.timing && tid == 0 && m == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 7] = wall_clock64();
     }
     if (A.timing && tid == 0) A.timing[4 * (size_t)A.nblocks + 8 * (size_t)L + 6] = wall_clock64();   // loop end

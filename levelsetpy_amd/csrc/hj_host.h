@@ -161,6 +161,7 @@ struct hj_ctx {
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)
     int last_nbuf = 2;
+    int last_nbase = 2;                             // LDS plane buffers of the last pair launch that are NOT planes parked ahead (2; HJ_TWO_PLANES builds: 4)
     int last_E[HJ_MAX_DIM] = {0, 0, 0, 0};           // chunk length and tile extents of the last tiled launch (hj_last_tile)
     // intended WENO5: max(D1^2) of a stage's output reduced inside the producing launch (hj_fused.h, eps_part) + eps_seam_kernel
     long long eps_fuse_min_cells = 2000000;         // HJ_EPS_FUSE_MIN_CELLS: below, launch floors make the pre-pass as fast (51^3: faster)

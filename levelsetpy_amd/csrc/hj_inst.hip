@@ -244,6 +244,7 @@ int launch_pair4_mode(hj_ctx* c, const SubstepCall& s) {
     A.halo_ahead = 0;
     A.npairs = 0;
     c->last_nbuf = 2;
+    c->last_nbase = 2;
     c->last_kernel = "fused_pair4_kernel";
     c->last_E[0] = t.chunk;
     for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = t.E[d];
@@ -348,6 +349,7 @@ int launch_flat4_mode(hj_ctx* c, const SubstepCall& s) {
     A.halo_ahead = 0;
     A.npairs = 0;
     c->last_nbuf = 2;
+    c->last_nbase = 2;
     if (t.lds_bytes > 64 * 1024) {
         static std::mutex mu;
         static std::map<std::pair<int, const void*>, size_t> granted_by_kernel;
@@ -690,7 +692,9 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
                 // 11 % fewer fetched bytes); the 256-thread configurations (several workgroups per CU) lose 1-3 %
                 // (2-D / 3-D only: the 4-D instantiations are built without the parked ring -- hj_fusedv.h, AHM -- whatever HJ_PAIR_RING says)
                 const bool ring = HAM::ND <= 3 && (c->pair_ring == 1 || (c->pair_ring < 0 && kp.NT == 512 && kp.R == 2 && c->total >= 6500000));
-                c->last_nbuf = ring ? 2 + c->pair_ah : 2;          // planes parked ahead + the double buffer
+                // (HJ_TWO_PLANES builds: two planes per barrier need four buffers under the planes parked ahead -- hj_fusedv.h, TWOB)
+                c->last_nbase = (HJ_TWO_PLANES && light_scheme(SCHEME) && HAM::ND <= 3 && !hj::ham_xp<HAM>::value) ? 4 : 2;
+                c->last_nbuf = c->last_nbase + (ring ? c->pair_ah : 0);          // planes parked ahead + the double buffer
                 const long long key = ((long long)SCHEME << 40) | ((long long)stage_class(s.stage) << 36) | (1ll << 35) |
                                       ((long long)kp.NT << 20) | ((long long)kp.R << 12) | ((long long)kp.KH << 4) | (long long)(ring ? 1 : 0) |
                                       (produce ? 2ll : 0ll);

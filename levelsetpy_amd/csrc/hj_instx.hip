@@ -84,6 +84,7 @@ int launch_xp_mode(hj_ctx* c, const SubstepCall& s, int nbuf) {
     c->last_E[0] = t.chunk;
     for (int d = 1; d < HJ_MAX_DIM; ++d) c->last_E[d] = d < 3 ? t.E[d] : 0;
     c->last_nbuf = nbuf;
+    c->last_nbase = 2;
     if (c->dry) return HJ_OK;
     if (c->debug) {
         fprintf(stderr, "[hj] transposed pair tiling NT=%d R=%d KH=%d OCC=%d window=[%lld,%lld) E=(%d,%d) pitch=%d ntiles=%d chunk=%d nchunks=%d blocks=%d wg/CU=%d lds=%zu\n",

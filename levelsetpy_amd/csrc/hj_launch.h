@@ -79,7 +79,7 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
     c->gate_posted = A.gate ? ep.edge_count : 0;
     grid_blocks = (unsigned)(A.edge_blocks + t.bpx * 8);
     A.lds_nbuf = pair ? c->last_nbuf : 2;
-    A.halo_ahead = (pair && c->last_nbuf > 2) ? c->last_nbuf - 2 : 0;
+    A.halo_ahead = (pair && c->last_nbuf > c->last_nbase) ? c->last_nbuf - c->last_nbase : 0;
     A.stage = s.stage;
     A.ydot_only = (s.stage == HJ_STAGE_YDOT);
     A.use_y0 = (s.stage >= HJ_STAGE_RK3_HALF);

@@ -422,6 +422,7 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
     // halo ring parked in LDS with the big shape (as the built-in launches do, hj_inst.hip)
     bool ring = shape == 1 && !u.no_big_lds && (c->pair_ring == 1 || (c->pair_ring < 0 && c->total >= 6500000));
     c->last_nbuf = ring ? 2 + c->pair_ah : 2;
+    c->last_nbase = 2;
     Tiling t = make_tiling(c, kc, s.p0, s.p1, sh.pair ? 2 : 1, c->last_nbuf);
     auto grant = [&](UserKernel* kk) -> bool {
         if (!(t.ok && t.lds_bytes > 64 * 1024 && kk->lds_granted < t.lds_bytes)) return true;
@@ -438,6 +439,7 @@ static int launch_user_nd(hj_ctx* c, const SubstepCall& s, UserHam& u) {
         u.no_big_lds = true;
         ring = false;
         c->last_nbuf = 2;
+        c->last_nbase = 2;
         t = make_tiling(c, kc, s.p0, s.p1, sh.pair ? 2 : 1, 2);
     }
     if (!t.ok) return fail(HJ_EUNSUPPORTED, "no tiling of this grid for the run-time kernel");

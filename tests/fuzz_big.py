@@ -54,6 +54,8 @@ def case(rng, k):
         n = [int(rng.integers(60, 240)) for _ in range(3)]
         if rng.random() < 0.04:                      # now and then beyond 40 M cells: the launch-time tile tuner rotates through shapes
             n = [int(rng.integers(340, 372)) for _ in range(3)]
+        if rng.random() < 0.25:                      # round 6: THIN grids (few axis-0 planes, long axis 1): the library marches them along axis 1 by itself
+            n = [int(rng.integers(8, 100)), int(rng.integers(300, 520)), int(rng.integers(180, 420))]
         pd = [d for d in range(3) if rng.random() < (0.8 if d == 2 else 0.15)]
         gmin, gmax = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi]
         ham, par, dtype = _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], ("float64" if rng.random() < 0.8 else "float32")

@@ -51,7 +51,15 @@ KINDS = {"glf": _ffi.DISS_GLF, "llf": _ffi.DISS_LLF, "lllf": _ffi.DISS_LLLF}
 
 
 def undivided(g, full, scheme, ham, par, dtype, order, steps, dt_cap=1e300, kind=None):
-    dg = DeviceGrid(g, dtype)
+    old_xp = os.environ.get("HJ_XP")
+    os.environ["HJ_XP"] = "0"               # the reference of every case: the axis-0 march (round 6: the slabs may march along axis 1)
+    try:
+        dg = DeviceGrid(g, dtype)
+    finally:
+        if old_xp is None:
+            os.environ.pop("HJ_XP", None)
+        else:
+            os.environ["HJ_XP"] = old_xp
     dg.bind_stream()
     if kind is not None:
         _ffi.check(dg.lib.hj_ctx_set_dissipation(dg.ctx, KINDS[kind]))
@@ -69,6 +77,11 @@ def undivided(g, full, scheme, ham, par, dtype, order, steps, dt_cap=1e300, kind
 
 
 def case(rng, k):
+    # round 6: the slab launches of 3-D cases march along axis 1 (transposed launch, hj_instx.hip) in half of the cases, and the 4-D fp32 cases take
+    # the full-row kernel (hj_flat4v.h) or the older tiles at random
+    os.environ["HJ_XP"] = str(rng.choice(["0", "2", "2", "1"]))
+    os.environ["HJ_PAIR"] = "2"
+    os.environ["HJ_FLAT4"] = str(rng.choice(["0", "1"]))
     four = rng.random() < 0.4
     order = int(rng.integers(1, 4))
     deep = rng.random() < 0.5
