@@ -742,7 +742,8 @@ def source_hash():
 
 
 TRACE_STEPS = 400      # steps of the kernel-trace child pass that are looked at (after its spin-up)
-STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel", "fused_pair4_kernel", "fused_flat4_kernel",
+N_SUBSTEP_KERNELS = 8      # the first N entries of STEP_KERNELS are the substep kernels themselves (the rest: helpers of the intended WENO5)
+STEP_KERNELS = ("fused_pair_kernel", "fused_substep_kernel", "fused12_pair_kernel", "fused12_kernel", "direct_substep_kernel", "fused_pair4_kernel", "fused_flat4_kernel", "coop_rk_kernel",
                 "max_d1sq_kernel", "partials_to_values_kernel", "keys_to_values_kernel", "eps_seam_kernel")
 
 
@@ -800,7 +801,7 @@ def live_traffic(a, n=None, scheme=None, single=None):
                             k = r["Kernel_Name"]
                             if r["Counter_Name"] == ctr and any(x in k for x in STEP_KERNELS):
                                 rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"]),
-                                             any(x in k for x in STEP_KERNELS[:6])))
+                                             any(x in k for x in STEP_KERNELS[:N_SUBSTEP_KERNELS])))
                 rows.sort()
                 per_step = len(rows) // nstep if rows else 0
                 if not per_step:
@@ -818,7 +819,7 @@ def live_traffic(a, n=None, scheme=None, single=None):
                         for r in csv.DictReader(fh):
                             if any(x in r["Kernel_Name"] for x in STEP_KERNELS):
                                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
-                                             any(x in r["Kernel_Name"] for x in STEP_KERNELS[:6])))
+                                             any(x in r["Kernel_Name"] for x in STEP_KERNELS[:N_SUBSTEP_KERNELS])))
                 rows.sort()
                 per_step = len(rows) // nstep if rows else 0
                 if per_step:
