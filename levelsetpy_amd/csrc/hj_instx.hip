@@ -144,7 +144,7 @@ int launch_xp_cfg(hj_ctx* c, const SubstepCall& s) {
 template <typename T, typename HAM>
 int launch_xp(hj_ctx* c, const SubstepCall& s) {
     const int64_t N0 = c->N[0];
-    if (c->ndim != 3 || s.q1 > s.q0 || s.gated || s.range_only || s.bound_pass || s.term || s.want_eps || s.eps_nrows > 0 || s.dt_dev ||
+    if (c->ndim != 3 || s.q1 > s.q0 || s.gated || s.range_only || s.bound_pass || s.term || (s.scheme == HJ_WENO5 && (s.want_eps || s.eps_nrows > 0)) || s.dt_dev ||
         c->timing_dump || s.p1 - s.p0 < 1 || (s.p0 < 0 && !c->halo_lo) || (s.p1 > N0 && !c->halo_hi) || c->N[2] < 8 || c->N[1] < 8 ||
         c->total / N0 * (N0 + 2 * HJ_STENCIL * 4) >= (1ll << 31))
         return HJ_XP_FALLBACK;

@@ -539,3 +539,28 @@ def test_runtime_kernel_table_keeps_fast_eno_fp64_and_eno_fp32_apart():
         tol = 1e-11 if dtype == "float64" else 2e-5
         d = (a - b).abs()
         assert float((d > tol).double().mean()) <= 2e-3 and float(d.max()) <= 1e-2, (dtype, sid, float(d.max()))
+
+
+def test_thin_grids_take_the_transposed_march_by_default(monkeypatch):
+    """The auto rule (hj_api.hip, xp_wanted): a 3-D grid of 8..100 axis-0 planes whose axis 1 is at least three times longer, at the pair kernel's
+    sizes, runs hj_rk_step / hj_rk_integrate through the transposed launch BY ITSELF -- no knob -- and gives the bits of the axis-0 march (HJ_XP=0)."""
+    n = (20, 640, 520)
+    g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, 2)
+    x0 = torch.as_tensor(np.asarray(g.vs[0]).ravel(), device="cuda").reshape(-1, 1, 1)
+    x1 = torch.as_tensor(np.asarray(g.vs[1]).ravel(), device="cuda").reshape(1, -1, 1)
+    x2 = torch.as_tensor(np.asarray(g.vs[2]).ravel(), device="cuda").reshape(1, 1, -1)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    y = ((x0 * x0 + x1 * x1).sqrt() - 0.5 + 0.05 * torch.sin(3 * x2) + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)).contiguous()
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+    res = {}
+    for tag, env in (("default", {}), ("axis0", dict(HJ_XP="0"))):
+        dg = _ctx(g, monkeypatch, **env)
+        a, b, w = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        tout, steps, where = C.c_double(), C.c_int64(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, 3, sid, _ffi.HAM_DUBINS_REL, _ffi.darr(PAR), 0., 1., 0.8, 1e300, 0, dg.ptr(y), dg.ptr(a), dg.ptr(b),
+                                          dg.ptr(w), 4, -1., C.byref(tout), C.byref(steps), C.byref(where)))
+        dg.sync()
+        assert dg.lib.hj_last_kernel(dg.ctx) == (XP_NAME if tag == "default" else b"fused_pair_kernel"), dg.lib.hj_last_kernel(dg.ctx)
+        res[tag] = (tout.value, steps.value, (a if where.value == 1 else b).clone())
+    assert res["default"][:2] == res["axis0"][:2] and res["default"][1] == 4
+    assert torch.equal(res["default"][2], res["axis0"][2]), float((res["default"][2] - res["axis0"][2]).abs().max())
