@@ -117,8 +117,12 @@ static Tiling make_tiling_uncached(const hj_ctx* c, const KernelCfg& k, int64_t 
         if (cells <= cap) {
             E[1] = (int)std::min<long long>(n[1], std::max<long long>(1, cap / cells));
             if (vec == 2 && nd == 2) E[1] &= ~1;
+            // VERTICAL PAIRS (hj_fusedv.h, HJ_VPAIR): a thread's two pair slots are the same columns of two adjacent tile rows -> an even row count
+            const bool vpair = vec == 2 && nd == 3 && k.R == 2 && HJ_VPAIR;
+            if (vpair) E[1] &= ~1;
+            const bool no_rows = E[1] < 1;          // (vertical pairs need two rows: a row extent that leaves room for one only is no candidate)
             if (E[1] < 1) E[1] = 1;
-            const bool odd_row = vec == 2 && (E[nd - 1] & 1);      // the pair kernel needs an even row extent
+            const bool odd_row = (vec == 2 && (E[nd - 1] & 1)) || no_rows;      // the pair kernel needs an even row extent (and, with vertical pairs, two rows at least)
             // E[1] must also be one of "n/parts" only for balance; any value works for correctness
             cells *= E[1];
             long long halo = 0, box = 1;

@@ -19,6 +19,12 @@
 
 namespace hj {
 
+// VERTICAL PAIRS (hj_fusedv.h): 1 = the two pair slots of a thread are vertically adjacent on 3-D grids (shared middle-axis rows); the tilings
+// (hj_api.hip, make_tiling) then give such launches an even row count.  Built and measured in round 6 (same bits, 12 -> 6 ds_read_b128 per
+// thread and plane on the middle axis) and left OFF: 3 % SLOWER at 201^3 and 513^3 in a same-run A/B (profiles/r06_stage1_bound.txt, appendix 3)
+#ifndef HJ_VPAIR
+#define HJ_VPAIR 0
+#endif
 template <typename T> struct Lim;
 template <> struct Lim<double> { static constexpr double tiny = 1e-99; static constexpr double lowest = -1.0e300; };
 template <> struct Lim<float>  { static constexpr float  tiny = 1e-30f; static constexpr float lowest = -3.0e38f; };

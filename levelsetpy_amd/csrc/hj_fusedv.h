@@ -101,7 +101,21 @@ __device__ __forceinline__ void buf_store2(Pair<float>::V v, __amdgpu_buffer_rsr
 #ifndef HJ_TWO_PLANES
 #define HJ_TWO_PLANES 0
 #endif
+// VERTICAL PAIRS (round 6): on 3-D grids the TWO pair slots of a thread (R = 2) are the pairs of the same columns in two ADJACENT tile rows, not two
+// slots dealt half a tile apart.  The middle-axis stencils of the two then overlap in all but two rows, and each one's missing neighbour row is the
+// other's own pair (in registers): 6 ds_read_b128 per thread and plane for that axis instead of 12 -- the LDS stencil reads are what the stage-1
+// launch of the headline cannot hide (13.6 % at 513^3, 16 % at 201^3: profiles/r06_stage1_bound.txt).  Same cells, same arithmetic: same bits.
+// The host gives such launches an EVEN tile extent on axis 1 (make_tiling, hj_api.hip).
+// MEASURED SLOWER (-3 %, same-run A/B at 201^3 and 513^3) and compiled out: HJ_VPAIR defaults to 0 (hj_device.h).
+
 template <int K> struct IntTag { static constexpr int value = K; };
+constexpr bool defined_ablate2() {
+#if defined(HJ_ABLATE) && (HJ_ABLATE & 2)
+    return true;
+#else
+    return false;
+#endif
+}
 constexpr bool light_scheme_dev(int s) { return s == HJ_WENO5_ASSHIPPED || s == HJ_ENO2 || s == HJ_ENO2_FAST; }
 constexpr int HJ_VPAD = 4;      // left pad of an LDS row (cells): even, so that tile cell 0 of a row is 16-byte aligned
 
@@ -205,11 +219,20 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
     unsigned own_g[R];
     typename HAM::Cell hcell[R][2];
     typename HAM::Raw hraw[R][2];
-    const bool last_real = (tid + (R - 1) * NT) < tile_slots;
+    constexpr bool VPAIR = HJ_VPAIR && ND == 3 && R == 2 && !HJ_WENO_LDS_SHARE && !defined_ablate2();
+    constexpr bool vp_on = VPAIR;                                         // (the host hands such launches an EVEN row count: make_tiling, hj_api.hip)
+    const int vp_hp = A.E[LA] >> 1, vp_half = (A.E[1] >> 1) * vp_hp;      // pairs of a tile row; threads that hold two real slots
+    const bool last_real = vp_on ? (tid < vp_half) : ((tid + (R - 1) * NT) < tile_slots);
     unsigned nbv[R];              // bit d: the pair's forward neighbour on plane axis d lies inside the tile (eps_part pairs)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int c = 2 * min(tid + r * NT, tile_slots - 1);
+        if constexpr (vp_on) {    // slot r of thread t: row 2 * (t / hp) + r, pair t % hp  (surplus threads shadow the last thread that holds real slots)
+            const int tt = min(tid, vp_half - 1);
+            int rp, col;
+            fdivmod(tt, fdiv_make(vp_hp), rp, col);
+            c = 2 * ((2 * rp + r) * vp_hp + col);
+        }
         int lo = 0, g = 0;
         int idx[ND];
         idx[0] = 0;
@@ -681,7 +704,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         // stage the centre plane: one 16-byte LDS store per pair
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (r < R - 1 || last_real) {
+            if ((!vp_on && r < R - 1) || last_real) {
                 V c2;
                 c2.x = q[r][0][3 + OFF];
                 c2.y = q[r][1][3 + OFF];
@@ -704,10 +727,32 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
         const unsigned so_out = (unsigned)(p - p_lo) * plane_bytes;
         const typename HAM::Plane pl_use = pl_c;
         pl_c = HAM::plane(A.ham, p2, A.sc);
+        // VPAIR: the middle-axis stencils of BOTH slots from six shared rows (the slots' rows are j1 and j1 + 1: rows j1 - 3 .. j1 - 1 and
+        // j1 + 2 .. j1 + 4 from LDS, each slot's missing neighbour row is the other's own pair) -- formed first, so that the rows do not stay live
+        T vpc[R][2], vhd[R][2];
+        if constexpr (vp_on) {
+            const T* base0 = buf + own_lds[0];
+            V vrow[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vrow[k] = *reinterpret_cast<const V*>(base0 + (k < 3 ? k - 3 : k - 1) * ls[1]);
+            V own0, own1;
+            own0.x = q[0][0][3 + OFF]; own0.y = q[0][1][3 + OFF];
+            own1.x = q[1][0][3 + OFF]; own1.y = q[1][1][3 + OFF];
+            const V l0[7] = {vrow[0], vrow[1], vrow[2], own0, own1, vrow[3], vrow[4]};
+            const V l1[7] = {vrow[1], vrow[2], own0, own1, vrow[3], vrow[4], vrow[5]};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                T va[7], vb[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) { va[j] = r == 0 ? l0[j].x : l1[j].x; vb[j] = r == 0 ? l0[j].y : l1[j].y; }
+                sten(IntTag<1>(), va, vpc[r][0], vhd[r][0], last_real);
+                sten(IntTag<1>(), vb, vpc[r][1], vhd[r][1], last_real);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             T pc[2][ND], hd[2][ND];
-            const bool slot_real = r < R - 1 || last_real;
+            const bool slot_real = (!vp_on && r < R - 1) || last_real;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (down) {
@@ -726,6 +771,10 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
             // plane axes other than the contiguous one: the pair's neighbours are pairs (16-byte LDS reads)
 #pragma unroll
             for (int d = 1; d < LA; ++d) {
+                if constexpr (vp_on) {
+                    pc[0][1] = vpc[r][0]; hd[0][1] = vhd[r][0]; pc[1][1] = vpc[r][1]; hd[1][1] = vhd[r][1];
+                    continue;
+                }
                 T va[7], vb[7];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
@@ -831,7 +880,7 @@ __global__ __launch_bounds__(NT, OCC) void fused_pair_kernel(const T* __restrict
                 }
                 if (c == 0) o2.x = o; else o2.y = o;
             }
-            if (r < R - 1 || last_real) buf_store2(o2, rout, own_g[r], so_out);
+            if ((!vp_on && r < R - 1) || last_real) buf_store2(o2, rout, own_g[r], so_out);
             if constexpr (SCHEME == HJ_WENO5) {
                 if (eps_prod) {
                     T* ob = obuf + ((p - p_begin) & 1) * lds_plane;
