@@ -156,7 +156,8 @@ struct hj_ctx {
     int last_bounds_n = 0;
     int tile4_sel = -1;                             // HJ_TILE4_SEL: which tile of HJ_TILE4 (hj_inst.hip) to take (-1: the first that fits)
     int flat4_sel = -1;                             // HJ_FLAT4_SEL: which shape of HJ_FLAT4 (hj_inst.hip) to take (-1: the first that fits)
-    int flat4 = 1;                                  // HJ_FLAT4: 4-D fp32 light stencils through the full-row kernel (hj_flat4v.h) where the grid's last axis fits
+    int flat4 = 1;                                  // HJ_FLAT4: 4-D fp32 light stencils through the full-row kernel (hj_flat4v.h) where the grid's last axis fits: 1 (default)
+                                                    // all-periodic plane axes only (where it is the faster one), 2 every grid it fits, 0 never
     int pair4 = 1;                                  // HJ_PAIR4: 4-D fp32 light stencils through the compile-time-tile kernel (hj_fused4v.h)
     int pair, pair_nt, pair_r, pair_kh, pair_occ;   // two cells per lane (hj_fusedv.h): 0 off, 1 on, 2 at any size; config overrides
     int pair_ring = -1;                             // pair kernel: halo ring parked in LDS 3 planes ahead (HJ_PAIR_RING: 0 never, 1 always, -1 auto)

@@ -660,7 +660,10 @@ int launch_cfg(hj_ctx* c, const SubstepCall& s) {
             const long long pair_from = (HAM::ND <= 3 && light_cfg(SCHEME, HAM::ND)) ? 6500000 : 2500000;
             // 4-D, fp32, light stencil: the compile-time-tile kernel (hj_fused4v.h) when its tile fits the grid (HJ_PAIR4=0: the generic pair kernel)
             if constexpr (HAM::ND == 4 && sizeof(T) == 4 && light_scheme(SCHEME)) {
-                if (c->pair != 0 && c->flat4 != 0 && c->pair_nt <= 0 && (c->total >= pair_from || c->pair == 2)) {
+                // (grids with an extrapolated plane axis keep the compile-time tiles: the ghost-row instantiation of the full-row kernel holds 256 VGPRs and
+                //  112-136 B of scratch and runs 7 % SLOWER than pair4 there -- 72^3 x 129: 0.262-0.270 against 0.284-0.290; HJ_FLAT4=2 takes it anyway)
+                const bool flat_pays = c->flat4 == 2 || (c->bc[1] == HJ_BC_PERIODIC && c->bc[2] == HJ_BC_PERIODIC && c->bc[3] == HJ_BC_PERIODIC);
+                if (c->pair != 0 && c->flat4 != 0 && flat_pays && c->pair_nt <= 0 && (c->total >= pair_from || c->pair == 2)) {
                     // full-row tiles with 16-byte row loads (hj_flat4v.h, round 6) when the contiguous axis fits a row of the box (HJ_FLAT4=0: never)
                     int kf = 0;          // (HJ_FLAT4_SEL = k: only the k-th shape of the list, for A/B runs)
 #define X(NT_, R_, E1_, E2_, P3_, OCC_) if ((c->flat4_sel < 0 || c->flat4_sel == kf) && flat4_fits(c, NT_, R_, E1_, E2_, P3_)) return launch_flat4<T, HAM, SCHEME, NT_, R_, E1_, E2_, P3_, OCC_>(c, s); ++kf;

@@ -119,6 +119,7 @@ def case(rng, k):
         os.environ["HJ_FLAT4"] = "0"
     elif kern == "flat4":                   # round 6: the 4-D full-row kernel wherever the last axis fits (other grids: whatever "pair" runs)
         os.environ["HJ_PAIR"] = "2"
+        os.environ["HJ_FLAT4"] = "2"
     elif kern == "xp":                      # round 6: the transposed march wherever a launch has that form (3-D Dubins)
         os.environ["HJ_PAIR"] = "2"
         os.environ["HJ_XP"] = "2"

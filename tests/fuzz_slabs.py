@@ -81,7 +81,7 @@ def case(rng, k):
     # the full-row kernel (hj_flat4v.h) or the older tiles at random
     os.environ["HJ_XP"] = str(rng.choice(["0", "2", "2", "1"]))
     os.environ["HJ_PAIR"] = "2"
-    os.environ["HJ_FLAT4"] = str(rng.choice(["0", "1"]))
+    os.environ["HJ_FLAT4"] = str(rng.choice(["0", "1", "2"]))
     four = rng.random() < 0.4
     order = int(rng.integers(1, 4))
     deep = rng.random() < 0.5

@@ -250,7 +250,7 @@ def test_fp32_4d_tiled_and_direct_vs_fp64_oracle(scheme, n, pd, monkeypatch):
     for force in variants:
         monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if force == "1" else "0")
         monkeypatch.setenv("HJ_PAIR", "2" if force in ("pair", "flat") else "0")
-        monkeypatch.setenv("HJ_FLAT4", "1" if force == "flat" else "0")
+        monkeypatch.setenv("HJ_FLAT4", "2" if force == "flat" else "0")
         g.__dict__.pop("_hj_device", None)
         yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
         dg = g.__dict__["_hj_device"]

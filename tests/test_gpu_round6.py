@@ -353,7 +353,7 @@ def test_flat4_kernel_vs_fp64_oracle_pair4_and_direct(scheme, n, pd, monkeypatch
         monkeypatch.setenv("HJ_FORCE_DIRECT", "1" if name == "direct" else "0")
         monkeypatch.setenv("HJ_PAIR", "2")
         monkeypatch.setenv("HJ_PAIR4", "0")
-        monkeypatch.setenv("HJ_FLAT4", "1" if name == "flat4" else "0")
+        monkeypatch.setenv("HJ_FLAT4", "2" if name == "flat4" else "0")        # (2: also on grids with extrapolated axes, which keep pair4 by default)
         g.__dict__.pop("_hj_device", None)
         yd, sb, _ = L.termLaxFriedrichs(0., y32, sdata(g, L.DoublePendulum4D(g, 1.0), DERIV[scheme]))
         dg = g.__dict__["_hj_device"]
@@ -390,6 +390,7 @@ def test_flat4_rk3_steps_clamp_ranges_and_bound(n, pd, monkeypatch):
     for name, force in (("flat4", "0"), ("direct", "1")):
         monkeypatch.setenv("HJ_FORCE_DIRECT", force)
         monkeypatch.setenv("HJ_PAIR", "2")
+        monkeypatch.setenv("HJ_FLAT4", "2")
         dg = DeviceGrid(g, "float32")
         dg.bind_stream()
         a, b, c, r = dg.empty(), dg.empty(), dg.empty(), dg.empty()
