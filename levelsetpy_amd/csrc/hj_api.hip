@@ -267,9 +267,11 @@ bool xp_wanted(const hj_ctx* c, int64_t p0, int64_t p1) {
     if (c->xp_mode == 0 || c->ndim != 3) return false;
     if (c->xp_mode == 2) return true;
     if (c->halo_lo || c->halo_hi) return false;
+    // CANDIDATES only: ranges of 8 planes up to a third of axis 1 at the pair kernel's sizes.  launch_scheme (hj_inst.hip) decides: a cost model over
+    // the two launch plans (dry contexts, hj_plan_substep), and on a live context both forms timed against each other on its first calls
     const int64_t w = p1 - p0;
-    const int64_t lim = c->xp_max_planes > 0 ? c->xp_max_planes : 100;
-    return w >= 8 && w <= lim && c->N[1] >= 3 * w && c->total >= 6500000;
+    const int64_t lim = c->xp_max_planes > 0 ? c->xp_max_planes : c->N[1] / 3;
+    return w >= 8 && w <= lim && c->total >= 6500000;
 }
 
 }  // namespace hjh
@@ -1130,6 +1132,7 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     c->cfg.KH = 0;
     c->force_direct = env_int("HJ_FORCE_DIRECT", 0);
     c->debug = env_int("HJ_DEBUG", 0);
+    c->debug_xp = c->debug;
     c->full_rows = env_int("HJ_FULL_ROWS", 0);
     // bank-friendly LDS row pitch: -1 (default) the pair kernel only (pitch in pairs congruent to the row length mod 16:
     // +1 % at 201^3, +1-1.5 % for ENO3 / intended WENO5, nothing lost elsewhere, round 3), 0 never, 1 both kernels (the
@@ -1190,6 +1193,7 @@ static int ctx_create_impl(hj_ctx** out, int ndim, const int64_t* N, const doubl
     c->pair_ah = std::max(1, std::min(3, env_int("HJ_PAIR_AH", c->total < 12000000 ? 2 : 3)));
     c->xp_mode = std::max(0, std::min(2, env_int("HJ_XP", 1)));          // transposed march (hj_instx.hip): 0 never, 1 thin slab windows, 2 wherever it exists
     c->xp_max_planes = env_int("HJ_XP_MAX_PLANES", 0);
+    c->xp_trials = std::max(0, std::min(16, env_int("HJ_XP_TRIALS", 2)));
     c->lds_pitch_add = env_int("HJ_LDS_PITCH_ADD", 0) & ~1;
     {
         // per-substep slab schedule: "serial" or "overlap" (rounds 1-2); default by slab thickness -- on the single-GPU self
@@ -1272,6 +1276,7 @@ int hj_plan_substep(int ndim, const int64_t* N, const int* bc, int dtype, int sc
     SubstepCall s{};
     s.scheme = scheme; s.ham = ham; s.stage = stage; s.restrict_sign = 0; s.par = par; s.dt = 0.0;
     s.y = s.y0 = nullptr; s.out = nullptr; s.bound = nullptr; s.p0 = p0; s.p1 = p1;
+    s.xp = xp_wanted(c, p0, p1);            // the launch form the library would take for this range (thin ranges without neighbours: the transposed march)
     rc = c->dtype == HJ_F64 ? launch_ham<double>(c, s) : launch_ham<float>(c, s);
     if (rc == HJ_OK) {
         out[0] = c->last_plan.threads; out[1] = c->last_plan.nblocks; out[2] = c->last_plan.ntiles; out[3] = c->last_plan.nchunks;
@@ -1301,6 +1306,7 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->partials) (void)hipFree(c->partials);
     for (int i = 0; i < 2; ++i) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
     if (c->ev_bounds) (void)hipEventDestroy(c->ev_bounds);
+    for (auto& kv : c->xp_choice) for (int i = 0; i < 4; ++i) if (kv.second.ev[i / 2][i % 2]) (void)hipEventDestroy(kv.second.ev[i / 2][i % 2]);
     if (c->coop_sync) (void)hipFree(c->coop_sync);
     if (c->eps_prod) (void)hipFree(c->eps_prod);
     if (c->eps_rows) (void)hipFree(c->eps_rows);

@@ -190,6 +190,27 @@ struct hj_ctx {
     unsigned long long coop_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, coop_all = 0;      // what they read once every launch issued so far has run
     int coop_ok = -1;                               // device attribute hipDeviceAttributeCooperativeLaunch (-1: not asked yet)
     int xp_max_planes = 0;                          // HJ_XP_MAX_PLANES: auto mode takes windows of at most this many planes (0: the built-in rule)
+    // Auto mode, per (scheme, plane range): the launch form.  `prior` is what the two launch PLANS say (launch_scheme's cost model; all a dry
+    // context has); a live context then TIMES both forms on its first calls -- same bits either way: runs of XP_RUN consecutive calls of one
+    // form (two RK3 steps: every stage kind, and the cache state that form leaves for itself) between a pair of events, the forms taking
+    // turns, each run read back without waiting at a later call of the key; after HJ_XP_TRIALS runs of each the faster form (minimum against
+    // minimum) is kept for the life of the context.
+    enum { XP_RUN = 6 };
+    struct XpTrial {
+        bool prior = false;
+        int decided = -1;                           // -1: still sampling; 0: axis-0 march; 1: transposed march
+        int n[2] = {0, 0};                          // completed, read runs per form
+        float best[2] = {1e30f, 1e30f};
+        int form = 0, calls = 0;                    // the run under way (calls == 0: none)
+        int started = 0;                            // runs begun (a run during which the axis-0 march was still rotating tile shapes is dropped)
+        unsigned seq0 = 0;                          // hj_ctx::tune_seq when the run began
+        bool pend[2] = {false, false};              // a finished run of this form has not been read back yet
+        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    };
+    std::map<long long, XpTrial> xp_choice;
+    unsigned tune_seq = 0;                          // tile-shape trials issued so far (tune_begin)
+    int debug_xp = 0;                               // HJ_DEBUG: report the decision once per key
+    int xp_trials = 2;                              // HJ_XP_TRIALS (0: the plan model alone decides)
     int dry = 0;
     struct { int ntiles = 0, nchunks = 0, nblocks = 0, threads = 0, wg_per_cu = 0; size_t lds_bytes = 0; } last_plan;
     const char* last_kernel = "";                   // name of the substep kernel of the last launch (hj_last_kernel)

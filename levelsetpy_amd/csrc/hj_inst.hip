@@ -36,14 +36,14 @@ int launch_tiled_mode(hj_ctx* c, const SubstepCall& s, Tiling t) {
         auto kern0 = tiled_kernel<T, HAM, SCHEME, NT, R, KH, OCC, PD, MODE, PAIR>();
         const auto key = std::make_pair(reinterpret_cast<const void*>(kern0), t.lds_bytes);
         auto it = c->occ_cache.find(key);
+        int occ_blocks = it != c->occ_cache.end() ? it->second : 0;
         if (it == c->occ_cache.end()) {
-            int nb = 0;
-            // (planning without a device: the launch bound's waves per SIMD, and the CU's 160 KB of LDS)
-            if (c->dry) nb = std::max(1, std::min(OCC * 256 / NT, (int)((size_t)(160 * 1024) / std::max<size_t>(1, t.lds_bytes))));
-            else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
-            it = c->occ_cache.emplace(key, nb).first;
+            // (planning without a device -- or a planning look from a live context, c->dry == 2, which must not cache its estimate: the launch
+            //  bound's waves per SIMD, and the CU's 160 KB of LDS)
+            if (c->dry) occ_blocks = std::max(1, std::min(OCC * 256 / NT, (int)((size_t)(160 * 1024) / std::max<size_t>(1, t.lds_bytes))));
+            else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, key.first, NT, t.lds_bytes) != hipSuccess || occ_blocks < 1) occ_blocks = 1;
+            if (c->dry != 2) c->occ_cache.emplace(key, occ_blocks);
         }
-        const int occ_blocks = it->second;
         {
             const int rc_plan = plan_chunks(c, s, t, occ_blocks, ep);
             if (rc_plan) return rc_plan;
@@ -437,6 +437,7 @@ Tiling tune_begin(hj_ctx* c, const SubstepCall& s, const KernelCfg& k, int vec, 
     if (ts->cand.empty()) return make_tiling(c, k, s.p0, s.p1, vec, nbuf);
     if (ts->chosen >= 0) return ts->cand[ts->chosen];
     tr.ts = ts;
+    c->tune_seq += 1;
     tr.cand = ts->trial % (int)ts->cand.size();
     if (!c->tune_ev[0]) {
         if (hipEventCreate(&c->tune_ev[0]) != hipSuccess || hipEventCreate(&c->tune_ev[1]) != hipSuccess) { tr.ts = nullptr; return ts->cand[0]; }
@@ -746,8 +747,116 @@ int launch_scheme(hj_ctx* c, const SubstepCall& s) {
     if constexpr (xp_available<T, HAM>()) {
         // the caller asked for the transposed march (thin slabs; HJ_XP=2): taken where the call has such a form, else the launch below
         if (s.xp && c->xp_mode != 0 && !c->force_direct && !c->cfg_from_env && c->pair != 0) {
-            const int rc_x = launch_xp<T, HAM>(c, s);
-            if (rc_x != HJ_XP_FALLBACK) return rc_x;
+            // Auto mode (HJ_XP=1).  PRIOR: the two launch plans.  Both forms are memory-system bound, so a launch costs about the cells its
+            // workgroups stage -- workgroups x (chunk + 6 warm-up planes) x the tile and its 3-cell frame -- stretched where the workgroups do
+            // not fill the CUs' slots evenly (x (1 + 0.4 (slots / workgroups - 1)), fitted on 19 shapes: profiles/r06_thin_slab.txt, "the auto choice over shapes");
+            // transposed iff that says <= 0.975 of the axis-0 march.  The model ranks 17 of the 19 shapes correctly and is all a dry context has;
+            // a LIVE context measures instead (hj_host.h, XpTrial): runs of six calls of one form between two events, the forms taking turns --
+            // same bits either way -- and after HJ_XP_TRIALS runs of each the faster form is kept for the life of the context.
+            bool take = true;
+            hj_ctx::XpTrial* tr = nullptr;
+            bool sample = false;
+            if (c->xp_mode == 1 && c->dry != 2) {
+                const long long key = ((long long)s.scheme << 56) ^ ((long long)(s.p0 & 0xffffff) << 24) ^ (long long)(s.p1 & 0xffffff);
+                auto it = c->xp_choice.find(key);
+                if (it == c->xp_choice.end()) {
+                    const auto keep_plan = c->last_plan;
+                    const char* keep_kernel = c->last_kernel;
+                    int keep_E[HJ_MAX_DIM], keep_nbuf = c->last_nbuf, keep_nbase = c->last_nbase;
+                    for (int d = 0; d < HJ_MAX_DIM; ++d) keep_E[d] = c->last_E[d];
+                    const int keep_dry = c->dry;
+                    c->dry = 2;
+                    SubstepCall a = s;
+                    a.xp = false;
+                    auto cost = [&]() {
+                        const double wg = std::max(1, c->last_plan.nblocks);
+                        const double cap = (double)std::max(1, c->num_cus) * std::max(1, c->last_plan.wg_per_cu);
+                        const double slots = cap * std::ceil(wg / cap);
+                        return wg * (c->last_E[0] + 2 * HJ_STENCIL) * (double)(c->last_E[1] + 2 * HJ_STENCIL) * (double)(c->last_E[2] + 2 * HJ_STENCIL) *
+                               (1.0 + 0.4 * (slots / wg - 1.0));
+                    };
+                    double c0 = -1, cx = -1;
+                    if (launch_scheme<T, HAM>(c, a) == HJ_OK && c->last_plan.ntiles > 0) c0 = cost();
+                    if (launch_xp<T, HAM>(c, s) == HJ_OK) cx = cost();
+                    c->dry = keep_dry;
+                    c->last_plan = keep_plan; c->last_kernel = keep_kernel; c->last_nbuf = keep_nbuf; c->last_nbase = keep_nbase;
+                    for (int d = 0; d < HJ_MAX_DIM; ++d) c->last_E[d] = keep_E[d];
+                    hj_ctx::XpTrial t;
+                    t.prior = cx > 0 && (c0 <= 0 || cx <= 0.975 * c0);
+                    if (cx <= 0) t.decided = 0;                                  // this call has no transposed form
+                    else if (c0 <= 0) t.decided = 1;
+                    else if (c->dry || c->xp_trials == 0) t.decided = t.prior;
+                    it = c->xp_choice.emplace(key, t).first;
+                }
+                tr = &it->second;
+                take = tr->decided >= 0 ? tr->decided == 1 : tr->prior;
+                if (tr->decided < 0 && !c->dry && !c->launch_stop) {
+                    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(call_stream(c, s), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+                        (void)hipGetLastError();
+                        tr->calls = 0;                                                 // (a run cut by a capture is dropped)
+                    } else {
+                        for (int f = 0; f < 2; ++f) {
+                            if (!tr->pend[f] || hipEventQuery(tr->ev[f][1]) != hipSuccess) continue;
+                            float ms = 0;
+                            if (hipEventElapsedTime(&ms, tr->ev[f][0], tr->ev[f][1]) == hipSuccess && ms > 0) {
+                                tr->best[f] = std::min(tr->best[f], ms);
+                                tr->n[f] += 1;
+                            }
+                            tr->pend[f] = false;
+                        }
+                        (void)hipGetLastError();                                       // (hipErrorNotReady is not this launch's error)
+                        if (tr->calls == 0 && tr->n[0] >= c->xp_trials && tr->n[1] >= c->xp_trials) {
+                            tr->decided = tr->best[1] < tr->best[0] ? 1 : 0;
+                            take = tr->decided == 1;
+                            if (c->debug_xp) fprintf(stderr, "[hj] planes [%lld, %lld): %d calls of the axis-0 march %.4f ms, of the transposed march %.4f ms (plan model: %s) -> %s\n",
+                                                     (long long)s.p0, (long long)s.p1, (int)hj_ctx::XP_RUN, tr->best[0], tr->best[1], tr->prior ? "transposed" : "axis-0",
+                                                     take ? "transposed" : "axis-0");
+                        } else if (tr->calls > 0) {
+                            take = tr->form == 1;                                      // inside a run
+                            sample = true;
+                        } else {
+                            const int f = tr->n[1] + (tr->pend[1] ? 1 : 0) < tr->n[0] + (tr->pend[0] ? 1 : 0) ? 1 : 0;      // take turns, the axis-0 march first
+                            if (!tr->ev[0][0]) {
+                                bool ok = true;
+                                for (int i = 0; i < 4; ++i) ok = ok && hipEventCreate(&tr->ev[i / 2][i % 2]) == hipSuccess;
+                                if (!ok) { (void)hipGetLastError(); tr->decided = tr->prior; }
+                            }
+                            if (tr->decided < 0 && tr->started >= 4 * c->xp_trials + 40) {
+                                // (never settled -- the stream is captured most of the time, or the tile-shape rotation never ends: what there is)
+                                tr->decided = tr->n[0] > 0 && tr->n[1] > 0 ? (tr->best[1] < tr->best[0] ? 1 : 0) : (tr->prior ? 1 : 0);
+                                take = tr->decided == 1;
+                            } else if (tr->decided < 0 && !tr->pend[f] && tr->n[f] < c->xp_trials + 2) {
+                                if (hipEventRecord(tr->ev[f][0], call_stream(c, s)) == hipSuccess) {
+                                    tr->form = f; tr->started += 1; tr->seq0 = c->tune_seq; take = f == 1; sample = true;
+                                } else (void)hipGetLastError();
+                            }
+                        }
+                    }
+                }
+            }
+            int rc = HJ_XP_FALLBACK;
+            if (take) {
+                rc = launch_xp<T, HAM>(c, s);
+                if (rc == HJ_XP_FALLBACK && tr) { tr->decided = 0; tr->calls = 0; sample = false; }
+            }
+            if (rc == HJ_XP_FALLBACK && tr) {
+                SubstepCall a = s;
+                a.xp = false;
+                rc = launch_scheme<T, HAM>(c, a);
+            }
+            if (rc != HJ_XP_FALLBACK) {
+                if (sample) {
+                    if (rc != HJ_OK) tr->calls = 0;
+                    else if (++tr->calls >= (int)hj_ctx::XP_RUN) {
+                        tr->calls = 0;
+                        if (c->tune_seq != tr->seq0) {}       // the axis-0 march was trying tile shapes (synchronising trials): not its steady state
+                        else if (hipEventRecord(tr->ev[tr->form][1], call_stream(c, s)) == hipSuccess) tr->pend[tr->form] = true;
+                        else (void)hipGetLastError();
+                    }
+                }
+                return rc;
+            }
         }
     }
     switch (s.scheme) {

@@ -63,13 +63,12 @@ int launch_xp_mode(hj_ctx* c, const SubstepCall& s, int nbuf) {
     if (!t.ok) return HJ_XP_FALLBACK;
     const auto key = std::make_pair(reinterpret_cast<const void*>(kern), t.lds_bytes);
     auto it = c->occ_cache.find(key);
+    int occ_blocks = it != c->occ_cache.end() ? it->second : 0;
     if (it == c->occ_cache.end()) {
-        int nb = 0;
-        if (c->dry) nb = std::max(1, std::min(OCC * 256 / NT, (int)((size_t)(160 * 1024) / std::max<size_t>(1, t.lds_bytes))));
-        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, key.first, NT, t.lds_bytes) != hipSuccess || nb < 1) nb = 1;
-        it = c->occ_cache.emplace(key, nb).first;
+        if (c->dry) occ_blocks = std::max(1, std::min(OCC * 256 / NT, (int)((size_t)(160 * 1024) / std::max<size_t>(1, t.lds_bytes))));
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, key.first, NT, t.lds_bytes) != hipSuccess || occ_blocks < 1) occ_blocks = 1;
+        if (c->dry != 2) c->occ_cache.emplace(key, occ_blocks);     // (2: a planning look from a live context -- its estimate is not the device's answer)
     }
-    const int occ_blocks = it->second;
     // the span of a buffer descriptor: the rows of the window and its halo (fixed) + a chunk of the march and 3 rows either side
     const long long xbase = std::min<int64_t>(0, c->halo_lo ? s.p0 - HJ_STENCIL : 0);
     const long long hi = c->halo_hi ? std::max<long long>(s.p1 + HJ_STENCIL, N0) : N0;

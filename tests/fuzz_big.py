@@ -49,6 +49,8 @@ def case(rng, k):
     which = str(rng.choice(["dubins", "dint", "pend"], p=[0.55, 0.2, 0.25]))
     scheme = str(rng.choice(["ENO2", "ENO3", "WENO5_ASSHIPPED", "WENO5"]))
     order = int(rng.integers(2, 4))
+    nsteps = 2
+    os.environ.pop("HJ_XP_TRIALS", None)
     gen = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
     if which == "dubins":
         n = [int(rng.integers(60, 240)) for _ in range(3)]
@@ -56,6 +58,11 @@ def case(rng, k):
             n = [int(rng.integers(340, 372)) for _ in range(3)]
         if rng.random() < 0.25:                      # round 6: THIN grids (few axis-0 planes, long axis 1): the library marches them along axis 1 by itself
             n = [int(rng.integers(8, 100)), int(rng.integers(300, 520)), int(rng.integers(180, 420))]
+            # a live context tries both forms in runs of six launches before it settles (hj_inst.hip, launch_scheme): enough steps to be in the middle of
+            # that, or -- HJ_XP_TRIALS=0 -- the plan model alone, the transposed form from the first launch where it says so
+            nsteps = int(rng.integers(2, 7))
+            if rng.random() < 0.5:
+                os.environ["HJ_XP_TRIALS"] = "0"
         pd = [d for d in range(3) if rng.random() < (0.8 if d == 2 else 0.15)]
         gmin, gmax = [-.75, -1.25, -np.pi], [3.25, 1.25, np.pi]
         ham, par, dtype = _ffi.HAM_DUBINS_REL, [1.0, 1.0, 1.0, 2.0], ("float64" if rng.random() < 0.8 else "float32")
@@ -82,8 +89,8 @@ def case(rng, k):
         + torch.zeros(n, device="cuda", dtype=torch.float64)
     full = full + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
     full = full.to(torch.float64 if dtype == "float64" else torch.float32).contiguous()
-    ta, ya, ka, tile = steps(g, full, scheme, ham, par, dtype, order, 2, False)
-    tb, yb, kb, _ = steps(g, full, scheme, ham, par, dtype, order, 2, True)
+    ta, ya, ka, tile = steps(g, full, scheme, ham, par, dtype, order, nsteps, False)
+    tb, yb, kb, _ = steps(g, full, scheme, ham, par, dtype, order, nsteps, True)
     ok = ta == tb and torch.equal(ya, yb) and kb == "direct_substep_kernel"
     worst = float((ya - yb).abs().max())
     print("%4d %-6s N=%-18s pd=%-12s %-16s %-7s order %d kernel %-20s tile %-16s max|diff| %.1e %s" % (

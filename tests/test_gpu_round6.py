@@ -26,7 +26,7 @@ PAR = [1., 1., 1., 2.]
 
 
 def _ctx(g, monkeypatch, dtype="float64", **env):
-    for k in ("HJ_XP", "HJ_PAIR", "HJ_FORCE_DIRECT", "HJ_MIN_CHUNK", "HJ_FULL_ROWS", "HJ_KEEP_BOUNDS"):
+    for k in ("HJ_XP", "HJ_XP_TRIALS", "HJ_PAIR", "HJ_FORCE_DIRECT", "HJ_MIN_CHUNK", "HJ_FULL_ROWS", "HJ_KEEP_BOUNDS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -543,8 +543,10 @@ def test_runtime_kernel_table_keeps_fast_eno_fp64_and_eno_fp32_apart():
 
 
 def test_thin_grids_take_the_transposed_march_by_default(monkeypatch):
-    """The auto rule (hj_api.hip, xp_wanted): a 3-D grid of 8..100 axis-0 planes whose axis 1 is at least three times longer, at the pair kernel's
-    sizes, runs hj_rk_step / hj_rk_integrate through the transposed launch BY ITSELF -- no knob -- and gives the bits of the axis-0 march (HJ_XP=0)."""
+    """The auto rule (hj_api.hip xp_wanted: thin 3-D ranges without neighbours at the pair kernel's sizes; hj_inst.hip launch_scheme: the plan model,
+    then -- on a live context -- runs of both forms timed against each other): hj_rk_integrate ends up on the transposed launch BY ITSELF on a grid
+    where it is ~20 % faster, gives the bits of the axis-0 march (HJ_XP=0) while it is still trying both, and HJ_XP_TRIALS=0 (the model alone) takes
+    the transposed launch from the first call."""
     n = (20, 640, 520)
     g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, 2)
     x0 = torch.as_tensor(np.asarray(g.vs[0]).ravel(), device="cuda").reshape(-1, 1, 1)
@@ -554,14 +556,17 @@ def test_thin_grids_take_the_transposed_march_by_default(monkeypatch):
     y = ((x0 * x0 + x1 * x1).sqrt() - 0.5 + 0.05 * torch.sin(3 * x2) + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)).contiguous()
     sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
     res = {}
-    for tag, env in (("default", {}), ("axis0", dict(HJ_XP="0"))):
+    nsteps = 10         # (2 x 2 runs of 6 substeps are the trial; the 9th step runs the form that won)
+    for tag, env in (("default", {}), ("model", dict(HJ_XP_TRIALS="0")), ("axis0", dict(HJ_XP="0"))):
         dg = _ctx(g, monkeypatch, **env)
         a, b, w = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
         tout, steps, where = C.c_double(), C.c_int64(), C.c_int()
         _ffi.check(dg.lib.hj_rk_integrate(dg.ctx, 3, sid, _ffi.HAM_DUBINS_REL, _ffi.darr(PAR), 0., 1., 0.8, 1e300, 0, dg.ptr(y), dg.ptr(a), dg.ptr(b),
-                                          dg.ptr(w), 4, -1., C.byref(tout), C.byref(steps), C.byref(where)))
+                                          dg.ptr(w), nsteps if tag != "model" else 1, -1., C.byref(tout), C.byref(steps), C.byref(where)))
         dg.sync()
-        assert dg.lib.hj_last_kernel(dg.ctx) == (XP_NAME if tag == "default" else b"fused_pair_kernel"), dg.lib.hj_last_kernel(dg.ctx)
+        assert dg.lib.hj_last_kernel(dg.ctx) == (XP_NAME if tag != "axis0" else b"fused_pair_kernel"), (tag, dg.lib.hj_last_kernel(dg.ctx))
+        if tag == "model":
+            continue
         res[tag] = (tout.value, steps.value, (a if where.value == 1 else b).clone())
-    assert res["default"][:2] == res["axis0"][:2] and res["default"][1] == 4
+    assert res["default"][:2] == res["axis0"][:2] and res["default"][1] == nsteps
     assert torch.equal(res["default"][2], res["axis0"][2]), float((res["default"][2] - res["axis0"][2]).abs().max())
