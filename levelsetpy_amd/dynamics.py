@@ -21,7 +21,8 @@ def native_again(system):
     is not native any more: what a cached plan is re-validated with (term.native_plan)."""
     att = getattr(system, "_hj_native", None)
     if att is not None:
-        return att.reg.ham_id, att.params(system)
+        par = att.params(system)            # (a traced pair re-traces here and may change its registration: the id is read after)
+        return att.reg.ham_id, par
     return system.native()
 
 

@@ -218,7 +218,7 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
             data[0] = data0_host()
     cur_np = None if dev_in else first        # host copy of the current state: kept only where it is consumed (SDModFunc)
 
-    plan = native_plan(schemeData)
+    plan = native_plan(schemeData, first)
     dg = device_grid(g, "float64") if plan is not None else None
     ops = _Ops(dg)
     col = (int(np.prod(g.shape)), 1) if schemeFunc is termLaxFriedrichs else (int(np.prod(g.shape)),)
@@ -251,7 +251,7 @@ def HJIPDE_solve(data0, tau, schemeData, compMethod=None, extraArgs=None):
                 sd_run = schemeData
             if schemeData.grid is not g:
                 error('SDModFunc must keep schemeData.grid (the stored arrays live on it)')
-            new_plan = native_plan(schemeData)
+            new_plan = native_plan(schemeData, y)
             if (new_plan is None) != (plan is None):
                 # the state changes sides (device tensor <-> NumPy) with the execution path
                 if new_plan is None:

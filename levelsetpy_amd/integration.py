@@ -127,10 +127,10 @@ def _device_plan(schemeFunc, schemeData, y0):
     if iscell(y0) or iscell(schemeData):
         return None
     if schemeFunc is termLaxFriedrichs:
-        plan, rs = native_plan(schemeData), 0
+        plan, rs = native_plan(schemeData, y0), 0
     elif schemeFunc is termRestrictUpdate and isfield(schemeData, 'innerFunc') \
             and schemeData.innerFunc is termLaxFriedrichs and isfield(schemeData, 'innerData'):
-        plan = native_plan(schemeData.innerData)
+        plan = native_plan(schemeData.innerData, y0)
         positive = schemeData.positive if isfield(schemeData, 'positive') else True
         rs = +1 if positive else -1
     else:

@@ -4,8 +4,10 @@
 
 Fused path: when hamFunc/partialFunc are the methods of one of dynamics.py's systems, dissFunc is
 this package's artificialDissipationGLF and the derivative function is one of spatial.py's, the
-whole term is ONE HIP kernel (hj_lf_term).  Anything else takes the split path: per-dimension
-hj_upwind kernels, then the user's callbacks on arrays, exactly as the reference sequences them.
+whole term is ONE HIP kernel (hj_lf_term).  Callbacks the package does not know are TRACED (trace_ham.py): called once
+with symbolic arrays, written out as a device expression, compiled with hipRTC and checked against the callbacks on the
+first data they meet -- then they run fused as well.  What cannot be traced takes the split path: per-dimension hj_upwind
+kernels, then the user's callbacks on arrays, exactly as the reference sequences them.
 """
 import copy
 import ctypes as C
@@ -19,6 +21,7 @@ from . import dissipation as _diss
 from .dissipation import artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF, glf_device
 from .dynamics import native_of, native_again
 from .user_ham import ATTACH_EPOCH as _ATTACH_EPOCH
+from . import trace_ham as _trace
 from .spatial import scheme_id_of, upwind_all_dims
 from .utilities import isfield, iscell
 
@@ -37,12 +40,13 @@ def _deriv_func(sd):
 
 class _Plan(tuple):
     """(grid, scheme_id, ham_id, params) plus .diss, the hj_ctx_set_dissipation kind; .parv = params as a C array;
-    .system = the object whose bound methods hamFunc / partialFunc are."""
+    .system = the object whose bound methods hamFunc / partialFunc are; .traced: the kernel was generated from the callbacks."""
 
-    def __new__(cls, items, diss, system=None, dynamic=False):
+    def __new__(cls, items, diss, system=None, dynamic=False, traced=False):
         self = super(_Plan, cls).__new__(cls, items)
         self.diss = diss
         self.system = system
+        self.traced = traced
         # alpha depends on the data (a run-time Hamiltonian that reads the costate range, user_ham.py): no static stepBound --
         # the integrators take deltaT from the first stage's reduced bound (hj_rk_step does, ode_cfl_3.py:142)
         self.dynamic = dynamic
@@ -88,9 +92,17 @@ class _Plan(tuple):
 _PLAN_CACHE = weakref.WeakKeyDictionary()
 
 
-def native_plan(schemeData):
-    """(grid, scheme_id, ham_id, params) if this LF schemeData can run fused, else None."""
+def native_plan(schemeData, y=None):
+    """(grid, scheme_id, ham_id, params) if this LF schemeData can run fused, else None.  y: the data the caller is about to step --
+    a plan TRACED from Python callbacks (trace_ham.py) is checked against them on the first data it meets, and is not used before."""
     sd = schemeData[0] if iscell(schemeData) else schemeData
+    plan = _plan_of(sd)
+    if plan is not None and plan.traced and not getattr(plan.system.reg, "verified", False):
+        plan = _verify_traced(plan, sd, y)
+    return plan
+
+
+def _plan_of(sd):
     d = sd.__dict__
     fn = d['CoStateCalc'] if 'CoStateCalc' in d else d.get('derivFunc')
     try:
@@ -131,19 +143,71 @@ def _classify(sd, fn):
     if sid is None or sd.dissFunc not in (artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF):
         return None
     nat = native_of(sd.hamFunc, sd.partialFunc)
-    if nat is None or nat[0].grid is not sd.grid:
-        return None
+    traced = False
     try:
         from .context import grid_bc
         grid_bc(sd.grid)
     except ValueError:
+        return None
+    if nat is None and 2 <= int(sd.grid.dim) <= 4 and callable(sd.hamFunc) and callable(sd.partialFunc):
+        # callbacks nobody has written a kernel for: record what they compute (trace_ham.py)
+        nat = _trace.traced_native(sd)
+        traced = nat is not None
+    if nat is None or nat[0].grid is not sd.grid:
         return None
     att = getattr(nat[0], "_hj_native", None)
     dynamic = bool(att is not None and getattr(att.reg, "uses_range", False))
     # (for a Hamiltonian that ignores the costate range the two local variants coincide; one that reads it gets the per-node ranges of
     #  diss_local_laxfried.py / diss_localsq_laxfried.py inside the fused kernel: hj_mi355x.h, HJ_DISS_LLF / HJ_DISS_LLLF)
     kind = {artificialDissipationGLF: _ffi.DISS_GLF, artificialDissipationLLF: _ffi.DISS_LLF, artificialDissipationLLLF: _ffi.DISS_LLLF}[sd.dissFunc]
-    return _Plan((sd.grid, sid, nat[1], nat[2]), kind, nat[0], dynamic)
+    return _Plan((sd.grid, sid, nat[1], nat[2]), kind, nat[0], dynamic, traced)
+
+
+def _verify_traced(plan, sd, y):
+    """First use of a kernel generated from Python callbacks: the term by BOTH paths on the caller's data.  Agreement to rounding marks the
+    registration verified (once per process and expression); anything else drops the trace with a warning and the split path stays."""
+    if y is None:
+        return None
+    reg = plan.system.reg
+    import warnings
+    try:
+        y0 = y.reshape(-1, 1)
+        fused, sb_f, dg = _fused_term(plan, 0.0, y0, 0)
+        split, sb_s, _ = _split_term(0.0, y0, sd, sd)
+        f = dg.like(fused, split, (dg.numel, 1))
+        if is_tensor(split):
+            diff = (f - split.reshape(-1, 1)).abs()
+            scale = float(split.abs().max()) + 1e-300
+            finite = bool(diff.isfinite().all())
+            tol = (1e-9 if str(split.dtype).endswith("64") else 2e-4) * scale
+            frac = float((diff > tol).double().mean())
+            worst = float(diff.max())
+        else:
+            f, s_ = np.asarray(f).reshape(-1, 1), np.asarray(split).reshape(-1, 1)
+            diff = np.abs(f - s_)
+            scale = float(np.abs(s_).max()) + 1e-300
+            finite = bool(np.isfinite(diff).all())
+            tol = (1e-9 if s_.dtype == np.float64 else 2e-4) * scale
+            frac = float((diff > tol).mean())
+            worst = float(diff.max())
+        # (an ENO stencil choice may flip where the two arithmetics differ in the last bit: a few isolated nodes, not an expression error)
+        ok = finite and frac <= 2e-3 and worst <= 1e-2 * scale and abs(sb_f - sb_s) <= 1e-7 * abs(sb_s)
+    except _ffi.Unsupported:
+        return None
+    except _trace.TraceError:
+        return None
+    if not ok:
+        _trace.mark_bad(reg)
+        try:
+            del _PLAN_CACHE[sd]
+        except (KeyError, TypeError):
+            pass
+        warnings.warn("levelsetpy_amd: the kernel traced from %r disagrees with the callbacks on this data (max |diff| %.3g of %.3g, %.2g %% of the "
+                      "nodes, stepBound %.17g / %.17g): the split path is used" % (getattr(sd.hamFunc, "__qualname__", sd.hamFunc), worst, scale,
+                                                                                 100 * frac, sb_f, sb_s))
+        return None
+    reg.verified = True
+    return plan
 
 
 def _fused_term(plan, t, y, restrict_sign):
@@ -171,7 +235,7 @@ def termLaxFriedrichs(t, y, schemeData):
     assert isfield(sd0, 'hamFunc'), 'hamFunc not in bundle thisschemeData'
     assert isfield(sd0, 'partialFunc'), 'partialFunc not in bundle thisschemeData'
     y0 = y[0] if iscell(y) else y
-    plan = native_plan(sd0)          # looked up on the caller's own Bundle (the plan cache is keyed by it)
+    plan = native_plan(sd0, y0)      # looked up on the caller's own Bundle (the plan cache is keyed by it)
     if plan is not None:
         try:
             out, stepBound, dg = _fused_term(plan, t, y0, 0)
@@ -181,6 +245,11 @@ def termLaxFriedrichs(t, y, schemeData):
             # the split path, as before the registration (the built-in systems fall back inside the library)
             if plan[2] < _ffi.HAM_USER_BASE:
                 raise
+    return _split_term(t, y0, sd0, schemeData)
+
+
+def _split_term(t, y0, sd0, schemeData):
+    """term_lax_friedrich.py:94-130: derivative kernels, the callbacks on arrays, the dissipation."""
     thisSchemeData = copy.copy(sd0)      # the reference's shallow copy (term_lax_friedrich.py:80-83)
     # ---- split path (term_lax_friedrich.py:94-130)
     grid = thisSchemeData.grid
@@ -219,7 +288,7 @@ def termRestrictUpdate(t, y, schemeData):
     positive = thisSchemeData.positive if isfield(thisSchemeData, 'positive') else True
     y0 = y[0] if iscell(y) else y
     if thisSchemeData.innerFunc is termLaxFriedrichs:
-        plan = native_plan(thisSchemeData.innerData)
+        plan = native_plan(thisSchemeData.innerData, y0)
         if plan is not None:
             out, stepBound, dg = _fused_term(plan, t, y0, +1 if positive else -1)
             return dg.like(out, y0, (dg.numel,), lazy=True), stepBound, schemeData

@@ -1,0 +1,197 @@
+"""CPU: the tracer that turns Python hamFunc / partialFunc callbacks into a device expression (levelsetpy_amd/trace_ham.py).
+
+No GPU here: the traced graph is evaluated in NumPy (Traced.evaluate) against the callbacks themselves on real arrays, the
+generated source is compiled with hipRTC (hj_ham_compile_check needs no device), and everything the tracer must refuse is
+checked to be refused -- a refused pair keeps the split path, a wrongly accepted one would compute something else."""
+import numpy as np
+import pytest
+
+import levelsetpy_amd as L
+from levelsetpy_amd import trace_ham as TH
+
+
+def grid3(n=(12, 10, 14), low_mem=False):
+    return L.createGrid(np.array([[-2., -2., -np.pi]]).T, np.array([[2., 2., np.pi * (1 - 2 / n[2])]]).T, np.array(n, dtype=np.int64).reshape(-1, 1), 2,
+                        low_mem=low_mem)
+
+
+class DubinsAbs(object):
+    """The reference's style: grid.xs read inside the callbacks (DynamicalSystems/dubins_absolute.py:150-170)."""
+
+    def __init__(self, grid, v, w):
+        self.grid, self.v, self.w = grid, v, w
+
+    def hamiltonian(self, t, data, p, sd=None):
+        x3 = self.grid.xs[2]
+        return self.v * (p[0] * np.cos(x3) + p[1] * np.sin(x3)) + self.w * np.abs(p[2])
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        x3 = self.grid.xs[2]
+        if dim == 0:
+            return np.abs(self.v * np.cos(x3))
+        if dim == 1:
+            return np.abs(self.v * np.sin(x3))
+        return self.w
+
+
+class Nonlinear(object):
+    """Every kind of node the tracer writes: comparisons, where, maximum / minimum, powers, sign, clip, booleans as numbers, the costate range."""
+
+    def __init__(self, grid, c):
+        self.grid, self.c, self.k = grid, c, 3
+
+    def hamiltonian(self, t, data, p, sd=None):
+        x = self.grid.xs
+        q = np.sqrt(p[0] ** 2 + p[1] ** 2 + 1e-12) + 0.5 * p[2] ** self.k
+        gate = (x[0] > 0) * 1.0 + (x[1] <= 0.25)
+        sw = np.where((p[0] > 0) & ~(p[1] > 0.5), np.maximum(p[0], 0.1 * x[1]), np.minimum(p[1], -p[2]))
+        return -q + self.c * x[0] * p[1] * gate + sw * np.sign(p[2]) + np.clip(p[0], -0.3, 0.7) / (2 + np.cos(x[2])) + np.tanh(p[1]) * np.exp(-x[1] ** 2)
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        a = np.maximum(np.abs(dmin[dim]), np.abs(dmax[dim]))
+        if dim == 1:
+            return a + np.abs(self.c * self.grid.xs[0])
+        if dim == 2:
+            return a + 1.5 * np.maximum(np.abs(dmin[2]), np.abs(dmax[2])) ** 2
+        return a + 0.5
+
+
+def real_eval(sysobj, g, p, dmin, dmax):
+    H = sysobj.hamiltonian(0., None, p, None)
+    al = [np.broadcast_to(np.asarray(sysobj.dissipation(0., None, dmin, dmax, None, d), dtype=np.float64), g.shape) for d in range(g.dim)]
+    return H, al
+
+
+@pytest.mark.parametrize("low_mem", [False, True])
+@pytest.mark.parametrize("cls,args", [(DubinsAbs, (1.3, 0.7)), (Nonlinear, (0.4,))])
+def test_traced_graph_computes_what_the_callbacks_compute(cls, args, low_mem):
+    g = grid3(low_mem=low_mem)
+    obj = cls(g, *args)
+    xs_before = [np.array(v, copy=True) for v in g.xs]
+    tr = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert all(np.array_equal(a, b) for a, b in zip(xs_before, g.xs)) and all(isinstance(v, np.ndarray) for v in g.xs)   # the grid is as it was
+    rng = np.random.default_rng(3)
+    p = [rng.standard_normal(g.shape) for _ in range(3)]
+    dmin, dmax = [-1.5, -0.75, -2.0], [1.25, 2.5, 0.5]
+    H, al = tr.evaluate(np.meshgrid(*[np.asarray(v).ravel() for v in g.vs], indexing="ij"), p, dmin, dmax)
+    Hr, alr = real_eval(obj, g, p, dmin, dmax)
+    assert np.allclose(H, Hr, rtol=1e-14, atol=1e-14), float(np.abs(H - Hr).max())
+    for d in range(3):
+        assert np.allclose(np.broadcast_to(al[d], g.shape), alr[d], rtol=1e-14, atol=1e-14), d
+    assert tr.uses_range == (cls is Nonlinear)
+    # hoisted column values depend on the in-plane coordinates only
+    if tr.column_source:
+        assert "x[0]" not in tr.column_source and "p[" not in tr.column_source and tr.ncol >= 1
+
+
+def test_parameters_become_par_and_a_changed_speed_keeps_the_source():
+    g = grid3()
+    obj = DubinsAbs(g, 1.3, 0.7)
+    a = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    obj.v = 2.5
+    b = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert a.params == [1.3, 0.7] and b.params == [2.5, 0.7]
+    assert a.source == b.source and a.column_source == b.column_source
+    assert "1.3" not in a.source and "par[0]" in (a.source + (a.column_source or ""))
+    # a fifth distinct float is a literal (HamTables::par has four slots): exact, as a hexadecimal floating literal
+    class Many(DubinsAbs):
+        def hamiltonian(self, t, data, p, sd=None):
+            return 0.1 * p[0] + 0.2 * p[1] + 0.3 * p[2] + 0.4 * self.grid.xs[0] + 0.7 * p[0] * p[1]
+    m = Many(g, 1., 1.)
+    c = TH.trace_callbacks(g, m.hamiltonian, m.dissipation, None)
+    assert len(c.params) == 4 and float(0.7).hex() in c.source
+
+
+def test_fingerprint_sees_in_place_changes():
+    g = grid3()
+    obj = DubinsAbs(g, 1.3, 0.7)
+    sd = L.Bundle(dict(grid=g, hamFunc=obj.hamiltonian, partialFunc=obj.dissipation))
+    f0 = TH.fingerprint(sd)
+    assert TH.fingerprint(sd) == f0
+    obj.w = 0.9
+    assert TH.fingerprint(sd) != f0
+
+
+class _Bad(object):
+    def __init__(self, grid, kind):
+        self.grid, self.kind = grid, kind
+        self.c3 = np.cos(np.asarray(grid.xs[2]))          # computed BEFORE the call
+
+    def hamiltonian(self, t, data, p, sd=None):
+        k = self.kind
+        if k == "branch":
+            return p[0] if p[0].max() > 0 else -p[0]
+        if k == "bool":
+            if p[0] > 0:
+                return p[0]
+            return p[1]
+        if k == "asarray":
+            return p[0].numpy() * 2
+        if k == "stored":
+            return p[0] * self.c3
+        if k == "data":
+            return p[0] + data
+        if k == "time":
+            return p[0] * t
+        if k == "mask":
+            out = np.zeros_like(p[0])
+            out[p[0] > 0] = 1.0
+            return out
+        if k == "reduce":
+            return p[0] * np.sum(p[1])
+        if k == "raises":
+            return p[0] + undefined_name      # noqa: F821
+        return p[0]
+
+    def dissipation(self, t, data, dmin, dmax, sd, dim):
+        if self.kind == "alpha_p":
+            return np.abs(self._p)
+        return 1.0
+
+
+@pytest.mark.parametrize("kind", ["branch", "bool", "asarray", "stored", "data", "time", "mask", "reduce", "raises"])
+def test_what_cannot_be_traced_is_refused(kind):
+    g = grid3()
+    obj = _Bad(g, kind)
+    with pytest.raises(TH.TraceError):
+        TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert isinstance(g.xs[0], np.ndarray)          # restored after a failed trace as well
+
+
+def test_torch_callbacks_and_stored_coordinate_tensors():
+    torch = pytest.importorskip("torch")
+    g = grid3()
+
+    class T(object):
+        def __init__(self, grid):
+            self.grid = grid
+            self.x0 = torch.as_tensor(np.asarray(grid.vs[0]).reshape(-1, 1, 1))       # a real tensor that IS a coordinate: recognised by value
+
+        def hamiltonian(self, t, data, p, sd=None):
+            x2 = torch.as_tensor(np.asarray(self.grid.xs[2]), device=p[0].device)       # the usual way from the grid to the callback's array type
+            return torch.cos(x2) * p[0] + torch.where(p[1] > 0, p[1].abs(), torch.sin(x2) * p[1]) + self.x0 * p[2].clamp(min=-1., max=1.) \
+                + torch.maximum(p[0], p[1]) * 0.25 - (p[2] ** 2).sqrt()
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            x2 = torch.as_tensor(np.asarray(self.grid.xs[2]))
+            return torch.cos(x2).abs() + 1.0 if dim == 0 else (torch.abs(self.x0 * torch.sin(x2)) if dim == 2 else 2.0)
+    obj = T(g)
+    tr = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert np.asarray is np.asarray.__class__ or not hasattr(np.asarray, "__wrapped__")            # the constructors are the originals again
+    assert not hasattr(torch.as_tensor, "__wrapped__")
+    rng = np.random.default_rng(5)
+    p = [rng.standard_normal(g.shape) for _ in range(3)]
+    H, al = tr.evaluate(g.xs, p)
+    Hr = obj.hamiltonian(0., None, [torch.as_tensor(q) for q in p]).numpy()
+    assert np.allclose(H, Hr, rtol=1e-14, atol=1e-14)
+    assert np.allclose(np.broadcast_to(al[0], g.shape), np.broadcast_to(obj.dissipation(0., None, None, None, None, 0).numpy(), g.shape))
+
+
+def test_generated_source_compiles():
+    """hipRTC, no device: the text the tracer writes is a valid expression block for every scheme's kernel (fp64 and fp32 instantiate T)."""
+    g = grid3()
+    obj = Nonlinear(g, 0.4)
+    tr = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    reg = L.register_native_hamiltonian("traced_compile_check", 3, tr.source, nparams=len(tr.params), column_src=tr.column_source, ncol=tr.ncol,
+                                        uses_range=tr.uses_range)
+    reg.check("ENO2")
