@@ -498,32 +498,59 @@ def time_runtime_ham(L, torch, _ffi, DeviceGrid, a, s_head):
     out["%d^3 run-time Hamiltonian (hipRTC)" % a.n] = {
         "workload": r["desc"], "value": s["value"], "ms_per_step": s["ms_per_step"], "roofline_frac": s["frac"], "repeats": s["repeats"],
         "kernel": r["kernel"], "vs_builtin": s["value"] / s_head["value"], "leg_wall_s_incl_compile": time.perf_counter() - t0}
-    # split path: the same formulas as Python callbacks on device tensors
+    # the same formulas as FOREIGN Python callbacks on device tensors (lambdas: nothing the library could recognise) through odeCFL3
+    # single-step calls: (a) HJ_TRACE=0 -- the split path every foreign hamFunc / partialFunc took until round 6; (b) default -- the
+    # callbacks are traced into a device expression (levelsetpy_amd/trace_ham.py), compiled with hipRTC, checked against the callbacks on
+    # the first data, and run fused
     g = dubins_grid(L, a.n, a.n)
     sysd = L.DubinsVehicleRel(g, 1, 1)
     calc = {"WENO5_ASSHIPPED": L.upwindFirstWENO5, "ENO3": L.upwindFirstENO3, "ENO2": L.upwindFirstENO2, "WENO5": L.upwindFirstWENO5Intended}[a.scheme]
-    sd = L.Bundle(dict(grid=g, hamFunc=lambda t, d, p, sd_: sysd.hamiltonian(t, d, p, sd_),
-                       partialFunc=lambda t, d, lo, hi, sd_, dim: sysd.dissipation(t, d, lo, hi, sd_, dim),
-                       dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
     op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
-    y, t = device_sdf(torch, g, 0.5, ignore=(2,)).reshape(-1, 1), 0.0
-    for _ in range(3):
-        t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
-    k = max(3, min(10, a.steps))
-    walls = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(k):
-            t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
-        torch.cuda.synchronize()
-        walls.append(time.perf_counter() - t1)
-    med = statistics.median(walls)
-    cells = y.numel()
-    out["%d^3 foreign Python callbacks (split path)" % a.n] = {
-        "workload": "the same system as Python hamFunc / partialFunc callbacks on device tensors through odeCFL3 (split path)",
-        "value": cells * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k,
-        "vs_run_time_hamiltonian": (cells * 3 * k / med) / s["value"]}
+    legs, finals = {}, {}
+    for kind in ("split", "traced"):
+        prev = os.environ.get("HJ_TRACE")
+        if kind == "split":
+            os.environ["HJ_TRACE"] = "0"
+        try:
+            sd = L.Bundle(dict(grid=g, hamFunc=lambda t, d, p, sd_: sysd.hamiltonian(t, d, p, sd_),
+                               partialFunc=lambda t, d, lo, hi, sd_, dim: sysd.dissipation(t, d, lo, hi, sd_, dim),
+                               dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
+            y, t = device_sdf(torch, g, 0.5, ignore=(2,)).reshape(-1, 1), 0.0
+            t0 = time.perf_counter()
+            for _ in range(3):
+                t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+            torch.cuda.synchronize()
+            first = time.perf_counter() - t0
+            finals[kind] = (t, y.clone())
+            k = max(3, min(10, a.steps)) if kind == "split" else a.steps
+            walls = []
+            for _ in range(3 if kind == "split" else min(9, a.repeats)):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t1)
+            med = statistics.median(walls)
+            cells = y.numel()
+            from levelsetpy_amd.context import device_grid as _dgrid
+            dgk = _dgrid(g)
+            legs[kind] = {"value": cells * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k, "first_three_steps_s_incl_trace_compile_check": first,
+                          "kernel": dgk.lib.hj_last_kernel(dgk.ctx).decode()}
+        finally:
+            if prev is None:
+                os.environ.pop("HJ_TRACE", None)
+            else:
+                os.environ["HJ_TRACE"] = prev
+    dmax = float((finals["traced"][1] - finals["split"][1]).abs().max())
+    assert abs(finals["traced"][0] - finals["split"][0]) <= 1e-12 and dmax <= 1e-10, (finals["traced"][0], finals["split"][0], dmax)
+    out["%d^3 foreign Python callbacks (split path)" % a.n] = dict(
+        legs["split"], workload="the same system as Python hamFunc / partialFunc callbacks (lambdas) on device tensors through odeCFL3 single steps, HJ_TRACE=0: "
+        "derivative kernels -> callbacks -> dissipation kernel", vs_run_time_hamiltonian=legs["split"]["value"] / s["value"])
+    out["%d^3 foreign Python callbacks (traced)" % a.n] = dict(
+        legs["traced"], workload="the same lambdas, default: traced into a device expression, compiled with hipRTC, checked against the callbacks, run fused "
+        "(odeCFL3 single-step calls: one Python call per step)", vs_split_path=legs["traced"]["value"] / legs["split"]["value"],
+        vs_run_time_hamiltonian=legs["traced"]["value"] / s["value"], max_abs_diff_vs_split_after_3_steps=dmax)
     return out
 
 

@@ -265,3 +265,24 @@ def test_traced_4d_fp32():
     assert b"hipRTC" in dg.lib.hj_last_kernel(dg.ctx)
     assert fused.dtype == torch.float32 and abs(sb_f - sb_s) <= 1e-5 * sb_s
     close(fused.cpu().numpy(), split.cpu().numpy(), 2e-4, what="4-D fp32 traced vs split")
+
+
+def test_traced_first_use_with_numpy_arrays():
+    """A NumPy caller: the check against the callbacks runs on host arrays, the result comes back as an ndarray(-like) and equals the split path's."""
+    n = (24, 22, 20)
+    g, og = mk([-2., -2., -np.pi], [2., 2., np.pi * (1 - 2 / n[2])], n, 2)
+
+    class Car(DubinsAbs):              # a class of its own: an expression no other test has registered and verified
+        def hamiltonian(self, t, data, p, sd=None):
+            return DubinsAbs.hamiltonian(self, t, data, p, sd) + 0.125 * p[0] * p[1]
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            a = DubinsAbs.dissipation(self, t, data, dmin, dmax, sd, dim)
+            return a + 0.125 * np.maximum(abs(dmin[1 - dim]), abs(dmax[1 - dim])) if dim < 2 else a
+    y = (O.shape_sphere(og, None, 1.0) + 0.02 * np.random.default_rng(4).standard_normal(og.shape)).reshape(-1, 1)
+    veh = Car(g, 1.1, 0.8)
+    fused, sb_f, _ = L.termLaxFriedrichs(0., y, sdata(g, veh, L.upwindFirstENO3))
+    assert "hipRTC" in _kernel(g), _kernel(g)
+    yo, sbo = O.term_lax_friedrichs(og, Car(og, 1.1, 0.8), "ENO3", 0., y)
+    close(np.asarray(fused), yo, 1e-11, what="NumPy in: traced vs oracle")
+    assert abs(sb_f - sbo) <= 1e-12 * sbo
