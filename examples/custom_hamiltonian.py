@@ -7,11 +7,13 @@ reference's artificialDissipationGLF, which hands partialFunc the minimum and ma
 
 H(x, p) = |p|^2 / 2 + c x_0 p_1   (a convex Hamiltonian with a drift),   alpha_d = max |dH/dp_d| over the costate range.
 
-The system is written ONCE as the reference wants it -- a Python object with .hamiltonian / .dissipation on arrays -- and runs as it
-is on the split path (derivative kernels -> these callbacks -> a dissipation kernel).  Writing the same pair once more as a device
-expression and attaching it to the object makes every schemeData built from that object run the fused kernels (compiled with hipRTC
-on first use, cached on disk): a range pass + the fused substep per RK stage, deltaT from the first stage's bound exactly as
-ode_cfl_3.py:142 takes it, no host round trip inside a step.  Needs an MI355X (the package has no CPU fallback)."""
+The system is written ONCE as the reference wants it -- a Python object with .hamiltonian / .dissipation on arrays.  Three ways to run it:
+(1) HJ_TRACE=0: the split path (derivative kernels -> these callbacks -> a dissipation kernel), what every foreign callable took until
+round 6; (2) default: the library TRACES the callbacks (calls them once with symbolic arrays), compiles the recorded expression with
+hipRTC, checks the kernel against the callbacks on the first data and runs fused -- nothing to write; (3) the same pair written by hand as
+a device expression and attached to the object (for callbacks the tracer refuses: Python control flow on array values, reductions, ...).
+Fused: a range pass + the fused substep per RK stage, deltaT from the first stage's bound exactly as ode_cfl_3.py:142 takes it, no host
+round trip inside a step.  Needs an MI355X (the package has no CPU fallback)."""
 import os
 import sys
 import time
@@ -38,7 +40,7 @@ class BurgersDrift(object):
         return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + c * x0 * p[1]
 
     def dissipation(self, t, data, derivMin, derivMax, schemeData, dim):
-        a = max(abs(float(derivMin[dim])), abs(float(derivMax[dim])))        # |dH/dp_d| = |p_d| (+ |c x_0| for d = 1), bounded over the range
+        a = np.maximum(abs(derivMin[dim]), abs(derivMax[dim]))               # |dH/dp_d| = |p_d| (+ |c x_0| for d = 1), bounded over the range
         if dim != 1:
             return a
         x0 = np.abs(c * np.asarray(self.grid.xs[0]))
@@ -49,12 +51,17 @@ gmin, gmax = -np.ones((3, 1)), np.ones((3, 1))
 g = lsp.createGrid(gmin, gmax, n * np.ones((3, 1), dtype=np.int64), None)
 system = BurgersDrift(g)
 data0 = lsp.shapeSphere(g, np.zeros((3, 1)), 0.5)
-sd = lsp.Bundle(dict(grid=g, hamFunc=system.hamiltonian, partialFunc=system.dissipation,
-                     dissFunc=lsp.artificialDissipationGLF, CoStateCalc=lsp.upwindFirstWENO5))
+def bundle():
+    # (a fresh Bundle per run: the library caches what it found out about a schemeData on the Bundle)
+    return lsp.Bundle(dict(grid=g, hamFunc=system.hamiltonian, partialFunc=system.dissipation,
+                           dissFunc=lsp.artificialDissipationGLF, CoStateCalc=lsp.upwindFirstWENO5))
+
+
 opts = lsp.odeCFLset(lsp.Bundle(dict(factorCFL=0.8, singleStep='on')))
 
 
 def run(label):
+    sd = bundle()
     y, t = torch.as_tensor(data0.reshape(-1, 1), device="cuda"), 0.0
     t, y, _ = lsp.odeCFL3(lsp.termLaxFriedrichs, [t, 1e9], y, opts, sd)            # warm-up (and, on the fused path, the compilation)
     torch.cuda.synchronize()
@@ -67,7 +74,11 @@ def run(label):
     return t, y
 
 
-t_split, y_split = run("as written (split path, Python callbacks):")
+os.environ["HJ_TRACE"] = "0"
+t_split, y_split = run("as written, HJ_TRACE=0 (split path):")
+del os.environ["HJ_TRACE"]
+t_traced, y_traced = run("as written, traced by the library (fused):")
+print("    the expression the tracer wrote:\n        " + lsp.trace_callbacks(g, system.hamiltonian, system.dissipation).source.replace("\n", "\n        "))
 
 # the same H / alpha once more, as a device expression: x[d] node, p[d] costate, par[k] parameters, dmin[d] / dmax[d] the costate range
 reg = lsp.register_native_hamiltonian("burgers_drift_example", 3, """
@@ -78,5 +89,6 @@ reg = lsp.register_native_hamiltonian("burgers_drift_example", 3, """
 """, nparams=1)
 reg.attach(system, params=lambda s: [c])          # the SAME object, the SAME schemeData: selected by callable identity
 
-t_fused, y_fused = run("attached device expression (fused path):")
-print("same trajectory: |t_fused - t_split| = %.1e, max |y_fused - y_split| = %.1e" % (abs(t_fused - t_split), float((y_fused - y_split).abs().max())))
+t_fused, y_fused = run("hand-written device expression attached (fused):")
+for name, tt, yy in (("traced", t_traced, y_traced), ("hand-written", t_fused, y_fused)):
+    print("same trajectory (%s): |t - t_split| = %.1e, max |y - y_split| = %.1e" % (name, abs(tt - t_split), float((yy - y_split).abs().max())))
