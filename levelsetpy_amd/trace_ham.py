@@ -12,8 +12,10 @@ that gap without asking the user for anything: the callbacks are called ONCE wit
 and every NumPy ufunc / torch function / operator they apply is recorded instead of computed.  The recorded expression graph is
 written out as the `H = ...; alpha[d] = ...;` block register_native_hamiltonian compiles with hipRTC (Python floats become par[k]
 so that changing a speed does not recompile; values that depend on the in-plane coordinates only are hoisted into col[k]).  What
-cannot be recorded -- data-dependent Python control flow (`if p.max() > 0`), reductions, in-place masks, arrays that are not grid
-coordinates, a Hamiltonian that reads `t` or `data` -- raises TraceError and the schemeData keeps the split path, as before.
+cannot be recorded -- data-dependent Python control flow (`if p.max() > 0`), reductions, in-place masks, a Hamiltonian that reads `t` or
+`data` -- raises TraceError and the schemeData keeps the split path, as before.  Real arrays among the operands are fine if they are a
+grid coordinate, constant, or vary along ONE grid axis (a cos(xs[2]) computed in __init__): those become tables in the source text,
+looked up by the node's coordinate.
 
 The traced kernel is not trusted blindly: the first time a plan built from it meets data (term.native_plan(sd, y)), the term is
 evaluated by BOTH paths on that data and the fused result must agree with the callbacks' to rounding, else the trace is dropped
@@ -406,6 +408,8 @@ def _is_tensor(v):
 class _Tracer(object):
     MAX_PAR = 4          # hj_ham_register2: a Hamiltonian takes 0..4 parameters (HamTables::par)
     MAX_COL = 8
+    MAX_TAB = 8          # per-axis tables written into the source (their values are part of the expression's text)
+    MAX_TAB_LEN = 4096
 
     def __init__(self, grid):
         self.grid = grid
@@ -425,6 +429,8 @@ class _Tracer(object):
         self.data = self._leaf(Sym, "data", 0)
         self.t = self._leaf(Sym, "t", 0)
         self.coord_hits = {}
+        self.tables = []          # (axis, values): real arrays among the operands that vary along one axis
+        self.table_index = {}
 
     def _leaf(self, cls, op, d):
         s = cls(op, (), "num", len(self.order), d)
@@ -497,7 +503,7 @@ class _Tracer(object):
         """A real array among the operands: fine if it IS a grid coordinate (grid.xs[d] read before the trace, a cached device copy)."""
         hit = self.coord_hits.get(id(v))
         if hit is not None and hit[0] is v:
-            return self.x[hit[1]]
+            return hit[1][1] if isinstance(hit[1], tuple) else self.x[hit[1]]
         shape = tuple(int(s) for s in v.shape)
         full = shape == self.shape
         cand = []
@@ -510,11 +516,14 @@ class _Tracer(object):
             bshape = tuple(self.shape[k] if k == d else 1 for k in range(self.dim))
             if host is not None:
                 a = host.reshape(bshape) if host.size == ref.size else host
-                ok = a.shape[d] == ref.size and bool(np.all(a == ref.reshape(bshape).astype(a.dtype, copy=False)))
+                # (compared in the ARRAY's floating type -- fp32 copies of the coordinates match -- but never in an integer or boolean one)
+                ct = a.dtype if a.dtype.kind == "f" else np.float64
+                ok = a.shape[d] == ref.size and bool(np.all(a.astype(ct, copy=False) == ref.reshape(bshape).astype(ct, copy=False)))
             else:
                 import torch
-                r = torch.as_tensor(ref, device=v.device, dtype=v.dtype).reshape(bshape)
-                a = v.reshape(bshape) if v.numel() == ref.size else v
+                ct = v.dtype if v.dtype.is_floating_point else torch.float64
+                r = torch.as_tensor(ref, device=v.device, dtype=ct).reshape(bshape)
+                a = (v.reshape(bshape) if v.numel() == ref.size else v).to(ct)
                 ok = a.shape[d] == ref.size and bool((a == r).all().item())
             if ok:
                 self.coord_hits[id(v)] = (v, d)
@@ -526,8 +535,36 @@ class _Tracer(object):
             lo, hi = v.min().item(), v.max().item()
         if lo == hi:
             return self.param(float(lo)) if float(lo) != int(lo) or abs(lo) > 16 else self.const(int(lo))
-        raise TraceError("an array of shape %s that is not a grid coordinate was combined with the symbolic arguments (values computed from "
-                         "grid.xs BEFORE the call, e.g. a stored cos(xs[2]), cannot be traced: compute them inside the callback)" % (shape,))
+        # an array that varies along ONE grid axis (a cos(xs[2]) stored before the call, a per-heading gain): a table over that axis, looked
+        # up by the node's coordinate
+        for d in cand:
+            bshape = tuple(self.shape[k] if k == d else 1 for k in range(self.dim))
+            first = tuple(slice(None) if k == d else slice(0, 1) for k in range(self.dim))
+            if host is not None:
+                a = host.reshape(bshape) if host.size == self.shape[d] else host
+                line = a[first]
+                ok = bool(np.all((a == line) | ((a != a) & (line != line))))
+                vals = np.asarray(line, dtype=np.float64).ravel()
+            else:
+                a = v.reshape(bshape) if v.numel() == self.shape[d] else v
+                line = a[first]
+                ok = bool(((a == line) | ((a != a) & (line != line))).all().item())
+                vals = line.detach().double().cpu().numpy().ravel()
+            if ok and vals.size == self.shape[d] and vals.size <= self.MAX_TAB_LEN and bool(np.all(np.isfinite(vals))):
+                key = (d, vals.tobytes())
+                k = self.table_index.get(key)
+                if k is None:
+                    if len(self.tables) >= self.MAX_TAB:
+                        break
+                    k = len(self.tables)
+                    self.tables.append((d, vals))
+                    self.table_index[key] = k
+                s = self.node("tab%d" % k, (self.x[d],), "num")
+                self.coord_hits[id(v)] = (v, ("tab", s))
+                return s
+        raise TraceError("an array of shape %s that is neither a grid coordinate, nor constant, nor a function of ONE grid axis was combined with the "
+                         "symbolic arguments (values computed from several coordinates BEFORE the call cannot be traced: compute them inside "
+                         "the callback)" % (shape,))
 
 
 # ---------------------------------------------------------------------------------------------- the result of a trace
@@ -547,6 +584,10 @@ class Traced(object):
     def __init__(self, tr, H, alpha):
         self.dim = tr.dim
         self.params = list(tr.params)
+        self.tables = list(tr.tables)
+        vs = tr.real_vs
+        # index of a node on axis d from its coordinate: the grid is uniform (grids.py), x = x0 + i dx
+        self._tab_geo = [(float(vs[d][0]), (len(vs[d]) - 1) / float(vs[d][-1] - vs[d][0]) if len(vs[d]) > 1 else 0.0, len(vs[d])) for d, _ in tr.tables]
         self._H, self._alpha, self._order = H, alpha, tr.order
         deps = {}
         for s in tr.order:                   # construction order is topological
@@ -582,7 +623,7 @@ class Traced(object):
             if s.uid in seen:
                 return False
             seen.add(s.uid)
-            return s.op in _EXPENSIVE or any(costly(a, seen) for a in s.args)
+            return s.op in _EXPENSIVE or s.op.startswith("tab") or any(costly(a, seen) for a in s.args)
         parents = {}
         for s in tr.order:
             if s.uid in live:
@@ -630,6 +671,11 @@ class Traced(object):
                     e = "(!%s)" % a[0]
                 elif s.op == "where":
                     e = "(%s ? %s : %s)" % (a[0], a[1], a[2])
+                elif s.op.startswith("tab"):
+                    k = int(s.op[3:])
+                    x0, inv, n = self._tab_geo[k]
+                    used_tables.add(k)
+                    e = "hjtab%d[min(max((int)rint((double)(%s - %s) * %r), 0), %d)]" % (k, a[0], _literal(x0), inv, n - 1)
                 else:
                     raise TraceError("no device expression for '%s'" % s.op)
                 nm = "v%d" % s.uid
@@ -638,16 +684,26 @@ class Traced(object):
             for s in targets:
                 visit(s)
 
+        def table_decls(which):
+            out = []
+            for k in sorted(which):
+                d, vals = self.tables[k]
+                out.append("static constexpr T hjtab%d[%d] = {%s};" % (k, len(vals), ", ".join(_literal(float(v)) for v in vals)))
+            return out
         col_lines = []
+        used_tables = set()
         if cols:
             emit(cols, col_lines, False)
             for k, s in enumerate(cols):
                 col_lines.append("col[%d] = %s;" % (k, names[s.uid]))
+            col_lines = table_decls(used_tables) + col_lines
         self.column_source = "\n".join(col_lines) if cols else None
         self.ncol = len(cols)
         names = {}
         lines = []
+        used_tables = set()
         emit([H] + list(alpha), lines, True)
+        lines = table_decls(used_tables) + lines
         lines.append("H = %s;" % names[H.uid])
         for d, a in enumerate(alpha):
             lines.append("alpha[%d] = %s;" % (d, names[a.uid]))
@@ -676,7 +732,12 @@ class Traced(object):
                 r = np.float64(s.value)
             else:
                 a = [ev(q) for q in s.args]
-                if s.op == "cast":
+                if s.op.startswith("tab"):
+                    k = int(s.op[3:])
+                    x0, inv, n = self._tab_geo[k]
+                    idx = np.clip(np.rint((np.asarray(a[0], dtype=np.float64) - x0) * inv).astype(np.int64), 0, n - 1)
+                    r = self.tables[k][1][idx]
+                elif s.op == "cast":
                     r = np.asarray(a[0], dtype=np.float64)
                 elif s.op == "where":
                     r = np.where(a[0], a[1], a[2])
@@ -801,8 +862,10 @@ def _fingerprint_of(obj, depth, seen, out):
             out.append((k, v))
         elif isinstance(v, (list, tuple)) and len(v) <= 16 and all(_scalarish(e) for e in v):
             out.append((k, tuple(v)))
-        elif isinstance(v, np.ndarray) and v.size <= 16:
-            out.append((k, v.tobytes()))
+        elif isinstance(v, np.ndarray) and v.size <= 8192:
+            out.append((k, hash(v.tobytes())))          # (stored per-axis tables: their values are part of the traced expression)
+        elif _is_tensor(v) and v.numel() <= 8192:
+            out.append((k, (v.data_ptr(), getattr(v, "_version", 0))))
         elif depth > 0 and hasattr(v, "__dict__") and not callable(v) and k not in ("grid",):
             _fingerprint_of(v, depth - 1, seen, out)
 
@@ -812,6 +875,12 @@ def fingerprint(sd):
     closure cells and module globals they name.  A cached traced plan is re-traced when this changes (or always: HJ_TRACE_RECHECK=1)."""
     out, seen = [], set()
     for f in (sd.hamFunc, sd.partialFunc):
+        while hasattr(f, "func") and hasattr(f, "args") and hasattr(f, "keywords"):          # functools.partial
+            out.append(("<partial>", tuple(a for a in f.args if _scalarish(a)), tuple(sorted((k, v) for k, v in (f.keywords or {}).items() if _scalarish(v)))))
+            for a in tuple(f.args) + tuple((f.keywords or {}).values()):
+                if not _scalarish(a):
+                    _fingerprint_of(a, 1, seen, out)
+            f = f.func
         owner = getattr(f, "__self__", None)
         if owner is not None:
             _fingerprint_of(owner, 2, seen, out)

@@ -124,26 +124,32 @@ class RandomSystem(object):
     def __init__(self, grid, rng, dim, use_range):
         self.grid, self.dim = grid, dim
         self.scale = float(np.round(rng.uniform(0.5, 1.5), 3))
+        # per-axis arrays computed before the call (as a system's __init__ would): cos of the coordinate
+        self.stored = [np.cos(1.7 * np.asarray(grid.vs[d]).ravel()).reshape([-1 if k == d else 1 for k in range(dim)]) for d in range(dim)]
         pl = ["p%d" % d for d in range(dim)]
-        xl = ["x%d" % d for d in range(dim)]
+        xl = ["x%d" % d for d in range(dim)] + ["c%d" % int(rng.integers(dim))]
         self.H = Expr(rng, int(rng.integers(2, 5)), pl + pl + xl, smooth=True)
         rl = (["lo%d" % d for d in range(dim)] + ["hi%d" % d for d in range(dim)]) if use_range else []
-        self.A = [Expr(rng, int(rng.integers(1, 4)), xl + rl, smooth=False) for _ in range(dim)]
+        # (an alpha that JUMPS as a function of the costate range would move the LF term by O(1) at nodes where the two paths' ranges differ in the last bit)
+        self.A = [Expr(rng, int(rng.integers(1, 4)), xl + rl, smooth=use_range) for _ in range(dim)]
 
     def _coords(self, like):
         out = {}
         for d in range(self.dim):
             x = self.grid.xs[d]
+            c = self.stored[d]
             if torch is not None and _is_t(like):
                 x = torch.as_tensor(np.asarray(x), device=like.device, dtype=like.dtype)
+                c = torch.as_tensor(c, device=like.device, dtype=like.dtype)
             out["x%d" % d] = x
+            out["c%d" % d] = c            # a REAL array in every mode: the tracer writes it into the source as a table over axis d
         return out
 
     def hamiltonian(self, t, data, p, sd=None):
         env = self._coords(p[0])
         for d in range(self.dim):
             env["p%d" % d] = p[d]
-        return self.scale * self.H(env)
+        return self.scale * self.H(env) + 0 * p[0]          # (the grid's shape even where the random tree happens to ignore the costates)
 
     def dissipation(self, t, data, dmin, dmax, sd, dim):
         env = self._coords(data)

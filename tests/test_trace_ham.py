@@ -115,7 +115,7 @@ def test_fingerprint_sees_in_place_changes():
 class _Bad(object):
     def __init__(self, grid, kind):
         self.grid, self.kind = grid, kind
-        self.c3 = np.cos(np.asarray(grid.xs[2]))          # computed BEFORE the call
+        self.c3 = np.cos(np.asarray(grid.xs[2])) * np.asarray(grid.xs[1])          # computed BEFORE the call, from TWO coordinates
 
     def hamiltonian(self, t, data, p, sd=None):
         k = self.kind
@@ -185,6 +185,41 @@ def test_torch_callbacks_and_stored_coordinate_tensors():
     Hr = obj.hamiltonian(0., None, [torch.as_tensor(q) for q in p]).numpy()
     assert np.allclose(H, Hr, rtol=1e-14, atol=1e-14)
     assert np.allclose(np.broadcast_to(al[0], g.shape), np.broadcast_to(obj.dissipation(0., None, None, None, None, 0).numpy(), g.shape))
+
+
+def test_stored_per_axis_arrays_become_tables():
+    """Arrays computed from ONE coordinate before the call (cos of the heading kept in __init__, a per-plane gain) are written into the source as
+    tables and looked up by the node's coordinate; in-plane ones are hoisted into the column expression."""
+    g = grid3()
+
+    class Stored(object):
+        def __init__(self, grid):
+            self.grid = grid
+            self.c3 = np.cos(np.asarray(grid.xs[2]))                                         # broadcastable (1, 1, n2)
+            self.s3 = np.broadcast_to(np.sin(np.asarray(grid.xs[2])), grid.shape).copy()     # the grid's full shape
+            self.gain = np.linspace(1., 2., int(grid.shape[0])).reshape(-1, 1, 1)            # along the marching axis
+
+        def hamiltonian(self, t, data, p, sd=None):
+            return p[0] * self.c3 + (p[1] * self.s3) * self.gain + 0.5 * abs(p[2])
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            return [abs(self.c3) + 0 * data, (abs(self.s3) + 0 * data) * self.gain, 0.5][dim]
+    obj = Stored(g)
+    tr = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert len(tr.tables) >= 3 and "hjtab" in tr.source and tr.column_source and "hjtab" in tr.column_source
+    rng = np.random.default_rng(8)
+    p = [rng.standard_normal(g.shape) for _ in range(3)]
+    H, al = tr.evaluate(g.xs, p)
+    assert np.array_equal(H, obj.hamiltonian(0., np.zeros(g.shape), p))
+    for d in range(3):
+        assert np.array_equal(np.broadcast_to(al[d], g.shape), np.broadcast_to(obj.dissipation(0., np.zeros(g.shape), None, None, None, d), g.shape))
+    L.register_native_hamiltonian("traced_table_check", 3, tr.source, nparams=len(tr.params), column_src=tr.column_source, ncol=tr.ncol).check("ENO3")
+    # a changed table is a changed expression (its values are part of the text), and the fingerprint of the schemeData sees it
+    sd = L.Bundle(dict(grid=g, hamFunc=obj.hamiltonian, partialFunc=obj.dissipation))
+    f0 = TH.fingerprint(sd)
+    obj.gain[3] = 7.0
+    assert TH.fingerprint(sd) != f0
+    assert TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None).source != tr.source
 
 
 def test_generated_source_compiles():
