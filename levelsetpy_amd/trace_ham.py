@@ -931,7 +931,7 @@ class _TracedSystem(object):
             self.reg = _NoReg
             return []
         if _key_of(tr) != self._key:
-            reg = _registration(tr)
+            reg = _registration(tr, getattr(self._sd.hamFunc, "__func__", self._sd.hamFunc))
             self.reg = reg if reg is not None else _NoReg
             self._key = _key_of(tr)
         self._params = list(tr.params)
@@ -952,11 +952,26 @@ def _key_of(tr):
     return (tr.dim, tr.source, tr.column_source, tr.uses_range, len(tr.params))
 
 
-def _registration(tr):
+# A callback pair whose EXPRESSION keeps changing (a fifth float that varies per step, a table rebuilt every call) would compile a kernel per
+# call -- a second or two each, where the split path takes milliseconds.  Distinct expressions per callback are counted; beyond the limit the
+# pair is left on the split path for the rest of the process.
+MAX_EXPRESSIONS_PER_CALLBACK = 8
+_CHURN = {}                  # id(function) -> set of expression keys seen
+
+
+def _registration(tr, ident=None):
     key = _key_of(tr)
     if key in _BAD_SOURCES:
         return None
     reg = _REG_BY_SOURCE.get(key)
+    if ident is not None:
+        seen = _CHURN.setdefault(id(ident), set())
+        if hash(key) not in seen:
+            if len(seen) >= MAX_EXPRESSIONS_PER_CALLBACK:
+                if os.environ.get("HJ_TRACE_VERBOSE"):
+                    warnings.warn("levelsetpy_amd: %r has produced more than %d different expressions: left on the split path" % (ident, MAX_EXPRESSIONS_PER_CALLBACK))
+                return None
+            seen.add(hash(key))
     if reg is None:
         from .user_ham import NativeRegistration
         import hashlib
@@ -983,7 +998,7 @@ def traced_native(sd):
     ident = getattr(sd.hamFunc, "__func__", sd.hamFunc)
     try:
         tr = trace_callbacks(sd.grid, sd.hamFunc, sd.partialFunc, sd)
-        reg = _registration(tr)
+        reg = _registration(tr, ident)
         if reg is None:
             return None
     except TraceError as e:

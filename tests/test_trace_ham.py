@@ -230,3 +230,25 @@ def test_generated_source_compiles():
     reg = L.register_native_hamiltonian("traced_compile_check", 3, tr.source, nparams=len(tr.params), column_src=tr.column_source, ncol=tr.ncol,
                                         uses_range=tr.uses_range)
     reg.check("ENO2")
+
+
+def test_a_callback_whose_expression_keeps_changing_is_left_alone(monkeypatch):
+    """A float beyond the four parameter slots is a literal: a callback that changes it per call would compile a kernel per call.  After
+    MAX_EXPRESSIONS_PER_CALLBACK different texts the pair stays on the split path."""
+    g = grid3()
+
+    class Drifting(DubinsAbs):
+        gain = 0.0
+
+        def hamiltonian(self, t, data, p, sd=None):
+            return 0.1 * p[0] + 0.2 * p[1] + 0.3 * p[2] + 0.4 * self.grid.xs[0] + self.gain * p[0] * p[1]      # the fifth float
+    obj = Drifting(g, 1., 1.)
+    sd = L.Bundle(dict(grid=g, hamFunc=obj.hamiltonian, partialFunc=obj.dissipation))
+    monkeypatch.setattr(TH, "MAX_EXPRESSIONS_PER_CALLBACK", 3)
+    got = []
+    for k in range(5):
+        obj.gain = 0.5 + k
+        got.append(TH.traced_native(sd) is not None)
+    assert got == [True, True, True, False, False]
+    obj.gain = 0.5                       # an expression seen before is still served
+    assert TH.traced_native(sd) is not None
