@@ -317,7 +317,7 @@ int hj_term_convection(hj_ctx* ctx, int scheme, const void* y, const void* const
  * (ExplicitIntegration/Term/term_lax_friedrich.py:111 hamFunc(t, data, derivC, schemeData);
  * Dissipation/artificial_diss_glf.py:98 partialFunc(t, data, derivMin, derivMax, schemeData, dim)).  `body` is the same
  * pair written once as a device expression: C++ statements that read x[d] (node coordinates), p[d] (costates,
- * = derivC), par[k] (the ham_params of a call, k < nparams <= 4) and assign  H  and  alpha[d]  for d = 0..ndim-1
+ * = derivC), par[k] (the ham_params of a call, k < nparams <= 8) and assign  H  and  alpha[d]  for d = 0..ndim-1
  * (alpha must not depend on p -- true of every system the reference ships).  Optional `column_body` (ncol <= 8 values):
  * statements assigning col[k] from x[1..] and par, evaluated ONCE per grid column outside the march along axis 0 and
  * readable in `body` as col[k] -- where trigonometric functions of the in-plane coordinates belong (the built-in Dubins

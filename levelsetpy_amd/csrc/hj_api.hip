@@ -289,6 +289,10 @@ int ham_ndim(int ham) {
     }
     return user_ham_ndim(ham);       // -1 unless registered at run time (hj_rtc.hip)
 }
+}  // namespace
+
+namespace hjh {
+// how many entries of the caller's `par` array a Hamiltonian reads (fill_ham copies exactly these)
 int ham_npar(int ham) {
     switch (ham) {
         case HJ_HAM_DUBINS_REL: return 4;
@@ -297,6 +301,9 @@ int ham_npar(int ham) {
     }
     return user_ham_npar(ham);
 }
+}  // namespace hjh
+
+namespace {
 
 template <typename T>
 int launch_ham(hj_ctx* c, const SubstepCall& s) {
@@ -1678,7 +1685,7 @@ int hj_static_step_bound(hj_ctx* c, int ham, const double* par, double* sb, doub
         GridArgs<T, HAM<T>::ND> G;                                                               \
         fill_grid<T, HAM<T>::ND>(c, G);                                                          \
         HamTables<T> P;                                                                          \
-        fill_ham<T>(c, par, P);                                                                  \
+        fill_ham<T>(c, par, P, ham);                                                             \
         DxArgs DX;                                                                               \
         for (int d = 0; d < HJ_MAX_DIM; ++d) DX.dx[d] = c->dx[d];                                \
         hipLaunchKernelGGL((alpha_bound_kernel<T, HAM<T>>), dim3(blocks), dim3(256), 0,          \

@@ -91,7 +91,7 @@ struct hj_ctx {
     int partials_cap;
     // static step bound cache
     int sb_ham;
-    double sb_par[4], sb_val, sb_local, sb_alpha[HJ_MAX_DIM];
+    double sb_par[8], sb_val, sb_local, sb_alpha[HJ_MAX_DIM];
     int diss_local;                    // hj_ctx_set_dissipation: step bound of the local LF variants
     int post_step_op;                  // hj_ctx_set_post_step: fused into the last stage of hj_rk_step
     const void* post_arr[2];           // hj_ctx_set_post_arrays
@@ -234,13 +234,16 @@ Tiling make_tiling_dims(const hj_ctx* c, const KernelCfg& k, int vec, int nbuf, 
 int cfg_kh(int nd, int nt, int r);
 int eps_rows_to_vals(hj_ctx* c, const double* rows, int nrows, hipStream_t stream);   // rows -> ctx->weno_vals (kernels that do not fold)
 
-template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H) {
+int ham_npar(int ham);
+template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTables<T>& H, int ham) {
     for (int d = 0; d < HJ_MAX_DIM; ++d) H.coord[d] = (const T*)c->coord[d];
     for (int s = 0; s < 4; ++s) H.aux[s] = (const T*)c->aux[s];
     if (c->coord0_ext) H.coord[0] = (const T*)c->coord0_ext + c->pad0;
     for (int s = 0; s < 2; ++s)
         if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
-    for (int s = 0; s < 4; ++s) H.par[s] = par ? (T)par[s] : T(0);
+    // (exactly the entries the caller's array has: hj_mi355x.h, "par: ham_npar values")
+    const int np = par ? std::max(0, std::min(8, ham_npar(ham))) : 0;
+    for (int s = 0; s < 8; ++s) H.par[s] = s < np ? (T)par[s] : T(0);
     H.range = c->range_src ? c->range_src : c->range_keys;
     H.local_mode = c->diss_kind;
 }

@@ -508,7 +508,7 @@ int launch_direct(hj_ctx* c, const SubstepCall& s) {
     A.post_op = s.post_op;
     A.restrict_sign = s.restrict_sign;
     A.dt = (T)s.dt;
-    fill_ham<T>(c, s.par, A.ham);
+    fill_ham<T>(c, s.par, A.ham, s.ham);
     c->gate_posted = 0;            // the direct kernel never publishes: the caller orders the exchange with an event
     for (int pass = 0; pass < 4; ++pass) {
         if (pass == 1) {
@@ -544,7 +544,7 @@ int launch_coop_cpt(hj_ctx* c, const CoopCall& s, int nblocks) {
     for (int d = 0; d < ND; ++d) A.sc[d] = scheme_scale<T>(SCHEME, c->dx[d]);
     A.order = s.order; A.restrict_sign = s.restrict_sign; A.post_op = s.post_op;
     A.dt = (T)s.dt;
-    fill_ham<T>(c, s.par, A.ham);
+    fill_ham<T>(c, s.par, A.ham, s.ham);
     A.sync = (CoopSync*)c->coop_sync;
     unsigned nper[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nx = 0;
     for (int b = 0; b < nblocks; ++b) nper[b & 7]++;
@@ -1024,7 +1024,7 @@ int launch_fused12(hj_ctx* c, const Stage12Call& s, Tiling12 t) {
     A.ca = (T)s.ca;
     A.cb = (T)s.cb;
     A.dt = (T)s.dt;
-    fill_ham<T>(c, s.par, A.ham);
+    fill_ham<T>(c, s.par, A.ham, s.ham);
 #ifdef HJ_F12_STAMP
     const char* dump = c->timing_dump;              // diagnostic build: per-wave phase clocks of the pair kernel (tools/f12_stamps.py)
     unsigned long long* tbuf = nullptr;

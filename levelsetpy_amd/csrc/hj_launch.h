@@ -95,7 +95,7 @@ int fill_fused_args(hj_ctx* c, const SubstepCall& s, const Tiling& t, const Edge
     A.do_clamp = s.restrict_sign != 0;
     A.clamp_lo = s.restrict_sign > 0 ? T(0) : -std::numeric_limits<T>::infinity();
     A.clamp_hi = s.restrict_sign < 0 ? T(0) : std::numeric_limits<T>::infinity();
-    fill_ham<T>(c, s.par, A.ham);
+    fill_ham<T>(c, s.par, A.ham, s.ham);
     if (s.term) {            // a TermOp launch: coefficient array 0 rides in the y0 stream whatever the stage says
         A.term = *static_cast<const hj::TermPar<T>*>(s.term);
         A.use_y0 = A.term.arr[0] != nullptr;

@@ -563,7 +563,7 @@ static int alpha_user_nd(hj_ctx* c, int ham, const double* par, unsigned long lo
     AlphaKernArgs<T, ND> K;
     memset(&K, 0, sizeof(K));
     fill_grid<T, ND>(c, K.G);
-    fill_ham<T>(c, par, K.P);
+    fill_ham<T>(c, par, K.P, ham);
     K.keys = keys;
     {
         int rc = alpha_partials(c);
@@ -623,7 +623,7 @@ int hj_ham_register2(const char* name, int ndim, int nparams, const char* body, 
     if (flags & ~HJ_HAM_RANGE) return fail(HJ_EINVAL, "unknown flags 0x%x", flags);
     const std::string cb = (column_body && ncol > 0) ? column_body : "";
     if (ndim < 2 || ndim > 4) return fail(HJ_EUNSUPPORTED, "run-time Hamiltonians: grid.dim must be 2, 3 or 4, got %d", ndim);
-    if (nparams < 0 || nparams > 4) return fail(HJ_EINVAL, "a Hamiltonian takes 0..4 parameters, got %d", nparams);
+    if (nparams < 0 || nparams > 8) return fail(HJ_EINVAL, "a Hamiltonian takes 0..8 parameters, got %d", nparams);
     for (size_t i = 0; i < g_user.size(); ++i)
         if (g_user[i].name == name && g_user[i].ndim == ndim && g_user[i].nparams == nparams && g_user[i].body == body &&
             g_user[i].column_body == cb && g_user[i].ncol == ncol && g_user[i].flags == flags) {

@@ -406,7 +406,7 @@ def _is_tensor(v):
 
 
 class _Tracer(object):
-    MAX_PAR = 4          # hj_ham_register2: a Hamiltonian takes 0..4 parameters (HamTables::par)
+    MAX_PAR = 8          # hj_ham_register2: a run-time Hamiltonian takes 0..8 parameters (HamTables::par)
     MAX_COL = 8
     MAX_TAB = 8          # per-axis tables written into the source (their values are part of the expression's text)
     MAX_TAB_LEN = 4096

@@ -329,3 +329,43 @@ def test_traced_stored_per_axis_tables(where, monkeypatch):
     yo, sbo = O.term_lax_friedrichs(og, Stored(og, False), "WENO5_ASSHIPPED", 0., d0.reshape(-1, 1))
     close(fused.cpu().numpy(), yo, 1e-11, what="tables: traced vs oracle")
     assert abs(sb_f - sbo) <= 1e-13 * sbo
+
+
+def test_traced_more_than_four_parameters_in_place(monkeypatch):
+    """Eight parameter slots (HamTables::par): seven floats of a system, one of them changed in place -- same kernel, new value."""
+    n = (21, 20, 22)
+    g, og = mk([-1., -1., -1.], [1., 1., 1.], n, None)
+
+    class Seven(object):
+        def __init__(self, grid):
+            self.grid = grid
+            self.a, self.b, self.c, self.d, self.e, self.f, self.g = 0.31, 0.47, 0.59, 0.73, 0.83, 0.97, 1.13
+
+        def hamiltonian(self, t, data, p, sd=None):
+            x = [_x(self.grid, k, p[0]) for k in range(3)]
+            return self.a * p[0] * x[1] + self.b * p[1] * x[2] + self.c * p[2] * x[0] + self.d * abs(p[0]) + self.e * abs(p[1]) + self.f * p[0] * p[1] \
+                + self.g * p[2] ** 2
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            x = [_x(self.grid, k, data) for k in range(3)]
+            lo, hi = abs(dmin[dim]), abs(dmax[dim])
+            m = torch.maximum(lo, hi) if _is_t(lo) else np.maximum(lo, hi)
+            return [abs(self.a * x[1]) + self.d + self.f * m, abs(self.b * x[2]) + self.e + self.f * m, abs(self.c * x[0]) + 2 * self.g * m][dim] + 0 * data
+    d0 = O.shape_sphere(og, None, 0.5) + 0.02 * np.random.default_rng(12).standard_normal(og.shape)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+    obj = Seven(g)
+    assert len(TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None).params) == 8          # a .. g and the product 2 g: all eight slots
+    sd = sdata(g, obj, L.upwindFirstENO3)
+    fused, sb_f, _ = L.termLaxFriedrichs(0., y, sd)
+    assert "hipRTC" in _kernel(g), _kernel(g)
+    ov = Seven(og)
+    yo, sbo = O.term_lax_friedrichs(og, ov, "ENO3", 0., d0.reshape(-1, 1))
+    close(fused.cpu().numpy(), yo, 1e-11, what="seven parameters")
+    assert abs(sb_f - sbo) <= 1e-12 * sbo
+    before = L.kernel_cache_stats()
+    obj.g = ov.g = 0.4                   # the LAST one: slot 6
+    f2, sb2, _ = L.termLaxFriedrichs(0., y, sd)
+    assert L.kernel_cache_stats() == before
+    yo2, sbo2 = O.term_lax_friedrichs(og, ov, "ENO3", 0., d0.reshape(-1, 1))
+    close(f2.cpu().numpy(), yo2, 1e-11, what="seven parameters, one changed")
+    assert abs(sb2 - sbo2) <= 1e-12 * sbo2 and abs(sb2 - sb_f) > 1e-6

@@ -93,13 +93,14 @@ def test_parameters_become_par_and_a_changed_speed_keeps_the_source():
     assert a.params == [1.3, 0.7] and b.params == [2.5, 0.7]
     assert a.source == b.source and a.column_source == b.column_source
     assert "1.3" not in a.source and "par[0]" in (a.source + (a.column_source or ""))
-    # a fifth distinct float is a literal (HamTables::par has four slots): exact, as a hexadecimal floating literal
+    # a ninth distinct float is a literal (HamTables::par has eight slots): exact, as a hexadecimal floating literal
     class Many(DubinsAbs):
         def hamiltonian(self, t, data, p, sd=None):
-            return 0.1 * p[0] + 0.2 * p[1] + 0.3 * p[2] + 0.4 * self.grid.xs[0] + 0.7 * p[0] * p[1]
+            x = self.grid.xs
+            return 0.1 * p[0] + 0.2 * p[1] + 0.3 * p[2] + 0.4 * x[0] + 0.6 * x[1] + 0.9 * x[2] + 1.1 * p[0] * p[1] + 1.3 * p[1] * p[2] + 0.7 * p[0] * p[2]
     m = Many(g, 1., 1.)
     c = TH.trace_callbacks(g, m.hamiltonian, m.dissipation, None)
-    assert len(c.params) == 4 and float(0.7).hex() in c.source
+    assert len(c.params) == 8 and float(0.7).hex() in c.source
 
 
 def test_fingerprint_sees_in_place_changes():
@@ -233,7 +234,7 @@ def test_generated_source_compiles():
 
 
 def test_a_callback_whose_expression_keeps_changing_is_left_alone(monkeypatch):
-    """A float beyond the four parameter slots is a literal: a callback that changes it per call would compile a kernel per call.  After
+    """A float beyond the eight parameter slots is a literal: a callback that changes it per call would compile a kernel per call.  After
     MAX_EXPRESSIONS_PER_CALLBACK different texts the pair stays on the split path."""
     g = grid3()
 
@@ -241,7 +242,9 @@ def test_a_callback_whose_expression_keeps_changing_is_left_alone(monkeypatch):
         gain = 0.0
 
         def hamiltonian(self, t, data, p, sd=None):
-            return 0.1 * p[0] + 0.2 * p[1] + 0.3 * p[2] + 0.4 * self.grid.xs[0] + self.gain * p[0] * p[1]      # the fifth float
+            x = self.grid.xs
+            return 0.1 * p[0] + 0.2 * p[1] + 0.3 * p[2] + 0.4 * x[0] + 0.6 * x[1] + 0.9 * x[2] + 1.1 * p[0] * p[1] + 1.3 * p[1] * p[2] \
+                + self.gain * p[0] * p[2]      # the ninth float
     obj = Drifting(g, 1., 1.)
     sd = L.Bundle(dict(grid=g, hamFunc=obj.hamiltonian, partialFunc=obj.dissipation))
     monkeypatch.setattr(TH, "MAX_EXPRESSIONS_PER_CALLBACK", 3)
