@@ -793,11 +793,62 @@ def _unpatch_constructors():
                 setattr(mod, n, orig)
 
 
+class _StateGuard(object):
+    """Callbacks may keep things for later (`self._x0 = as_tensor(grid.vs[0])` on first use, a dict of per-device copies): whatever they
+    store during the trace is symbolic and must not survive it.  The attributes of the objects the callbacks are bound to (and of the
+    schemeData) are put back as they were, dict / list attributes with their contents."""
+
+    def __init__(self, objs):
+        self.saved = []
+        seen = set()
+        for o in objs:
+            d = getattr(o, "__dict__", None)
+            if d is None or id(o) in seen or not isinstance(d, dict):
+                continue
+            seen.add(id(o))
+            inner = []
+            for v in d.values():
+                if isinstance(v, dict):
+                    inner.append((v, dict(v)))
+                elif isinstance(v, list):
+                    inner.append((v, list(v)))
+            self.saved.append((o, dict(d), inner))
+
+    def restore(self):
+        for o, d, inner in self.saved:
+            try:
+                o.__dict__.clear()
+                o.__dict__.update(d)
+            except Exception:           # (an object that guards its attributes: leave it)
+                pass
+            for v, copy_ in inner:
+                if isinstance(v, dict):
+                    v.clear()
+                    v.update(copy_)
+                else:
+                    v[:] = copy_
+
+
+def _owners(hamFunc, partialFunc, schemeData):
+    out = []
+    for f in (hamFunc, partialFunc):
+        while hasattr(f, "func") and hasattr(f, "args"):             # functools.partial
+            out.extend(a for a in f.args if hasattr(a, "__dict__") and not callable(a))
+            f = f.func
+        o = getattr(f, "__self__", None)
+        if o is not None:
+            out.append(o)
+    if schemeData is not None:
+        out.append(schemeData)
+    return out
+
+
 def trace_callbacks(grid, hamFunc, partialFunc, schemeData=None):
     """Call hamFunc / partialFunc once with symbolic arrays; Traced, or TraceError with the reason."""
     tr = _Tracer(grid)
     saved = {}
     prev = getattr(_TLS, "tracer", None)
+    guard = _StateGuard(_owners(hamFunc, partialFunc, schemeData))
     _TLS.tracer = tr
     _patch_constructors()
     try:
@@ -821,8 +872,11 @@ def trace_callbacks(grid, hamFunc, partialFunc, schemeData=None):
                 a = tr.lift(partialFunc(tr.t, tr.data, list(tr.dmin), list(tr.dmax), schemeData, d))
                 alpha.append(tr.node("cast", (a,), "num") if a.kind == "bool" else a)
         finally:
+            guard.restore()
             for name, v in saved.items():
                 setattr(grid, name, v)
+            for k in [k for k, v in grid.__dict__.items() if isinstance(v, Sym) or (isinstance(v, (list, tuple)) and any(isinstance(e, Sym) for e in v))]:
+                del grid.__dict__[k]          # (anything symbolic a callback parked on the grid)
             grid.__dict__.update(hidden)
         return Traced(tr, H, alpha)
     except TraceError:

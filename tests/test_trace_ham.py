@@ -255,3 +255,42 @@ def test_a_callback_whose_expression_keeps_changing_is_left_alone(monkeypatch):
     assert got == [True, True, True, False, False]
     obj.gain = 0.5                       # an expression seen before is still served
     assert TH.traced_native(sd) is not None
+
+
+def test_what_a_callback_caches_during_the_trace_does_not_survive_it():
+    """Lazily cached arrays (`self._x0 = ...` on first use, a dict of per-device copies) are symbolic while tracing: the objects' attributes are put
+    back afterwards, so the real calls that follow compute their caches from real data."""
+    g = grid3()
+
+    class Lazy(object):
+        def __init__(self, grid):
+            self.grid, self._x0, self.per_device = grid, None, {}
+
+        def x0(self, like):
+            if self._x0 is None:
+                self._x0 = np.asarray(self.grid.vs[0]).ravel().reshape(-1, 1, 1)
+            self.per_device.setdefault("cpu", self._x0)
+            self.touched = True
+            return self._x0
+
+        def hamiltonian(self, t, data, p, sd=None):
+            return 0.7 * self.x0(p[0]) * p[1] + 0.5 * (p[0] ** 2 + p[1] ** 2 + p[2] ** 2)
+
+        def dissipation(self, t, data, dmin, dmax, sd, dim):
+            return np.maximum(abs(dmin[dim]), abs(dmax[dim])) + (abs(0.7 * self.x0(data)) if dim == 1 else 0.0)
+    obj = Lazy(g)
+    tr = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert obj._x0 is None and obj.per_device == {} and not hasattr(obj, "touched")
+    rng = np.random.default_rng(2)
+    p = [rng.standard_normal(g.shape) for _ in range(3)]
+    H = obj.hamiltonian(0., None, p)                      # a real call afterwards works on real arrays
+    assert isinstance(obj._x0, np.ndarray) and np.allclose(tr.evaluate(g.xs, p, [-1.] * 3, [1.] * 3)[0], H, rtol=1e-14, atol=1e-14)
+    # and a failed trace restores as well
+    class LazyBad(Lazy):
+        def hamiltonian(self, t, data, p, sd=None):
+            self.x0(p[0])
+            return p[0] if float(p[0].max()) > 0 else p[1]
+    bad = LazyBad(g)
+    with pytest.raises(TH.TraceError):
+        TH.trace_callbacks(g, bad.hamiltonian, bad.dissipation, None)
+    assert bad._x0 is None and bad.per_device == {}
