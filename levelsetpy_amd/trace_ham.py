@@ -629,12 +629,26 @@ class Traced(object):
             if s.uid in live:
                 for a in s.args:
                     parents.setdefault(a.uid, []).append(s)
-        cols = []
+        # candidates: the MAXIMAL column-only values (a parent that is not column-only reads them) that contain a transcendental, a division or
+        # a table.  HJ_TRACE_HOIST=all adds plain arithmetic of two operations or more (alpha_0 = |a - b cos x2| + |w x1| of a Dubins car, five
+        # flops per node and plane, as the built-in kernel's Cell keeps it): measured at 201^3, no difference (0.1168-0.1189 ms either way) --
+        # the substep is not bound by those flops; off by default, a column value costs registers for the length of the march
+        def weight(s, seen):
+            if s.uid in seen or not s.args:
+                return 0
+            seen.add(s.uid)
+            return 1 + sum(weight(a, seen) for a in s.args)
+        hoist_all = os.environ.get("HJ_TRACE_HOIST", "costly") == "all"
+        cand = []
         for s in tr.order:
-            if s.uid in live and s.kind == "num" and column_only(s) and costly(s, set()):
+            if s.uid in live and s.kind == "num" and s.args and column_only(s):
                 ps = parents.get(s.uid, [])
-                if (not ps or any(not column_only(q) for q in ps)) and len(cols) < _Tracer.MAX_COL:
-                    cols.append(s)
+                if not ps or any(not column_only(q) for q in ps):
+                    c_, w_ = costly(s, set()), weight(s, set())
+                    if c_ or (hoist_all and w_ >= 2):
+                        cand.append((0 if c_ else 1, -w_, s.uid, s))
+        cols = [c[3] for c in sorted(cand)[:_Tracer.MAX_COL]]
+        cols.sort(key=lambda s: s.uid)
         self._cols = cols
         col_of = {s.uid: k for k, s in enumerate(cols)}
         # ---- source text
