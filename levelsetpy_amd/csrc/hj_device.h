@@ -477,10 +477,13 @@ __device__ __forceinline__ void upwind_cd(const T* v, const T* K, T eps, const W
 // ------------------------------------------------------------------------------------------
 // Native Hamiltonians.  eval(): idx[d] = node index per dim, p[d] = centred costate
 // 0.5*(derivL+derivR) (term_lax_friedrich.py:108); returns H and alpha[d] = partialFunc(.., d).
+#ifndef HJ_PAR_SLOTS
+#define HJ_PAR_SLOTS 8
+#endif
 template <typename T> struct HamTables {
     const T* coord[HJ_MAX_DIM];  // grid.vs[d]
     const T* aux[4];             // Hamiltonian-specific 1-D tables
-    T par[8];                    // the Hamiltonian's parameters (built-in systems: up to 4; run-time expressions: up to 8)
+    T par[HJ_PAR_SLOTS];         // the Hamiltonian's parameters (built-in systems: up to 4; run-time expressions: up to 8)
     // Hamiltonians whose alpha depends on the costate RANGE (round 5; artificial_diss_glf.py:80-99 hands partialFunc derivMin / derivMax):
     // 2*ND order-preserving keys written by the range pass of the substep (MODE 3 of the tiled kernels): [d] = key(max(derivL_d, derivR_d)
     // over the grid), [ND + d] = key(-min(...)); null for everybody else

@@ -242,8 +242,8 @@ template <typename T> void fill_ham(const hj_ctx* c, const double* par, HamTable
     for (int s = 0; s < 2; ++s)
         if (c->aux_ext[s]) H.aux[s] = (const T*)c->aux_ext[s] + c->pad0;
     // (exactly the entries the caller's array has: hj_mi355x.h, "par: ham_npar values")
-    const int np = par ? std::max(0, std::min(8, ham_npar(ham))) : 0;
-    for (int s = 0; s < 8; ++s) H.par[s] = s < np ? (T)par[s] : T(0);
+    const int np = par ? std::max(0, std::min((int)HJ_PAR_SLOTS, ham_npar(ham))) : 0;
+    for (int s = 0; s < (int)HJ_PAR_SLOTS; ++s) H.par[s] = s < np ? (T)par[s] : T(0);
     H.range = c->range_src ? c->range_src : c->range_keys;
     H.local_mode = c->diss_kind;
 }
