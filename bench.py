@@ -596,13 +596,24 @@ def time_range_ham(L, torch, a):
     op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
     res = {}
     ys = {}
-    for kind in ("split", "fused"):
+    # split: HJ_TRACE=0, the callbacks as they are; traced (round 6): the same callbacks, traced by the library (their float() / max() of the
+    # range are rewritten for the trace: trace_ham._rewritten); fused: the hand-written expression RANGE_SRC attached to the object
+    for kind in ("split", "traced", "fused"):
         if kind == "fused":
             L.register_native_hamiltonian("bench_range", 3, RANGE_SRC, nparams=1).attach(sysd, params=lambda o: [o.c])
+        prev_trace = os.environ.get("HJ_TRACE")
+        if kind == "split":
+            os.environ["HJ_TRACE"] = "0"
         sd = L.Bundle(dict(grid=g, hamFunc=sysd.hamiltonian, partialFunc=sysd.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=calc))
         y, t = device_sdf(torch, g, 0.5, ignore=(2,)).reshape(-1, 1), 0.0
-        for _ in range(3):
-            t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+        try:
+            for _ in range(3):
+                t, y, _sd = L.odeCFL3(L.termLaxFriedrichs, [t, 1e9], y, op, sd)
+        finally:
+            if prev_trace is None:
+                os.environ.pop("HJ_TRACE", None)
+            else:
+                os.environ["HJ_TRACE"] = prev_trace
         ys[kind] = (t, y.clone())
         k = max(3, min(10, a.steps)) if kind == "split" else a.steps
         walls = []
@@ -615,7 +626,9 @@ def time_range_ham(L, torch, a):
             walls.append(time.perf_counter() - t1)
         assert bool(torch.isfinite(y).all())
         med = statistics.median(walls)
-        res[kind] = {"value": y.numel() * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k}
+        from levelsetpy_amd.context import device_grid as _dgrid
+        dgk = _dgrid(g)
+        res[kind] = {"value": y.numel() * 3 * k / med, "ms_per_step": 1e3 * med / k, "steps": k, "kernel": dgk.lib.hj_last_kernel(dgk.ctx).decode()}
     local = {}
     for name, fn in (("LLF", L.artificialDissipationLLF), ("LLLF", L.artificialDissipationLLLF)):
         try:
@@ -645,6 +658,9 @@ def time_range_ham(L, torch, a):
         "roofline_frac": res["fused"]["value"] * bps / 1e9 / HBM_PEAK_GBS,
         "split_path_ms_per_step": res["split"]["ms_per_step"], "vs_split_path": res["fused"]["value"] / res["split"]["value"],
         "fused_vs_split_max_abs_diff_after_3_steps": dmax,
+        # the SAME Python callbacks traced by the library instead of the hand-written expression (round 6)
+        "traced_callbacks": dict(res["traced"], vs_split_path=res["traced"]["value"] / res["split"]["value"],
+                                 max_abs_diff_vs_split_after_3_steps=float((ys["traced"][1] - ys["split"][1]).abs().max())),
         # the same system under the LOCAL Lax-Friedrichs variants (per-node costate ranges inside the fused kernel, round 5): fused only
         "local_variants_fused_ms_per_step": local}}
 
@@ -1370,6 +1386,8 @@ def run(a, rank, world, local, slab_leg, cpu):
                 del r2, wl2
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001 -- an extra workload must not take the headline down
+                import traceback
+                traceback.print_exc(file=sys.stderr)
                 also[name] = {"error": repr(e)}
     if also:
         out["also"] = also

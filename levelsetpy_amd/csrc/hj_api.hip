@@ -372,11 +372,25 @@ unsigned long long* next_ring(hj_ctx* c, int user_slot, int* rc) {
         // stream can launch into it again
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess && c->edge_stream) e = hipStreamSynchronize(c->edge_stream);
+        // What the user slots hold SURVIVES the reset (round 6): a sequence of launches whose bounds are read together -- the stages of
+        // one hj_rk_step, a caller's substeps before its hj_read_step_bound -- may straddle the wrap; zeroing the entry of stage 2 while
+        // stage 3 was being enqueued lost its bound ("bound slot holds no reduction", once per 2048 launches at the unlucky alignment).
+        // The live entries (final: the streams are drained) are parked, the ring zeroed, and they move to its first entries.
+        int live[HJ_BOUND_SLOTS], nlive = 0;
+        const size_t eb = sizeof(unsigned long long) * HJ_MAX_DIM;
+        if (e == hipSuccess && !c->ring_keep) e = hipMalloc((void**)&c->ring_keep, eb * HJ_BOUND_SLOTS);
+        for (int i = 0; i < HJ_BOUND_SLOTS && e == hipSuccess; ++i)
+            if (c->slot_ring[i] >= 0) {
+                e = hipMemcpyAsync(c->ring_keep + (size_t)nlive * HJ_MAX_DIM, c->ring + (size_t)c->slot_ring[i] * HJ_MAX_DIM, eb, hipMemcpyDeviceToDevice, c->stream);
+                live[nlive++] = i;
+            }
         if (e == hipSuccess) e = hipMemsetAsync(c->ring, 0, sizeof(unsigned long long) * RING_SLOTS * HJ_MAX_DIM, c->stream);
+        if (e == hipSuccess && nlive) e = hipMemcpyAsync(c->ring, c->ring_keep, eb * nlive, hipMemcpyDeviceToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { *rc = fail(HJ_EHIP, "bound ring reset: %s", hipGetErrorString(e)); return nullptr; }
-        c->ring_pos = 0;
         for (int i = 0; i < HJ_BOUND_SLOTS; ++i) c->slot_ring[i] = -1;
+        for (int k = 0; k < nlive; ++k) c->slot_ring[live[k]] = k;
+        c->ring_pos = nlive;
     }
     const int pos = c->ring_pos++;
     if (user_slot >= 0 && user_slot < HJ_BOUND_SLOTS) c->slot_ring[user_slot] = pos;
@@ -1307,6 +1321,7 @@ void hj_ctx_destroy(hj_ctx* c) {
     if (c->coord0_ext) (void)hipFree(c->coord0_ext);
     for (int s = 0; s < 2; ++s) if (c->aux_ext[s]) (void)hipFree(c->aux_ext[s]);
     if (c->ring) (void)hipFree(c->ring);
+    if (c->ring_keep) (void)hipFree(c->ring_keep);
     if (c->keys) (void)hipFree(c->keys);
     if (c->weno_vals) (void)hipFree(c->weno_vals);
     if (c->flag) (void)hipFree(c->flag);

@@ -83,6 +83,7 @@ struct hj_ctx {
     unsigned long long* ring;          // RING_SLOTS * HJ_MAX_DIM keys
     int ring_pos;
     int slot_ring[HJ_BOUND_SLOTS];     // user slot -> ring index (-1 = none)
+    unsigned long long* ring_keep = nullptr;     // where the live slots' entries wait while the ring is zeroed (next_ring)
     unsigned long long* keys;          // scratch keys: [0,32) weno eps (8 groups x 4 dims), [32,36) upwind min/max
     void* weno_vals;                   // HJ_MAX_DIM values of dtype
     const void* weno_src;              // caller-provided eps source or null

@@ -12,8 +12,9 @@ that gap without asking the user for anything: the callbacks are called ONCE wit
 and every NumPy ufunc / torch function / operator they apply is recorded instead of computed.  The recorded expression graph is
 written out as the `H = ...; alpha[d] = ...;` block register_native_hamiltonian compiles with hipRTC (Python floats become par[k]
 so that changing a speed does not recompile; values that depend on the in-plane coordinates only are hoisted into col[k]).  What
-cannot be recorded -- data-dependent Python control flow (`if p.max() > 0`), reductions, in-place masks, a Hamiltonian that reads `t` or
-`data` -- raises TraceError and the schemeData keeps the split path, as before.  Real arrays among the operands are fine if they are a
+cannot be recorded -- data-dependent `if` statements (`if p.max() > 0:`), reductions, in-place masks, a Hamiltonian that reads `t` or
+`data` -- raises TraceError and the schemeData keeps the split path, as before.  (Scalar idioms -- float(derivMin[d]), the builtin max / min,
+math.cos, `a if c else b` -- are rewritten in the callbacks' source for a second attempt: see _rewritten.)  Real arrays among the operands are fine if they are a
 grid coordinate, constant, or vary along ONE grid axis (a cos(xs[2]) computed in __init__): those become tables in the source text,
 looked up by the node's coordinate.
 
@@ -30,6 +31,7 @@ import os
 import struct
 import threading
 import warnings
+from types import ModuleType as _ModuleType
 
 import numpy as np
 
@@ -402,7 +404,7 @@ def _pow(a, b):
 
 
 def _is_tensor(v):
-    return type(v).__module__.split(".")[0] == "torch" and hasattr(v, "data_ptr")
+    return not isinstance(v, type) and type(v).__module__.split(".")[0] == "torch" and hasattr(v, "data_ptr") and hasattr(v, "numel")
 
 
 class _Tracer(object):
@@ -857,12 +859,140 @@ def _owners(hamFunc, partialFunc, schemeData):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- second chance: scalar idioms
+# artificialDissipationGLF hands partialFunc NUMBERS (the range over the grid), so callbacks are written for numbers:
+#     a = max(abs(float(derivMin[d])), abs(float(derivMax[d])));   math.cos(...);   v if v > 0 else 0
+# float(), the builtin max / min, the math module and a conditional expression all need a real number NOW and refuse a symbolic one.
+# When the first trace fails, the callbacks' SOURCE is rewritten -- float(x) -> x, max / min -> the element-wise pair, math.f -> the NumPy
+# ufunc, `a if c else b` -> where(c, a, b), each only where an argument is symbolic, the builtin otherwise -- and traced again.  The rewritten
+# function exists for the length of the trace only; the kernel it yields is checked against the ORIGINAL callbacks like any other.
+def _hj_float(x):
+    return x if isinstance(x, Sym) else float(x)
+
+
+def _hj_minmax(op, builtin):
+    def f(*args, **kwargs):
+        flat = args[0] if len(args) == 1 and isinstance(args[0], (list, tuple)) else args
+        if kwargs or not any(isinstance(a, Sym) for a in flat):
+            return builtin(*args, **kwargs)
+        r = flat[0]
+        for a in flat[1:]:
+            r = _bin(op, r, a)
+        return r
+    return f
+
+
+class _MathShim(object):
+    """`math` for the rewritten source: the NumPy ufunc of the same name where the argument is symbolic."""
+    _NAMES = {"fabs": "abs", "acos": "arccos", "asin": "arcsin", "atan": "arctan", "atan2": "arctan2", "pow": "power"}
+
+    def __getattr__(self, name):
+        import math
+        real = getattr(math, name)
+        if not callable(real):
+            return real
+        uf = getattr(np, self._NAMES.get(name, name), None)
+
+        def f(*args):
+            if uf is not None and any(isinstance(a, Sym) for a in args):
+                return uf(*args)
+            return real(*args)
+        return f
+
+
+def _hj_ifexp(cond, a, b):
+    if isinstance(cond, Sym):
+        return _where(cond, a(), b())
+    return a() if cond else b()
+
+
+def _rewritten(cb):
+    """The callback with its scalar idioms rewritten (see above), or None if its source cannot be had or nothing in it needs rewriting."""
+    import ast
+    import inspect
+    import textwrap
+    import types
+    fn = getattr(cb, "__func__", cb)
+    if not isinstance(fn, types.FunctionType):
+        return None
+    try:
+        tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+    except (OSError, TypeError, SyntaxError, IndentationError):
+        return None
+    if len(tree.body) != 1 or not isinstance(tree.body[0], ast.FunctionDef):
+        return None               # (a lambda in the middle of an expression, a decorated oddity)
+    changed = [0]
+
+    class R(ast.NodeTransformer):
+        def visit_Call(self, node):
+            self.generic_visit(node)
+            if isinstance(node.func, ast.Name) and node.func.id in ("float", "max", "min"):
+                node.func = ast.Name(id="__hj_" + node.func.id, ctx=ast.Load())
+                changed[0] += 1
+            return node
+
+        def visit_Attribute(self, node):
+            self.generic_visit(node)
+            if isinstance(node.value, ast.Name) and node.value.id == "math" and isinstance(node.ctx, ast.Load):
+                node.value = ast.Name(id="__hj_math", ctx=ast.Load())
+                changed[0] += 1
+            return node
+
+        def visit_IfExp(self, node):
+            self.generic_visit(node)
+            changed[0] += 1
+            lam = lambda body: ast.Lambda(args=ast.arguments(posonlyargs=[], args=[], vararg=None, kwonlyargs=[], kw_defaults=[], kwarg=None, defaults=[]), body=body)  # noqa: E731
+            return ast.Call(func=ast.Name(id="__hj_ifexp", ctx=ast.Load()), args=[node.test, lam(node.body), lam(node.orelse)], keywords=[])
+    fdef = R().visit(tree.body[0])
+    if not changed[0]:
+        return None
+    fdef.decorator_list = []
+    free = list(fn.__code__.co_freevars)
+    if "__class__" in free:
+        return None               # (zero-argument super())
+    factory = ast.FunctionDef(name="__hj_factory", args=ast.arguments(posonlyargs=[], args=[ast.arg(arg=v) for v in free], vararg=None, kwonlyargs=[],
+                                                                      kw_defaults=[], kwarg=None, defaults=[]),
+                              body=[fdef, ast.Return(value=ast.Name(id=fdef.name, ctx=ast.Load()))], decorator_list=[])
+    mod = ast.Module(body=[factory], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    glb = dict(fn.__globals__)
+    glb.update(__hj_float=_hj_float, __hj_max=_hj_minmax("max", max), __hj_min=_hj_minmax("min", min), __hj_math=_MathShim(), __hj_ifexp=_hj_ifexp)
+    try:
+        exec(compile(mod, "<levelsetpy_amd trace of %s>" % getattr(fn, "__qualname__", fn.__name__), "exec"), glb)
+        cells = []
+        for c in fn.__closure__ or ():
+            cells.append(c.cell_contents)
+        new = glb["__hj_factory"](*cells)
+    except Exception:
+        return None
+    new.__defaults__ = fn.__defaults__
+    new.__kwdefaults__ = fn.__kwdefaults__
+    owner = getattr(cb, "__self__", None)
+    return types.MethodType(new, owner) if owner is not None else new
+
+
 def trace_callbacks(grid, hamFunc, partialFunc, schemeData=None):
-    """Call hamFunc / partialFunc once with symbolic arrays; Traced, or TraceError with the reason."""
+    """Call hamFunc / partialFunc once with symbolic arrays; Traced, or TraceError with the reason.  A pair that fails as written is tried
+    once more with its scalar idioms rewritten (float(), max / min, math.*, conditional expressions)."""
+    try:
+        return _trace_once(grid, hamFunc, partialFunc, schemeData)
+    except TraceError as first:
+        if os.environ.get("HJ_TRACE_REWRITE", "1") in ("0", "off"):
+            raise
+        h2, p2 = _rewritten(hamFunc), _rewritten(partialFunc)
+        if h2 is None and p2 is None:
+            raise
+        try:
+            return _trace_once(grid, h2 or hamFunc, p2 or partialFunc, schemeData, owners=(hamFunc, partialFunc))
+        except TraceError:
+            raise first
+
+
+def _trace_once(grid, hamFunc, partialFunc, schemeData=None, owners=None):
     tr = _Tracer(grid)
     saved = {}
     prev = getattr(_TLS, "tracer", None)
-    guard = _StateGuard(_owners(hamFunc, partialFunc, schemeData))
+    guard = _StateGuard(_owners(*(owners or (hamFunc, partialFunc)), schemeData))
     _TLS.tracer = tr
     _patch_constructors()
     try:
@@ -934,8 +1064,8 @@ def _fingerprint_of(obj, depth, seen, out):
             out.append((k, hash(v.tobytes())))          # (stored per-axis tables: their values are part of the traced expression)
         elif _is_tensor(v) and v.numel() <= 8192:
             out.append((k, (v.data_ptr(), getattr(v, "_version", 0))))
-        elif depth > 0 and hasattr(v, "__dict__") and not callable(v) and k not in ("grid",):
-            _fingerprint_of(v, depth - 1, seen, out)
+        elif depth > 0 and hasattr(v, "__dict__") and not callable(v) and k not in ("grid",) and not isinstance(v, (type, _ModuleType)):
+            _fingerprint_of(v, depth - 1, seen, out)          # (not into modules or classes an object keeps a reference to: `self.torch = torch`)
 
 
 def fingerprint(sd):

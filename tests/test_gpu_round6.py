@@ -570,3 +570,40 @@ def test_thin_grids_take_the_transposed_march_by_default(monkeypatch):
         res[tag] = (tout.value, steps.value, (a if where.value == 1 else b).clone())
     assert res["default"][:2] == res["axis0"][:2] and res["default"][1] == nsteps
     assert torch.equal(res["default"][2], res["axis0"][2]), float((res["default"][2] - res["axis0"][2]).abs().max())
+
+
+def test_bound_ring_reset_keeps_the_live_slots(monkeypatch):
+    """The ring of CFL-bound keys is zeroed once per 2048 launches.  A step whose later-stage bounds are read together (hj_rk_step of a Hamiltonian
+    whose alpha reads the costate range: two kept bounds per RK3 step) may straddle the reset: the entry of stage 2 used to be zeroed while stage 3
+    was being enqueued ("bound slot holds no reduction").  Run across the reset at BOTH alignments; the run that straddles it must give the bits of
+    the one that does not."""
+    n = (26, 24, 22)
+    g, og = mk([-1., -1., -1.], [1., 1., 1.], n, None)
+    import levelsetpy_amd as L
+    reg = L.register_native_hamiltonian("ring_reset_probe", 3, """
+        H = par[0] * x[0] * p[1] + 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        alpha[0] = fmax(fabs(dmin[0]), fabs(dmax[0]));
+        alpha[1] = fmax(fabs(dmin[1]), fabs(dmax[1])) + fabs(par[0] * x[0]);
+        alpha[2] = fmax(fabs(dmin[2]), fabs(dmax[2]));
+    """, nparams=1)
+    xs = np.meshgrid(*[np.asarray(v).ravel() for v in g.vs], indexing="ij")
+    y0 = torch.as_tensor(np.sqrt(sum(x * x for x in xs)) - 0.5, device="cuda").contiguous()
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+    outs = []
+    for shift in (0, 1):
+        dg = _ctx(g, monkeypatch)
+        cur, nxt, w0, w1 = y0.clone(), torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)
+        for _ in range(shift):           # one more ring entry before the run: the other alignment
+            _sub(dg, sid, _ffi.STAGE_EULER, 1e-3, cur, None, nxt, 0, n[0], slot=5)
+        tout, dtout = C.c_double(), C.c_double()
+        t = 0.
+        for _ in range(1100):            # 2 entries per step: the reset falls inside this run
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, sid, reg.ham_id, _ffi.darr([0.7]), t, 1e9, 0.8, 1e300, 0, dg.ptr(cur), dg.ptr(nxt), dg.ptr(w0), dg.ptr(w1),
+                                         C.byref(tout), C.byref(dtout)))
+            cur, nxt = nxt, cur
+            t = float(tout.value)
+        sb, nb = (C.c_double * 4)(), C.c_int()
+        _ffi.check(dg.lib.hj_rk_last_bounds(dg.ctx, sb, C.byref(nb)))
+        assert nb.value == 3 and all(0 < sb[k] < 1 for k in range(3))
+        outs.append((t, cur.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])

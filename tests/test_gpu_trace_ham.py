@@ -369,3 +369,45 @@ def test_traced_more_than_four_parameters_in_place(monkeypatch):
     yo2, sbo2 = O.term_lax_friedrichs(og, ov, "ENO3", 0., d0.reshape(-1, 1))
     close(f2.cpu().numpy(), yo2, 1e-11, what="seven parameters, one changed")
     assert abs(sb2 - sbo2) <= 1e-12 * sbo2 and abs(sb2 - sb_f) > 1e-6
+
+
+def test_traced_scalar_idioms_of_the_glf_protocol(monkeypatch):
+    """partialFunc written for the numbers GLF hands it -- max(abs(float(derivMin[d])), abs(float(derivMax[d]))) -- is traced after the source rewrite
+    and runs the range pass + fused substep; against the split path (the callbacks as written) and the oracle."""
+    from test_trace_ham import ScalarIdioms
+    n = (24, 22, 20)
+    g, og = mk([-1., -1., -1.], [1., 1., 1.], n, None)
+    d0 = O.shape_sphere(og, None, 0.5) + 0.02 * np.random.default_rng(3).standard_normal(og.shape)
+    y = torch.as_tensor(d0.reshape(-1, 1), device="cuda")
+
+    class Sys(ScalarIdioms):
+        def hamiltonian(self, t, data, p, sd=None):
+            x0 = _x(self.grid, 0, p[0])
+            return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * x0 * p[1] + 0.955 * p[2]
+
+        def dissipation(self, t, data, derivMin, derivMax, sd, dim):
+            a = max(abs(float(derivMin[dim])), abs(float(derivMax[dim])))
+            a = a + self.gain if dim == 2 else a
+            if dim != 1:
+                return a
+            return a + abs(self.c * _x(self.grid, 0, data))
+    obj = Sys(g, 0.7)
+    monkeypatch.setenv("HJ_TRACE", "0")
+    split, sb_s, _ = L.termLaxFriedrichs(0., y, sdata(g, obj, L.upwindFirstWENO5))
+    monkeypatch.delenv("HJ_TRACE")
+    sd = sdata(g, obj, L.upwindFirstWENO5)
+    fused, sb_f, _ = L.termLaxFriedrichs(0., y, sd)
+    assert "hipRTC" in _kernel(g), _kernel(g)
+    assert abs(sb_f - sb_s) <= 1e-12 * sb_s
+    close(fused.cpu().numpy(), split.cpu().numpy(), 1e-11, what="scalar idioms: traced vs split")
+    yo, sbo = O.term_lax_friedrichs(og, Sys(og, 0.7), "WENO5_ASSHIPPED", 0., d0.reshape(-1, 1))
+    close(fused.cpu().numpy(), yo, 1e-11, what="scalar idioms: traced vs oracle")
+    op = L.odeCFLset(L.Bundle(dict(factorCFL=.8, singleStep='on')))
+    t1, y1 = 0., y
+    for _ in range(3):
+        t1, y1, _ = L.odeCFL3(L.termLaxFriedrichs, [t1, 10.], y1, op, sd)
+    to, yoo = 0., d0.reshape(-1, 1)
+    for _ in range(3):
+        to, yoo = O.ode_cfl_3(lambda tt, yy: O.term_lax_friedrichs(og, Sys(og, 0.7), "WENO5_ASSHIPPED", tt, yy), [to, 10.], yoo, 0.8, single_step=True)
+    assert abs(float(t1) - to) <= 1e-12
+    close(y1.cpu().numpy(), yoo, 1e-10, what="scalar idioms: three RK3 steps vs oracle")

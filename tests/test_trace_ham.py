@@ -3,6 +3,8 @@
 No GPU here: the traced graph is evaluated in NumPy (Traced.evaluate) against the callbacks themselves on real arrays, the
 generated source is compiled with hipRTC (hj_ham_compile_check needs no device), and everything the tracer must refuse is
 checked to be refused -- a refused pair keeps the split path, a wrongly accepted one would compute something else."""
+import math
+
 import numpy as np
 import pytest
 
@@ -111,6 +113,9 @@ def test_fingerprint_sees_in_place_changes():
     assert TH.fingerprint(sd) == f0
     obj.w = 0.9
     assert TH.fingerprint(sd) != f0
+    # an object that keeps a module or a class around (`self.np = np`) is not walked into
+    obj.np, obj.cls = np, DubinsAbs
+    assert len(TH.fingerprint(sd)) < 50
 
 
 class _Bad(object):
@@ -294,3 +299,66 @@ def test_what_a_callback_caches_during_the_trace_does_not_survive_it():
     with pytest.raises(TH.TraceError):
         TH.trace_callbacks(g, bad.hamiltonian, bad.dissipation, None)
     assert bad._x0 is None and bad.per_device == {}
+
+
+class ScalarIdioms(object):
+    """partialFunc written for the NUMBERS artificialDissipationGLF hands it (artificial_diss_glf.py:80-88): float(), the builtin max, math.*, a
+    conditional expression.  None of these accepts a symbolic argument; the tracer rewrites them in the source for a second attempt."""
+    gain = 0.25
+
+    def __init__(self, grid, c):
+        self.grid, self.c = grid, c
+
+    def hamiltonian(self, t, data, p, sd=None):
+        x0 = np.asarray(self.grid.xs[0])
+        return 0.5 * (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + self.c * x0 * p[1] + math.cos(0.3) * p[2]
+
+    def dissipation(self, t, data, derivMin, derivMax, sd, dim):
+        a = max(abs(float(derivMin[dim])), abs(float(derivMax[dim])))
+        a = a + self.gain if dim == 2 else a
+        lo = min(float(derivMin[dim]), 0.0)
+        a = a + 0.125 * math.fabs(lo)
+        if dim != 1:
+            return a
+        return a + np.abs(self.c * np.asarray(self.grid.xs[0]))
+
+
+def test_scalar_idioms_are_rewritten_for_a_second_attempt(monkeypatch):
+    g = grid3()
+    obj = ScalarIdioms(g, 0.7)
+    tr = TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+    assert tr.uses_range
+    rng = np.random.default_rng(4)
+    p = [rng.standard_normal(g.shape) for _ in range(3)]
+    for lo, hi in (([-1.5, -0.5, -2.0], [1.0, 2.5, 0.5]), ([0.25, -3.0, -0.1], [0.5, -1.0, 4.0])):     # both orders of |min| and |max|, min above zero
+        H, al = tr.evaluate(g.xs, p, lo, hi)
+        assert np.allclose(H, obj.hamiltonian(0., None, p), rtol=1e-14, atol=1e-14)
+        for d in range(3):
+            ref = np.broadcast_to(np.asarray(obj.dissipation(0., None, lo, hi, None, d), dtype=np.float64), g.shape)
+            assert np.allclose(np.broadcast_to(al[d], g.shape), ref, rtol=1e-14, atol=1e-14), d
+    # the callbacks themselves are untouched
+    assert obj.dissipation(0., None, [-1., -1., -1.], [2., 2., 2.], None, 0) == 2.0 + 0.125
+    monkeypatch.setenv("HJ_TRACE_REWRITE", "0")
+    with pytest.raises(TH.TraceError):
+        TH.trace_callbacks(g, obj.hamiltonian, obj.dissipation, None)
+
+
+def test_rewrite_keeps_closures_and_refuses_what_it_cannot_fix():
+    g = grid3()
+    k = 0.4
+
+    def ham(t, data, p, sd):
+        return k * p[0] + (p[1] if k > 0 else -p[1]) + 0 * p[2]                      # a free variable, a conditional expression on a number
+
+    def alpha(t, data, lo, hi, sd, dim):
+        return max(abs(float(lo[dim])), abs(float(hi[dim]))) + k
+
+    tr = TH.trace_callbacks(g, ham, alpha, None)
+    assert tr.uses_range and k in tr.params
+
+    def branchy(t, data, p, sd):
+        if float(p[0].max()) > 0:                                                     # an if STATEMENT on array values stays untraceable
+            return p[0]
+        return -p[0]
+    with pytest.raises(TH.TraceError):
+        TH.trace_callbacks(g, branchy, alpha, None)
