@@ -1067,10 +1067,11 @@ def test_deep_halo_stepper_refuses_the_intended_weno5_on_an_external_transport()
     st.close()
 
 
-def test_attach_after_first_use_is_picked_up_by_an_existing_schemedata():
+def test_attach_after_first_use_is_picked_up_by_an_existing_schemedata(monkeypatch):
     """A schemeData that ran on the split path (its system object not yet attached) must take the fused path once the object IS attached:
     the classification cached per schemeData is revisited when attach() has been called since (round 5: examples/custom_hamiltonian.py
-    ran both of its legs on the split path)."""
+    ran both of its legs on the split path).  (HJ_TRACE=0: since round 6 the library would trace these callbacks by itself.)"""
+    monkeypatch.setenv("HJ_TRACE", "0")
     n = (22, 20, 24)
     g, og = mk([-1.0] * 3, [1.0, 1.0, 1.0], n, None)
     d0 = O.shape_sphere(og, None, 0.5) + 0.05 * np.sin(3 * og.xs[0])
