@@ -1154,7 +1154,7 @@ def _key_of(tr):
 # call -- a second or two each, where the split path takes milliseconds.  Distinct expressions per callback are counted; beyond the limit the
 # pair is left on the split path for the rest of the process.
 MAX_EXPRESSIONS_PER_CALLBACK = 8
-_CHURN = {}                  # id(function) -> set of expression keys seen
+_CHURN = {}                  # id(code object) -> hashes of the expression keys seen
 
 
 def _registration(tr, ident=None):
@@ -1163,7 +1163,8 @@ def _registration(tr, ident=None):
         return None
     reg = _REG_BY_SOURCE.get(key)
     if ident is not None:
-        seen = _CHURN.setdefault(id(ident), set())
+        # (keyed by the CODE object: a lambda or a closure made anew for every call is still the same callback)
+        seen = _CHURN.setdefault(id(getattr(ident, "__code__", ident)), set())
         if hash(key) not in seen:
             if len(seen) >= MAX_EXPRESSIONS_PER_CALLBACK:
                 if os.environ.get("HJ_TRACE_VERBOSE"):
