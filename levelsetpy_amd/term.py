@@ -193,9 +193,11 @@ def _verify_traced(plan, sd, y):
         # (an ENO stencil choice may flip where the two arithmetics differ in the last bit: a few isolated nodes, not an expression error)
         single = not str(getattr(split, "dtype", "float64")).endswith("64")
         ok = finite and frac <= 2e-3 and worst <= 5e-2 * scale and abs(sb_f - sb_s) <= (1e-4 if single else 1e-7) * abs(sb_s)
-    except _ffi.Unsupported:
-        return None
-    except _trace.TraceError:
+    except (_ffi.Unsupported, _trace.TraceError) as e:
+        # (no kernel for this grid -- no tiling, too few nodes -- or a callback that met something symbolic it had kept: the split path)
+        import os
+        if os.environ.get("HJ_TRACE_VERBOSE"):
+            warnings.warn("levelsetpy_amd: the traced kernel of %r was not used: %s: %s" % (getattr(sd.hamFunc, "__qualname__", sd.hamFunc), type(e).__name__, e))
         return None
     if not ok:
         _trace.mark_bad(reg)

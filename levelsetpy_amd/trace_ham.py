@@ -1129,7 +1129,7 @@ class _TracedSystem(object):
             self.reg = _NoReg
             return []
         if _key_of(tr) != self._key:
-            reg = _registration(tr, getattr(self._sd.hamFunc, "__func__", self._sd.hamFunc))
+            reg = _registration(tr, getattr(self._sd.hamFunc, "__func__", self._sd.hamFunc), getattr(self._sd.hamFunc, "__self__", None))
             self.reg = reg if reg is not None else _NoReg
             self._key = _key_of(tr)
         self._params = list(tr.params)
@@ -1154,17 +1154,18 @@ def _key_of(tr):
 # call -- a second or two each, where the split path takes milliseconds.  Distinct expressions per callback are counted; beyond the limit the
 # pair is left on the split path for the rest of the process.
 MAX_EXPRESSIONS_PER_CALLBACK = 8
-_CHURN = {}                  # id(code object) -> hashes of the expression keys seen
+_CHURN = {}                  # (id(code object), id(bound object)) -> hashes of the expression keys seen
 
 
-def _registration(tr, ident=None):
+def _registration(tr, ident=None, owner=None):
     key = _key_of(tr)
     if key in _BAD_SOURCES:
         return None
     reg = _REG_BY_SOURCE.get(key)
     if ident is not None:
-        # (keyed by the CODE object: a lambda or a closure made anew for every call is still the same callback)
-        seen = _CHURN.setdefault(id(getattr(ident, "__code__", ident)), set())
+        # (keyed by the CODE object -- a lambda or a closure made anew for every call is still the same callback -- and, for a bound method, the
+        #  object it is bound to: one class may serve many systems, each with its own expression)
+        seen = _CHURN.setdefault((id(getattr(ident, "__code__", ident)), id(owner) if owner is not None else 0), set())
         if hash(key) not in seen:
             if len(seen) >= MAX_EXPRESSIONS_PER_CALLBACK:
                 if os.environ.get("HJ_TRACE_VERBOSE"):
@@ -1197,7 +1198,7 @@ def traced_native(sd):
     ident = getattr(sd.hamFunc, "__func__", sd.hamFunc)
     try:
         tr = trace_callbacks(sd.grid, sd.hamFunc, sd.partialFunc, sd)
-        reg = _registration(tr, ident)
+        reg = _registration(tr, ident, getattr(sd.hamFunc, "__self__", None))
         if reg is None:
             return None
     except TraceError as e:
