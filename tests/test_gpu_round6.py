@@ -607,3 +607,48 @@ def test_bound_ring_reset_keeps_the_live_slots(monkeypatch):
         assert nb.value == 3 and all(0 < sb[k] < 1 for k in range(3))
         outs.append((t, cur.clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("n", [(20, 640, 520), (64, 60, 66)])
+def test_rk_steps_captured_into_a_graph(monkeypatch, n):
+    """hj_rk_step enqueued while the stream is being captured (torch.cuda.graph -> hipGraph): the launch-form trial of thin grids (events, queries) and
+    the tile-shape rotation stand still during a capture and the launches are plain kernel nodes; replays give the bits of the eager steps."""
+    g, og = mk([-.75, -1.25, -np.pi], [3.25, 1.25, np.pi * (1 - 2 / n[2])], n, 2)
+    x0 = torch.as_tensor(np.asarray(g.vs[0]).ravel(), device="cuda").reshape(-1, 1, 1)
+    x1 = torch.as_tensor(np.asarray(g.vs[1]).ravel(), device="cuda").reshape(1, -1, 1)
+    y = ((x0 * x0 + x1 * x1).sqrt() - 0.5).expand(*n).contiguous()
+    sid = _ffi.SCHEME_IDS["WENO5_ASSHIPPED"]
+    dg = _ctx(g, monkeypatch)
+    bufs = [y.clone(), torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)]
+    tout, dtout = C.c_double(), C.c_double()
+
+    def steps(k):
+        cur, nxt = 0, 1
+        for _ in range(k):
+            _ffi.check(dg.lib.hj_rk_step(dg.ctx, 3, sid, _ffi.HAM_DUBINS_REL, _ffi.darr(PAR), 0., 1e9, 0.8, 1e300, 0, dg.ptr(bufs[cur]), dg.ptr(bufs[nxt]),
+                                         dg.ptr(bufs[2]), dg.ptr(bufs[3]), C.byref(tout), C.byref(dtout)))
+            cur, nxt = nxt, cur
+        return cur
+    last = steps(2)                       # eager: the static bound, the first trial runs
+    dg.sync()
+    ref2 = bufs[last].clone()
+    bufs[0].copy_(y)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dg.bind_stream()
+        with torch.cuda.graph(graph, stream=side):
+            last_g = steps(2)
+    dg.bind_stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        bufs[0].copy_(y)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[last_g], ref2)
+    # and the context goes on eagerly afterwards
+    bufs[0].copy_(y)
+    last = steps(2)
+    dg.sync()
+    assert torch.equal(bufs[last], ref2)
