@@ -25,7 +25,7 @@ from .dissipation import (artificialDissipationGLF, artificialDissipationLLF,   
 from .dynamics import DubinsVehicleRel, DoubleIntegrator, DoublePendulum4D      # noqa: F401
 from .user_ham import register_native_hamiltonian, NativeRegistration, RegisteredSystem, kernel_cache_stats   # noqa: F401
 from .trace_ham import trace_callbacks, TraceError                              # noqa: F401
-from .term import termLaxFriedrichs, termRestrictUpdate                         # noqa: F401
+from .term import termLaxFriedrichs, termRestrictUpdate, explain_plan           # noqa: F401
 from .integration import (odeCFL1, odeCFL2, odeCFL3, odeCFLset, odeCFLget,      # noqa: F401
                           odeCFLmultipleSteps, odeCFLcallPostTimestep)
 from .hji_solver import HJIPDE_solve                                            # noqa: F401

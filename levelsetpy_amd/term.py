@@ -25,7 +25,7 @@ from . import trace_ham as _trace
 from .spatial import scheme_id_of, upwind_all_dims
 from .utilities import isfield, iscell
 
-__all__ = ["termLaxFriedrichs", "termRestrictUpdate"]
+__all__ = ["termLaxFriedrichs", "termRestrictUpdate", "explain_plan"]
 
 
 def _deriv_func(sd):
@@ -100,6 +100,35 @@ def native_plan(schemeData, y=None):
     if plan is not None and plan.traced and not getattr(plan.system.reg, "verified", False):
         plan = _verify_traced(plan, sd, y)
     return plan
+
+
+def explain_plan(schemeData):
+    """Which path a Lax-Friedrichs schemeData takes and why -- for the question "why is this slow?".  Returns a dict: path = 'built-in' |
+    'registered' (user_ham.attach) | 'traced' | 'split', reason (split: what stopped the classification or the tracer), source (traced: the
+    generated device expression), verified (traced: has the kernel been checked against the callbacks yet -- it is on first use)."""
+    sd = schemeData[0] if iscell(schemeData) else schemeData
+    for f in ('grid', 'dissFunc', 'hamFunc', 'partialFunc'):
+        if not isfield(sd, f):
+            return dict(path='split', reason='schemeData has no %s' % f)
+    fn = _deriv_func(sd)
+    if fn is None or scheme_id_of(fn) is None:
+        return dict(path='split', reason='the derivative function is not one of this package\'s upwindFirst* schemes')
+    if sd.dissFunc not in (artificialDissipationGLF, artificialDissipationLLF, artificialDissipationLLLF):
+        return dict(path='split', reason='dissFunc is not one of this package\'s artificialDissipation* functions')
+    plan = _plan_of(sd)
+    if plan is not None and not plan.traced:
+        return dict(path='registered' if plan[2] >= _ffi.HAM_USER_BASE else 'built-in', ham_id=plan[2], params=list(plan[3]))
+    if not _trace.enabled():
+        return dict(path='split', reason='the callbacks are not known to the package and HJ_TRACE=0')
+    try:
+        tr = _trace.trace_callbacks(sd.grid, sd.hamFunc, sd.partialFunc, sd)
+    except _trace.TraceError as e:
+        return dict(path='split', reason='the callbacks cannot be traced: %s' % e)
+    if plan is None:
+        return dict(path='split', reason='the traced kernel disagreed with the callbacks on first use, the expression keeps changing, or the library '
+                                         'refused the registration (HJ_TRACE_VERBOSE=1 says which)', source=tr.source)
+    return dict(path='traced', ham_id=plan[2], params=list(plan[3]), source=tr.source, column_source=tr.column_source,
+                uses_range=tr.uses_range, verified=bool(getattr(plan.system.reg, "verified", False)))
 
 
 def _plan_of(sd):

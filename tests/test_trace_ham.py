@@ -362,3 +362,17 @@ def test_rewrite_keeps_closures_and_refuses_what_it_cannot_fix():
         return -p[0]
     with pytest.raises(TH.TraceError):
         TH.trace_callbacks(g, branchy, alpha, None)
+
+
+def test_explain_plan_says_which_path_and_why():
+    g = grid3()
+    mk = lambda o: L.Bundle(dict(grid=g, hamFunc=o.hamiltonian, partialFunc=o.dissipation, dissFunc=L.artificialDissipationGLF, CoStateCalc=L.upwindFirstENO2))  # noqa: E731
+    e = L.explain_plan(mk(DubinsAbs(g, 1.3, 0.7)))
+    assert e["path"] == "traced" and "alpha[2]" in e["source"] and e["params"] == [1.3, 0.7] and e["verified"] is False
+    e = L.explain_plan(mk(_Bad(g, "reduce")))
+    assert e["path"] == "split" and "reductions" in e["reason"]
+    e = L.explain_plan(mk(L.DubinsVehicleRel(g, 1, 1)))
+    assert e["path"] == "built-in"
+    sd = mk(DubinsAbs(g, 1., 1.))
+    sd.dissFunc = lambda *a: None
+    assert L.explain_plan(sd)["path"] == "split" and "dissFunc" in L.explain_plan(sd)["reason"]
