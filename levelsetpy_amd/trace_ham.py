@@ -56,6 +56,7 @@ def _tracer():
 _NUM_UNARY = {"neg": "(-{0})", "abs": "fabs({0})", "cos": "cos({0})", "sin": "sin({0})", "tan": "tan({0})", "exp": "exp({0})", "log": "log({0})",
               "sqrt": "sqrt({0})", "tanh": "tanh({0})", "sinh": "sinh({0})", "cosh": "cosh({0})", "asin": "asin({0})", "acos": "acos({0})",
               "atan": "atan({0})", "floor": "floor({0})", "ceil": "ceil({0})", "square": "({0} * {0})", "recip": "(T(1) / {0})",
+              "log1p": "log1p({0})", "expm1": "expm1({0})", "log2": "log2({0})", "log10": "log10({0})",
               "sign": "(T)(({0} > T(0)) - ({0} < T(0)))", "cast": "({0} ? T(1) : T(0))"}
 _NUM_BINARY = {"add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})", "div": "({0} / {1})", "pow": "pow({0}, {1})",
                "atan2": "atan2({0}, {1})", "hypot": "hypot({0}, {1})", "fmod": "fmod({0}, {1})",
@@ -63,11 +64,12 @@ _NUM_BINARY = {"add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})",
                "max": "((({0} >= {1}) || ({0} != {0})) ? {0} : {1})", "min": "((({0} <= {1}) || ({0} != {0})) ? {0} : {1})"}
 _CMP = {"gt": ">", "ge": ">=", "lt": "<", "le": "<=", "eq": "==", "ne": "!="}
 _BOOL_BINARY = {"and": "({0} && {1})", "or": "({0} || {1})", "xor": "({0} != {1})"}
-_EXPENSIVE = {"cos", "sin", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan", "pow", "atan2", "hypot", "div", "recip", "fmod"}
+_EXPENSIVE = {"log1p", "expm1", "log2", "log10", "cos", "sin", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan", "pow", "atan2", "hypot", "div", "recip", "fmod"}
 
 _NP_EVAL = {"neg": np.negative, "abs": np.abs, "cos": np.cos, "sin": np.sin, "tan": np.tan, "exp": np.exp, "log": np.log, "sqrt": np.sqrt,
             "tanh": np.tanh, "sinh": np.sinh, "cosh": np.cosh, "asin": np.arcsin, "acos": np.arccos, "atan": np.arctan, "floor": np.floor,
-            "ceil": np.ceil, "square": np.square, "recip": np.reciprocal, "sign": np.sign, "add": np.add, "sub": np.subtract, "mul": np.multiply,
+            "ceil": np.ceil, "square": np.square, "recip": np.reciprocal, "sign": np.sign, "log1p": np.log1p, "expm1": np.expm1, "log2": np.log2,
+            "log10": np.log10, "add": np.add, "sub": np.subtract, "mul": np.multiply,
             "div": np.divide, "pow": np.power, "atan2": np.arctan2, "hypot": np.hypot, "fmod": np.fmod, "max": np.maximum, "min": np.minimum,
             "gt": np.greater, "ge": np.greater_equal, "lt": np.less, "le": np.less_equal, "eq": np.equal, "ne": np.not_equal,
             "and": np.logical_and, "or": np.logical_or, "xor": np.logical_xor, "not": np.logical_not}
@@ -143,6 +145,10 @@ class Sym(object):
     def __rtruediv__(self, o): return _bin("div", o, self)
     def __pow__(self, o): return _pow(self, o)
     def __rpow__(self, o): return _pow(o, self)
+    def __floordiv__(self, o): return _apply("floor_divide", (self, o))
+    def __rfloordiv__(self, o): return _apply("floor_divide", (o, self))
+    def __mod__(self, o): return _apply("remainder", (self, o))
+    def __rmod__(self, o): return _apply("remainder", (o, self))
     def __neg__(self): return _un("neg", self)
     def __pos__(self): return self
     def __abs__(self): return _un("abs", self)
@@ -254,7 +260,7 @@ class CoordSym(Sym):
 _UNARY_NAMES = {"negative": "neg", "neg": "neg", "absolute": "abs", "abs": "abs", "fabs": "abs", "cos": "cos", "sin": "sin", "tan": "tan", "exp": "exp",
                 "log": "log", "sqrt": "sqrt", "tanh": "tanh", "sinh": "sinh", "cosh": "cosh", "arcsin": "asin", "asin": "asin", "arccos": "acos",
                 "acos": "acos", "arctan": "atan", "atan": "atan", "floor": "floor", "ceil": "ceil", "square": "square", "reciprocal": "recip",
-                "sign": "sign", "sgn": "sign"}
+                "sign": "sign", "sgn": "sign", "log1p": "log1p", "expm1": "expm1", "log2": "log2", "log10": "log10"}
 _BINARY_NAMES = {"add": "add", "subtract": "sub", "sub": "sub", "multiply": "mul", "mul": "mul", "divide": "div", "true_divide": "div", "div": "div",
                  "truediv": "div", "maximum": "max", "fmax": "max", "minimum": "min", "fmin": "min", "arctan2": "atan2", "atan2": "atan2",
                  "hypot": "hypot", "fmod": "fmod", "radd": "add", "rmul": "mul"}
@@ -286,6 +292,17 @@ def _apply(name, inputs):
         return _boolop(_BOOL_NAMES[name], inputs[0], inputs[1])
     if name in ("logical_not", "invert", "bitwise_not"):
         return _not(inputs[0])
+    if name in ("floor_divide", "floordiv"):
+        return _un("floor", _bin("div", inputs[0], inputs[1]))
+    if name in ("rfloordiv",):
+        return _un("floor", _bin("div", inputs[1], inputs[0]))
+    if name in ("remainder", "mod"):                      # NumPy / Python: the sign of the divisor -- a - floor(a / b) b
+        return _bin("sub", inputs[0], _bin("mul", _un("floor", _bin("div", inputs[0], inputs[1])), inputs[1]))
+    if name in ("rmod",):
+        return _apply("remainder", (inputs[1], inputs[0]))
+    if name == "heaviside":
+        x = _num(inputs[0])
+        return _where(_cmp("gt", x, 0), 1, _where(_cmp("lt", x, 0), 0, inputs[1]))
     raise TraceError("np.%s / torch.%s has no device expression here" % (name, name))
 
 
@@ -315,9 +332,150 @@ def _apply_function(name, args, kwargs):
         return _lift(args[0])
     if name in ("max", "min", "amax", "amin") and len(args) == 2 and not isinstance(args[1], (int, tuple)):
         return _bin(name[-3:], args[0], args[1])          # torch.max(a, b): the binary form
+    if name in ("stack", "vstack") and len(args) >= 1 and isinstance(args[0], (list, tuple)):
+        if kwargs.get("axis", kwargs.get("dim", 0)) not in (0, None) or (len(args) > 1 and args[1] != 0):
+            raise TraceError("stack along an axis other than 0")
+        return SymStack([_num(a) for a in args[0]])
+    if name == "select" and len(args) >= 2:
+        r = _lift(args[2] if len(args) > 2 else kwargs.get("default", 0))
+        for c, v in reversed(list(zip(args[0], args[1]))):
+            r = _where(c, v, r)
+        return r
+    if name == "sinc":
+        x = _bin("mul", args[0], math_pi())
+        return _where(_cmp("eq", x, 0), 1, _bin("div", _un("sin", x), x))
     if name in ("sum", "mean", "max", "min", "amax", "amin", "prod", "any", "all", "norm", "argmax", "argmin"):
         raise TraceError("%s() of a symbolic array: reductions have no per-node expression" % name)
     return _apply(name, args)
+
+
+def math_pi():
+    return 3.141592653589793
+
+
+class SymStack(object):
+    """np.stack([a, b, c]) of symbolic arrays: a short list along a NEW leading axis -- the one kind of reduction that has a per-node expression
+    (|p| = np.linalg.norm(np.stack(p), axis=0); np.stack(...).sum(0) / .max(0) / .min(0)).  Element-wise operations act on every member."""
+    __array_priority__ = 20000.0
+
+    def __init__(self, members):
+        self.members = list(members)
+
+    def __len__(self):
+        return len(self.members)
+
+    def __getitem__(self, k):
+        if isinstance(k, (int, np.integer)):
+            return self.members[int(k)]
+        if isinstance(k, slice):
+            return SymStack(self.members[k])
+        raise TraceError("indexing a stack of symbolic arrays with %r" % (k,))
+
+    def __iter__(self):
+        return iter(self.members)
+
+    @property
+    def shape(self):
+        return (len(self.members),) + tuple(_tracer().shape)
+
+    def _map(self, f):
+        return SymStack([f(m) for m in self.members])
+
+    def _zip(self, o, f):
+        if isinstance(o, SymStack):
+            if len(o.members) != len(self.members):
+                raise TraceError("stacks of different lengths")
+            return SymStack([f(a, b) for a, b in zip(self.members, o.members)])
+        return SymStack([f(a, o) for a in self.members])
+
+    def __add__(self, o): return self._zip(o, lambda a, b: _bin("add", a, b))
+    __radd__ = __add__
+    def __sub__(self, o): return self._zip(o, lambda a, b: _bin("sub", a, b))
+    def __rsub__(self, o): return self._zip(o, lambda a, b: _bin("sub", b, a))
+    def __mul__(self, o): return self._zip(o, lambda a, b: _bin("mul", a, b))
+    __rmul__ = __mul__
+    def __truediv__(self, o): return self._zip(o, lambda a, b: _bin("div", a, b))
+    def __rtruediv__(self, o): return self._zip(o, lambda a, b: _bin("div", b, a))
+    def __pow__(self, o): return self._map(lambda a: _pow(a, o))
+    def __neg__(self): return self._map(lambda a: _un("neg", a))
+    def __abs__(self): return self._map(lambda a: _un("abs", a))
+
+    def _axis0(self, axis, what):
+        if axis not in (0,):
+            raise TraceError("%s of a stack along axis %r: only the stacking axis (0) has a per-node expression" % (what, axis))
+
+    def _fold(self, op):
+        r = self.members[0]
+        for m in self.members[1:]:
+            r = _bin(op, r, m)
+        return r
+
+    def sum(self, axis=None, dim=None, **kw):
+        self._axis0(axis if dim is None else dim, "sum")
+        return self._fold("add")
+
+    def prod(self, axis=None, dim=None, **kw):
+        self._axis0(axis if dim is None else dim, "prod")
+        return self._fold("mul")
+
+    def max(self, axis=None, dim=None, **kw):
+        self._axis0(axis if dim is None else dim, "max")
+        return self._fold("max")
+
+    def min(self, axis=None, dim=None, **kw):
+        self._axis0(axis if dim is None else dim, "min")
+        return self._fold("min")
+
+    def mean(self, axis=None, dim=None, **kw):
+        self._axis0(axis if dim is None else dim, "mean")
+        return _bin("div", self._fold("add"), len(self.members))
+
+    amax, amin = max, min
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if kwargs.get("out") is not None:
+            raise TraceError("out= on a stack of symbolic arrays")
+        if method == "reduce":
+            self._axis0(kwargs.get("axis", 0), ufunc.__name__ + ".reduce")
+            op = {"add": "add", "multiply": "mul", "maximum": "max", "minimum": "min", "fmax": "max", "fmin": "min"}.get(ufunc.__name__)
+            if op is None:
+                raise TraceError("np.%s.reduce of a stack" % ufunc.__name__)
+            return inputs[0]._fold(op)
+        if method != "__call__":
+            raise TraceError("np.%s.%s of a stack of symbolic arrays" % (ufunc.__name__, method))
+        n = len(self.members)
+        cols = [[(a.members[k] if isinstance(a, SymStack) else a) for a in inputs] for k in range(n)]
+        return SymStack([_apply(ufunc.__name__, c) for c in cols])
+
+    def __array_function__(self, func, types, args, kwargs):
+        name = func.__name__
+        if name in ("sum", "prod", "max", "min", "amax", "amin", "mean"):
+            return getattr(self, name)(kwargs.get("axis", args[1] if len(args) > 1 else None))
+        if name == "norm":
+            order = kwargs.get("ord", args[1] if len(args) > 1 else None)
+            self._axis0(kwargs.get("axis", args[2] if len(args) > 2 else None), "norm")
+            if order in (None, 2):
+                return _un("sqrt", self._map(lambda a: _un("square", a))._fold("add"))
+            if order == 1:
+                return self._map(lambda a: _un("abs", a))._fold("add")
+            if order == np.inf:
+                return self._map(lambda a: _un("abs", a))._fold("max")
+            raise TraceError("np.linalg.norm of order %r" % (order,))
+        raise TraceError("np.%s of a stack of symbolic arrays" % name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", str(func))
+        st = next(a for a in args if isinstance(a, SymStack))
+        if name in ("sum", "prod", "amax", "amin", "mean"):
+            return getattr(st, name)(kwargs.get("dim", args[1] if len(args) > 1 else None))
+        if name in ("max", "min") and (len(args) > 1 or "dim" in kwargs):
+            raise TraceError("torch.%s(stack, dim) returns indices as well: use amax / amin" % name)
+        if name in ("norm", "vector_norm", "linalg_vector_norm"):
+            return st.__array_function__(np.linalg.norm, (), (st,), {"axis": kwargs.get("dim", args[2] if len(args) > 2 else None),
+                                                                        "ord": kwargs.get("p", kwargs.get("ord", args[1] if len(args) > 1 else None))})
+        raise TraceError("torch.%s of a stack of symbolic arrays" % name)
 
 
 # ---------------------------------------------------------------------------------------------- graph construction
@@ -492,6 +650,8 @@ class _Tracer(object):
             if v.numel() == 1:
                 return self.param(float(v.reshape(-1)[0].item())) if v.dtype.is_floating_point else self.const(int(v.reshape(-1)[0].item()))
             return self._coordinate(v, None)
+        if isinstance(v, SymStack):
+            raise TraceError("a stack of symbolic arrays where ONE array was expected (reduce it along axis 0 first: .sum(0), .max(0), norm(axis=0))")
         if isinstance(v, (list, tuple)):
             raise TraceError("a %s where an array was expected" % type(v).__name__)
         try:

@@ -376,3 +376,48 @@ def test_explain_plan_says_which_path_and_why():
     sd = mk(DubinsAbs(g, 1., 1.))
     sd.dissFunc = lambda *a: None
     assert L.explain_plan(sd)["path"] == "split" and "dissFunc" in L.explain_plan(sd)["reason"]
+
+
+def _inplace(g):
+    def f(t, d, p, sd):
+        h = p[0] * 1.0
+        h += p[1]
+        h *= 2.0
+        h -= g.xs[0]
+        h /= 4.0
+        return h
+    return f
+
+
+IDIOMS = {
+    "ufunc calls": lambda g: lambda t, d, p, sd: np.add(np.multiply(p[0], g.xs[1]), np.subtract(p[1], 2.0)),
+    "power, float exponent": lambda g: lambda t, d, p, sd: np.power(np.abs(p[0]) + 1.0, 1.5),
+    "square, hypot": lambda g: lambda t, d, p, sd: np.square(p[0]) + np.hypot(p[1], p[2]),
+    "in-place operators": _inplace,
+    "full_like / ones": lambda g: lambda t, d, p, sd: np.full_like(p[0], 0.3) * p[1] + np.ones(g.shape) * 0.5 * p[0],
+    "booleans as numbers": lambda g: lambda t, d, p, sd: (p[0] >= 0) * 2.0 * p[0] + (p[0] < 0) * (-1.0) * p[0],
+    "where with numbers": lambda g: lambda t, d, p, sd: np.where(p[0] > 0, 1.0, -1.0) * p[1],
+    "builtin sum / abs": lambda g: lambda t, d, p, sd: np.sqrt(sum(q ** 2 for q in p) + 1e-9) + abs(p[0]),
+    "norm of a stack": lambda g: lambda t, d, p, sd: np.linalg.norm(np.stack(p), axis=0) + np.stack([p[0], p[1]]).sum(axis=0) + np.max(np.stack(p) ** 2, axis=0),
+    "arctan2, minimum, maximum": lambda g: lambda t, d, p, sd: np.arctan2(p[0], p[1] + 3.0) + np.minimum(p[0], 0.0) + np.maximum(0.0, p[1]),
+    "NumPy scalars": lambda g: lambda t, d, p, sd: np.float64(0.3) * p[0] + np.float32(0.5) * p[1] + np.array(0.25) * p[2],
+    "reshape, vs": lambda g: lambda t, d, p, sd: (p[0].reshape(g.shape) * g.xs[0]).reshape(-1).reshape(g.shape) + p[1] * np.asarray(g.vs[0]).reshape(-1, 1, 1),
+    "log1p, expm1": lambda g: lambda t, d, p, sd: np.log1p(np.exp(p[0])) + np.expm1(-np.abs(p[1])),
+    "mod, floor division": lambda g: lambda t, d, p, sd: np.mod(g.xs[2] + 2.0, 0.75) * p[0] + (p[1] // 0.5) + (p[2] % 0.3),
+    "select, heaviside, sinc": lambda g: lambda t, d, p, sd: np.select([p[0] > 0.5, p[0] < -0.5], [p[1], p[2]], 0.0) + np.heaviside(p[0], 0.5) * p[1] + np.sinc(p[2]),
+    "a small linear map": lambda g: lambda t, d, p, sd: (np.array([[1., 2.], [3., 4.]]) @ np.array([1., 1.]))[0] * p[0],
+    "(ham, schemeData) returned": lambda g: lambda t, d, p, sd: (p[0] * 1.5, sd),
+}
+
+
+@pytest.mark.parametrize("name", sorted(IDIOMS))
+def test_array_idioms_trace_and_compute_the_same(name):
+    g = grid3()
+    f = IDIOMS[name](g)
+    tr = TH.trace_callbacks(g, f, lambda t, d, lo, hi, sd, dim: 1.0, None)
+    rng = np.random.default_rng(1)
+    p = [rng.standard_normal(g.shape) for _ in range(3)]
+    H, _ = tr.evaluate(g.xs, p)
+    ref = f(0., None, p, None)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert np.allclose(np.broadcast_to(H, g.shape), ref, rtol=1e-13, atol=1e-13), float(np.abs(H - ref).max())
