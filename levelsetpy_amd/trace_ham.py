@@ -432,6 +432,13 @@ class SymStack(object):
 
     amax, amin = max, min
 
+    def abs(self): return abs(self)
+    def square(self): return self._map(lambda a: _un("square", a))
+    def pow(self, o): return self ** o
+
+    def norm(self, p=2, dim=None, axis=None, **kw):
+        return self.__array_function__(np.linalg.norm, (), (self,), {"axis": dim if dim is not None else axis, "ord": p})
+
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         if kwargs.get("out") is not None:
             raise TraceError("out= on a stack of symbolic arrays")
