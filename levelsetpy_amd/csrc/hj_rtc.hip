@@ -694,9 +694,14 @@ int hj_ham_compile_check(int ham_id, int scheme) {
     rtcProgram prog = nullptr;
     int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);
     if (e) return fail(HJ_EHIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(e));
-    e = g_rtc.AddNameExpression(prog, kernel_name(sh, "double", scheme, 0).c_str());
-    if (!e && dynamic) e = g_rtc.AddNameExpression(prog, kernel_name(sh, "double", scheme, 3).c_str());
-    if (!e && !dynamic) e = g_rtc.AddNameExpression(prog, "hj::alpha_bound_kernel<double, hj::HamUser<double>>");
+    // every instantiation a step can launch, in BOTH dtypes (an expression that fails only in the float instantiation, or in the
+    // bound kernel of a range-reading Hamiltonian -- hj_rk_step under GLF and hj_range_alpha_max launch it -- passed the check and failed at the
+    // first step)
+    for (const char* tn : {"double", "float"}) {
+        if (!e) e = g_rtc.AddNameExpression(prog, kernel_name(sh, tn, scheme, 0).c_str());
+        if (!e && dynamic) e = g_rtc.AddNameExpression(prog, kernel_name(sh, tn, scheme, 3).c_str());
+        if (!e) e = g_rtc.AddNameExpression(prog, (std::string("hj::alpha_bound_kernel<") + tn + ", hj::HamUser<" + tn + ">>").c_str());
+    }
     const std::string inc1 = "-I" + u->include_dir, inc2 = "-I" + u->include_dir + "/../../include";
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", inc1.c_str(), inc2.c_str(), "-DHJ_RTC=1"};
     if (!e) e = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
