@@ -691,6 +691,9 @@ int hj_ham_compile_check(int ham_id, int scheme) {
     const bool dynamic = (u->flags & HJ_HAM_RANGE) != 0;
     const UShape sh = shape_of(u->ndim == 4 ? 2 : 0, false);
     const std::string src = user_source(*u, ham_id);
+    if (const char* dump = getenv("HJ_RTC_DUMP")) {        // the translation unit hipRTC is given, for a look at it (or an offline hipcc -S)
+        if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
+    }
     rtcProgram prog = nullptr;
     int e = g_rtc.CreateProgram(&prog, src.c_str(), "hj_user_ham.hip", 0, nullptr, nullptr);
     if (e) return fail(HJ_EHIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(e));
