@@ -1257,6 +1257,10 @@ def fingerprint(sd):
                 continue
             if _scalarish(v):
                 out.append(("<cell>", v))
+            elif isinstance(v, np.ndarray) and v.size <= 8192:
+                out.append(("<cell>", hash(v.tobytes())))             # (a per-axis table the closure captured)
+            elif _is_tensor(v) and v.numel() <= 8192:
+                out.append(("<cell>", (v.data_ptr(), getattr(v, "_version", 0))))
             else:
                 _fingerprint_of(v, 1, seen, out)
         code, glb = getattr(fn, "__code__", None), getattr(fn, "__globals__", None)
@@ -1265,6 +1269,8 @@ def fingerprint(sd):
                 v = glb.get(name)
                 if v is not None and _scalarish(v):
                     out.append((name, v))
+                elif isinstance(v, np.ndarray) and v.size <= 8192:
+                    out.append((name, hash(v.tobytes())))
     _fingerprint_of(sd, 1, seen, out)
     return tuple(out)
 

@@ -113,6 +113,12 @@ def test_fingerprint_sees_in_place_changes():
     assert TH.fingerprint(sd) == f0
     obj.w = 0.9
     assert TH.fingerprint(sd) != f0
+    # a table captured by a closure is part of the state as well
+    tab = np.linspace(0., 1., 12).reshape(-1, 1, 1)
+    sd2 = L.Bundle(dict(grid=g, hamFunc=lambda t, d, p, s: p[0] * tab, partialFunc=lambda t, d, lo, hi, s, dim: 1.0))
+    f1 = TH.fingerprint(sd2)
+    tab[3] = 5.0
+    assert TH.fingerprint(sd2) != f1
     # an object that keeps a module or a class around (`self.np = np`) is not walked into
     obj.np, obj.cls = np, DubinsAbs
     assert len(TH.fingerprint(sd)) < 50
